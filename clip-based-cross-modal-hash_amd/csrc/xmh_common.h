@@ -1,0 +1,44 @@
+// Shared host-side helpers for libxmh.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/xmh.h"
+
+namespace xmh {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return code;
+}
+
+// Launch check: HIP reports bad configs at launch; asynchronous faults surface at the caller's sync.
+#define XMH_LAUNCH_CHECK(what)                                                                        \
+    do {                                                                                              \
+        hipError_t e__ = hipGetLastError();                                                           \
+        if (e__ != hipSuccess) return ::xmh::fail(XMH_EHIP, "%s: %s", what, hipGetErrorString(e__));  \
+    } while (0)
+
+#define XMH_HIP(call)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess) return ::xmh::fail(XMH_EHIP, "%s: %s", #call, hipGetErrorString(e__));          \
+    } while (0)
+
+inline hipStream_t as_stream(xmh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int device_cu_count();
+
+}  // namespace xmh

@@ -1,0 +1,72 @@
+"""ctypes binding of libxmh.so (the C ABI declared in include/xmh.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C
+clip-based-cross-modal-hash_amd`` with ``hipcc --offload-arch=gfx950``.  If it
+is missing this module raises at import: the product path never falls back to
+PyTorch/CPU arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("XMH_LIB", os.path.join(_HERE, "libxmh.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libxmh.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C clip-based-cross-modal-hash_amd). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+
+
+class ScanPlan(C.Structure):
+    _fields_ = [("chunk", i64), ("nchunk", i64), ("nqtile", i64), ("qpad", i64), ("nbuckets", i64), ("ws_bytes", sz)]
+
+
+# name -> (restype, argtypes); mirrors include/xmh.h one to one
+PROTOTYPES = {
+    "xmh_version": (i32, []),
+    "xmh_last_error": (C.c_char_p, []),
+    "xmh_pack_sign": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
+    "xmh_pack_pair_argmax": (i32, [vp, i64, i32, vp, vp, vp]),
+    "xmh_unpack_pm1": (i32, [vp, vp, i64, i32, vp, vp]),
+    "xmh_pack_labels": (i32, [vp, i32, i64, i32, vp, vp]),
+    "xmh_hamming_dist": (i32, [vp, vp, vp, vp, i64, i64, i32, vp, vp, vp]),
+    "xmh_label_sim": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "xmh_scan_plan_make": (i32, [i64, i64, i32, i32, C.POINTER(ScanPlan)]),
+    "xmh_hamming_hist": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp]),
+    "xmh_hamming_ap": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp, i64, vp, vp, vp]),
+    "xmh_map_finalize": (i32, [vp, vp, i64, vp, vp]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class XmhError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map a non-zero C status to RuntimeError(xmh_last_error()) (SURVEY 8b 'Errors')."""
+    if rc != 0:
+        msg = lib.xmh_last_error().decode("utf-8", "replace")
+        raise XmhError("%s failed (%d): %s" % (what or "libxmh call", rc, msg))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None -> c_void_p."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,97 @@
+"""Drop-in for the reference's ``common/calc_utils.py`` -- same names, positional arguments, return
+types and error behaviour; the arithmetic runs in libxmh.so on the GPU.
+
+    calc_hammingDist      common/calc_utils.py:51-56   -> xmh_hamming_dist (bit-packed XOR/popcount)
+    calc_map_k            common/calc_utils.py:58-92   -> xmh_hamming_hist + xmh_hamming_ap + xmh_map_finalize
+    calc_label_sim        common/calc_utils.py:8-10    -> xmh_label_sim
+    cosine_similarity     common/calc_utils.py:38-49   -> xmh_rownorm + xmh_gemm_nt_f32
+    euclidean_similarity  common/calc_utils.py:28-36   -> xmh_pairwise_l2
+
+Differences that are deliberate and documented (DESIGN.md "Parity"):
+  * ranking ties are broken by gallery index (torch.sort(stable=True)); the reference's unstable sort
+    leaves them unspecified.
+  * inputs may live on the CPU like in the reference (calc_map_k moves them there, :62-64); here they
+    are moved TO the GPU instead, and calc_map_k still returns a CPU 0-dim float32 tensor.
+  * there is no CPU fallback: without a GPU these functions raise.
+"""
+from __future__ import annotations
+
+from typing import Union
+
+import numpy as np
+import torch
+
+from .. import retrieval as R
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("xmh.common.calc_utils needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_gpu(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_cuda else t.to(_device(), non_blocking=True)
+
+
+def _pack_codes(B: torch.Tensor) -> R.PackedCodes:
+    p = R.pack_sign(_to_gpu(B))
+    return p
+
+
+def _is_quantised(*packed: R.PackedCodes) -> bool:
+    return not any(p.flags & 2 for p in packed)
+
+
+def calc_label_sim(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(a @ b^T > 0).float() for multi-hot label matrices; result on the GPU (inputs' device if CUDA)."""
+    a, b = _to_gpu(a), _to_gpu(b)
+    return R.label_sim(R.pack_labels(a), R.pack_labels(b), a.shape[1])
+
+
+def calc_hammingDist(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
+    """0.5 * (K - B1 @ B2^T), float32 [Q,R]; a 1-D B1 is one query (reference :53-54)."""
+    if B1.dim() < 2:
+        B1 = B1.unsqueeze(0)
+    q, r = _pack_codes(B1), _pack_codes(B2)
+    if _is_quantised(q, r):
+        return R.hamming_dist(q, r)
+    from .. import dense                           # un-quantised float "codes" (UMoED-style)
+    return dense.hamming_dist_float(_to_gpu(B1).float(), _to_gpu(B2).float())
+
+
+def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
+    """mAP@k with the reference's semantics: ``k`` caps the number of relevant items averaged (:81),
+    a query without relevant items makes the result NaN (:87-89), a single query raises IndexError
+    (the squeeze at :72).  Returns a CPU 0-dim float32 tensor like the reference."""
+    num_query = query_L.shape[0]
+    if num_query == 1:
+        raise IndexError("calc_map_k needs more than one query (reference squeezes the query axis, calc_utils.py:72)")
+    q, r = _pack_codes(qB), _pack_codes(rB)
+    qL, rL = _to_gpu(query_L), _to_gpu(retrieval_L)
+    if _is_quantised(q, r):
+        res = R.map_k_packed(q, r, R.pack_labels(qL), R.pack_labels(rL), qL.shape[1], k)
+    else:
+        from .. import dense
+        res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), R.pack_labels(qL), R.pack_labels(rL), qL.shape[1], k)
+    return res.to(torch.float32).cpu().reshape(())
+
+
+def cosine_similarity(a: Union[torch.Tensor, np.ndarray], b: Union[torch.Tensor, np.ndarray]):
+    if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+        from .. import dense
+        return dense.cosine(_to_gpu(a).float(), _to_gpu(b).float())
+    if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
+        from .. import dense
+        return dense.cosine(_to_gpu(torch.from_numpy(a)).float(), _to_gpu(torch.from_numpy(b)).float()).cpu().numpy()
+    raise ValueError("input value must in [torch.Tensor, numpy.ndarray], but it is %s, %s" % (type(a), type(b)))
+
+
+def euclidean_similarity(a: Union[torch.Tensor, np.ndarray], b: Union[torch.Tensor, np.ndarray]):
+    if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+        from .. import dense
+        return dense.pairwise_l2(_to_gpu(a).float(), _to_gpu(b).float())
+    if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
+        from .. import dense
+        return dense.pairwise_l2(_to_gpu(torch.from_numpy(a)).float(), _to_gpu(torch.from_numpy(b)).float()).cpu().numpy()
+    raise ValueError("input value must in [torch.Tensor, numpy.ndarray], but it is %s, %s" % (type(a), type(b)))

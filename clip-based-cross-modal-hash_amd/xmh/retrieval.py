@@ -1,0 +1,224 @@
+"""Bit-packed hash codes on the GPU and the retrieval ops over them.
+
+Thin host wrappers: allocate outputs with torch, hand raw device pointers and the
+current HIP stream to ``libxmh.so``.  No arithmetic happens here.
+
+Reference counterparts (file:line under the reference repo):
+  pack_sign / pack_pair_argmax  -> make_hash_code, runners/base.py:407-410, runners/DCMHT/runner.py:82-95
+  hamming_dist                  -> calc_hammingDist, common/calc_utils.py:51-56
+  map_k_packed                  -> calc_map_k, common/calc_utils.py:58-92
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr
+
+_DT = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("xmh ops need CUDA/HIP tensors (got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def words(K: int) -> int:
+    return (K + 31) // 32
+
+
+@dataclass
+class PackedCodes:
+    """n hash codes of K bits.  ``bits`` int32 [n, W] (bit set <=> +1); ``zero`` int32 [n, W] or None
+    (bit set <=> the code element is exactly 0, padding bits set)."""
+    bits: torch.Tensor
+    zero: Optional[torch.Tensor]
+    K: int
+    flags: int = 0          # bit0: an exact 0 was seen, bit1: a value outside {-1,0,+1} was seen (pack_sign)
+
+    @property
+    def n(self) -> int:
+        return self.bits.shape[0]
+
+    @property
+    def ternary(self) -> bool:
+        return self.zero is not None
+
+    def rows(self, lo: int, hi: int) -> "PackedCodes":
+        return PackedCodes(self.bits[lo:hi], None if self.zero is None else self.zero[lo:hi], self.K)
+
+    def unpack(self) -> torch.Tensor:
+        """-> float32 [n, K] of -1/0/+1 (what BaseTrainer.get_code hands to calc_map_k / save_mat)."""
+        out = torch.empty(self.n, self.K, dtype=torch.float32, device=self.bits.device)
+        check(lib.xmh_unpack_pm1(ptr(self.bits), ptr(self.zero), self.n, self.K, ptr(out), current_stream()), "xmh_unpack_pm1")
+        return out
+
+
+def empty_packed(n: int, K: int, device, with_zero: bool = False) -> PackedCodes:
+    bits = torch.zeros(n, words(K), dtype=torch.int32, device=device)
+    zero = None
+    if with_zero:
+        zero = torch.zeros(n, words(K), dtype=torch.int32, device=device)
+    return PackedCodes(bits, zero, K)
+
+
+def pack_sign(codes: torch.Tensor, out: Optional[PackedCodes] = None, row_index: Optional[torch.Tensor] = None,
+              flags: Optional[torch.Tensor] = None) -> PackedCodes:
+    """sign-quantise + pack float codes [n, K] (BaseTrainer.make_hash_code + the row scatter of get_code).
+
+    Stand-alone (``out is None``): returns a fresh PackedCodes; one 4-byte D2H read of the value flags
+    decides whether the zero plane is kept (``sign(0) = 0`` seen) and records ``.flags`` (bit1 = some
+    element was not in {-1,0,+1}, i.e. the input was not yet quantised -- harmless here, sign is applied).
+    Scatter mode (``out``/``row_index``): rows land in ``out`` at ``row_index``; ``flags`` (int32 [1] device
+    tensor) accumulates the value flags without any sync."""
+    _require_cuda(codes, row_index, flags)
+    codes = codes.contiguous().float()
+    n, K = codes.shape
+    if out is not None:
+        if out.zero is None or out.K != K:
+            raise ValueError("scatter target needs a zero plane and the same K")
+        check(lib.xmh_pack_sign(ptr(codes), n, K, ptr(row_index), ptr(out.bits), ptr(out.zero), ptr(flags), current_stream()),
+              "xmh_pack_sign")
+        return out
+    res = empty_packed(n, K, codes.device, with_zero=True)
+    fl = torch.zeros(1, dtype=torch.int32, device=codes.device) if flags is None else flags
+    check(lib.xmh_pack_sign(ptr(codes), n, K, ptr(row_index), ptr(res.bits), ptr(res.zero), ptr(fl), current_stream()),
+          "xmh_pack_sign")
+    res.flags = int(fl.item())
+    if not (res.flags & 1):
+        res.zero = None
+    return res
+
+
+def pack_pair_argmax(probs: torch.Tensor, out: Optional[PackedCodes] = None,
+                     row_index: Optional[torch.Tensor] = None) -> PackedCodes:
+    """DCMHT quantiser: probs [n, 2K] -> K bits, bit = p[2j+1] > p[2j]."""
+    _require_cuda(probs, row_index)
+    probs = probs.contiguous().float()
+    n, K2 = probs.shape
+    if K2 % 2:
+        raise ValueError("pair-argmax needs an even last dimension")
+    K = K2 // 2
+    if out is None:
+        out = empty_packed(n, K, probs.device)
+    check(lib.xmh_pack_pair_argmax(ptr(probs), n, K, ptr(row_index), ptr(out.bits), current_stream()), "xmh_pack_pair_argmax")
+    return out
+
+
+def pack_labels(L: torch.Tensor) -> torch.Tensor:
+    """multi-hot labels [n, C] (float32 / int64 / int32 / uint8 / bool) -> int32 [n, ceil(C/32)]."""
+    _require_cuda(L)
+    if L.dtype not in _DT:
+        L = L.to(torch.float32)
+    L = L.contiguous()
+    n, Cn = L.shape
+    lab = torch.empty(n, words(Cn), dtype=torch.int32, device=L.device)
+    check(lib.xmh_pack_labels(ptr(L), _DT[L.dtype], n, Cn, ptr(lab), current_stream()), "xmh_pack_labels")
+    return lab
+
+
+def _both_planes(q: PackedCodes, r: PackedCodes):
+    """zero planes for both sides or neither (the kernels' contract)."""
+    if q.zero is None and r.zero is None:
+        return None, None
+
+    def plane(p):
+        if p.zero is not None:
+            return p.zero
+        z = torch.zeros_like(p.bits)
+        pad = p.bits.shape[1] * 32 - p.K
+        if pad:
+            z[:, -1] = -1 << (32 - pad)              # padding bits set (int32 two's complement)
+        return z
+    return plane(q), plane(r)
+
+
+def hamming_dist(q: PackedCodes, r: PackedCodes, as_u16: bool = False) -> torch.Tensor:
+    """[Q,R] distances: float32 0.5*(K - q.r) (reference semantics) or raw popcounts as int16 storage."""
+    _require_cuda(q.bits, r.bits)
+    if q.K != r.K:
+        raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
+    qz, rz = _both_planes(q, r)
+    Q, R = q.n, r.n
+    dev = q.bits.device
+    if as_u16:
+        out = torch.empty(Q, R, dtype=torch.int16, device=dev)
+        check(lib.xmh_hamming_dist(ptr(q.bits), ptr(qz), ptr(r.bits), ptr(rz), Q, R, q.K, None, ptr(out), current_stream()),
+              "xmh_hamming_dist")
+    else:
+        out = torch.empty(Q, R, dtype=torch.float32, device=dev)
+        check(lib.xmh_hamming_dist(ptr(q.bits), ptr(qz), ptr(r.bits), ptr(rz), Q, R, q.K, ptr(out), None, current_stream()),
+              "xmh_hamming_dist")
+    return out
+
+
+def label_sim(qlab: torch.Tensor, rlab: torch.Tensor, Cn: int) -> torch.Tensor:
+    _require_cuda(qlab, rlab)
+    out = torch.empty(qlab.shape[0], rlab.shape[0], dtype=torch.float32, device=qlab.device)
+    check(lib.xmh_label_sim(ptr(qlab), ptr(rlab), qlab.shape[0], rlab.shape[0], Cn, ptr(out), current_stream()), "xmh_label_sim")
+    return out
+
+
+def scan_plan(Q: int, R: int, K: int, ternary: bool) -> _lib.ScanPlan:
+    p = _lib.ScanPlan()
+    check(lib.xmh_scan_plan_make(Q, R, K, int(ternary), C.byref(p)), "xmh_scan_plan_make")
+    return p
+
+
+class RankingScan:
+    """The two-pass fused scan for one (query set, gallery shard): owns the workspace and exposes the
+    pieces the sharded driver needs (histogram totals, AP partial sums)."""
+
+    def __init__(self, q: PackedCodes, qlab: torch.Tensor, r: PackedCodes, rlab: torch.Tensor, Cn: int):
+        _require_cuda(q.bits, r.bits, qlab, rlab)
+        if q.K != r.K:
+            raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
+        self.q, self.r, self.qlab, self.rlab, self.C = q, r, qlab.contiguous(), rlab.contiguous(), Cn
+        self.qz, self.rz = _both_planes(q, r)
+        self.plan = scan_plan(q.n, r.n, q.K, self.qz is not None)
+        self.ws = torch.empty(self.plan.ws_bytes, dtype=torch.uint8, device=q.bits.device)
+
+    def _common(self):
+        return (ptr(self.q.bits), ptr(self.qz), ptr(self.qlab), ptr(self.r.bits), ptr(self.rz), ptr(self.rlab),
+                self.q.n, self.r.n, self.q.K, self.C, ptr(self.ws), self.plan.ws_bytes)
+
+    def histograms(self, want_totals: bool = True):
+        """pass 1.  Returns (hist_all, hist_rel) int32 [Q, nbuckets] shard totals (or (None, None))."""
+        ha = hr = None
+        if want_totals:
+            ha = torch.empty(self.q.n, self.plan.nbuckets, dtype=torch.int32, device=self.ws.device)
+            hr = torch.empty_like(ha)
+        check(lib.xmh_hamming_hist(*self._common(), ptr(ha), ptr(hr), current_stream()), "xmh_hamming_hist")
+        return ha, hr
+
+    def ap_sums(self, k: Optional[int] = None, base_all=None, base_rel=None, nrel_total=None):
+        """pass 2.  Returns (ap_sum float64 [Q], cap int32 [Q])."""
+        dev = self.ws.device
+        ap = torch.empty(self.q.n, dtype=torch.float64, device=dev)
+        cap = torch.empty(self.q.n, dtype=torch.int32, device=dev)
+        kk = 0 if k is None else int(k)
+        if k is not None and kk <= 0:
+            raise ValueError("k must be positive or None")
+        check(lib.xmh_hamming_ap(*self._common(), ptr(base_all), ptr(base_rel), ptr(nrel_total), kk, ptr(ap), ptr(cap),
+                                 current_stream()), "xmh_hamming_ap")
+        return ap, cap
+
+
+def map_finalize(ap_sum: torch.Tensor, cap: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.float64, device=ap_sum.device)
+    check(lib.xmh_map_finalize(ptr(ap_sum), ptr(cap), ap_sum.shape[0], ptr(out), current_stream()), "xmh_map_finalize")
+    return out
+
+
+def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch.Tensor, Cn: int,
+                 k: Optional[int] = None) -> torch.Tensor:
+    """mAP of one query set against one (unsharded) gallery; float64 [1] on the device."""
+    scan = RankingScan(q, qlab, r, rlab, Cn)
+    scan.histograms(want_totals=False)
+    ap, cap = scan.ap_sums(k)
+    return map_finalize(ap, cap)

@@ -1,0 +1,105 @@
+"""Gallery-sharded retrieval across the GPUs of one node.
+
+Replaces the reference's eval gather -- a dense all_reduce(SUM) of the zero-initialised [N,K] fp32 code
+buffers that leaves every rank with the whole gallery (runners/base.py:259-264) -- with:
+
+  * rank r keeps the packed codes + label masks of a CONTIGUOUS gallery index range (so the canonical
+    (distance, index) order is shard-major and in-bucket offsets are prefix sums over lower ranks);
+  * packed query codes/labels are all-gathered (<= 210 KB in total);
+  * mAP: per-shard bucket histograms [Q, K+1] x2 are all-gathered, every rank derives its rank offsets,
+    runs pass 2 on its shard and the [Q] partial sums are all-reduced (RCCL over xGMI; gloo in CPU tests);
+  * top-k: per-shard exact top-k lists are gathered and merged on the host.
+
+The collectives are the only thing this module does itself; per-shard compute is delegated to a
+``ShardOps`` object -- the HIP ops in production, injectable so the exchange logic can be exercised with
+world_size-2 gloo tests on CPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int) -> list:
+    """contiguous, balanced: first n % world shards get one extra row."""
+    base, extra = divmod(n, world)
+    out = [0]
+    for r in range(world):
+        out.append(out[-1] + base + (1 if r < extra else 0))
+    return out
+
+
+class HipShardOps:
+    """Per-shard compute through libxmh.so (the product path)."""
+
+    def __init__(self, q, qlab, r, rlab, C):
+        from . import retrieval as R
+        self._R = R
+        self.scan = R.RankingScan(q, qlab, r, rlab, C)
+
+    def histograms(self):
+        return self.scan.histograms(True)
+
+    def ap_sums(self, k, base_all, base_rel, nrel_total):
+        return self.scan.ap_sums(k, base_all, base_rel, nrel_total)
+
+
+def _all_gather_cat(t: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of equally-shaped tensors -> stacked [world, ...]."""
+    world = dist.get_world_size(group)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.stack(out)
+
+
+def all_gather_rows(t: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """all_gather of row-ragged tensors (rank i contributes counts[i] rows) -> concatenated rows."""
+    world = dist.get_world_size(group)
+    m = max(counts)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
+def rank_offsets(hist_all: torch.Tensor, hist_rel: torch.Tensor, rank: int):
+    """[world, Q, nb] per-shard bucket counts -> (base_all, base_rel, nrel_total) for ``rank``:
+    base[q, d] = (# items in buckets < d on ANY shard) + (# items in bucket d on shards < rank)."""
+    ha, hr = hist_all.to(torch.int64), hist_rel.to(torch.int64)
+    tot_a, tot_r = ha.sum(0), hr.sum(0)
+    lower_a = torch.cumsum(tot_a, 1) - tot_a
+    lower_r = torch.cumsum(tot_r, 1) - tot_r
+    base_a = lower_a + ha[:rank].sum(0)
+    base_r = lower_r + hr[:rank].sum(0)
+    nrel = tot_r.sum(1)
+    i32 = torch.int32
+    return base_a.to(i32).contiguous(), base_r.to(i32).contiguous(), nrel.to(i32).contiguous()
+
+
+def map_k_sharded(ops, k: Optional[int] = None, group=None):
+    """mAP over a gallery sharded across ``group``.  ``ops`` wraps this rank's shard (HipShardOps or a test
+    double) and already holds the FULL (all-gathered) query set.  Returns (map float64 tensor [1], ap_sum,
+    cap) -- identical on every rank."""
+    rank = dist.get_rank(group)
+    ha, hr = ops.histograms()                                    # pass 1 on the local shard
+    g_all = _all_gather_cat(ha, group)                           # [world, Q, nb] -- 2.6 MB/rank @ Q=5000,K=64
+    g_rel = _all_gather_cat(hr, group)
+    base_a, base_r, nrel = rank_offsets(g_all, g_rel, rank)
+    ap, cap = ops.ap_sums(k, base_a, base_r, nrel)               # pass 2 on the local shard
+    dist.all_reduce(ap, op=dist.ReduceOp.SUM, group=group)       # [Q] f64
+    m = (ap / cap.to(torch.float64)).mean().reshape(1)           # cap == 0 -> NaN like the reference
+    return m, ap, cap
+
+
+def merge_topk(dists: torch.Tensor, idxs: torch.Tensor, k: int):
+    """Host merge of per-shard exact top-k lists (north_star: 'partial top-k lists merged on the host').
+    dists/idxs: [world, Q, k] (any device).  Order key = (distance, global index); unused slots carry
+    idx -1 and are pushed to the end."""
+    d = dists.to("cpu").to(torch.int64).permute(1, 0, 2).reshape(dists.shape[1], -1)
+    i = idxs.to("cpu").to(torch.int64).permute(1, 0, 2).reshape(idxs.shape[1], -1)
+    key = torch.where(i < 0, torch.full_like(d, 1 << 62), (d << 32) | i)
+    order = torch.argsort(key, dim=1)[:, :k]
+    return torch.gather(d, 1, order).to(torch.int32), torch.gather(i, 1, order).to(torch.int32)

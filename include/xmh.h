@@ -1,0 +1,140 @@
+/*
+ * xmh.h -- C ABI of libxmh.so, the MI355X (gfx950) encode-and-retrieve library that sits behind the
+ * plugin surface of kalenforn/clip-based-cross-modal-hash.
+ *
+ * Conventions:
+ *   - every entry point is extern "C", takes plain pointers and sizes, returns 0 on success or a
+ *     negative errno-style code; nothing throws, nothing is owned by the library, no global state
+ *     except a thread-local last-error string (xmh_last_error).
+ *   - pointers are DEVICE pointers unless the parameter name ends in _host.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, stream-ordered, and the
+ *     call returns without synchronising.
+ *   - codes are bit-packed: word w bit j of `bits[n][W]` (W = ceil(K/32)) is 1 iff code[n][32w+j] > 0;
+ *     `zero[n][W]` marks code == 0 (sign(0) = 0, reference runners/base.py:410) and has its padding
+ *     bits (positions >= K) SET so that padded positions never count.
+ *   - labels are bit-packed multi-hot masks `lab[n][Lw]`, Lw = ceil(C/32).
+ *
+ * Each declaration cites the reference interface it replaces (file:line under the reference repo).
+ */
+#ifndef XMH_H
+#define XMH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMH_OK 0
+#define XMH_EINVAL (-22)
+#define XMH_ENOMEM (-12)
+#define XMH_ENOTSUP (-95)
+#define XMH_EHIP (-5)
+
+/* element types accepted for label / mask inputs */
+#define XMH_DT_F32 0
+#define XMH_DT_I64 1
+#define XMH_DT_I32 2
+#define XMH_DT_U8 3
+
+typedef void* xmh_stream_t;
+
+int xmh_version(void);
+/* thread-local description of the last failure on this thread ("" if none) */
+const char* xmh_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quantisers (a-6).
+ * xmh_pack_sign        replaces BaseTrainer.make_hash_code  (runners/base.py:407-410): sign -> -1/0/+1.
+ *                      `flags` (device int32, nullable, caller zeroes it) gets bit0 OR-ed in if any element was
+ *                      exactly 0 and bit1 if any element was not in {-1,0,+1} (un-quantised input: the
+ *                      packed path does not apply).
+ * xmh_pack_pair_argmax replaces DCMHTTrainer.make_hash_code (runners/DCMHT/runner.py:82-95):
+ *                      probs[n][2K] -> bit j = (probs[2j+1] > probs[2j]) strictly (ties -> -1).
+ * xmh_unpack_pm1       packed -> +-1/0 float32 [n][K] (the buffers get_code returns, runners/base.py:245-257,
+ *                      and the .mat writer, :386-405).  `zero` may be NULL.
+ * `row_index` (device int64[n], nullable): when given, row i of the input is written to packed row
+ * row_index[i] (the scatter `buffer[index,:] = code` of runners/base.py:256-257).
+ * ------------------------------------------------------------------------------------------- */
+int xmh_pack_sign(const float* codes, int64_t n, int K, const int64_t* row_index,
+                  uint32_t* bits, uint32_t* zero, int32_t* flags, xmh_stream_t stream);
+int xmh_pack_pair_argmax(const float* probs, int64_t n, int K, const int64_t* row_index,
+                         uint32_t* bits, xmh_stream_t stream);
+int xmh_unpack_pm1(const uint32_t* bits, const uint32_t* zero, int64_t n, int K, float* out,
+                   xmh_stream_t stream);
+/* multi-hot labels [n][C] of dtype `dt` (XMH_DT_*) -> packed masks [n][ceil(C/32)] (label > 0).
+ * Replaces the int64 label matmul operands of calc_map_k (common/calc_utils.py:72) and calc_label_sim (:8-10). */
+int xmh_pack_labels(const void* labels, int dt, int64_t n, int C, uint32_t* lab, xmh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Materialised distances (a-1): calc_hammingDist (common/calc_utils.py:51-56).
+ *   out_f32[Q][R] = 0.5 * (K - q.r)   (exact for -1/0/+1 codes; pass zero masks as NULL for binary)
+ *   out_u16[Q][R] = popcount(q xor r) (binary codes only)
+ * Exactly one of out_f32 / out_u16 must be non-NULL.
+ * ------------------------------------------------------------------------------------------- */
+int xmh_hamming_dist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero,
+                     int64_t Q, int64_t R, int K, float* out_f32, uint16_t* out_u16, xmh_stream_t stream);
+/* calc_label_sim (common/calc_utils.py:8-10): out[Q][R] = 1.0f iff the two items share a label. */
+int xmh_label_sim(const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C, float* out,
+                  xmh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused ranking scan (a-2): calc_map_k (common/calc_utils.py:58-92) without the [Q,R] intermediates.
+ *
+ * Canonical order = (distance asc, gallery index asc)  == torch.sort(stable=True).
+ * Two streaming passes over the gallery shard, queries one-per-lane, gallery through scalar loads:
+ *   pass 1 (xmh_hamming_hist): per (query, gallery chunk) bucket counts of all / relevant items;
+ *   pass 2 (xmh_hamming_ap):   rank of every relevant item = bucket base + running in-bucket count,
+ *                              accumulates sum_j j/rank_j for ordinals j <= min(n_rel, k).
+ * `xmh_scan_plan` reports the chunking and the workspace both passes share.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct xmh_scan_plan {
+    int64_t chunk;      /* gallery items per chunk                                  */
+    int64_t nchunk;     /* chunks in this shard                                     */
+    int64_t nqtile;     /* 64-query tiles                                           */
+    int64_t qpad;       /* Q rounded up to 64                                       */
+    int64_t nbuckets;   /* K+1 (binary) or 2K+1 (ternary, distances in half units)  */
+    size_t ws_bytes;    /* workspace the caller must provide to hist/ap             */
+} xmh_scan_plan;
+
+int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host);
+
+/* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).
+ * qzero / rzero NULL => binary codes. */
+int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,
+                     const uint32_t* rbits, const uint32_t* rzero, const uint32_t* rlab,
+                     int64_t Q, int64_t R, int K, int C, void* ws, size_t ws_bytes,
+                     uint32_t* hist_all, uint32_t* hist_rel, xmh_stream_t stream);
+
+/* pass 2 (needs the workspace pass 1 filled for the same inputs).
+ *   base_all / base_rel [Q][nbuckets] u32 and nrel_total [Q] u32: rank offsets contributed by items
+ *   OUTSIDE this shard (all lower buckets anywhere + same bucket on lower-ranked shards) and the global
+ *   relevant count; all three NULL => single shard, derived locally.
+ *   k <= 0 means "all" (k = None in the reference).
+ *   ap_sum[Q] (f64) = sum over this shard's relevant items of ordinal/rank, for ordinal <= cap;
+ *   cap[Q] (i32)    = min(n_rel, k)  (the divisor, common/calc_utils.py:81). */
+int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,
+                   const uint32_t* rbits, const uint32_t* rzero, const uint32_t* rlab,
+                   int64_t Q, int64_t R, int K, int C, void* ws, size_t ws_bytes,
+                   const uint32_t* base_all, const uint32_t* base_rel, const uint32_t* nrel_total,
+                   int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
+
+/* mean over queries of ap_sum/cap -> map_out[0] (f64, device).  A query with cap == 0 makes the result
+ * NaN, as torch.mean of an empty tensor does in the reference (common/calc_utils.py:87-89). */
+int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-query top-k (north_star: "fused bit-packed XOR-popcount + per-query top-k kernel").
+ * Exact top-k under the canonical order.  dist[Q][k] u16, idx[Q][k] i32 hold GLOBAL indices
+ * (base_index + local row).  k <= 1024.  Workspace: xmh_topk_ws_bytes(Q, R, K, k).
+ * ------------------------------------------------------------------------------------------- */
+size_t xmh_topk_ws_bytes(int64_t Q, int64_t R, int K, int k);
+int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
+                     int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
+                     xmh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMH_H */
