@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""HBM-bound regime of the retrieval path: exact top-k of a handful of queries over a 10 M x 256-bit gallery
+(BASELINE configs[4] shape, the whole gallery on ONE GPU: 320 MB of codes > 256 MB Infinity Cache).
+
+Called by bench.py (``measure()``) and runnable on its own:  python bench_topk.py [--R 10000000 --K 256 --Q 8 --k 100]
+Prints / returns the `roofline` object of k_topk_stream: algorithmic bytes = R*K/8 (gallery read once)
++ Q*K/8 + partial lists written, divided by the HIP-event time of the launch bracket.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3):
+    from xmh import retrieval as X
+    from xmh._lib import lib
+    W = (K + 31) // 32
+    g = torch.Generator(device="cuda").manual_seed(1814)
+    rb = torch.randint(-2**31, 2**31 - 1, (R, W), dtype=torch.int32, device="cuda", generator=g)
+    qb = torch.randint(-2**31, 2**31 - 1, (Q, W), dtype=torch.int32, device="cuda", generator=g)
+    q, r = X.PackedCodes(qb, None, K), X.PackedCodes(rb, None, K)
+    for _ in range(warmup):
+        d, i = X.hamming_topk(q, r, k)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for n in range(iters):
+        d, i = X.hamming_topk(q, r, k)
+        ev[n + 1].record()
+    torch.cuda.synchronize()
+    t = sum(ev[n].elapsed_time(ev[n + 1]) for n in range(iters)) / iters * 1e-3
+    ws = lib.xmh_topk_ws_bytes(Q, R, K, k)
+    alg = R * W * 4 + Q * W * 4 + ws + Q * k * 6
+    return {"kernel": "k_topk_stream (+k_topk_merge, same bracket)", "bound": "hbm", "achieved": alg / t / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
+            "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU" % (k, Q, R, K),
+            "pairs_per_s": Q * R / t, "min_dist": int(d.view(torch.uint8).view(torch.int16)[0, 0].item()) & 0xFFFF}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--R", type=int, default=10_000_000)
+    ap.add_argument("--K", type=int, default=256)
+    ap.add_argument("--Q", type=int, default=8)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.R, a.K, a.Q, a.k, a.iters)))

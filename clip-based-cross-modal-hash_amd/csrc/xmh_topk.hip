@@ -1,0 +1,525 @@
+// Exact per-query top-k over bit-packed codes in ONE streaming pass over the gallery shard
+// (north_star: "fused bit-packed XOR-popcount + per-query top-k kernel with wavefront reductions and
+// coalesced HBM reads over the gallery").  Order = (distance asc, gallery index asc).
+//
+// Shape: one lane per gallery item (16-byte coalesced loads, next tile prefetched into a second register
+// set), up to 8 queries per block held in SGPRs.  Each persistent block owns a CONTIGUOUS range of tiles and
+// walks it in index order, keeping for every query a small candidate buffer in LDS plus a bucket histogram
+// of the buffer.  t_run = current k-th smallest distance; an item is a candidate only if d < t_run, so after
+// the first few tiles almost every tile costs: loads + XOR/popcount + one ballot + ONE barrier.  Candidates
+// are appended in index order (wave-local ballot prefix + one cross-wave exchange), which makes "first n
+// ties in buffer order" the exact index tie-break -- no sort in the streaming loop.  A second tiny kernel
+// merges the per-block lists with the same machinery and bitonic-sorts the final k keys.
+//
+// Bound: HBM for few queries.  Algorithmic bytes per launch = R*W*4 (gallery read once)
+// + Q*W*4 + nblocks*Q*k*6 (partial lists) ; per pair 2W lane-ops.
+#include "xmh_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kQG = 8;             // queries per block
+constexpr uint32_t kInf = 0xFFFFu;
+
+// ---- per-query selection state in LDS -------------------------------------------------------------
+struct Sel {
+    uint32_t* hist;   // [nb]   counts of appended entries (superset of the live top-k)
+    int32_t* bi;      // [cap]  item index (local row / global index)
+    uint16_t* bd;     // [cap]  distance
+    int* meta;        // [0]=n entries  [1]=t_run  [2]=cnt_lt (entries with d < t_run)
+};
+
+struct Shared {
+    int* wave_tot;    // [kWaves]
+    int* mask;        // [2]
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// k-th smallest bucket of hist (wave 0 only).  Writes meta[1] = t (kInf if fewer than k entries), meta[2] = #entries < t.
+__device__ void find_threshold(const Sel& s, int nb, int k) {
+    const int lane = lane_id();
+    const int per = (nb + 63) / 64;
+    const int lo = lane * per;
+    const int hi = lo + per < nb ? lo + per : nb;
+    int mine = 0;
+    for (int d = lo; d < hi; ++d) mine += (int)s.hist[d];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    const int excl = incl - mine;
+    if (total < k) {
+        if (lane == 0) {
+            s.meta[1] = (int)kInf;
+            s.meta[2] = total;
+        }
+        return;
+    }
+    if (excl < k && k <= incl) {          // exactly one lane
+        int run = excl;
+        for (int d = lo; d < hi; ++d) {
+            const int h = (int)s.hist[d];
+            if (run + h >= k) {
+                s.meta[1] = d;
+                s.meta[2] = run;
+                break;
+            }
+            run += h;
+        }
+    }
+}
+
+// Stable in-place compaction of the buffer to the live top-k: all d < t, then... no: keep ORDER (index order),
+// drop entries with d > t and ties at t beyond the first (k - cnt_lt).  All threads; ends with a barrier.
+__device__ void compact(const Sel& s, const Shared& sh, int cap, int k) {
+    const int n = s.meta[0];
+    const int t = s.meta[1];
+    const int need = (t == (int)kInf) ? 0x7fffffff : k - s.meta[2];   // t == kInf: fewer than k entries, d < t keeps all
+    const int per = (cap + kThreads - 1) / kThreads;     // contiguous segment per thread
+    const int lo = threadIdx.x * per;
+    const int hi = (lo + per < n) ? lo + per : n;
+    // pass 1: ties per thread -> ordered block prefix
+    int my_ties = 0;
+    for (int p = lo; p < hi; ++p) my_ties += ((int)s.bd[p] == t);
+    // block exclusive scan of my_ties (wave scan + wave totals)
+    const int lane = lane_id(), w = wave_id();
+    int incl = my_ties;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) sh.wave_tot[w] = incl;
+    __syncthreads();
+    int tie_before = incl - my_ties;
+    for (int x = 0; x < w; ++x) tie_before += sh.wave_tot[x];
+    __syncthreads();
+    // pass 2: read the whole segment into registers (static indices -> VGPRs, not scratch) with a keep mask,
+    // ordered prefix of the keep counts, then write back: positions only move down, and nobody writes before
+    // everybody has read.
+    constexpr int kMaxSeg = 24;
+    int32_t ri[kMaxSeg];
+    uint16_t rd[kMaxSeg];
+    uint32_t keepm = 0;
+    {
+        int tr = tie_before;
+#pragma unroll
+        for (int u = 0; u < kMaxSeg; ++u) {
+            const int p = lo + u;
+            if (p < hi) {
+                const int d = (int)s.bd[p];
+                ri[u] = s.bi[p];
+                rd[u] = (uint16_t)d;
+                bool ok = d < t;
+                if (d == t) {
+                    ok = tr < need;
+                    ++tr;
+                }
+                if (ok) keepm |= 1u << u;
+            }
+        }
+    }
+    const int keep = __popc(keepm);
+    incl = keep;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) sh.wave_tot[w] = incl;
+    __syncthreads();
+    int pos = incl - keep;
+    int total = 0;
+    for (int x = 0; x < kWaves; ++x) {
+        if (x < w) pos += sh.wave_tot[x];
+        total += sh.wave_tot[x];
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxSeg; ++u) {
+        if (keepm & (1u << u)) {
+            s.bi[pos] = ri[u];
+            s.bd[pos] = rd[u];
+            ++pos;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s.meta[0] = total;
+    __syncthreads();
+}
+
+// Feed one tile (IPT items per lane, lane-strided inside the wave's contiguous sub-range, so that order is
+// (wave, j, lane)) into the selection state of one query.  Called uniformly by all threads.
+template <int IPT>
+__device__ void feed_tile(const Sel& s, const Shared& sh, const int (&d)[IPT], const int32_t (&item)[IPT], int nb, int k,
+                          int cap, int tile_items) {
+    const int lane = lane_id(), w = wave_id();
+    const int t_old = s.meta[1];
+    // a. histogram of candidates
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+        if (d[j] < t_old) atomicAdd(&s.hist[d[j]], 1u);
+    __syncthreads();
+    // b. new threshold
+    if (w == 0) find_threshold(s, nb, k);
+    __syncthreads();
+    const int t_new = s.meta[1];
+    const int n0 = s.meta[0];
+    // c. ordered append of candidates with d <= t_new
+    int wcnt = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const bool acc = d[j] < t_old && d[j] <= t_new;
+        wcnt += __popcll(__ballot(acc));
+    }
+    if (lane == 0) sh.wave_tot[w] = wcnt;
+    __syncthreads();
+    int off = n0, total = 0;
+    for (int x = 0; x < kWaves; ++x) {
+        if (x < w) off += sh.wave_tot[x];
+        total += sh.wave_tot[x];
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const bool acc = d[j] < t_old && d[j] <= t_new;
+        const unsigned long long m = __ballot(acc);
+        if (acc) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            s.bi[pos] = item[j];
+            s.bd[pos] = (uint16_t)d[j];
+        }
+        off += __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s.meta[0] = n0 + total;
+    __syncthreads();
+    if (cap - (n0 + total) < tile_items) compact(s, sh, cap, k);
+}
+
+struct Layout {
+    int nb, cap;
+    __host__ __device__ size_t hist_off(int q) const { return (size_t)q * nb * 4; }
+    __host__ __device__ size_t bi_off(int q) const { return (size_t)kQG * nb * 4 + (size_t)q * cap * 4; }
+    __host__ __device__ size_t bd_off(int q) const { return (size_t)kQG * nb * 4 + (size_t)kQG * cap * 4 + (size_t)q * cap * 2; }
+    __host__ __device__ size_t meta_off() const {
+        size_t o = (size_t)kQG * nb * 4 + (size_t)kQG * cap * 6;
+        return (o + 15) & ~(size_t)15;
+    }
+    __host__ __device__ size_t bytes() const { return meta_off() + (kQG * 4 + kWaves + 2 + 2) * 4; }
+};
+
+__device__ __forceinline__ Sel sel_of(char* smem, const Layout& L, int q) {
+    Sel s;
+    s.hist = reinterpret_cast<uint32_t*>(smem + L.hist_off(q));
+    s.bi = reinterpret_cast<int32_t*>(smem + L.bi_off(q));
+    s.bd = reinterpret_cast<uint16_t*>(smem + L.bd_off(q));
+    s.meta = reinterpret_cast<int*>(smem + L.meta_off()) + q * 4;
+    return s;
+}
+__device__ __forceinline__ Shared shared_of(char* smem, const Layout& L) {
+    Shared sh;
+    int* base = reinterpret_cast<int*>(smem + L.meta_off()) + kQG * 4;
+    sh.wave_tot = base;
+    sh.mask = base + kWaves;
+    return sh;
+}
+
+__device__ void init_state(char* smem, const Layout& L) {
+    for (int q = 0; q < kQG; ++q) {
+        Sel s = sel_of(smem, L, q);
+        for (int d = threadIdx.x; d < L.nb; d += kThreads) s.hist[d] = 0u;
+        if (threadIdx.x == 0) {
+            s.meta[0] = 0;
+            s.meta[1] = (int)kInf;
+            s.meta[2] = 0;
+        }
+    }
+    Shared sh = shared_of(smem, L);
+    if (threadIdx.x < 2) sh.mask[threadIdx.x] = 0;
+    __syncthreads();
+}
+
+template <int W>
+struct Rec {
+    uint32_t w[W];
+};
+
+template <int W>
+__device__ __forceinline__ void load_rec(Rec<W>& r, const uint32_t* __restrict__ base, int64_t item, bool ok) {
+    if (!ok) {
+#pragma unroll
+        for (int x = 0; x < W; ++x) r.w[x] = 0u;
+        return;
+    }
+    const uint32_t* p = base + item * W;
+    if constexpr (W % 4 == 0) {
+#pragma unroll
+        for (int x = 0; x < W / 4; ++x) {
+            const uint4 v = reinterpret_cast<const uint4*>(p)[x];
+            r.w[4 * x] = v.x; r.w[4 * x + 1] = v.y; r.w[4 * x + 2] = v.z; r.w[4 * x + 3] = v.w;
+        }
+    } else if constexpr (W == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        r.w[0] = v.x; r.w[1] = v.y;
+    } else {
+#pragma unroll
+        for (int x = 0; x < W; ++x) r.w[x] = p[x];
+    }
+}
+
+// ---- streaming kernel -----------------------------------------------------------------------------
+template <int W, int IPT>
+__global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __restrict__ qbits,
+                                                          const uint32_t* __restrict__ rbits, int Q, int64_t R, int k,
+                                                          Layout L, int tiles_per_block, int nblocks,
+                                                          uint16_t* __restrict__ part_d, int32_t* __restrict__ part_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = kThreads * IPT;
+    const int lane = lane_id(), w = wave_id();
+    const int q0 = blockIdx.y * kQG;
+    const int nq = (Q - q0 < kQG) ? Q - q0 : kQG;
+    init_state(smem, L);
+    Shared sh = shared_of(smem, L);
+
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    const int64_t ntiles_all = (R + TILE - 1) / TILE;
+    const int64_t tile1 = (tile0 + tiles_per_block < ntiles_all) ? tile0 + tiles_per_block : ntiles_all;
+
+    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)w * (64 * IPT) + j * 64 + lane; };
+
+    Rec<W> cur[IPT], nxt[IPT];
+    if (tile0 < tile1) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t it = item_of(tile0, j);
+            load_rec<W>(cur[j], rbits, it, it < R);
+        }
+    }
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const bool more = tile + 1 < tile1;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int64_t it = item_of(tile + 1, j);
+                load_rec<W>(nxt[j], rbits, it, it < R);
+            }
+        }
+        int d[kQG][IPT];
+        int32_t item[IPT];
+        int mask = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) item[j] = (int32_t)item_of(tile, j);
+#pragma unroll
+        for (int q = 0; q < kQG; ++q) {
+            if (q < nq) {
+                const uint32_t* __restrict__ qw = qbits + (int64_t)(q0 + q) * W;     // uniform -> SGPRs
+                const int t_run = sel_of(smem, L, q).meta[1];
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    int acc = 0;
+#pragma unroll
+                    for (int x = 0; x < W; ++x) acc += __popc(cur[j].w[x] ^ qw[x]);
+                    d[q][j] = ((int64_t)item[j] < R && item[j] >= 0) ? acc : (int)kInf;
+                    any |= d[q][j] < t_run;
+                }
+                if (__ballot(any)) mask |= 1 << q;
+            }
+        }
+        if (__syncthreads_or(mask)) {                      // rare after warm-up: somebody has a candidate
+            if (threadIdx.x == 0) sh.mask[0] = 0;
+            __syncthreads();
+            if (mask && lane == 0) atomicOr(&sh.mask[0], mask);
+            __syncthreads();
+            const int m = sh.mask[0];
+#pragma unroll
+            for (int q = 0; q < kQG; ++q) {
+                if (m & (1 << q)) feed_tile<IPT>(sel_of(smem, L, q), sh, d[q], item, L.nb, k, L.cap, TILE);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
+        }
+    }
+    __syncthreads();
+    // final: live top-k of this block's range, in index order
+    for (int q = 0; q < nq; ++q) {
+        Sel s = sel_of(smem, L, q);
+        compact(s, sh, L.cap, k);
+        const int n = s.meta[0];
+        uint16_t* od = part_d + ((int64_t)(q0 + q) * nblocks + blockIdx.x) * k;
+        int32_t* oi = part_i + ((int64_t)(q0 + q) * nblocks + blockIdx.x) * k;
+        for (int p = threadIdx.x; p < k; p += kThreads) {
+            od[p] = p < n ? s.bd[p] : (uint16_t)kInf;
+            oi[p] = p < n ? s.bi[p] : -1;
+        }
+    }
+}
+
+// ---- merge kernel: one block per query, streams [nblocks][k] partial lists (already in index order) ----
+template <int IPT>
+__global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restrict__ part_d, const int32_t* __restrict__ part_i,
+                                                         int nblocks, int k, Layout L, int64_t base_index,
+                                                         uint16_t* __restrict__ out_d, int32_t* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = kThreads * IPT;
+    const int lane = lane_id(), w = wave_id();
+    const int q = blockIdx.x;
+    init_state(smem, L);
+    Shared sh = shared_of(smem, L);
+    Sel s = sel_of(smem, L, 0);
+    const int64_t n_in = (int64_t)nblocks * k;
+    const uint16_t* pd = part_d + (int64_t)q * n_in;
+    const int32_t* pi = part_i + (int64_t)q * n_in;
+    for (int64_t base = 0; base < n_in; base += TILE) {
+        int d[IPT];
+        int32_t item[IPT];
+        bool any = false;
+        const int t_run = s.meta[1];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t e = base + (int64_t)w * (64 * IPT) + j * 64 + lane;
+            int32_t ii = -1;
+            int dd = (int)kInf;
+            if (e < n_in) {
+                ii = pi[e];
+                dd = ii >= 0 ? (int)pd[e] : (int)kInf;
+            }
+            d[j] = dd;
+            item[j] = ii;
+            any |= dd < t_run;
+        }
+        if (__syncthreads_or(any ? 1 : 0)) feed_tile<IPT>(s, sh, d, item, L.nb, k, L.cap, TILE);
+    }
+    __syncthreads();
+    compact(s, sh, L.cap, k);
+    // sort the <= k survivors by (distance, index): bitonic on 64-bit keys in the (now free) tail of the buffer
+    const int n = s.meta[0];
+    int P = 1;
+    while (P < k) P <<= 1;
+    // keys live in the (unused) buffer slots of queries 1.. of the layout: (kQG-1)*cap*4 B >= 8 KB = 1024 keys
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem + L.bi_off(1));
+    for (int p = threadIdx.x; p < P; p += kThreads)
+        key[p] = p < n ? (((unsigned long long)s.bd[p] << 32) | (unsigned int)s.bi[p]) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = threadIdx.x; p < P / 2; p += kThreads) {
+                const int i = 2 * p - (p & (stride - 1));
+                const int j2 = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long a = key[i], b = key[j2];
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[j2] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int p = threadIdx.x; p < k; p += kThreads) {
+        const unsigned long long v = key[p];
+        const bool ok = v != ~0ull;
+        out_d[(int64_t)q * k + p] = ok ? (uint16_t)(v >> 32) : (uint16_t)kInf;
+        out_i[(int64_t)q * k + p] = ok ? (int32_t)(base_index + (int64_t)(uint32_t)v) : -1;
+    }
+}
+
+struct TopkPlan {
+    int W, ipt, tile, nblocks, tiles_per_block, nqg;
+    Layout L, Lm;
+    size_t ws_bytes;
+};
+
+int ipt_for(int W) { return W >= 8 ? 4 : 8; }
+
+int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
+    if (Q <= 0 || R <= 0 || K <= 0) return xmh::fail(XMH_EINVAL, "topk: bad shape Q=%lld R=%lld K=%d", (long long)Q, (long long)R, K);
+    if (k <= 0 || k > 1024) return xmh::fail(XMH_EINVAL, "topk: k=%d out of range (1..1024)", k);
+    if (R >= (1ll << 31) - 65536) return xmh::fail(XMH_ENOTSUP, "topk: shard of %lld rows (max 2^31-1)", (long long)R);
+    const int W = (K + 31) / 32;
+    if (W != 1 && W != 2 && W != 4 && W != 8) return xmh::fail(XMH_ENOTSUP, "topk: K=%d unsupported (code words must be 1,2,4 or 8)", K);
+    p->W = W;
+    p->ipt = ipt_for(W);
+    p->tile = kThreads * p->ipt;
+    p->L.nb = K + 1;
+    p->L.cap = k + p->tile + 64;
+    if (p->L.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d needs %zu B of LDS (max 163840)", k, K, p->L.bytes());
+    if ((p->L.cap + kThreads - 1) / kThreads > 24) return xmh::fail(XMH_ENOTSUP, "topk: candidate buffer too large for the compaction segment");
+    const int64_t ntiles = xmh::ceil_div(R, p->tile);
+    int bpc = (int)((160 * 1024) / p->L.bytes());
+    if (bpc > 4) bpc = 4;
+    if (bpc < 1) bpc = 1;
+    int64_t nblocks = (int64_t)xmh::device_cu_count() * bpc;
+    if (nblocks > ntiles) nblocks = ntiles;
+    p->tiles_per_block = (int)xmh::ceil_div(ntiles, nblocks);
+    p->nblocks = (int)xmh::ceil_div(ntiles, p->tiles_per_block);
+    p->nqg = (int)xmh::ceil_div(Q, kQG);
+    p->Lm.nb = K + 1;
+    p->Lm.cap = k + kThreads * 4 + 64;
+    p->ws_bytes = (size_t)Q * p->nblocks * k * 6;
+    return XMH_OK;
+}
+
+template <typename KernT>
+int raise_lds(KernT kern, size_t bytes, const char* who) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, bytes, hipGetErrorString(e));
+    }
+    return XMH_OK;
+}
+
+}  // namespace
+
+extern "C" size_t xmh_topk_ws_bytes(int64_t Q, int64_t R, int K, int k) {
+    TopkPlan p;
+    if (plan_topk(Q, R, K, k, &p) != XMH_OK) return 0;
+    return p.ws_bytes;
+}
+
+extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
+                                int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
+                                xmh_stream_t stream) {
+    TopkPlan p;
+    int rc = plan_topk(Q, R, K, k, &p);
+    if (rc) return rc;
+    if (!qbits || !rbits || !ws || !dist || !idx) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk: null pointer");
+    if (ws_bytes < p.ws_bytes) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+    int32_t* part_i = static_cast<int32_t*>(ws);
+    uint16_t* part_d = reinterpret_cast<uint16_t*>(static_cast<char*>(ws) + (size_t)Q * p.nblocks * k * 4);
+    hipStream_t st = xmh::as_stream(stream);
+    const dim3 grid(p.nblocks, p.nqg);
+    const size_t lds = p.L.bytes();
+#define XMH_TOPK_LAUNCH(WW, II)                                                                                        \
+    {                                                                                                                  \
+        auto kern = k_topk_stream<WW, II>;                                                                             \
+        rc = raise_lds(kern, lds, "xmh_hamming_topk");                                                                 \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, qbits, rbits, (int)Q, R, k, p.L, p.tiles_per_block,    \
+                           p.nblocks, part_d, part_i);                                                                 \
+    }
+    switch (p.W) {
+        case 1: XMH_TOPK_LAUNCH(1, 8) break;
+        case 2: XMH_TOPK_LAUNCH(2, 8) break;
+        case 4: XMH_TOPK_LAUNCH(4, 8) break;
+        default: XMH_TOPK_LAUNCH(8, 4) break;
+    }
+#undef XMH_TOPK_LAUNCH
+    XMH_LAUNCH_CHECK("xmh_hamming_topk stream");
+    {
+        auto kern = k_topk_merge<4>;
+        const size_t ldsm = p.Lm.bytes();
+        rc = raise_lds(kern, ldsm, "xmh_hamming_topk merge");
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), ldsm, st, part_d, part_i, p.nblocks, k, p.Lm, base_index, dist, idx);
+    }
+    XMH_LAUNCH_CHECK("xmh_hamming_topk merge");
+    return XMH_OK;
+}

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "xmh_hamming_hist": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp]),
     "xmh_hamming_ap": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp, i64, vp, vp, vp]),
     "xmh_map_finalize": (i32, [vp, vp, i64, vp, vp]),
+    "xmh_topk_ws_bytes": (sz, [i64, i64, i32, i32]),
+    "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -222,3 +222,25 @@ def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch
     scan.histograms(want_totals=False)
     ap, cap = scan.ap_sums(k)
     return map_finalize(ap, cap)
+
+
+def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0):
+    """Exact top-k of every query over this gallery shard under (distance, index) order.
+    Returns (dist int16-storage [Q,k] (uint16 bit pattern, 0xFFFF = unused slot), idx int32 [Q,k] global
+    indices = base_index + row, -1 = unused slot when the shard has fewer than k rows)."""
+    _require_cuda(q.bits, r.bits)
+    if q.K != r.K:
+        raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
+    if q.zero is not None or r.zero is not None:
+        raise NotImplementedError("top-k over ternary codes is not supported; quantise without zeros")
+    Q, R = q.n, r.n
+    dev = q.bits.device
+    need = lib.xmh_topk_ws_bytes(Q, R, q.K, k)
+    if need == 0:
+        check(lib.xmh_hamming_topk(None, None, Q, R, q.K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dist = torch.empty(Q, k, dtype=torch.int16, device=dev)
+    idx = torch.empty(Q, k, dtype=torch.int32, device=dev)
+    check(lib.xmh_hamming_topk(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(ws), need, ptr(dist), ptr(idx),
+                               current_stream()), "xmh_hamming_topk")
+    return dist, idx

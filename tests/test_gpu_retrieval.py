@@ -180,7 +180,7 @@ def test_scan_internals_match_oracle(xr, Q, R, K, C):
 
 def test_ragged_and_tiny_shapes(xr, cu):
     orc = _orc()
-    for (Q, R, K, C) in [(2, 1, 16, 3), (3, 7, 16, 5), (2, 255, 64, 80), (63, 257, 64, 33), (65, 513, 32, 1)]:
+    for (Q, R, K, C) in [(2, 2, 16, 3), (3, 7, 16, 5), (2, 255, 64, 80), (63, 257, 64, 33), (65, 513, 32, 1)]:
         qB, rB, qL, rL = _synth(Q, R, K, C, seed=Q * 1000 + R, structured=False)
         want = orc.map_k(qB, rB, qL, rL)
         got = cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())
@@ -260,3 +260,72 @@ def test_full_size_properties_coco_shape(xr):
     r2 = xr.PackedCodes(torch.cat([r.bits, r.bits]), None, K)
     ha2, _ = xr.RankingScan(q, ql, r2, torch.cat([rl, rl]), C).histograms()
     assert torch.equal(ha2, 2 * ha)
+
+
+# ------------------------------------------------------------------------------------------------
+# exact per-query top-k (streaming kernel + merge)
+# ------------------------------------------------------------------------------------------------
+def _topk_check(xr, Q, R, K, k, seed, base_index=0, dup=False):
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(seed)
+    W = (K + 31) // 32
+    qb = rng.integers(0, 2**32, size=(Q, W), dtype=np.uint32)
+    rb = rng.integers(0, 2**32, size=(R, W), dtype=np.uint32)
+    if K % 32:
+        qb[:, -1] &= (1 << (K % 32)) - 1
+        rb[:, -1] &= (1 << (K % 32)) - 1
+    if dup:                                    # heavy ties: few distinct gallery codes
+        rb = rb[rng.integers(0, 5, size=R)]
+    q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+    r = xr.PackedCodes(torch.from_numpy(rb.view(np.int32)).cuda(), None, K)
+    d, i = xr.hamming_topk(q, r, k, base_index)
+    wd, wi = co.topk(qb, rb, K + 1, k, base_index)
+    assert np.array_equal(i.cpu().numpy(), wi), (Q, R, K, k)
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), wd)
+
+
+@pytest.mark.parametrize("Q,R,K,k", [(3, 5000, 64, 10), (8, 70000, 256, 100), (9, 33333, 128, 1), (17, 20000, 16, 50),
+                                     (2, 100, 64, 200), (1, 1, 32, 1), (5, 2049, 64, 1024), (4, 300000, 32, 100)])
+def test_topk_matches_oracle(xr, Q, R, K, k):
+    _topk_check(xr, Q, R, K, k, seed=Q + R + K + k, base_index=12345)
+
+
+def test_topk_heavy_ties_index_order(xr):
+    _topk_check(xr, 6, 40000, 64, 100, seed=1, dup=True)
+    _topk_check(xr, 3, 9000, 16, 1000, seed=2, dup=True)
+
+
+def test_topk_adversarial_descending_distance(xr):
+    """gallery ordered from far to near: every tile brings better candidates (exercises compaction)."""
+    from oracle import c_oracle as co
+    K, R, k = 64, 60000, 64
+    qb = np.zeros((2, 2), dtype=np.uint32)
+    ones = np.sort(np.random.default_rng(0).integers(0, 65, size=R))[::-1]           # popcount per item, descending
+    rb = np.zeros((R, 2), dtype=np.uint32)
+    for n_ in range(65):
+        m = (1 << n_) - 1
+        rb[ones == n_] = [m & 0xFFFFFFFF, m >> 32]
+    q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+    r = xr.PackedCodes(torch.from_numpy(rb.view(np.int32)).cuda(), None, K)
+    d, i = xr.hamming_topk(q, r, k)
+    wd, wi = co.topk(qb, rb, K + 1, k)
+    assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy().view(np.uint16), wd)
+
+
+def test_topk_sharded_merge_equals_global(xr):
+    from oracle import c_oracle as co
+    from xmh import sharded
+    rng = np.random.default_rng(9)
+    Q, R, K, k, S = 7, 50000, 64, 100, 4
+    qb = rng.integers(0, 2**32, size=(Q, 2), dtype=np.uint32)
+    rb = rng.integers(0, 2**32, size=(R, 2), dtype=np.uint32)[rng.integers(0, 3000, size=R)]
+    q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+    bounds = sharded.shard_bounds(R, S)
+    ds, is_ = [], []
+    for s in range(S):
+        r = xr.PackedCodes(torch.from_numpy(rb[bounds[s]:bounds[s + 1]].view(np.int32)).cuda(), None, K)
+        d, i = xr.hamming_topk(q, r, k, base_index=bounds[s])
+        ds.append(d), is_.append(i)
+    md, mi = sharded.merge_topk(torch.stack(ds), torch.stack(is_), k)
+    wd, wi = co.topk(qb, rb, K + 1, k)
+    assert np.array_equal(mi.numpy(), wi) and np.array_equal(md.numpy().astype(np.uint16), wd)
