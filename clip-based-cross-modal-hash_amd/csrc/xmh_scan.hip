@@ -2,24 +2,35 @@
 // bit-packed codes, no [Q,R] intermediate, no sort.
 //
 // Execution shape ("query per lane"): a wave owns 64 queries -- their code words and label masks live in
-// VGPRs -- and walks a contiguous gallery chunk in index order.  The gallery record is wave-uniform, so it
-// arrives through SCALAR loads (s_load_dwordxN into SGPRs) and feeds v_xor_b32 / v_bcnt_u32_b32 as the
-// scalar operand; HBM sees every gallery byte once per (query tile, chunk) and the L2 of the XCD the
-// chunk is pinned to serves the other query tiles.  Per-lane bucket counters sit in LDS as cnt[d][lane]
-// (row stride = 64 lanes), so lane l always hits bank l%32: conflict-free ds_add for any distance pattern.
+// VGPRs -- and walks a contiguous gallery chunk in index order.  Per-lane bucket counters sit in LDS as
+// cnt[d][lane] (row stride = 64 lanes), so lane l always hits bank l%32: conflict-free for any distance
+// pattern, and because every lane owns its column the read-modify-write needs no cross-lane atomicity.
 // Walking in index order makes "number of same-distance items with a smaller index" a running counter,
 // which is exactly the tie-break of the canonical (distance, index) order.
 //
-// Bound: VALU: ~10 lane-ops/pair in pass 1, ~20 in pass 2, vs K/8+4*Lw bytes per gallery item
-// shared by 64 queries.  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) + workspace.
+// The gallery record is wave-uniform.  Two ways to broadcast it, chosen per pass from measurements
+// (tools/ubench_lds.hip):
+//   GM_SCALAR  s_load_dwordxN into SGPRs, used directly as the scalar operand of v_xor/v_and; zero VALU cost.
+//              Scalar loads share the lgkm counter with LDS returns, so both passes ping-pong two SGPR
+//              groups and issue the loads of group g+1 before group g is evaluated (default for both passes);
+//   GM_LANE    lane i loads record base+i (coalesced, vmcnt), record u is broadcast with v_readlane; costs
+//              W+LW VALU issues per item (kept for experiments: XMH_SCAN_GM_HIST / XMH_SCAN_GM_AP = 1).
+//
+// Bound: integer VALU issue (a wave64 integer op occupies its SIMD for 4 cycles = 39.3 T lane-ops/s
+// per chip, measured with SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU): ~11 (pass 1) / ~19 (pass 2) VALU instructions
+// per wave-item at K=64, C=80, against K/8+4*Lw gallery bytes shared by the 64 queries of a wave.
+// Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
 constexpr int kMaxChunk = 32768;   // u16 halves of the packed pass-1 counters must not overflow
 constexpr int kMinChunk = 256;
+constexpr int GM_SCALAR = 0;
+constexpr int GM_LANE = 1;
 
 struct ScanArgs {
     const uint32_t* qbits;
@@ -61,65 +72,92 @@ struct QueryRegs {
     }
 };
 
-// A batch of 64 consecutive gallery records, one per lane (coalesced vector loads, tracked by vmcnt so the
-// next batch can be in flight while the LDS counters of this one are being updated).  Record u of the batch
-// is broadcast to all lanes with v_readlane (-> SGPR operands of the XOR/AND), which costs W+LW VALU issues
-// per item but no LDS bandwidth and, unlike scalar loads, does not share a wait counter with the LDS atomics.
+// one gallery record as plain words (uniform across the wave)
 template <int W, int LW, bool TERN>
-struct GalleryBatch {
+struct Rec {
     uint32_t b[W];
     uint32_t z[TERN ? W : 1];
     uint32_t l[LW];
-    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
-        const int64_t i = base + lane;
-        const bool ok = i < hi;
-#pragma unroll
-        for (int w = 0; w < W; ++w) b[w] = ok ? a.rbits[i * W + w] : 0u;
-        if (TERN) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) z[w] = ok ? a.rzero[i * W + w] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int w = 0; w < LW; ++w) l[w] = ok ? a.rlab[i * LW + w] : 0u;
-    }
 };
 
-// distance bucket + relevance of (this lane's query, record u of the batch)
 template <int W, int LW, bool TERN>
-__device__ __forceinline__ void pair_eval(const QueryRegs<W, LW, TERN>& qr, const GalleryBatch<W, LW, TERN>& g, int u, int K,
-                                          int& d, bool& rel) {
+__device__ __forceinline__ void rec_eval(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, bool& rel) {
     if (!TERN) {
         int acc = 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) acc += __popc(qr.b[w] ^ (uint32_t)__builtin_amdgcn_readlane((int)g.b[w], u));
+        for (int w = 0; w < W; ++w) acc += __popc(qr.b[w] ^ r.b[w]);
         d = acc;
     } else {
         int live_n = 0, diff_n = 0;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)g.b[w], u);
-            const uint32_t rz = (uint32_t)__builtin_amdgcn_readlane((int)g.z[w], u);
-            const uint32_t live = ~(qr.z[w] | rz);
+            const uint32_t live = ~(qr.z[w] | r.z[w]);
             live_n += __popc(live);
-            diff_n += __popc((qr.b[w] ^ rb) & live);
+            diff_n += __popc((qr.b[w] ^ r.b[w]) & live);
         }
         d = K - live_n + 2 * diff_n;                           // 2 * (0.5 * (K - q.r)), in [0, 2K]
     }
     uint32_t hit = 0;
 #pragma unroll
-    for (int w = 0; w < LW; ++w) hit |= qr.l[w] & (uint32_t)__builtin_amdgcn_readlane((int)g.l[w], u);
+    for (int w = 0; w < LW; ++w) hit |= qr.l[w] & r.l[w];
     rel = hit != 0;
 }
 
-template <int W>
+// GM_SCALAR: record i through a wave-uniform address (the compiler emits s_load_dwordxN)
+template <int W, int LW, bool TERN>
+__device__ __forceinline__ void rec_load_uniform(Rec<W, LW, TERN>& r, const ScanArgs& a, int64_t i) {
+    const uint32_t* __restrict__ pb = a.rbits + i * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) r.b[w] = pb[w];
+    if (TERN) {
+        const uint32_t* __restrict__ pz = a.rzero + i * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) r.z[w] = pz[w];
+    }
+    const uint32_t* __restrict__ pl = a.rlab + i * LW;
+#pragma unroll
+    for (int w = 0; w < LW; ++w) r.l[w] = pl[w];
+}
+
+// GM_LANE: a batch of 64 consecutive records, one per lane (coalesced, vmcnt-tracked); broadcast by readlane
+template <int W, int LW, bool TERN>
+struct LaneBatch {
+    Rec<W, LW, TERN> mine;
+    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
+        const int64_t i = base + lane;
+        const bool ok = i < hi;
+#pragma unroll
+        for (int w = 0; w < W; ++w) mine.b[w] = ok ? a.rbits[i * W + w] : 0u;
+        if (TERN) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) mine.z[w] = ok ? a.rzero[i * W + w] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int w = 0; w < LW; ++w) mine.l[w] = ok ? a.rlab[i * LW + w] : 0u;
+    }
+    __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, int u) const {
+#pragma unroll
+        for (int w = 0; w < W; ++w) r.b[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.b[w], u);
+        if (TERN) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) r.z[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.z[w], u);
+        }
+#pragma unroll
+        for (int w = 0; w < LW; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.l[w], u);
+    }
+};
+
+// items per unrolled group: two groups of records must fit the SGPR file (<= ~80 of 102) in GM_SCALAR mode
+template <int W, int LW, bool TERN>
 struct Unroll {
-    static constexpr int value = W <= 2 ? 8 : 4;
+    static constexpr int words = W * (TERN ? 2 : 1) + LW;
+    static constexpr int value = words <= 5 ? 8 : (words <= 10 ? 4 : 2);
 };
 
 // ---------------------------------------------------------------------------------------------------
 // pass 1: chunk_hist[chunk][d][q] = (#items at distance d) | (#relevant items at distance d) << 16
 // ---------------------------------------------------------------------------------------------------
-template <int W, int LW, bool TERN>
+template <int W, int LW, bool TERN, int GM>
 __global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][64]
     int chunk_id, qtile;
@@ -129,159 +167,308 @@ __global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restri
     for (int d = 0; d < a.nb; ++d) lds[d * 64 + lane] = 0u;
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
-
+    using R = Rec<W, LW, TERN>;
+    constexpr int U = Unroll<W, LW, TERN>::value;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
-    constexpr int U = Unroll<W>::value;
-    GalleryBatch<W, LW, TERN> cur, nxt;
-    cur.load(a, lo, hi, lane);
-    for (int64_t base = lo; base < hi; base += 64) {
-        nxt.load(a, base + 64, hi, lane);                      // prefetch (all-zero past the end)
-        const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
-        int u0 = 0;
-        for (; u0 + U <= cnt; u0 += U) {
-            int d[U];
-            bool rel[U];
+
+    auto count_group = [&](const R (&g)[U]) {
+        int d[U];
+        bool rel[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) pair_eval<W, LW, TERN>(qr, cur, u0 + u, a.K, d[u], rel[u]);
+        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) atomicAdd(&lds[d[u] * 64 + lane], rel[u] ? 0x10001u : 1u);
+        for (int u = 0; u < U; ++u) atomicAdd(&lds[d[u] * 64 + lane], rel[u] ? 0x10001u : 1u);
+    };
+    auto count_one = [&](const R& r) {
+        int d;
+        bool rel;
+        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
+        atomicAdd(&lds[d * 64 + lane], rel ? 0x10001u : 1u);
+    };
+
+    if (GM == GM_SCALAR) {
+        // ping-pong two SGPR-resident groups: group g+1 is in flight while group g is counted
+        R ga[U], gb[U];
+        int64_t i = lo;
+        const int64_t ngroups = (hi - lo) / U;
+        if (ngroups > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
         }
-        for (; u0 < cnt; ++u0) {
-            int d;
-            bool rel;
-            pair_eval<W, LW, TERN>(qr, cur, u0, a.K, d, rel);
-            atomicAdd(&lds[d * 64 + lane], rel ? 0x10001u : 1u);
+        int64_t g = 0;
+        for (; g + 2 <= ngroups; g += 2) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
+            count_group(ga);
+            if (g + 2 < ngroups) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
+            }
+            count_group(gb);
+            i += 2 * U;
         }
-        cur = nxt;
+        if (g < ngroups) {
+            count_group(ga);
+            i += U;
+        }
+        for (; i < hi; ++i) {
+            R r;
+            rec_load_uniform<W, LW, TERN>(r, a, i);
+            count_one(r);
+        }
+    } else {
+        LaneBatch<W, LW, TERN> cur, nxt;
+        cur.load(a, lo, hi, lane);
+        for (int64_t base = lo; base < hi; base += 64) {
+            nxt.load(a, base + 64, hi, lane);                  // prefetch (all-zero past the end)
+            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
+            int u0 = 0;
+            for (; u0 + U <= cnt; u0 += U) {
+                R g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur.get(g[u], u0 + u);
+                count_group(g);
+            }
+            for (; u0 < cnt; ++u0) {
+                R r;
+                cur.get(r, u0);
+                count_one(r);
+            }
+            cur = nxt;
+        }
     }
     uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q;
     for (int d = 0; d < a.nb; ++d) out[(int64_t)d * a.qpad] = lds[d * 64 + lane];
 }
 
-// shard totals for the multi-GPU exchange: hist_all/hist_rel [Q][nb]
-__global__ __launch_bounds__(256) void k_hist_totals(const uint32_t* __restrict__ chunk_hist, int Q, int qpad, int nb,
-                                                     int nchunk, uint32_t* __restrict__ hist_all,
-                                                     uint32_t* __restrict__ hist_rel) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int d = blockIdx.y;
-    if (q >= Q) return;
-    uint32_t sa = 0, sr = 0;
-    for (int c = 0; c < nchunk; ++c) {
-        const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
-        sa += h & 0xffffu;
-        sr += h >> 16;
+// ---------------------------------------------------------------------------------------------------
+// bucket tables between the passes (tiny, latency-bound -> spread over many waves, loads independent)
+//   below[c][d][q] = (#all, #relevant) items of bucket d in chunks < c of this shard
+//   tot[d][q]      = (#all, #relevant) items of bucket d in this shard
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__ chunk_hist, int qpad, int nb, int nchunk,
+                                                    uint2* __restrict__ below, uint2* __restrict__ tot) {
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.x * 64 + lane;
+    if (d >= nb) return;
+    uint32_t ra = 0, rr = 0;
+    int c = 0;
+    for (; c + 4 <= nchunk; c += 4) {
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = chunk_hist[((int64_t)(c + j) * nb + d) * qpad + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            below[((int64_t)(c + j) * nb + d) * qpad + q] = make_uint2(ra, rr);
+            ra += h[j] & 0xffffu;
+            rr += h[j] >> 16;
+        }
     }
-    if (hist_all) hist_all[(int64_t)q * nb + d] = sa;
-    if (hist_rel) hist_rel[(int64_t)q * nb + d] = sr;
+    for (; c < nchunk; ++c) {
+        const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
+        below[((int64_t)c * nb + d) * qpad + q] = make_uint2(ra, rr);
+        ra += h & 0xffffu;
+        rr += h >> 16;
+    }
+    tot[(int64_t)d * qpad + q] = make_uint2(ra, rr);
+}
+
+//   dpre[d][q] = rank offset of bucket d from outside this shard's bucket d: all lower buckets
+//                (locally: exclusive prefix of tot; sharded: the caller's base_all/base_rel)
+//   cap[q]     = min(n_rel, k)
+__global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot, int Q, int qpad, int nb,
+                                                  const uint32_t* __restrict__ base_all,
+                                                  const uint32_t* __restrict__ base_rel,
+                                                  const uint32_t* __restrict__ nrel_total, int64_t kcap,
+                                                  uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
+                                                  int32_t* __restrict__ cap_out, uint32_t* __restrict__ hist_all,
+                                                  uint32_t* __restrict__ hist_rel) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const bool qok = q < Q;
+    uint32_t ra = 0, rr = 0;
+    int d = 0;
+    for (; d + 8 <= nb; d += 8) {
+        uint2 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tot[(int64_t)(d + j) * qpad + q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 o = make_uint2(ra, rr);
+            if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d + j], base_rel[(int64_t)q * nb + d + j]);
+            if (dpre) dpre[(int64_t)(d + j) * qpad + q] = o;
+            if (qok && hist_all) hist_all[(int64_t)q * nb + d + j] = t[j].x;
+            if (qok && hist_rel) hist_rel[(int64_t)q * nb + d + j] = t[j].y;
+            ra += t[j].x;
+            rr += t[j].y;
+        }
+    }
+    for (; d < nb; ++d) {
+        const uint2 t = tot[(int64_t)d * qpad + q];
+        uint2 o = make_uint2(ra, rr);
+        if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d], base_rel[(int64_t)q * nb + d]);
+        if (dpre) dpre[(int64_t)d * qpad + q] = o;
+        if (qok && hist_all) hist_all[(int64_t)q * nb + d] = t.x;
+        if (qok && hist_rel) hist_rel[(int64_t)q * nb + d] = t.y;
+        ra += t.x;
+        rr += t.y;
+    }
+    if (cap_ws) {
+        const uint32_t nrel = nrel_total ? (qok ? nrel_total[q] : 0u) : rr;
+        const uint32_t cap = (kcap > 0 && (uint64_t)kcap < (uint64_t)nrel) ? (uint32_t)kcap : nrel;
+        cap_ws[q] = cap;
+        if (qok) cap_out[q] = (int32_t)cap;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // pass 2: ranks of relevant items.  cnt[d][lane] is a 64-bit counter {lo: rank of the NEXT item of bucket d,
 // hi: ordinal of the NEXT relevant item of bucket d} (both 1-based); it starts at the bucket's global base
 // and one ds_add_rtn_u64 per pair both advances it and returns (rank, ordinal) of the current item.
-// The loop is software-pipelined by one group: the atomics of group g are in flight while group g+1's
-// distances are computed, and only then are group g's returns credited.
+// The loop is software-pipelined by one group: the returns of group g are consumed after group g+1's
+// distances have been computed.
 // ---------------------------------------------------------------------------------------------------
-template <int W, int LW, bool TERN, bool CAPPED>
-__global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint32_t* __restrict__ chunk_hist,
-                                                const uint32_t* __restrict__ base_all,
-                                                const uint32_t* __restrict__ base_rel,
-                                                const uint32_t* __restrict__ nrel_total, int64_t kcap,
-                                                float* __restrict__ ap_part, int32_t* __restrict__ cap_out) {
+template <int W, int LW, bool TERN, bool CAPPED, int GM>
+__global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+                                                const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long cnt[];   // [nb][64]
     int chunk_id, qtile;
     if (!map_block(a, chunk_id, qtile)) return;
     const int lane = threadIdx.x;
     const int q = qtile * 64 + lane;
-    const bool qok = q < a.Q;
-
-    // bucket bases: (everything in lower buckets) + (same bucket, lower chunks) [+ other shards]
-    uint32_t run_all = 0, run_rel = 0;
-    for (int d = 0; d < a.nb; ++d) {
-        uint32_t tot_a = 0, tot_r = 0, below_a = 0, below_r = 0;
-        for (int c = 0; c < a.nchunk; ++c) {
-            const uint32_t h = chunk_hist[((int64_t)c * a.nb + d) * a.qpad + q];
-            const uint32_t ha = h & 0xffffu, hr = h >> 16;
-            tot_a += ha;
-            tot_r += hr;
-            if (c < chunk_id) {
-                below_a += ha;
-                below_r += hr;
+    {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q;
+        const uint2* __restrict__ pd = dpre + q;
+        int d = 0;
+        for (; d + 8 <= a.nb; d += 8) {
+            uint2 x[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] = pb[(int64_t)(d + j) * a.qpad];
+                y[j] = pd[(int64_t)(d + j) * a.qpad];
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                cnt[(d + j) * 64 + lane] = (unsigned long long)(x[j].x + y[j].x + 1u) | ((unsigned long long)(x[j].y + y[j].y + 1u) << 32);
         }
-        uint32_t ba, br;
-        if (base_all) {
-            ba = (qok ? base_all[(int64_t)q * a.nb + d] : 0u) + below_a;
-            br = (qok ? base_rel[(int64_t)q * a.nb + d] : 0u) + below_r;
-        } else {
-            ba = run_all + below_a;
-            br = run_rel + below_r;
+        for (; d < a.nb; ++d) {
+            const uint2 x = pb[(int64_t)d * a.qpad], y = pd[(int64_t)d * a.qpad];
+            cnt[d * 64 + lane] = (unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32);
         }
-        run_all += tot_a;
-        run_rel += tot_r;
-        cnt[d * 64 + lane] = (unsigned long long)(ba + 1u) | ((unsigned long long)(br + 1u) << 32);
     }
-    const uint32_t nrel = nrel_total ? (qok ? nrel_total[q] : 0u) : run_rel;
-    const uint32_t cap = (kcap > 0 && (uint64_t)kcap < (uint64_t)nrel) ? (uint32_t)kcap : nrel;
-    if (chunk_id == 0 && qok) cap_out[q] = (int32_t)cap;
+    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
 
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
+    using R = Rec<W, LW, TERN>;
+    constexpr int U = Unroll<W, LW, TERN>::value;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     float acc = 0.0f;
 
     // (rank, ordinal) of a relevant item -> ordinal / rank.  v_rcp_f32 is good to 1 ulp: a term is off by
     // <= 1.5e-7 relative, far inside the 1e-4 mAP tolerance (measured ~1e-8 on the goldens).
-    auto credit = [&](unsigned long long old, bool rel) {
+    // `hit` is the 0/1 relevance that was also the high-word increment: ordinal*hit zeroes non-relevant terms
+    // without keeping a lane mask alive across the pipeline stage.
+    auto credit = [&](unsigned long long old, uint32_t hit) {
         const uint32_t rank = (uint32_t)old;
-        const uint32_t ord = (uint32_t)(old >> 32);
-        const float term = (float)ord * __builtin_amdgcn_rcpf((float)rank);
-        const bool take = CAPPED ? (rel && ord <= cap) : rel;
-        acc += take ? term : 0.0f;
+        uint32_t ord = (uint32_t)(old >> 32);
+        if (CAPPED) hit = ord <= cap ? hit : 0u;
+        const float of = (float)__umul24(ord, hit);            // ordinals < 2^24 (R < 16.7 M per shard checked in the plan)
+        acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
+    };
+    unsigned long long old[U];
+    uint32_t hitp[U];
+    auto eval_issue = [&](const R (&g)[U], bool have_prev) {
+        int d[U];
+        bool rel[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
+        if (have_prev) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);              // previous group's returns
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            hitp[u] = rel[u] ? 1u : 0u;
+            old[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)hitp[u] << 32));
+        }
+    };
+    auto drain = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+    };
+    auto one = [&](const R& r) {
+        int d;
+        bool rel;
+        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
+        const uint32_t hit = rel ? 1u : 0u;
+        credit(atomicAdd(&cnt[d * 64 + lane], 1ull | ((unsigned long long)hit << 32)), hit);
     };
 
-    constexpr int U = Unroll<W>::value;
-    GalleryBatch<W, LW, TERN> cur, nxt;
-    cur.load(a, lo, hi, lane);
-    for (int64_t base = lo; base < hi; base += 64) {
-        nxt.load(a, base + 64, hi, lane);                      // prefetch (all-zero past the end)
-        const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-        const int ngroups = cntb / U;
-        unsigned long long old[U];
-        bool relp[U];
+    if (GM == GM_SCALAR) {
+        // ping-pong two SGPR-resident groups; the scalar loads of group g+1 are issued before group g is
+        // evaluated, so by the time the LDS returns force an lgkmcnt(0) they have long landed
+        R ga[U], gb[U];
+        int64_t i = lo;
+        const int64_t ngroups = (hi - lo) / U;
         if (ngroups > 0) {
-            int d[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) pair_eval<W, LW, TERN>(qr, cur, u, a.K, d[u], relp[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) old[u] = atomicAdd(&cnt[d[u] * 64 + lane], relp[u] ? 0x100000001ull : 1ull);
+            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
         }
-        for (int g = 1; g < ngroups; ++g) {
-            int d[U];
-            bool rel[U];
+        int64_t g = 0;
+        bool prev = false;
+        for (; g + 2 <= ngroups; g += 2) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) pair_eval<W, LW, TERN>(qr, cur, g * U + u, a.K, d[u], rel[u]);
+            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
+            eval_issue(ga, prev);
+            if (g + 2 < ngroups) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) credit(old[u], relp[u]);                  // previous group's returns
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                old[u] = atomicAdd(&cnt[d[u] * 64 + lane], rel[u] ? 0x100000001ull : 1ull);
-                relp[u] = rel[u];
+                for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
             }
+            eval_issue(gb, true);
+            prev = true;
+            i += 2 * U;
         }
-        if (ngroups > 0) {
+        if (g < ngroups) {
+            eval_issue(ga, prev);
+            prev = true;
+            i += U;
+        }
+        if (prev) drain();
+        for (; i < hi; ++i) {
+            R r;
+            rec_load_uniform<W, LW, TERN>(r, a, i);
+            one(r);
+        }
+    } else {
+        LaneBatch<W, LW, TERN> cur, nxt;
+        cur.load(a, lo, hi, lane);
+        bool prev = false;
+        for (int64_t base = lo; base < hi; base += 64) {
+            nxt.load(a, base + 64, hi, lane);                  // prefetch (all-zero past the end)
+            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+            int u0 = 0;
+            for (; u0 + U <= cntb; u0 += U) {
+                R g[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) credit(old[u], relp[u]);
+                for (int u = 0; u < U; ++u) cur.get(g[u], u0 + u);
+                eval_issue(g, prev);
+                prev = true;
+            }
+            if (u0 < cntb) {
+                if (prev) drain();
+                prev = false;
+                for (; u0 < cntb; ++u0) {
+                    R r;
+                    cur.get(r, u0);
+                    one(r);
+                }
+            }
+            cur = nxt;
         }
-        for (int u0 = ngroups * U; u0 < cntb; ++u0) {
-            int d;
-            bool rel;
-            pair_eval<W, LW, TERN>(qr, cur, u0, a.K, d, rel);
-            credit(atomicAdd(&cnt[d * 64 + lane], rel ? 0x100000001ull : 1ull), rel);
-        }
-        cur = nxt;
+        if (prev) drain();
     }
     ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
@@ -312,18 +499,45 @@ __global__ __launch_bounds__(256) void k_map_finalize(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+struct WsLayout {
+    size_t chunk_hist, below, tot, dpre, cap, ap_part, total;
+};
+
+WsLayout ws_layout(const xmh_scan_plan& p) {
+    WsLayout L;
+    const size_t cells = (size_t)p.nchunk * p.nbuckets * p.qpad;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    L.chunk_hist = take(cells * 4);
+    L.below = take(cells * 8);
+    L.tot = take((size_t)p.nbuckets * p.qpad * 8);
+    L.dpre = take((size_t)p.nbuckets * p.qpad * 8);
+    L.cap = take((size_t)p.qpad * 4);
+    L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
+    L.total = o;
+    return L;
+}
+
 int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (Q <= 0 || R <= 0 || K <= 0) return xmh::fail(XMH_EINVAL, "scan plan: bad shape Q=%lld R=%lld K=%d", (long long)Q, (long long)R, K);
-    if (R >= (1ll << 31) || Q >= (1ll << 24)) return xmh::fail(XMH_ENOTSUP, "scan plan: shard too large (R=%lld, Q=%lld)", (long long)R, (long long)Q);
+    if (R >= (1ll << 24) || Q >= (1ll << 24)) return xmh::fail(XMH_ENOTSUP, "scan plan: shard too large (R=%lld, Q=%lld)", (long long)R, (long long)Q);
     const int64_t nb = ternary ? 2 * (int64_t)K + 1 : (int64_t)K + 1;
     const int64_t lds_ap = nb * 64 * 8;
     if (lds_ap > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave (max 163840); K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const int64_t nqt = xmh::ceil_div(Q, 64);
     int64_t wpc = (160 * 1024) / lds_ap;          // waves per CU the pass-2 LDS footprint admits
     if (wpc > 8) wpc = 8;
+    // pass 2 runs `rounds` resident sets of waves; pass 1 (half the LDS) then gets 2 waves per SIMD
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
-    int64_t nchunk = slots / nqt;
+    static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
+    const int64_t rounds = rounds_env > 0 ? rounds_env : 4;
+    int64_t nchunk = rounds * slots / nqt;
     if (nchunk < 1) nchunk = 1;
+    if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
     int64_t chunk = xmh::ceil_div(R, nchunk);
     if (chunk < kMinChunk) chunk = kMinChunk;
     if (chunk > kMaxChunk) chunk = kMaxChunk;
@@ -334,11 +548,17 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     p->nqtile = nqt;
     p->qpad = nqt * 64;
     p->nbuckets = nb;
-    p->ws_bytes = (size_t)(nchunk * nb * p->qpad) * 4 + (size_t)(nchunk * p->qpad) * 4;
+    p->ws_bytes = ws_layout(*p).total;
     return XMH_OK;
 }
 
-template <bool TERN, typename F>
+int gallery_mode(const char* env, int dflt) {
+    const char* v = getenv(env);
+    if (!v) return dflt;
+    return atoi(v) ? GM_LANE : GM_SCALAR;
+}
+
+template <typename F>
 int dispatch_shape(int W, int LW, F&& f) {
 #define XMH_CASE(WW, LL) \
     if (W == WW && LW == LL) return f(std::integral_constant<int, WW>{}, std::integral_constant<int, LL>{});
@@ -372,6 +592,15 @@ ScanArgs make_args(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
 
 inline int scan_grid(const xmh_scan_plan& p) { return (int)(8 * p.nqtile * xmh::ceil_div(p.nchunk, 8)); }
 
+template <typename KernT>
+int raise_lds(KernT kern, size_t lds, const char* who) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, lds, hipGetErrorString(e));
+    }
+    return XMH_OK;
+}
+
 }  // namespace
 
 extern "C" int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host) {
@@ -390,28 +619,41 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     rc = check_common("xmh_hamming_hist", qbits, qzero, qlab, rbits, rzero, rlab, C, ws, ws_bytes, p);
     if (rc) return rc;
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    uint32_t* chunk_hist = static_cast<uint32_t*>(ws);
+    const WsLayout L = ws_layout(p);
+    char* base = static_cast<char*>(ws);
+    uint32_t* chunk_hist = reinterpret_cast<uint32_t*>(base + L.chunk_hist);
+    uint2* below = reinterpret_cast<uint2*>(base + L.below);
+    uint2* tot = reinterpret_cast<uint2*>(base + L.tot);
     hipStream_t st = xmh::as_stream(stream);
     const size_t lds = (size_t)p.nbuckets * 64 * 4;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    auto launch = [&](auto tern_c) {
+    const int gm = gallery_mode("XMH_SCAN_GM_HIST", GM_SCALAR);
+    auto launch = [&](auto tern_c, auto gm_c) {
         constexpr bool T = decltype(tern_c)::value;
-        return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
-            auto kern = k_scan_hist<decltype(w)::value, decltype(l)::value, T>;
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_hamming_hist: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-            }
+        constexpr int G = decltype(gm_c)::value;
+        return dispatch_shape(W, LW, [&](auto w, auto l) {
+            auto kern = k_scan_hist<decltype(w)::value, decltype(l)::value, T, G>;
+            const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+            if (r2) return r2;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, chunk_hist);
-            return XMH_OK;
+            return (int)XMH_OK;
         });
     };
-    rc = tern ? launch(std::true_type{}) : launch(std::false_type{});
+    using T1 = std::true_type;
+    using T0 = std::false_type;
+    using GS = std::integral_constant<int, GM_SCALAR>;
+    using GL = std::integral_constant<int, GM_LANE>;
+    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : launch(T1{}, GL{});
+    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : launch(T0{}, GL{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
+    hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, below, tot);
+    XMH_LAUNCH_CHECK("xmh_hamming_hist below");
     if (hist_all || hist_rel) {
-        hipLaunchKernelGGL(k_hist_totals, dim3((unsigned)xmh::ceil_div(Q, 256), (unsigned)p.nbuckets), dim3(256), 0, st, chunk_hist,
-                           (int)Q, (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, hist_all, hist_rel);
+        hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int64_t)0,
+                           (uint2*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, hist_all, hist_rel);
         XMH_LAUNCH_CHECK("xmh_hamming_hist totals");
     }
     return XMH_OK;
@@ -431,27 +673,44 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     const int ext = (base_all != nullptr) + (base_rel != nullptr) + (nrel_total != nullptr);
     if (ext != 0 && ext != 3) return xmh::fail(XMH_EINVAL, "xmh_hamming_ap: base_all, base_rel and nrel_total go together");
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    const uint32_t* chunk_hist = static_cast<const uint32_t*>(ws);
-    float* ap_part = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)(p.nchunk * p.nbuckets * p.qpad) * 4);
+    const WsLayout L = ws_layout(p);
+    char* base = static_cast<char*>(ws);
+    const uint2* below = reinterpret_cast<const uint2*>(base + L.below);
+    const uint2* tot = reinterpret_cast<const uint2*>(base + L.tot);
+    uint2* dpre = reinterpret_cast<uint2*>(base + L.dpre);
+    uint32_t* cap_ws = reinterpret_cast<uint32_t*>(base + L.cap);
+    float* ap_part = reinterpret_cast<float*>(base + L.ap_part);
     hipStream_t st = xmh::as_stream(stream);
+    hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
+                       base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
     const size_t lds = (size_t)p.nbuckets * 64 * 8;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    auto launch = [&](auto tern_c) {
+    const int gm = gallery_mode("XMH_SCAN_GM_AP", GM_SCALAR);
+    auto launch = [&](auto tern_c, auto cap_c, auto gm_c) {
         constexpr bool T = decltype(tern_c)::value;
-        return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
-            auto go = [&](auto kern) {
-                if (lds > 64 * 1024) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_hamming_ap: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-                }
-                hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, chunk_hist, base_all, base_rel, nrel_total, k, ap_part, cap);
-                return (int)XMH_OK;
-            };
-            return k > 0 ? go(k_scan_ap<decltype(w)::value, decltype(l)::value, T, true>)
-                         : go(k_scan_ap<decltype(w)::value, decltype(l)::value, T, false>);
+        constexpr bool CP = decltype(cap_c)::value;
+        constexpr int G = decltype(gm_c)::value;
+        return dispatch_shape(W, LW, [&](auto w, auto l) {
+            auto kern = k_scan_ap<decltype(w)::value, decltype(l)::value, T, CP, G>;
+            const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
+            if (r2) return r2;
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part);
+            return (int)XMH_OK;
         });
     };
-    rc = tern ? launch(std::true_type{}) : launch(std::false_type{});
+    using T1 = std::true_type;
+    using T0 = std::false_type;
+    using GS = std::integral_constant<int, GM_SCALAR>;
+    using GL = std::integral_constant<int, GM_LANE>;
+    const bool capped = k > 0;
+    if (gm == GM_SCALAR) {
+        if (tern) rc = capped ? launch(T1{}, T1{}, GS{}) : launch(T1{}, T0{}, GS{});
+        else rc = capped ? launch(T0{}, T1{}, GS{}) : launch(T0{}, T0{}, GS{});
+    } else {
+        if (tern) rc = capped ? launch(T1{}, T1{}, GL{}) : launch(T1{}, T0{}, GL{});
+        else rc = capped ? launch(T0{}, T1{}, GL{}) : launch(T0{}, T0{}, GL{});
+    }
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
     hipLaunchKernelGGL(k_ap_reduce, dim3((unsigned)xmh::ceil_div(Q, 256)), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);

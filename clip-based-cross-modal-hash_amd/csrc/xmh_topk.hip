@@ -15,6 +15,8 @@
 // + Q*W*4 + nblocks*Q*k*6 (partial lists) ; per pair 2W lane-ops.
 #include "xmh_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -277,8 +279,10 @@ template <int W, int IPT>
 __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __restrict__ qbits,
                                                           const uint32_t* __restrict__ rbits, int Q, int64_t R, int k,
                                                           Layout L, int tiles_per_block, int nblocks,
-                                                          uint16_t* __restrict__ part_d, int32_t* __restrict__ part_i) {
+                                                          uint16_t* __restrict__ part_d, int32_t* __restrict__ part_i,
+                                                          const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate && *gate == 0) return;                       // fast path already produced the exact answer
     constexpr int TILE = kThreads * IPT;
     const int lane = lane_id(), w = wave_id();
     const int q0 = blockIdx.y * kQG;
@@ -366,8 +370,10 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
 template <int IPT>
 __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restrict__ part_d, const int32_t* __restrict__ part_i,
                                                          int nblocks, int k, Layout L, int64_t base_index,
-                                                         uint16_t* __restrict__ out_d, int32_t* __restrict__ out_i) {
+                                                         uint16_t* __restrict__ out_d, int32_t* __restrict__ out_i,
+                                                         const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate && *gate == 0) return;
     constexpr int TILE = kThreads * IPT;
     const int lane = lane_id(), w = wave_id();
     const int q = blockIdx.x;
@@ -431,9 +437,174 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
     }
 }
 
+// ===================================================================================================
+// Fast path: sample -> per-query distance threshold -> ONE streaming filter pass -> exact select.
+// The filter kernel has no LDS state and no barrier: lanes own gallery items (16-byte coalesced loads,
+// next tile prefetched), queries sit in SGPRs, and an item is appended to its query's global candidate
+// list only if d <= t_est[q] (a few hundred items out of millions).  k_topk_select then sorts the
+// candidates of a query by the 64-bit key (distance, index) and emits the first k.
+// Exactness is verified, not assumed: if a list overflowed or holds fewer than k items the select kernel
+// raises `fail`, and the robust streaming kernels above (gated on that flag) recompute the call.
+// ===================================================================================================
+constexpr int kCandCap = 8192;        // candidates kept per query (keys of 8 B)
+constexpr int kSampleBlocks = 256;
+constexpr int kSamplePerBlock = 1024;
+
+struct FastWs {
+    uint32_t* hist;            // [Q][nb]  sample histogram
+    uint32_t* t_est;           // [Q]
+    uint32_t* cnt;             // [Q]      candidates appended
+    int* fail;                 // [1]
+    unsigned long long* cand;  // [Q][kCandCap]
+};
+
+template <int W>
+__device__ __forceinline__ int dist_words(const Rec<W>& r, const uint32_t* __restrict__ qw) {
+    int acc = 0;
+#pragma unroll
+    for (int x = 0; x < W; ++x) acc += __popc(r.w[x] ^ qw[x]);
+    return acc;
+}
+
+// sample histogram: block b reads kSamplePerBlock consecutive rows starting at b*stride (whole gallery if small)
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                          int Q, int64_t R, int nb, int64_t stride, int per_block,
+                                                          uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];     // [qg][nb]
+    constexpr int QG = 16;
+    const int64_t lo = (int64_t)blockIdx.x * stride;
+    const int64_t hi = (lo + per_block < R) ? lo + per_block : R;
+    for (int q0 = 0; q0 < Q; q0 += QG) {
+        const int nq = (Q - q0 < QG) ? Q - q0 : QG;
+        for (int e = threadIdx.x; e < nq * nb; e += kThreads) sh[e] = 0u;
+        __syncthreads();
+        for (int64_t it = lo + threadIdx.x; it < hi; it += kThreads) {
+            Rec<W> r;
+            load_rec<W>(r, rbits, it, true);
+            for (int q = 0; q < nq; ++q) atomicAdd(&sh[q * nb + dist_words<W>(r, qbits + (int64_t)(q0 + q) * W)], 1u);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nq * nb; e += kThreads)
+            if (sh[e]) atomicAdd(&hist[(int64_t)q0 * nb + e], sh[e]);
+        __syncthreads();
+    }
+}
+
+// t_est[q] = smallest distance whose sampled cumulative count reaches `target` (nb-1 if it never does)
+__global__ __launch_bounds__(64) void k_topk_pick(const uint32_t* __restrict__ hist, int Q, int nb, uint32_t target,
+                                                  uint32_t* __restrict__ t_est) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Q) return;
+    uint32_t run = 0;
+    int t = nb - 1;
+    for (int d = 0; d < nb; ++d) {
+        run += hist[(int64_t)q * nb + d];
+        if (run >= target) {
+            t = d;
+            break;
+        }
+    }
+    t_est[q] = (uint32_t)t;
+}
+
+template <int W, int IPT>
+__global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                          int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    constexpr int TILE = kThreads * IPT;
+    const int lane = lane_id();
+    const int64_t ntiles = (R + TILE - 1) / TILE;
+    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    Rec<W> cur[IPT], nxt[IPT];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t it = item_of(tile, j);
+            load_rec<W>(cur[j], rbits, it, it < R);
+        }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int64_t it = item_of(tn, j);
+                load_rec<W>(nxt[j], rbits, it, it < R);
+            }
+        }
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t* __restrict__ qw = qbits + (int64_t)q * W;     // uniform -> SGPRs
+            const int t = (int)t_est[q];
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int64_t it = item_of(tile, j);
+                const int d = dist_words<W>(cur[j], qw);
+                const bool hit = it < R && d <= t;
+                const unsigned long long m = __ballot(hit);
+                if (m) {                                               // rare: a few hundred items per query per pass
+                    const int lead = __ffsll((long long)m) - 1;
+                    uint32_t base = 0;
+                    if (lane == lead) base = atomicAdd(&cnt[q], (uint32_t)__popcll(m));
+                    base = (uint32_t)__shfl((int)base, lead);
+                    if (hit) {
+                        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)d << 32) | (uint32_t)it;
+                    }
+                }
+            }
+        }
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
+        }
+    }
+}
+
+// one block per query: verify, bitonic-sort the candidate keys, write the first k
+__global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ cnt,
+                                                          int64_t R, int k, int64_t base_index, uint16_t* __restrict__ out_d,
+                                                          int32_t* __restrict__ out_i, int* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long key[];
+    const int q = blockIdx.x;
+    const uint32_t n = cnt[q];
+    const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
+    if (n > (uint32_t)kCandCap || n < want) {
+        if (threadIdx.x == 0) atomicOr(fail, 1);
+        return;
+    }
+    int P = 1;
+    while (P < (int)n || P < k) P <<= 1;
+    for (int p = threadIdx.x; p < P; p += kThreads) key[p] = p < (int)n ? cand[(int64_t)q * kCandCap + p] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = threadIdx.x; p < P / 2; p += kThreads) {
+                const int i = 2 * p - (p & (stride - 1));
+                const int j2 = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long x = key[i], y = key[j2];
+                if ((x > y) == up) {
+                    key[i] = y;
+                    key[j2] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int p = threadIdx.x; p < k; p += kThreads) {
+        const unsigned long long v = key[p];
+        const bool ok = v != ~0ull;
+        out_d[(int64_t)q * k + p] = ok ? (uint16_t)(v >> 32) : (uint16_t)kInf;
+        out_i[(int64_t)q * k + p] = ok ? (int32_t)(base_index + (int64_t)(uint32_t)v) : -1;
+    }
+}
+
 struct TopkPlan {
     int W, ipt, tile, nblocks, tiles_per_block, nqg;
     Layout L, Lm;
+    size_t robust_bytes, off_hist, off_test, off_cnt, off_fail, off_cand;
     size_t ws_bytes;
 };
 
@@ -463,7 +634,19 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->nqg = (int)xmh::ceil_div(Q, kQG);
     p->Lm.nb = K + 1;
     p->Lm.cap = k + kThreads * 4 + 64;
-    p->ws_bytes = (size_t)Q * p->nblocks * k * 6;
+    p->robust_bytes = ((size_t)Q * p->nblocks * k * 6 + 255) & ~(size_t)255;
+    size_t o = p->robust_bytes;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    p->off_hist = take((size_t)Q * (K + 1) * 4);      // hist, t_est, cnt, fail are contiguous: one memset clears them
+    p->off_test = take((size_t)Q * 4);
+    p->off_cnt = take((size_t)Q * 4);
+    p->off_fail = take(256);
+    p->off_cand = take((size_t)Q * kCandCap * 8);
+    p->ws_bytes = o;
     return XMH_OK;
 }
 
@@ -495,6 +678,62 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
     int32_t* part_i = static_cast<int32_t*>(ws);
     uint16_t* part_d = reinterpret_cast<uint16_t*>(static_cast<char*>(ws) + (size_t)Q * p.nblocks * k * 4);
     hipStream_t st = xmh::as_stream(stream);
+    char* wsb = static_cast<char*>(ws);
+    FastWs f;
+    f.hist = reinterpret_cast<uint32_t*>(wsb + p.off_hist);
+    f.t_est = reinterpret_cast<uint32_t*>(wsb + p.off_test);
+    f.cnt = reinterpret_cast<uint32_t*>(wsb + p.off_cnt);
+    f.fail = reinterpret_cast<int*>(wsb + p.off_fail);
+    f.cand = reinterpret_cast<unsigned long long*>(wsb + p.off_cand);
+    const bool robust_only = getenv("XMH_TOPK_ROBUST_ONLY") != nullptr;   // test hook: skip the fast path
+    const int* gate = nullptr;
+    if (!robust_only) {
+        // ---- fast path: sample -> threshold -> filter -> select (all stream-ordered, no host sync) ----
+        XMH_HIP(hipMemsetAsync(wsb + p.off_hist, 0, p.off_cand - p.off_hist, st));
+        const int nb = K + 1;
+        int sblocks = kSampleBlocks;
+        int64_t stride = R / sblocks;
+        int per_block = kSamplePerBlock;
+        bool exact = false;
+        if (stride <= per_block) {                      // small gallery: the "sample" is the whole gallery
+            sblocks = (int)xmh::ceil_div(R, per_block);
+            stride = per_block;
+            exact = true;
+        }
+        const double frac = exact ? 1.0 : (double)((int64_t)sblocks * per_block) / (double)R;
+        const uint32_t target = exact ? (uint32_t)((int64_t)k < R ? (int64_t)k : R) : (uint32_t)(2.0 * k * frac + 8.0);
+        const size_t slds = (size_t)16 * nb * 4;
+#define XMH_FAST(WW, II)                                                                                                   \
+        {                                                                                                                  \
+            hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
+                               per_block, f.hist);                                                                         \
+            hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)xmh::ceil_div(Q, 64)), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
+                               target, f.t_est);                                                                           \
+            const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
+            int64_t fb = (int64_t)xmh::device_cu_count() * 8;                                                              \
+            if (fb > ft) fb = ft;                                                                                          \
+            hipLaunchKernelGGL((k_topk_filter<WW, II>), dim3((unsigned)fb), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                               (const uint32_t*)f.t_est, f.cnt, f.cand);                                                   \
+        }
+        switch (p.W) {
+            case 1: XMH_FAST(1, 8) break;
+            case 2: XMH_FAST(2, 8) break;
+            case 4: XMH_FAST(4, 4) break;
+            default: XMH_FAST(8, 4) break;
+        }
+#undef XMH_FAST
+        XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
+        {
+            auto kern = k_topk_select;
+            const size_t sel_lds = (size_t)kCandCap * 8;
+            rc = raise_lds(kern, sel_lds, "xmh_hamming_topk select");
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), sel_lds, st, (const unsigned long long*)f.cand,
+                               (const uint32_t*)f.cnt, R, k, base_index, dist, idx, f.fail);
+        }
+        XMH_LAUNCH_CHECK("xmh_hamming_topk select");
+        gate = f.fail;                                   // the robust kernels below run only if a query failed
+    }
     const dim3 grid(p.nblocks, p.nqg);
     const size_t lds = p.L.bytes();
 #define XMH_TOPK_LAUNCH(WW, II)                                                                                        \
@@ -503,7 +742,7 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
         rc = raise_lds(kern, lds, "xmh_hamming_topk");                                                                 \
         if (rc) return rc;                                                                                             \
         hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, qbits, rbits, (int)Q, R, k, p.L, p.tiles_per_block,    \
-                           p.nblocks, part_d, part_i);                                                                 \
+                           p.nblocks, part_d, part_i, gate);                                                           \
     }
     switch (p.W) {
         case 1: XMH_TOPK_LAUNCH(1, 8) break;
@@ -518,7 +757,7 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
         const size_t ldsm = p.Lm.bytes();
         rc = raise_lds(kern, ldsm, "xmh_hamming_topk merge");
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), ldsm, st, part_d, part_i, p.nblocks, k, p.Lm, base_index, dist, idx);
+        hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), ldsm, st, part_d, part_i, p.nblocks, k, p.Lm, base_index, dist, idx, gate);
     }
     XMH_LAUNCH_CHECK("xmh_hamming_topk merge");
     return XMH_OK;

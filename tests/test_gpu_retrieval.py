@@ -329,3 +329,17 @@ def test_topk_sharded_merge_equals_global(xr):
     md, mi = sharded.merge_topk(torch.stack(ds), torch.stack(is_), k)
     wd, wi = co.topk(qb, rb, K + 1, k)
     assert np.array_equal(mi.numpy(), wi) and np.array_equal(md.numpy().astype(np.uint16), wd)
+
+
+def test_topk_robust_path_alone(xr, monkeypatch):
+    """the gated streaming kernels must be exact on their own (they are the fallback of the fast path)."""
+    monkeypatch.setenv("XMH_TOPK_ROBUST_ONLY", "1")
+    _topk_check(xr, 8, 70000, 256, 100, seed=11)
+    _topk_check(xr, 5, 30000, 64, 17, seed=12, dup=True)
+    _topk_check(xr, 3, 3000, 16, 1000, seed=13)
+
+
+def test_topk_full_size_sample_path(xr):
+    """a gallery large enough that the threshold comes from a 2.6 % sample (fast path proper)."""
+    _topk_check(xr, 8, 2_000_000, 64, 100, seed=21)
+    _topk_check(xr, 4, 1_500_000, 256, 10, seed=22)
