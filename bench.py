@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_GLOPS = 78643.2         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (fp32 vector peak / 2)
+VALU_PEAK_GLOPS = 39321.6         # integer VALU: 256 CU x 4 SIMD x 64 lanes / 4 cycles x 2.4 GHz (SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU = 4)
 
 
 def synth(Q, R, K, C, seed, p=0.04, device="cuda"):
@@ -48,19 +48,23 @@ def synth(Q, R, K, C, seed, p=0.04, device="cuda"):
     return qB, qL, rB, rL
 
 
-def cpu_baseline(qB, qL, rB, rL, qsub):
+def cpu_baseline(qB, qL, rB, rL, budget_s=20.0):
     """The oracle's step-by-step port of the reference calc_map_k (float GEMM + int64 label matmul + full
-    sort + per-query loop) on a bounded query subsample, on this host's cores."""
+    sort + per-query loop) on a bounded query subsample, on this host's cores.  A 32-query probe sizes the
+    sample so the whole leg takes about `budget_s` seconds."""
     from oracle import retrieval as orc
-    threads = os.cpu_count() or 1
+    threads = min(32, os.cpu_count() or 1)       # the int64 label matmul stops scaling (and thrashes) beyond that
     torch.set_num_threads(threads)
-    q, l = qB[:qsub].clone(), qL[:qsub].clone()
     t0 = time.perf_counter()
-    m = orc.map_k(q, rB, l, rL, None, stable=True)
+    orc.map_k(qB[:32].clone(), rB, qL[:32].clone(), rL, None, stable=True)
+    probe = time.perf_counter() - t0
+    qsub = int(max(32, min(qB.shape[0], 32 * budget_s / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    m = orc.map_k(qB[:qsub].clone(), rB, qL[:qsub].clone(), rL, None, stable=True)
     dt = time.perf_counter() - t0
-    return {"value": qsub * rB.shape[0] / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "first %d of %d queries x full %d-item gallery, oracle.retrieval.map_k (torch CPU), %.2f s"
-                      % (qsub, qB.shape[0], rB.shape[0], dt), "map": float(m)}
+    return {"value": qsub * rB.shape[0] / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "first %d of %d queries x full %d-item gallery, oracle.retrieval.map_k (torch CPU, %d threads), %.1f s"
+                      % (qsub, qB.shape[0], rB.shape[0], threads, dt), "map": float(m)}
 
 
 def ev():
@@ -78,7 +82,7 @@ def main():
     ap.add_argument("--C", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-regime", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=500)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,24 +137,23 @@ def main():
         dt = float(t.item())
     map_value = float(m.item())
 
-    # per-kernel timing of the two passes on this stream (HIP events, torch's current stream = launch stream)
-    n_k = max(args.steps, 10)
-    e = [ev() for _ in range(3 * n_k)]
-    for i in range(n_k):
-        e[3 * i].record()
+    # per-kernel timing: the library brackets each scan kernel with HIP events on the launch stream
+    from xmh import _lib
+    _lib.prof_enable(True)
+    for _ in range(max(args.steps, 10)):
         scan.histograms(False)
-        e[3 * i + 1].record()
         scan.ap_sums(None)
-        e[3 * i + 2].record()
     torch.cuda.synchronize()
-    t_hist = sum(e[3 * i].elapsed_time(e[3 * i + 1]) for i in range(n_k)) / n_k * 1e-3
-    t_ap = sum(e[3 * i + 1].elapsed_time(e[3 * i + 2]) for i in range(n_k)) / n_k * 1e-3
+    t_hist = _lib.prof_read("scan_hist")[0] * 1e-3
+    t_ap, n_ap = _lib.prof_read("scan_ap")
+    t_ap *= 1e-3
+    _lib.prof_enable(False)
 
     W, Lw = (K + 31) // 32, (C + 31) // 32
     alg_bytes = Rn * 4 * (W + Lw) + Q * 4 * (W + Lw) + Q * 12          # gallery once + queries + ap_sum/cap out
-    ops_pair_ap = 2 * W + (Lw + 1) + 3 + 10                            # xor+bcnt, and/or+cmp, addr/inc/ds, credit
+    ops_pair_ap = 2 * W + (Lw + 1) + 1 + 3 + 6                         # xor+bcnt, and/or3, cmp, cndmask/or/addr, credit (VALU instr per wave-item)
     roofline = {
-        "kernel": "k_scan_ap (pass 2 of xmh_hamming_ap; timed bracket includes the [Q]-wide k_ap_reduce)",
+        "kernel": "k_scan_ap (pass 2 of the fused mAP scan), HIP events around the launch, %d launches" % n_ap,
         "bound": "hbm", "achieved": alg_bytes / t_ap / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": None,
         "algorithmic_bytes": alg_bytes, "avg_launch_ms": t_ap * 1e3,
@@ -175,12 +178,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_hbm_regime:
         try:
             import bench_topk
-            out["roofline_hbm_regime"] = bench_topk.measure()
+            out["roofline_hbm_regime"] = bench_topk.measure(Q=1)
+            out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _, _, rB0, rL0 = rB, rL, rB, rL
-        out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, min(args.cpu_queries, Q))
+        out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, args.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -41,4 +41,13 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int device_cu_count();
 
+// Optional per-kernel timing for bench.py (xmh_prof_enable): HIP events recorded on the launch stream right
+// around ONE kernel launch, keyed by a short name.  Disabled by default: no events, no overhead.
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t st);
+    ~ProfScope();
+    int slot;
+    hipStream_t st;
+};
+
 }  // namespace xmh

@@ -24,7 +24,89 @@ int device_cu_count() {
     return n;
 }
 
+// ---- per-kernel event timing (bench only) ----------------------------------------------------------
+constexpr int kProfSlots = 32;
+struct ProfSlot {
+    char name[48];
+    hipEvent_t a, b;
+    bool made, pending;
+    double total_ms;
+    long count;
+};
+static ProfSlot g_prof[kProfSlots];
+static int g_prof_n = 0;
+static bool g_prof_on = false;
+
+static int prof_slot(const char* name) {
+    for (int i = 0; i < g_prof_n; ++i)
+        if (!strcmp(g_prof[i].name, name)) return i;
+    if (g_prof_n == kProfSlots) return -1;
+    ProfSlot& s = g_prof[g_prof_n];
+    snprintf(s.name, sizeof(s.name), "%s", name);
+    s.made = s.pending = false;
+    s.total_ms = 0.0;
+    s.count = 0;
+    return g_prof_n++;
+}
+
+static void prof_collect(ProfSlot& s) {
+    if (!s.pending) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+        s.total_ms += ms;
+        s.count += 1;
+    }
+    s.pending = false;
+}
+
+ProfScope::ProfScope(const char* name, hipStream_t stream) : slot(-1), st(stream) {
+    if (!g_prof_on) return;
+    slot = prof_slot(name);
+    if (slot < 0) return;
+    ProfSlot& s = g_prof[slot];
+    if (!s.made) {
+        if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) {
+            slot = -1;
+            return;
+        }
+        s.made = true;
+    }
+    prof_collect(s);                 // fold the previous launch of this kernel before re-recording
+    (void)hipEventRecord(s.a, st);
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    (void)hipEventRecord(g_prof[slot].b, st);
+    g_prof[slot].pending = true;
+}
+
 }  // namespace xmh
+
+extern "C" int xmh_prof_enable(int on) {
+    xmh::g_prof_on = on != 0;
+    for (int i = 0; i < xmh::g_prof_n; ++i) {
+        xmh::prof_collect(xmh::g_prof[i]);
+        xmh::g_prof[i].total_ms = 0.0;
+        xmh::g_prof[i].count = 0;
+    }
+    return XMH_OK;
+}
+
+extern "C" int xmh_prof_read(const char* name, double* avg_ms, int64_t* launches) {
+    if (!name || !avg_ms || !launches) return xmh::fail(XMH_EINVAL, "xmh_prof_read: null argument");
+    for (int i = 0; i < xmh::g_prof_n; ++i) {
+        if (!strcmp(xmh::g_prof[i].name, name)) {
+            xmh::prof_collect(xmh::g_prof[i]);
+            *launches = xmh::g_prof[i].count;
+            *avg_ms = xmh::g_prof[i].count ? xmh::g_prof[i].total_ms / (double)xmh::g_prof[i].count : 0.0;
+            return XMH_OK;
+        }
+    }
+    *launches = 0;
+    *avg_ms = 0.0;
+    return XMH_OK;
+}
 
 extern "C" int xmh_version(void) { return 100; }
 

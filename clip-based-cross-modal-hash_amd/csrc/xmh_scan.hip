@@ -635,6 +635,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
             auto kern = k_scan_hist<decltype(w)::value, decltype(l)::value, T, G>;
             const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
             if (r2) return r2;
+            xmh::ProfScope prof("scan_hist", st);
             hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, chunk_hist);
             return (int)XMH_OK;
         });
@@ -695,6 +696,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
             auto kern = k_scan_ap<decltype(w)::value, decltype(l)::value, T, CP, G>;
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
+            xmh::ProfScope prof("scan_ap", st);
             hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part);
             return (int)XMH_OK;
         });

@@ -712,6 +712,7 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
             const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
             int64_t fb = (int64_t)xmh::device_cu_count() * 8;                                                              \
             if (fb > ft) fb = ft;                                                                                          \
+            xmh::ProfScope prof("topk_filter", st);                                                                        \
             hipLaunchKernelGGL((k_topk_filter<WW, II>), dim3((unsigned)fb), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
                                (const uint32_t*)f.t_est, f.cnt, f.cand);                                                   \
         }

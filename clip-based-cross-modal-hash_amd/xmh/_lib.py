@@ -31,6 +31,8 @@ class ScanPlan(C.Structure):
 PROTOTYPES = {
     "xmh_version": (i32, []),
     "xmh_last_error": (C.c_char_p, []),
+    "xmh_prof_enable": (i32, [i32]),
+    "xmh_prof_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
     "xmh_pack_sign": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "xmh_pack_pair_argmax": (i32, [vp, i64, i32, vp, vp, vp]),
     "xmh_unpack_pm1": (i32, [vp, vp, i64, i32, vp, vp]),
@@ -72,3 +74,14 @@ def ptr(t):
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def prof_enable(on: bool = True) -> None:
+    check(lib.xmh_prof_enable(int(on)), "xmh_prof_enable")
+
+
+def prof_read(name: str):
+    """-> (mean launch ms, launches) of the named kernel since prof_enable(True)."""
+    ms, n = C.c_double(0.0), i64(0)
+    check(lib.xmh_prof_read(name.encode(), C.byref(ms), C.byref(n)), "xmh_prof_read")
+    return ms.value, n.value

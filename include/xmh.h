@@ -44,6 +44,12 @@ int xmh_version(void);
 /* thread-local description of the last failure on this thread ("" if none) */
 const char* xmh_last_error(void);
 
+/* Per-kernel timing for bench.py: when enabled, the library brackets its dominant kernels with HIP events
+ * on the launch stream (names: "scan_hist", "scan_ap", "topk_filter", "gemm", ...).  xmh_prof_read blocks
+ * on the last recorded event of that name and returns the mean launch duration since xmh_prof_enable(1). */
+int xmh_prof_enable(int on);
+int xmh_prof_read(const char* name_host, double* avg_ms_host, int64_t* launches_host);
+
 /* ---------------------------------------------------------------------------------------------
  * Quantisers (a-6).
  * xmh_pack_sign        replaces BaseTrainer.make_hash_code  (runners/base.py:407-410): sign -> -1/0/+1.
