@@ -1,0 +1,330 @@
+// Non-GEMM pieces of the CLIP ViT-B/32 image / text forward and of the hash heads.
+// All activations are fp32, token-major [B, L, D] (the reference works in LND; only the layout differs).
+//
+//   xmh_layernorm_f32     models/CLIP/model.py:153-159 (fp32 LayerNorm, eps 1e-5), one wave per row
+//   xmh_attention_f32     nn.MultiheadAttention inside ResidualAttentionBlock (model.py:167-197): per (batch, head)
+//                         softmax(Q K^T / sqrt(dh) + mask) V with the whole head resident in LDS (L <= 128)
+//   xmh_im2col_patch      the non-overlapping Conv2d(3, width, k=32, s=32) of VisionTransformer (model.py:219,235)
+//                         as a gather into GEMM rows (k index = c*P*P + dy*P + dx, the conv weight's own order)
+//   xmh_vit_assemble      cls token concat + positional embedding + ln_pre (model.py:237-243)
+//   xmh_text_embed        token embedding + positional embedding, EOS = argmax(ids) (model.py:374-379)
+//   xmh_gather_rows       cls / EOS row selection (model.py:262-265, :392)
+//   xmh_affine_cols       eval-mode BatchNorm1d of the DCMHT image head (models/DCMHT/hash/hash.py:22,40)
+//   xmh_pair_softmax      softmax_hash (models/common/hash.py:21-31) on relu'd logits
+// Every one of these is HBM-bound elementwise / row-reduction work; the GEMMs around them dominate the time.
+#include "xmh_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- LayerNorm: one wave per row, row cached in registers (D <= 64*16) -------------------------------
+constexpr int kLnMaxPerLane = 16;
+
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, float* __restrict__ y, int64_t ldy,
+                                                   int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float v[kLnMaxPerLane];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        v[j] = c < D ? xr[c] : 0.0f;
+        s += v[j];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        const float d = c < D ? v[j] - mean : 0.0f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float* yr = y + row * ldy;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        if (c < D) yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ---- small-sequence attention: one block per (batch, head), one thread per query row -------------------
+// qkv: [B, L, 3*H*dh] rows = tokens, columns [q | k | v] each H*dh wide (nn.MultiheadAttention in_proj order).
+// LDS: K and V of this head [L][dh+1], scores [L][L+1].
+template <int DH>
+__global__ void k_attention(const float* __restrict__ qkv, int L, int H, int causal, const uint8_t* __restrict__ kpm,
+                            float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * DH;
+    float* sK = smem;                          // [L][DH+1]
+    float* sV = sK + L * (DH + 1);             // [L][DH+1]
+    float* sS = sV + L * (DH + 1);             // [L][L+1]
+    const float* base = qkv + (int64_t)b * L * 3 * D;
+    for (int e = threadIdx.x; e < L * DH; e += blockDim.x) {
+        const int j = e / DH, c = e % DH;
+        sK[j * (DH + 1) + c] = base[(int64_t)j * 3 * D + D + h * DH + c];
+        sV[j * (DH + 1) + c] = base[(int64_t)j * 3 * D + 2 * D + h * DH + c];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= L) return;
+    float q[DH];
+    const float scale = rsqrtf((float)DH);
+#pragma unroll
+    for (int c = 0; c < DH; ++c) q[c] = base[(int64_t)i * 3 * D + h * DH + c] * scale;   // PyTorch scales q before QK^T
+    float* srow = sS + i * (L + 1);
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) s = fmaf(q[c], sK[j * (DH + 1) + c], s);
+        if ((causal && j > i) || (kpm && kpm[(int64_t)b * L + j])) s = -INFINITY;
+        srow[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.0f;
+    for (int j = 0; j < L; ++j) {
+        const float p = expf(srow[j] - mx);
+        srow[j] = p;
+        sum += p;
+    }
+    const float inv = 1.0f / sum;
+    float o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) o[c] = 0.0f;
+    for (int j = 0; j < L; ++j) {
+        const float p = srow[j] * inv;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) o[c] = fmaf(p, sV[j * (DH + 1) + c], o[c]);
+    }
+    float* orow = out + ((int64_t)b * L + i) * D + h * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) orow[c] = o[c];
+}
+
+// ---- patch gather: cols[(b*G*G + gy*G + gx)][c*P*P + dy*P + dx] = image[b][c][gy*P+dy][gx*P+dx] --------
+__global__ __launch_bounds__(256) void k_im2col_patch(const float* __restrict__ img, int64_t B, int Cin, int res, int P,
+                                                      float* __restrict__ cols) {
+    const int G = res / P;
+    const int64_t kdim = (int64_t)Cin * P * P;
+    const int64_t total4 = B * G * G * kdim / 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+        const int64_t flat = e * 4;
+        const int64_t row = flat / kdim;
+        const int k = (int)(flat % kdim);
+        const int c = k / (P * P), dy = (k / P) % P, dx = k % P;              // dx is a multiple of 4
+        const int64_t b = row / (G * G);
+        const int g = (int)(row % (G * G)), gy = g / G, gx = g % G;
+        const float4 v = *reinterpret_cast<const float4*>(img + ((b * Cin + c) * res + gy * P + dy) * res + gx * P + dx);
+        *reinterpret_cast<float4*>(cols + flat) = v;
+    }
+}
+
+// ---- x[b][0] = cls + pos[0]; x[b][1+p] = patch[b*NP+p] + pos[1+p]; then LayerNorm (ln_pre) ----------------
+__global__ __launch_bounds__(256) void k_vit_assemble(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                      const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float* __restrict__ x,
+                                                      int64_t B, int NP, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int L = NP + 1;
+    if (row >= B * L) return;
+    const int64_t b = row / L;
+    const int t = (int)(row % L);
+    const float* src = t == 0 ? cls : patch + (b * NP + (t - 1)) * D;
+    float v[kLnMaxPerLane];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        v[j] = c < D ? src[c] + pos[(int64_t)t * D + c] : 0.0f;
+        s += v[j];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        const float d = c < D ? v[j] - mean : 0.0f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float* yr = x + row * D;
+#pragma unroll
+    for (int j = 0; j < kLnMaxPerLane; ++j) {
+        const int c = j * 64 + lane;
+        if (c < D) yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ---- text: x[b][l] = tok_emb[ids[b][l]] + pos[l]; eos[b] = argmax_l ids[b][l] (first maximum) -----------
+__global__ __launch_bounds__(256) void k_text_embed(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                                    const float* __restrict__ pos, float* __restrict__ x,
+                                                    int32_t* __restrict__ eos, int64_t B, int L, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int64_t b = row / L;
+    const int l = (int)(row % L);
+    int64_t id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    for (int c = lane; c < D; c += 64) x[row * D + c] = tok[id * D + c] + pos[(int64_t)l * D + c];
+    if (l == 0 && lane == 0 && eos) {
+        int best = 0;
+        int64_t bv = ids[b * L];
+        for (int j = 1; j < L; ++j) {
+            const int64_t v = ids[b * L + j];
+            if (v > bv) {
+                bv = v;
+                best = j;
+            }
+        }
+        eos[b] = best;
+    }
+}
+
+// out[r] = x[(r*group + (idx ? idx[r] : offset))]: idx==NULL -> fixed offset inside each group of rows
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx,
+                                                     int offset, int group, float* __restrict__ out, int64_t rows, int D) {
+    const int64_t total = rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D;
+        const int c = (int)(e % D);
+        const int64_t srcrow = r * group + (idx ? idx[r] : offset);
+        out[e] = x[srcrow * ldx + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_affine_cols(const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                     int64_t rows, int D) {
+    const int64_t total = rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % D);
+        // ATen's eval-mode batch_norm: alpha = weight / sqrt(var + eps), beta' = bias - mean * alpha, y = x * alpha + beta'
+        const float alpha = (1.0f / sqrtf(var[c] + eps)) * gamma[c];
+        y[e] = x[e] * alpha + (beta[c] - mean[c] * alpha);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_softmax(const float* __restrict__ x, float* __restrict__ y, int64_t pairs) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (int64_t)gridDim.x * 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[e];
+        const float m = fmaxf(v.x, v.y);
+        const float e0 = expf(v.x - m), e1 = expf(v.y - m);
+        const float s = e0 + e1;
+        reinterpret_cast<float2*>(y)[e] = make_float2(e0 / s, e1 / s);
+    }
+}
+
+inline int grid1d(int64_t work, int per_block = 256) {
+    int64_t g = xmh::ceil_div(work, per_block);
+    const int64_t cap = (int64_t)xmh::device_cu_count() * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
+                                 int64_t ldy, int64_t rows, int D, xmh_stream_t stream) {
+    if (rows < 0 || D <= 0 || D > 64 * kLnMaxPerLane) return xmh::fail(XMH_EINVAL, "xmh_layernorm_f32: bad shape rows=%lld D=%d (D <= %d)", (long long)rows, D, 64 * kLnMaxPerLane);
+    if (rows == 0) return XMH_OK;
+    if (!x || !gamma || !beta || !y) return xmh::fail(XMH_EINVAL, "xmh_layernorm_f32: null pointer");
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)xmh::ceil_div(rows, 4)), dim3(256), 0, xmh::as_stream(stream), x, ldx, gamma, beta, eps, y, ldy, rows, D);
+    XMH_LAUNCH_CHECK("xmh_layernorm_f32");
+    return XMH_OK;
+}
+
+extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
+                                 float* out, xmh_stream_t stream) {
+    if (B < 0 || L <= 0 || H <= 0) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: bad shape");
+    if (B == 0) return XMH_OK;
+    if (dh != 64) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
+    if (L > 128) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
+    if (!qkv || !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
+    const size_t lds = ((size_t)2 * L * (dh + 1) + (size_t)L * (L + 1)) * 4;
+    const int threads = L <= 64 ? 64 : 128;
+    auto kern = k_attention<64>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_attention_f32: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(threads), lds, xmh::as_stream(stream), qkv, L, H, causal, key_padding_mask, out);
+    XMH_LAUNCH_CHECK("xmh_attention_f32");
+    return XMH_OK;
+}
+
+extern "C" int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,
+                                xmh_stream_t stream) {
+    if (B < 0 || channels <= 0 || patch <= 0 || resolution % patch || patch % 4) return xmh::fail(XMH_EINVAL, "xmh_im2col_patch: bad geometry res=%d patch=%d", resolution, patch);
+    if (B == 0) return XMH_OK;
+    if (!image || !cols) return xmh::fail(XMH_EINVAL, "xmh_im2col_patch: null pointer");
+    const int64_t total4 = B * channels * resolution * resolution / 4;
+    hipLaunchKernelGGL(k_im2col_patch, dim3(grid1d(total4)), dim3(256), 0, xmh::as_stream(stream), image, B, channels, resolution, patch, cols);
+    XMH_LAUNCH_CHECK("xmh_im2col_patch");
+    return XMH_OK;
+}
+
+extern "C" int xmh_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,
+                                float eps, float* x, int64_t B, int n_patches, int D, xmh_stream_t stream) {
+    if (B < 0 || n_patches <= 0 || D <= 0 || D > 64 * kLnMaxPerLane) return xmh::fail(XMH_EINVAL, "xmh_vit_assemble: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!patch_out || !cls || !pos || !gamma || !beta || !x) return xmh::fail(XMH_EINVAL, "xmh_vit_assemble: null pointer");
+    hipLaunchKernelGGL(k_vit_assemble, dim3((unsigned)xmh::ceil_div(B * (n_patches + 1), 4)), dim3(256), 0, xmh::as_stream(stream), patch_out, cls, pos,
+                       gamma, beta, eps, x, B, n_patches, D);
+    XMH_LAUNCH_CHECK("xmh_vit_assemble");
+    return XMH_OK;
+}
+
+extern "C" int xmh_text_embed(const int64_t* ids, const float* tok_emb, const float* pos, float* x, int32_t* eos_index, int64_t B,
+                              int L, int D, int vocab, xmh_stream_t stream) {
+    if (B < 0 || L <= 0 || D <= 0 || vocab <= 0) return xmh::fail(XMH_EINVAL, "xmh_text_embed: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!ids || !tok_emb || !pos || !x) return xmh::fail(XMH_EINVAL, "xmh_text_embed: null pointer");
+    hipLaunchKernelGGL(k_text_embed, dim3((unsigned)xmh::ceil_div(B * L, 4)), dim3(256), 0, xmh::as_stream(stream), ids, tok_emb, pos, x, eos_index, B, L, D, vocab);
+    XMH_LAUNCH_CHECK("xmh_text_embed");
+    return XMH_OK;
+}
+
+extern "C" int xmh_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int offset, int group, float* out, int64_t rows,
+                               int D, xmh_stream_t stream) {
+    if (rows < 0 || D <= 0 || group <= 0) return xmh::fail(XMH_EINVAL, "xmh_gather_rows: bad shape");
+    if (rows == 0) return XMH_OK;
+    if (!x || !out) return xmh::fail(XMH_EINVAL, "xmh_gather_rows: null pointer");
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid1d(rows * D)), dim3(256), 0, xmh::as_stream(stream), x, ldx, idx, offset, group, out, rows, D);
+    XMH_LAUNCH_CHECK("xmh_gather_rows");
+    return XMH_OK;
+}
+
+extern "C" int xmh_affine_cols(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                               float eps, float* y, int64_t rows, int D, xmh_stream_t stream) {
+    if (rows < 0 || D <= 0) return xmh::fail(XMH_EINVAL, "xmh_affine_cols: bad shape");
+    if (rows == 0) return XMH_OK;
+    if (!x || !mean || !var || !gamma || !beta || !y) return xmh::fail(XMH_EINVAL, "xmh_affine_cols: null pointer");
+    hipLaunchKernelGGL(k_affine_cols, dim3(grid1d(rows * D)), dim3(256), 0, xmh::as_stream(stream), x, mean, var, gamma, beta, eps, y, rows, D);
+    XMH_LAUNCH_CHECK("xmh_affine_cols");
+    return XMH_OK;
+}
+
+extern "C" int xmh_pair_softmax(const float* x, float* y, int64_t rows, int K, xmh_stream_t stream) {
+    if (rows < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_pair_softmax: bad shape");
+    if (rows == 0) return XMH_OK;
+    if (!x || !y) return xmh::fail(XMH_EINVAL, "xmh_pair_softmax: null pointer");
+    hipLaunchKernelGGL(k_pair_softmax, dim3(grid1d(rows * K)), dim3(256), 0, xmh::as_stream(stream), x, y, rows * K);
+    XMH_LAUNCH_CHECK("xmh_pair_softmax");
+    return XMH_OK;
+}

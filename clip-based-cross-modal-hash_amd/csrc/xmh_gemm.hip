@@ -1,0 +1,326 @@
+// Dense contraction for the encoder: C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]).
+// W is in nn.Linear layout (row n = output feature n), i.e. an "NT" GEMM -- what every Linear / in_proj /
+// out_proj / c_fc / c_proj of the reference's CLIP (models/CLIP/model.py:167-197) and hash heads computes.
+//
+// Two MFMA paths, same tiling (128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32):
+//   f32   v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- "parity mode", bit-for-bit an fmaf
+//         chain (cdna_hip_programming.md section 3); peak 157 TFLOP/s.
+//   f16   v_mfma_f32_32x32x16_f16: operands rounded to fp16 on the way into LDS, fp32 accumulate -- "fast mode";
+//         the reference's weights are fp16-exact (convert_weights, model.py:415-436) so only activations round;
+//         peak 2.5 PFLOP/s.
+// LDS tiles are [128][BK] with rows padded so that the ds_read_b128 of a 16-lane group lands on 16 distinct
+// 16-byte slots (guide section 2 / Guideline 4).  k-order inside a BK slab is permuted identically for A and
+// W (lane half h reads the contiguous k range h*BK/2 ...), which lets every lane fetch its MFMA operands with
+// two b128 reads instead of eight b32 reads; a sum over k does not care about the order of k.
+//
+// Bound: MFMA.  Algorithmic flops per launch = 2*M*N*K.
+#include "xmh_common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int kThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3, ACT_RELU = 4 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_QUICKGELU: return x * (1.0f / (1.0f + expf(-1.702f * x)));   // x * sigmoid(1.702 x), model.py:162-164
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_TANH: return tanhf(x);
+        case ACT_RELU: return x > 0.0f ? x : 0.0f;
+        default: return x;
+    }
+}
+
+struct GemmArgs {
+    const float* A;
+    const float* W;
+    const float* bias;
+    const float* residual;
+    float* C;
+    int64_t lda, ldw, ldr, ldc;
+    int M, N, K, act;
+};
+
+// XCD-aware tile order: consecutive blocks on one XCD (b, b+8, ...) walk down one column panel of W so the
+// panel stays in that XCD's L2 (guide T1, bijective form).
+__device__ __forceinline__ void tile_of_block(int nbm, int nbn, int& tm, int& tn) {
+    const int nwg = nbm * nbn;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tn = id / nbm;
+    tm = id % nbm;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f32 path: BK = 16, LDS row = 16 floats + 4 pad (80 B)
+// ---------------------------------------------------------------------------------------------------
+constexpr int BK32 = 16, LD32 = 20;
+
+__global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LD32];
+    __shared__ __attribute__((aligned(16))) float sW[2][BN * LD32];
+    const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // staging: 128 rows x 16 floats = 512 float4 per operand -> 2 per thread
+    const int srow = tid >> 2, scol = (tid & 3) * 4;          // rows srow and srow+64
+    const bool k_vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldw % 4 == 0);
+    float4 ra[2], rw[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = srow + h * 64;
+            const int k = k0 + scol;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
+            if (m0 + r < g.M) {
+                const float* p = g.A + (int64_t)(m0 + r) * g.lda + k;
+                if (k_vec && k + 3 < g.K) va = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < g.K) va.x = p[0];
+                    if (k + 1 < g.K) va.y = p[1];
+                    if (k + 2 < g.K) va.z = p[2];
+                    if (k + 3 < g.K) va.w = p[3];
+                }
+            }
+            if (n0 + r < g.N) {
+                const float* p = g.W + (int64_t)(n0 + r) * g.ldw + k;
+                if (k_vec && k + 3 < g.K) vw = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < g.K) vw.x = p[0];
+                    if (k + 1 < g.K) vw.y = p[1];
+                    if (k + 2 < g.K) vw.z = p[2];
+                    if (k + 3 < g.K) vw.w = p[3];
+                }
+            }
+            ra[h] = va;
+            rw[h] = vw;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = srow + h * 64;
+            *reinterpret_cast<float4*>(&sA[buf][r * LD32 + scol]) = ra[h];
+            *reinterpret_cast<float4*>(&sW[buf][r * LD32 + scol]) = rw[h];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = (g.K + BK32 - 1) / BK32;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;                  // fragment row/col, k half
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK32);               // global loads fly under the MFMAs below
+        float4 a[2][2], b[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* pa = &sA[buf][(wm + i * 32 + fr) * LD32 + fh * 8];
+            const float* pb = &sW[buf][(wn + i * 32 + fr) * LD32 + fh * 8];
+            a[i][0] = *reinterpret_cast<const float4*>(pa);
+            a[i][1] = *reinterpret_cast<const float4*>(pa + 4);
+            b[i][0] = *reinterpret_cast<const float4*>(pb);
+            b[i][1] = *reinterpret_cast<const float4*>(pb + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float av = reinterpret_cast<const float*>(&a[i][0])[s];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float bv = reinterpret_cast<const float*>(&b[j][0])[s];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nk) {
+            swrite(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds column (lane&31) and rows (e&3) + 8*(e>>2) + 4*(lane>>5) of each 32x32 tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][e] + bv, g.act);
+                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f16 path: BK = 32, operands rounded to fp16 when staged; LDS row = 32 halves + 8 pad (80 B)
+// v_mfma_f32_32x32x16_f16: lane l supplies A[i=l&31][k = 8*(l>>5) .. +7] (8 halves), same for B.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BK16 = 32, LD16 = 40;
+
+__global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LD16];
+    __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LD16];
+    const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // staging: 128 rows x 32 floats = 1024 float4 per operand -> 4 per thread
+    const int srow = tid >> 3, scol = (tid & 7) * 4;           // rows srow + 32*h
+    const bool k_vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldw % 4 == 0);
+    float4 ra[4], rw[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int r = srow + h * 32;
+            const int k = k0 + scol;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
+            if (m0 + r < g.M) {
+                const float* p = g.A + (int64_t)(m0 + r) * g.lda + k;
+                if (k_vec && k + 3 < g.K) va = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < g.K) va.x = p[0];
+                    if (k + 1 < g.K) va.y = p[1];
+                    if (k + 2 < g.K) va.z = p[2];
+                    if (k + 3 < g.K) va.w = p[3];
+                }
+            }
+            if (n0 + r < g.N) {
+                const float* p = g.W + (int64_t)(n0 + r) * g.ldw + k;
+                if (k_vec && k + 3 < g.K) vw = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < g.K) vw.x = p[0];
+                    if (k + 1 < g.K) vw.y = p[1];
+                    if (k + 2 < g.K) vw.z = p[2];
+                    if (k + 3 < g.K) vw.w = p[3];
+                }
+            }
+            ra[h] = va;
+            rw[h] = vw;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int r = srow + h * 32;
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 pa, pw;
+            pa[0] = (_Float16)ra[h].x; pa[1] = (_Float16)ra[h].y; pa[2] = (_Float16)ra[h].z; pa[3] = (_Float16)ra[h].w;
+            pw[0] = (_Float16)rw[h].x; pw[1] = (_Float16)rw[h].y; pw[2] = (_Float16)rw[h].z; pw[3] = (_Float16)rw[h].w;
+            *reinterpret_cast<h4*>(&sA[buf][r * LD16 + scol]) = pa;
+            *reinterpret_cast<h4*>(&sW[buf][r * LD16 + scol]) = pw;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = (g.K + BK16 - 1) / BK16;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK16);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                          // two k-slabs of 16 per BK
+            f16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const f16x8*>(&sA[buf][(wm + i * 32 + fr) * LD16 + s * 16 + fh * 8]);
+                b[i] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + i * 32 + fr) * LD16 + s * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            swrite(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][e] + bv, g.act);
+                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                               const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                               int act, int precision, xmh_stream_t stream) {
+    if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    if (M == 0 || N == 0) return XMH_OK;
+    if (!A || !W || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: null pointer");
+    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: leading dimension too small");
+    if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: unknown activation %d", act);
+    if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_f32: dimension >= 2^31");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
+    const int64_t nblk = xmh::ceil_div(M, BM) * xmh::ceil_div(N, BN);
+    hipStream_t st = xmh::as_stream(stream);
+    xmh::ProfScope prof(precision == 1 ? "gemm_f16" : "gemm_f32", st);
+    if (precision == 0) hipLaunchKernelGGL(k_gemm_nt_f32, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    else if (precision == 1) hipLaunchKernelGGL(k_gemm_nt_f16, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    else return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: precision must be 0 (f32 MFMA) or 1 (f16 MFMA, f32 accumulate)");
+    XMH_LAUNCH_CHECK("xmh_gemm_nt_f32");
+    return XMH_OK;
+}

@@ -43,6 +43,15 @@ PROTOTYPES = {
     "xmh_hamming_hist": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp]),
     "xmh_hamming_ap": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp, i64, vp, vp, vp]),
     "xmh_map_finalize": (i32, [vp, vp, i64, vp, vp]),
+    "xmh_gemm_nt_f32": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, i32, vp]),
+    "xmh_layernorm_f32": (i32, [vp, i64, vp, vp, C.c_float, vp, i64, i64, i32, vp]),
+    "xmh_attention_f32": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
+    "xmh_im2col_patch": (i32, [vp, i64, i32, i32, i32, vp, vp]),
+    "xmh_vit_assemble": (i32, [vp, vp, vp, vp, vp, C.c_float, vp, i64, i32, i32, vp]),
+    "xmh_text_embed": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "xmh_gather_rows": (i32, [vp, i64, vp, i32, i32, vp, i64, i32, vp]),
+    "xmh_affine_cols": (i32, [vp, vp, vp, vp, vp, C.c_float, vp, i64, i32, vp]),
+    "xmh_pair_softmax": (i32, [vp, vp, i64, i32, vp]),
     "xmh_topk_ws_bytes": (sz, [i64, i64, i32, i32]),
     "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
 }

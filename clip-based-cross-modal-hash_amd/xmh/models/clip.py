@@ -1,0 +1,162 @@
+"""CLIP ViT-B/32 image and text towers executed by libxmh.so.
+
+The ``nn.Module`` tree below exists to hold parameters under the reference's state_dict key names
+(``visual.conv1.weight``, ``transformer.resblocks.3.attn.in_proj_weight`` ... -- SURVEY 8c), so reference
+checkpoints load with ``load_state_dict``; none of its torch ``forward`` methods is ever called.  The forward
+pass is the kernel chain of SURVEY 2.2:
+
+  image: im2col -> GEMM(conv1) -> cls/pos/ln_pre -> 12 x [LN, GEMM qkv, attention, GEMM out + residual,
+         LN, GEMM c_fc + QuickGELU, GEMM c_proj + residual] -> ln_post -> GEMM proj
+         (reference models/CLIP/model.py:232-268, :167-197)
+  text : embed + pos -> 12 blocks with the causal mask (+ key padding mask) -> ln_final -> GEMM
+         text_projection -> EOS row (reference :373-396)
+
+Differences, deliberate: activations are token-major [B, L, D] (the reference permutes to LND); attention weights
+are not materialised (no in-scope caller consumes them); with ``return_patches=False`` ln_post / the projection run
+on the cls / EOS row only (the reference projects every token and then discards all but one, :257-265)."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class _Block(nn.Module):
+    def __init__(self, width: int, heads: int):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(width, heads)
+        self.ln_1 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, width * 4)), ("gelu", nn.Identity()),
+                                              ("c_proj", nn.Linear(width * 4, width))]))
+        self.ln_2 = nn.LayerNorm(width)
+        self.heads = heads
+
+    def run(self, x: torch.Tensor, causal: bool, kpm) -> torch.Tensor:
+        h = ops.layernorm(x, self.ln_1.weight, self.ln_1.bias)
+        qkv = ops.gemm_nt(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        a = ops.attention(qkv, self.heads, causal=causal, key_padding_mask=kpm)
+        x = ops.gemm_nt(a, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=x, out=x)
+        h = ops.layernorm(x, self.ln_2.weight, self.ln_2.bias)
+        f = ops.gemm_nt(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+        return ops.gemm_nt(f, self.mlp.c_proj.weight, self.mlp.c_proj.bias, residual=x, out=x)
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[_Block(width, heads) for _ in range(layers)])
+
+    def run(self, x: torch.Tensor, causal: bool = False, key_padding_mask=None) -> torch.Tensor:
+        """x [B, L, D] fp32 on the GPU; updated in place and returned."""
+        for blk in self.resblocks:
+            x = blk.run(x, causal, key_padding_mask)
+        return x
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, return_patches=False):
+        super().__init__()
+        self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        self.class_embedding = nn.Parameter(torch.zeros(width))
+        self.positional_embedding = nn.Parameter(torch.zeros((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(torch.zeros(width, output_dim))
+        self.return_patches = return_patches
+
+    def run(self, image: torch.Tensor):
+        B = image.shape[0]
+        width = self.conv1.weight.shape[0]
+        n_patches = self.positional_embedding.shape[0] - 1
+        cols = ops.im2col_patch(image, self.patch_size)
+        patches = ops.gemm_nt(cols, self.conv1.weight.reshape(width, -1))
+        x = ops.vit_assemble(patches, self.class_embedding, self.positional_embedding, self.ln_pre.weight, self.ln_pre.bias, B, n_patches)
+        x = self.transformer.run(x)
+        proj_t = self.proj.t().contiguous()
+        L = n_patches + 1
+        if not self.return_patches:
+            cls = ops.gather_rows(x, group=L, offset=0)
+            cls = ops.layernorm(cls, self.ln_post.weight, self.ln_post.bias)
+            return ops.gemm_nt(cls, proj_t)
+        y = ops.gemm_nt(ops.layernorm(x, self.ln_post.weight, self.ln_post.bias), proj_t)      # [B, L, out]
+        return y[:, 0, :], y[:, 1:, :].permute(1, 0, 2), None                                    # cls, tokens (LND), attn
+
+
+class CLIP(nn.Module):
+    def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 vocab_size, transformer_width, transformer_heads, transformer_layers, return_patches=False):
+        super().__init__()
+        self.context_length, self.vocab_size, self.return_patches = context_length, vocab_size, return_patches
+        self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers, vision_width // 64,
+                                        embed_dim, return_patches=return_patches)
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads)
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.zeros(context_length, transformer_width))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.zeros(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]))
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    @torch.no_grad()
+    def encode_image(self, image):
+        return self.visual.run(image)
+
+    @torch.no_grad()
+    def encode_text(self, text, key_padding_mask=None):
+        x, eos = ops.text_embed(text, self.token_embedding.weight, self.positional_embedding)
+        B, L, _ = x.shape
+        kpm = None if key_padding_mask is None else key_padding_mask.to(x.device)
+        x = self.transformer.run(x, causal=True, key_padding_mask=kpm)
+        proj_t = self.text_projection.t().contiguous()
+        if not self.return_patches:
+            e = ops.gather_rows(x, group=L, idx=eos)
+            return ops.gemm_nt(ops.layernorm(e, self.ln_final.weight, self.ln_final.bias), proj_t)
+        y = ops.gemm_nt(ops.layernorm(x, self.ln_final.weight, self.ln_final.bias), proj_t)        # [B, L, out]
+        eos_tok = ops.gather_rows(y, group=L, idx=eos)
+        new_mask = None if kpm is None else (kpm.bool() | (text.to(x.device) == self.vocab_size - 1))
+        return eos_tok, y.permute(1, 0, 2), None, new_mask
+
+
+def round_like_convert_weights(model: CLIP) -> None:
+    """The reference casts Conv/Linear/MultiheadAttention/proj tensors to fp16 before loading the checkpoint
+    (convert_weights, models/CLIP/model.py:415-436) and the runner later calls .float(): those tensors end up as
+    fp16-rounded fp32.  Same rounding here, applied after load."""
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                m.weight.copy_(m.weight.half().float())
+                if m.bias is not None:
+                    m.bias.copy_(m.bias.half().float())
+            if isinstance(m, nn.MultiheadAttention):
+                m.in_proj_weight.copy_(m.in_proj_weight.half().float())
+                m.in_proj_bias.copy_(m.in_proj_bias.half().float())
+        for p in (model.visual.proj, model.text_projection):
+            p.copy_(p.half().float())
+
+
+def build_model(state_dict: dict, return_patches: bool = False) -> CLIP:
+    """Infer the architecture from tensor shapes like the reference's build_model (models/CLIP/model.py:438-489);
+    ViT checkpoints only (the ResNet branch is unused by every config)."""
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("only ViT CLIP checkpoints are supported (no config of the reference uses RN50)")
+    vw = state_dict["visual.conv1.weight"].shape[0]
+    v_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    patch = state_dict["visual.conv1.weight"].shape[-1]
+    grid = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    tw = state_dict["ln_final.weight"].shape[0]
+    t_layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(state_dict["text_projection"].shape[1], patch * grid, v_layers, vw, patch, state_dict["positional_embedding"].shape[0],
+                 state_dict["token_embedding.weight"].shape[0], tw, tw // 64, t_layers, return_patches=return_patches)
+    sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model.load_state_dict(sd)
+    round_like_convert_weights(model)
+    return model.float().eval()

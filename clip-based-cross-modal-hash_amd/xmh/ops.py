@@ -1,0 +1,136 @@
+"""Host wrappers of the encoder primitives in libxmh.so (see include/xmh.h).  They allocate outputs with
+torch and pass raw device pointers + the current HIP stream; no arithmetic happens in Python."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import check, current_stream, lib, ptr
+
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH, ACT_RELU = range(5)
+PREC_F32, PREC_F16 = 0, 1
+
+_precision = PREC_F32
+
+
+def set_precision(name: str) -> None:
+    """'f32' = exact fp32 MFMA (parity mode, default); 'f16' = fp16 operands / fp32 accumulate (fast mode)."""
+    global _precision
+    _precision = {"f32": PREC_F32, "f16": PREC_F16}[name]
+
+
+def get_precision() -> str:
+    return "f16" if _precision == PREC_F16 else "f32"
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("xmh ops need CUDA/HIP tensors (got %s); there is no CPU fallback" % t.device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """view as [rows, D] with a single row stride (what the kernels take as leading dimension)."""
+    t = _f32c(t)
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.stride(-1) == 1 else t2.contiguous()
+
+
+def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            act: int = ACT_NONE, out: Optional[torch.Tensor] = None, precision: Optional[int] = None) -> torch.Tensor:
+    """act(A @ W^T + bias) (+ residual); A [..., K], W [N, K] (nn.Linear layout) -> [..., N]."""
+    lead = A.shape[:-1]
+    A2, W2 = _rows(A), _rows(W)
+    M, K = A2.shape
+    N = W2.shape[0]
+    if W2.shape[1] != K:
+        raise ValueError("gemm_nt: A is [*, %d] but W is [%d, %d]" % (K, N, W2.shape[1]))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
+    out2 = out.reshape(-1, N)
+    res2 = None if residual is None else _rows(residual)
+    b = None if bias is None else _f32c(bias)
+    check(lib.xmh_gemm_nt_f32(ptr(A2), A2.stride(0), ptr(W2), W2.stride(0), ptr(b), ptr(res2), 0 if res2 is None else res2.stride(0),
+                              ptr(out2), out2.stride(0), M, N, K, act, _precision if precision is None else precision,
+                              current_stream()), "xmh_gemm_nt_f32")
+    return out2.reshape(*lead, N)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    x2 = _rows(x)
+    y = torch.empty_like(x2)
+    check(lib.xmh_layernorm_f32(ptr(x2), x2.stride(0), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps, ptr(y), y.stride(0), x2.shape[0],
+                                x2.shape[1], current_stream()), "xmh_layernorm_f32")
+    return y.reshape(x.shape)
+
+
+def attention(qkv: torch.Tensor, heads: int, causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [B, L, 3*D] -> [B, L, D]; key_padding_mask [B, L] bool/uint8 (True = ignore that key)."""
+    qkv = _f32c(qkv).contiguous()
+    B, L, D3 = qkv.shape
+    D = D3 // 3
+    kpm = None
+    if key_padding_mask is not None:
+        kpm = key_padding_mask.to(device=qkv.device, dtype=torch.uint8).contiguous()
+    out = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
+    check(lib.xmh_attention_f32(ptr(qkv), B, L, heads, D // heads, int(causal), ptr(kpm), ptr(out), current_stream()), "xmh_attention_f32")
+    return out
+
+
+def im2col_patch(image: torch.Tensor, patch: int) -> torch.Tensor:
+    image = _f32c(image).contiguous()
+    B, Cin, H, Wd = image.shape
+    if H != Wd:
+        raise ValueError("square images only")
+    G = H // patch
+    cols = torch.empty(B * G * G, Cin * patch * patch, dtype=torch.float32, device=image.device)
+    check(lib.xmh_im2col_patch(ptr(image), B, Cin, H, patch, ptr(cols), current_stream()), "xmh_im2col_patch")
+    return cols
+
+
+def vit_assemble(patch_out, cls, pos, gamma, beta, B: int, n_patches: int, eps: float = 1e-5) -> torch.Tensor:
+    D = patch_out.shape[-1]
+    x = torch.empty(B, n_patches + 1, D, dtype=torch.float32, device=patch_out.device)
+    check(lib.xmh_vit_assemble(ptr(_rows(patch_out)), ptr(_f32c(cls)), ptr(_f32c(pos).contiguous()), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps,
+                               ptr(x), B, n_patches, D, current_stream()), "xmh_vit_assemble")
+    return x
+
+
+def text_embed(ids: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor):
+    if not ids.is_cuda:
+        raise RuntimeError("xmh ops need CUDA/HIP tensors; there is no CPU fallback")
+    ids = ids.to(torch.int64).contiguous()
+    B, L = ids.shape
+    tok, pos = _f32c(tok_emb).contiguous(), _f32c(pos).contiguous()
+    D = tok.shape[1]
+    x = torch.empty(B, L, D, dtype=torch.float32, device=ids.device)
+    eos = torch.empty(B, dtype=torch.int32, device=ids.device)
+    check(lib.xmh_text_embed(ptr(ids), ptr(tok), ptr(pos), ptr(x), ptr(eos), B, L, D, tok.shape[0], current_stream()), "xmh_text_embed")
+    return x, eos
+
+
+def gather_rows(x: torch.Tensor, group: int, idx: Optional[torch.Tensor] = None, offset: int = 0) -> torch.Tensor:
+    """x [R*group, D] -> [R, D]: row r*group + (idx[r] | offset)."""
+    x2 = _rows(x)
+    rows = x2.shape[0] // group
+    out = torch.empty(rows, x2.shape[1], dtype=torch.float32, device=x2.device)
+    check(lib.xmh_gather_rows(ptr(x2), x2.stride(0), ptr(idx), offset, group, ptr(out), rows, x2.shape[1], current_stream()), "xmh_gather_rows")
+    return out
+
+
+def affine_cols(x, mean, var, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    x2 = _rows(x).contiguous()
+    y = torch.empty_like(x2)
+    check(lib.xmh_affine_cols(ptr(x2), ptr(_f32c(mean)), ptr(_f32c(var)), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps, ptr(y), x2.shape[0],
+                              x2.shape[1], current_stream()), "xmh_affine_cols")
+    return y
+
+
+def pair_softmax(x: torch.Tensor) -> torch.Tensor:
+    x2 = _rows(x).contiguous()
+    y = torch.empty_like(x2)
+    check(lib.xmh_pair_softmax(ptr(x2), ptr(y), x2.shape[0], x2.shape[1] // 2, current_stream()), "xmh_pair_softmax")
+    return y

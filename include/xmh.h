@@ -140,6 +140,49 @@ int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, in
                      int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
                      xmh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Encoder primitives (a-9 .. a-12).  fp32 activations, token-major [B, L, D].  The Python model classes
+ * (xmh/models) chain them exactly like models/CLIP/model.py chains torch ops.
+ * ------------------------------------------------------------------------------------------- */
+#define XMH_ACT_NONE 0
+#define XMH_ACT_QUICKGELU 1   /* x * sigmoid(1.702 x), models/CLIP/model.py:162-164 */
+#define XMH_ACT_GELU_ERF 2    /* nn.GELU() of the MITH ResidualMLPs, models/MITH/hash/hash.py:22 */
+#define XMH_ACT_TANH 3
+#define XMH_ACT_RELU 4
+#define XMH_PREC_F32 0        /* v_mfma_f32_32x32x2_f32: exact fp32 products ("parity mode") */
+#define XMH_PREC_F16 1        /* operands rounded to fp16, fp32 accumulate ("fast mode")     */
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]).  W in nn.Linear layout.  bias / residual may
+ * be NULL.  Replaces every nn.Linear / MultiheadAttention projection / x @ proj of the reference's encoder. */
+int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                    const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                    int act, int precision, xmh_stream_t stream);
+/* models/CLIP/model.py:153-159 (fp32 LayerNorm) */
+int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
+                      int64_t ldy, int64_t rows, int D, xmh_stream_t stream);
+/* nn.MultiheadAttention core inside ResidualAttentionBlock (models/CLIP/model.py:167-197):
+ * qkv [B, L, 3*H*dh] -> out [B, L, H*dh]; causal != 0 applies build_attention_mask (:358-364);
+ * key_padding_mask [B, L] bytes (non-zero = ignore key) or NULL. */
+int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
+                      float* out, xmh_stream_t stream);
+/* VisionTransformer.conv1 input gather (models/CLIP/model.py:219,235): image [B,C,res,res] -> cols [B*G*G, C*P*P] */
+int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,
+                     xmh_stream_t stream);
+/* class token + positional embedding + ln_pre (models/CLIP/model.py:237-243) -> x [B, n_patches+1, D] */
+int xmh_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,
+                     float eps, float* x, int64_t B, int n_patches, int D, xmh_stream_t stream);
+/* token + positional embedding and EOS position = argmax(ids) (models/CLIP/model.py:374-379) */
+int xmh_text_embed(const int64_t* ids, const float* tok_emb, const float* pos, float* x, int32_t* eos_index, int64_t B,
+                   int L, int D, int vocab, xmh_stream_t stream);
+/* out[r] = x[r*group + (idx ? idx[r] : offset)]   (cls row: offset 0, group L; EOS row: idx) */
+int xmh_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int offset, int group, float* out, int64_t rows,
+                    int D, xmh_stream_t stream);
+/* eval BatchNorm1d of the DCMHT image head (models/DCMHT/hash/hash.py:22,40) */
+int xmh_affine_cols(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                    float eps, float* y, int64_t rows, int D, xmh_stream_t stream);
+/* softmax over each consecutive pair: softmax_hash (models/common/hash.py:21-31); x, y [rows, 2K] */
+int xmh_pair_softmax(const float* x, float* y, int64_t rows, int K, xmh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""Pin the encoder oracle (oracle/encode.py) against goldens produced by the reference's own modules (CPU only)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import encode as enc
+
+
+def _weights():
+    from xmh.models import weights
+    return weights
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+
+def test_clip_towers_match_reference_goldens():
+    g = np.load(os.path.join(GOLDEN, "encode_clip_b2.npz"))
+    W = _weights()
+    seed = int(g["seed"])
+    sd = enc.fp16_round_like_reference(W.synth_clip_state_dict(seed))
+    image = W.synth_images(seed, 2)
+    ids, pad = W.synth_text(seed, 2)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        probe = []
+        cls = enc.clip_image(sd, image, probe=probe)
+        assert _rel(cls, g["img_cls"]) < 2e-5
+        assert _rel(torch.stack(probe), g["img_block_cls"]) < 2e-5
+        assert _rel(enc.clip_text(sd, ids), g["txt_eos"]) < 2e-5
+        cls2, tok = enc.clip_image(sd, image, return_patches=True)
+        assert _rel(cls2, g["img_cls_rp"]) < 2e-5 and _rel(tok, g["img_tokens_rp"]) < 2e-5
+        eos, ttok, nm = enc.clip_text(sd, ids, key_padding_mask=pad, return_patches=True)
+        assert _rel(eos, g["txt_eos_rp"]) < 2e-5
+        assert np.array_equal(nm.numpy(), g["txt_mask_rp"])
+        keep = ~g["txt_mask_rp"].T                                    # [L, B]: padded rows are NaN-free but unspecified
+        assert _rel(ttok.numpy()[keep], g["txt_tokens_rp"][keep]) < 2e-5
+
+
+def head_params(W, seed, prefix, shapes):
+    return {k: v for k, v in shapes.items()}
+
+
+def dcmht_params(W, seed, K, modality):
+    """the same named tensors oracle/make_golden_encode.py loaded into the reference head."""
+    pre = "dcmht%d.%s_hash." % (K, modality)
+    p = {
+        "atten.in_proj_weight": W.synth_tensor(seed, pre + "atten.in_proj_weight", (1536, 512), 0.05),
+        "atten.in_proj_bias": W.synth_tensor(seed, pre + "atten.in_proj_bias", (1536,), 0.02),
+        "atten.out_proj.weight": W.synth_tensor(seed, pre + "atten.out_proj.weight", (512, 512), 0.05),
+        "atten.out_proj.bias": W.synth_tensor(seed, pre + "atten.out_proj.bias", (512,), 0.02),
+        "norm.weight": 1.0 + W.synth_tensor(seed, pre + "norm.weight", (512,), 0.1),
+        "norm.bias": W.synth_tensor(seed, pre + "norm.bias", (512,), 0.02),
+        "fc2.weight": W.synth_tensor(seed, pre + "fc2.weight", (2 * K, 512), 0.05),
+        "fc2.bias": W.synth_tensor(seed, pre + "fc2.bias", (2 * K,), 0.02),
+    }
+    if modality == "img":
+        p["norm.running_mean"] = W.synth_tensor(seed, pre + "norm.running_mean", (512,), 0.02)
+        p["norm.running_var"] = W.synth_tensor(seed, pre + "norm.running_var", (512,), 0.2).abs() + 0.5
+    return p
+
+
+def dsph_params(W, seed, K, modality):
+    pre = "dsph%d.%s_hash." % (K, modality)
+    return {"fc.weight": W.synth_tensor(seed, pre + "fc.weight", (K, 512), 0.05), "fc.bias": W.synth_tensor(seed, pre + "fc.bias", (K,), 0.02)}
+
+
+def test_heads_match_reference_goldens():
+    from oracle import retrieval as orc
+    g = np.load(os.path.join(GOLDEN, "encode_heads.npz"))
+    W = _weights()
+    seed = int(g["seed"])
+    emb = torch.from_numpy(g["emb"])
+    assert torch.equal(emb, W.synth_tensor(seed, "head_input", (40, 512), 0.5))
+    for K in (16, 64):
+        for mod in ("img", "txt"):
+            out = enc.dcmht_head(dcmht_params(W, seed, K, mod), emb, image=(mod == "img"))
+            assert np.abs(out.numpy() - g["dcmht%d_%s" % (K, mod)]).max() < 2e-6
+            code = orc.hash_code_pair_argmax(out.clone()).numpy()
+            assert (code != g["dcmht%d_%s_code" % (K, mod)]).mean() < 0.002        # only 1-ulp near-ties may differ
+    for mod in ("img", "txt"):
+        out = enc.dsph_head(dsph_params(W, seed, 128, mod), emb)
+        assert np.abs(out.numpy() - g["dsph128_%s" % mod]).max() < 2e-6
+        assert (np.sign(out.numpy()) != g["dsph128_%s_code" % mod]).mean() < 0.002
