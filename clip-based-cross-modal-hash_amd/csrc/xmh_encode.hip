@@ -11,6 +11,8 @@
 //   xmh_gather_rows       cls / EOS row selection (model.py:262-265, :392)
 //   xmh_affine_cols       eval-mode BatchNorm1d of the DCMHT image head (models/DCMHT/hash/hash.py:22,40)
 //   xmh_pair_softmax      softmax_hash (models/common/hash.py:21-31) on relu'd logits
+//   xmh_lta_aggregate     MITH LocalizedTokenAggregation + positional encoding (models/MITH/hash/hash.py:41-65,109-169)
+//   xmh_bitwise_hash      MITH BitwiseHashing (models/MITH/hash/hash.py:68-85)
 // Every one of these is HBM-bound elementwise / row-reduction work; the GEMMs around them dominate the time.
 #include "xmh_common.h"
 
@@ -229,6 +231,93 @@ __global__ __launch_bounds__(256) void k_pair_softmax(const float* __restrict__ 
     }
 }
 
+
+// ---- MITH LocalizedTokenAggregation (models/MITH/hash/hash.py:109-169) + positional encoding (:41-65) ----------
+// One block per sample.  S [B, L, K] concept scores (tanh outputs), X [B, L, D] raw CLIP tokens.
+//   sim = S (+ -inf on masked tokens); sim = sim > 0 ? sim : -inf                                   (:142-153)
+//   per token keep the concepts >= its 8th-largest score (ties kept), others -inf                     (:114-124)
+//   softmax over the TOKEN axis per (sample, concept); a concept with no token gives NaN -> 0         (:159-160)
+//   M[b,k,:] = sum_l A[b,k,l] X[b,l,:]   (+ pe[k,:], the sin/cos table already divided by sqrt(D))    (:164-168, :63)
+__global__ __launch_bounds__(256) void k_lta_aggregate(const float* __restrict__ S, const float* __restrict__ X,
+                                                       const uint8_t* __restrict__ mask, const float* __restrict__ pe,
+                                                       float* __restrict__ M, int L, int K, int D, int topk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [L][K+1]
+    const int b = blockIdx.x;
+    const int ld = K + 1;
+    for (int e = threadIdx.x; e < L * K; e += 256) {
+        const int l = e / K, k = e % K;
+        float v = S[((int64_t)b * L + l) * K + k];
+        if (mask && mask[(int64_t)b * L + l]) v = -INFINITY;
+        sm[l * ld + k] = v > 0.0f ? v : -INFINITY;
+    }
+    __syncthreads();
+    // per-token top-k threshold: the value v with #(> v) < topk <= #(>= v)
+    for (int l = threadIdx.x; l < L; l += 256) {
+        float* row = sm + l * ld;
+        float thr = -INFINITY;
+        for (int i = 0; i < K; ++i) {
+            const float v = row[i];
+            int gt = 0, ge = 0;
+            for (int j = 0; j < K; ++j) {
+                gt += row[j] > v;
+                ge += row[j] >= v;
+            }
+            if (gt < topk && topk <= ge) thr = v;
+        }
+        for (int i = 0; i < K; ++i)
+            if (!(row[i] >= thr)) row[i] = -INFINITY;
+    }
+    __syncthreads();
+    // softmax over tokens per concept
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float mx = -INFINITY;
+        for (int l = 0; l < L; ++l) mx = fmaxf(mx, sm[l * ld + k]);
+        if (mx == -INFINITY) {
+            for (int l = 0; l < L; ++l) sm[l * ld + k] = 0.0f;                       // NaN -> 0 in the reference
+        } else {
+            float sum = 0.0f;
+            for (int l = 0; l < L; ++l) {
+                const float p = expf(sm[l * ld + k] - mx);
+                sm[l * ld + k] = p;
+                sum += p;
+            }
+            for (int l = 0; l < L; ++l) sm[l * ld + k] = sm[l * ld + k] / sum;
+        }
+    }
+    __syncthreads();
+    // aggregate: thread owns feature columns d, walks concepts
+    for (int d = threadIdx.x; d < D; d += 256) {
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+            for (int l = 0; l < L; ++l) {
+                const float x = X[((int64_t)b * L + l) * D + d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < K) acc[u] = fmaf(sm[l * ld + k0 + u], x, acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < K) M[((int64_t)b * K + k0 + u) * D + d] = acc[u] + (pe ? pe[(int64_t)(k0 + u) * D + d] : 0.0f);
+        }
+    }
+}
+
+// ---- MITH BitwiseHashing (models/MITH/hash/hash.py:68-85): out[b,k] = tanh(w_k . z[b,k,:] + bias_k) (+ addend) ----
+__global__ __launch_bounds__(256) void k_bitwise_hash(const float* __restrict__ Z, const float* __restrict__ Wb,
+                                                      const float* __restrict__ bias, const float* __restrict__ addend,
+                                                      float* __restrict__ out, int64_t rows, int K, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // r = b*K + k
+    if (r >= rows) return;
+    const int k = (int)(r % K);
+    float s = 0.0f;
+    for (int c = lane; c < D; c += 64) s = fmaf(Z[r * D + c], Wb[(int64_t)k * D + c], s);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = tanhf(s + bias[k]) + (addend ? addend[r] : 0.0f);
+}
+
 inline int grid1d(int64_t work, int per_block = 256) {
     int64_t g = xmh::ceil_div(work, per_block);
     const int64_t cap = (int64_t)xmh::device_cu_count() * 16;
@@ -326,5 +415,31 @@ extern "C" int xmh_pair_softmax(const float* x, float* y, int64_t rows, int K, x
     if (!x || !y) return xmh::fail(XMH_EINVAL, "xmh_pair_softmax: null pointer");
     hipLaunchKernelGGL(k_pair_softmax, dim3(grid1d(rows * K)), dim3(256), 0, xmh::as_stream(stream), x, y, rows * K);
     XMH_LAUNCH_CHECK("xmh_pair_softmax");
+    return XMH_OK;
+}
+
+extern "C" int xmh_lta_aggregate(const float* scores, const float* tokens, const uint8_t* token_mask, const float* pos_enc,
+                                 float* out, int64_t B, int L, int K, int D, int top_k, xmh_stream_t stream) {
+    if (B < 0 || L <= 0 || K <= 0 || D <= 0 || top_k <= 0 || top_k > K) return xmh::fail(XMH_EINVAL, "xmh_lta_aggregate: bad shape L=%d K=%d top_k=%d", L, K, top_k);
+    if (B == 0) return XMH_OK;
+    if (!scores || !tokens || !out) return xmh::fail(XMH_EINVAL, "xmh_lta_aggregate: null pointer");
+    const size_t lds = (size_t)L * (K + 1) * 4;
+    if (lds > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "xmh_lta_aggregate: L*K too large for LDS");
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lta_aggregate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_lta_aggregate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_lta_aggregate, dim3((unsigned)B), dim3(256), lds, xmh::as_stream(stream), scores, tokens, token_mask, pos_enc, out, L, K, D, top_k);
+    XMH_LAUNCH_CHECK("xmh_lta_aggregate");
+    return XMH_OK;
+}
+
+extern "C" int xmh_bitwise_hash(const float* z, const float* w, const float* bias, const float* addend, float* out, int64_t B,
+                                int K, int D, xmh_stream_t stream) {
+    if (B < 0 || K <= 0 || D <= 0) return xmh::fail(XMH_EINVAL, "xmh_bitwise_hash: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!z || !w || !bias || !out) return xmh::fail(XMH_EINVAL, "xmh_bitwise_hash: null pointer");
+    hipLaunchKernelGGL(k_bitwise_hash, dim3((unsigned)xmh::ceil_div(B * K, 4)), dim3(256), 0, xmh::as_stream(stream), z, w, bias, addend, out, B * K, K, D);
+    XMH_LAUNCH_CHECK("xmh_bitwise_hash");
     return XMH_OK;
 }

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "xmh_gather_rows": (i32, [vp, i64, vp, i32, i32, vp, i64, i32, vp]),
     "xmh_affine_cols": (i32, [vp, vp, vp, vp, vp, C.c_float, vp, i64, i32, vp]),
     "xmh_pair_softmax": (i32, [vp, vp, i64, i32, vp]),
+    "xmh_lta_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "xmh_bitwise_hash": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "xmh_topk_ws_bytes": (sz, [i64, i64, i32, i32]),
     "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
 }

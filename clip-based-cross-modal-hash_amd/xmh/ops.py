@@ -134,3 +134,27 @@ def pair_softmax(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x2)
     check(lib.xmh_pair_softmax(ptr(x2), ptr(y), x2.shape[0], x2.shape[1] // 2, current_stream()), "xmh_pair_softmax")
     return y
+
+
+def lta_aggregate(scores: torch.Tensor, tokens: torch.Tensor, token_mask: Optional[torch.Tensor], pos_enc: Optional[torch.Tensor],
+                  top_k: int = 8) -> torch.Tensor:
+    """scores [B, L, K], tokens [B, L, D] -> [B, K, D] (MITH LocalizedTokenAggregation + positional encoding)."""
+    scores, tokens = _f32c(scores).contiguous(), _f32c(tokens).contiguous()
+    B, L, K = scores.shape
+    D = tokens.shape[-1]
+    m = None if token_mask is None else token_mask.to(device=scores.device, dtype=torch.uint8).contiguous()
+    pe = None if pos_enc is None else _f32c(pos_enc).reshape(-1, D)[:K].contiguous()
+    out = torch.empty(B, K, D, dtype=torch.float32, device=scores.device)
+    check(lib.xmh_lta_aggregate(ptr(scores), ptr(tokens), ptr(m), ptr(pe), ptr(out), B, L, K, D, top_k, current_stream()), "xmh_lta_aggregate")
+    return out
+
+
+def bitwise_hash(z: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """z [B, K, D], w [K, D], bias [K] -> tanh(w_k . z[b,k] + bias_k) (+ addend) [B, K]."""
+    z = _f32c(z).contiguous()
+    B, K, D = z.shape
+    out = torch.empty(B, K, dtype=torch.float32, device=z.device)
+    a = None if addend is None else _f32c(addend).contiguous()
+    check(lib.xmh_bitwise_hash(ptr(z), ptr(_f32c(w).contiguous()), ptr(_f32c(bias).contiguous()), ptr(a), ptr(out), B, K, D, current_stream()),
+          "xmh_bitwise_hash")
+    return out

@@ -122,20 +122,22 @@ def pack_labels(L: torch.Tensor) -> torch.Tensor:
     return lab
 
 
+def zero_plane_or_default(p: PackedCodes) -> torch.Tensor:
+    """the code's zero plane, or the plane of a code without zeros (only the padding bits set)."""
+    if p.zero is not None:
+        return p.zero
+    z = torch.zeros_like(p.bits)
+    pad = p.bits.shape[1] * 32 - p.K
+    if pad:
+        z[:, -1] = -1 << (32 - pad)                  # padding bits set (int32 two's complement)
+    return z
+
+
 def _both_planes(q: PackedCodes, r: PackedCodes):
     """zero planes for both sides or neither (the kernels' contract)."""
     if q.zero is None and r.zero is None:
         return None, None
-
-    def plane(p):
-        if p.zero is not None:
-            return p.zero
-        z = torch.zeros_like(p.bits)
-        pad = p.bits.shape[1] * 32 - p.K
-        if pad:
-            z[:, -1] = -1 << (32 - pad)              # padding bits set (int32 two's complement)
-        return z
-    return plane(q), plane(r)
+    return zero_plane_or_default(q), zero_plane_or_default(r)
 
 
 def hamming_dist(q: PackedCodes, r: PackedCodes, as_u16: bool = False) -> torch.Tensor:

@@ -1,0 +1,317 @@
+"""``BaseTrainer``: the encode-and-retrieve driver with the reference's runner surface (runners/base.py:22-415).
+
+Same constructor arguments, the same overridable seams (``generate_hash``, ``make_hash_code``, ``get_code``,
+``valid``, ``test``, the instance attribute ``self.calc_map_k``), the same outputs (log line :338/:357, ``.mat``
+keys and dtypes :397-404, ``model-<epoch>.pth`` :379-384).  What changes underneath:
+
+* codes never exist as fp32 on the hot path: the quantiser writes bit-packed rows straight into the code buffer
+  at ``index`` (xmh_pack_sign / xmh_pack_pair_argmax with row_index) and retrieval consumes the packed buffers;
+  ``get_code`` still hands back ``[N, K]`` fp32 +-1 tensors to callers that ask for them (unpacked on demand);
+* distributed eval keeps the gallery sharded (contiguous index ranges, one per rank) instead of all-reducing dense
+  zero-initialised buffers (runners/base.py:259-264): packed query codes are all-gathered, per-shard bucket
+  histograms are exchanged, every rank ranks its own shard (xmh/sharded.py);
+* optimisation (``train_epoch``) is outside the encode-and-retrieve path and raises, exactly like the reference's
+  own base class does (:296-297).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+from torch import distributed as dist
+from torch.utils.data import DataLoader, Sampler
+
+from .. import retrieval as R
+from .. import sharded
+from ..common.calc_utils import calc_map_k
+from ..common.register import registry
+from ..utils.logger import get_color_logger
+
+
+def set_seed(seed=1814):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class ContiguousShardSampler(Sampler):
+    """rank r iterates dataset rows [bounds[r], bounds[r+1]) in order -- the contiguous partition of SURVEY 8e
+    (the reference's strided DistributedSampler, runners/base.py:180-191, is an internal detail it replaces)."""
+
+    def __init__(self, n: int, rank: int, world: int):
+        b = sharded.shard_bounds(n, world)
+        self.lo, self.hi = b[rank], b[rank + 1]
+
+    def __iter__(self):
+        return iter(range(self.lo, self.hi))
+
+    def __len__(self):
+        return self.hi - self.lo
+
+
+class BaseTrainer:
+
+    def __init__(self, cfg, is_train=True, device=None, world_size=torch.cuda.device_count(), output_dim=16, train_num=10000,
+                 query_num=5000, epochs=100, save_dir="./result", display_step=20, top_k=5000, model_state="", batch_size=128,
+                 distributed=False, logger=None, **kwags) -> None:
+        set_seed(seed=cfg.run.get("seed", 1814))
+        self.cfg = cfg
+        self.is_train = is_train
+        log_dir = cfg.run.get("log_dir", save_dir)
+        name = cfg.dataset.get("name", "data") + "-" + str(device)
+        self.logger = logger or get_color_logger(log_dir, name, display=(not distributed) or device == 0)
+        self.rank = 0
+        if distributed:
+            self._init_distribution(rank=device, world_size=world_size)
+        self.logger.info(f"parameters: {dict(cfg)}")
+        self.device = device
+        self.output_dim, self.train_num, self.query_num = output_dim, train_num, query_num
+        self.epochs, self.display_step, self.top_k = epochs, display_step, top_k
+        self.model_state, self.batch_size, self.save_dir = model_state, batch_size, save_dir
+        os.makedirs(save_dir, exist_ok=True)
+        self.global_step = 0
+        self.max_mapi2t = self.max_mapt2i = 0
+        self.best_epoch_i = self.best_epoch_t = 0
+        self.calc_map_k = calc_map_k                     # instance attribute: the injection point (runners/base.py:78)
+        self.distributed = distributed
+        self.world_size = world_size if distributed else 1
+        self.model_ddp = None
+        self._qlab = self._rlab = None
+
+    # ---- distributed ------------------------------------------------------------------------------------
+    def _init_distribution(self, rank=0, world_size=4):
+        self.rank, self.world_size = rank, world_size
+        self.logger.info("Initializing distributed")
+        assert self.cfg.run.get("distributed_addr"), "DDP needs the 'distributed_addr' field."
+        assert self.cfg.run.get("distributed_port"), "DDP needs the 'distributed_port' field"
+        os.environ["MASTER_ADDR"] = str(self.cfg.run.distributed_addr)
+        os.environ["MASTER_PORT"] = str(self.cfg.run.distributed_port)
+        torch.cuda.set_device(rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world_size)     # "nccl" is RCCL on ROCm
+
+    # ---- builders ---------------------------------------------------------------------------------------
+    def build_model(self, cfg_model, output_dim=16, **kwags):
+        arch = cfg_model.get("arch", "DCMHT")
+        cls = registry.get_model_class(arch)
+        assert cls is not None, "model '%s' is not registered (known: %s)" % (arch, registry.list_models())
+        self.model = cls.from_config(cfg_model, output_dim=output_dim, train_num=self.train_num)
+        if os.path.isfile(self.model_state):
+            self.logger.info("loading model...")
+            self.model.load_state_dict(torch.load(self.model_state, map_location=f"cuda:{self.device}"))
+        self.model.float()
+        self.model.to(self.device)
+        self.logger.info("Building model!")
+        self.logger.info(f"Output dim: {self.output_dim}")
+
+    def build_optimizer(self, cfg_optimizer=None, parameters=None):
+        raise NotImplementedError("optimisation is outside the encode-and-retrieve path (SURVEY 2.1 #13)")
+
+    def build_dataset(self, cfg, train_num=10000, query_num=5000, batch_size=128, num_workers=4, pin_memory=True, shuffle=True):
+        arch = cfg.get("arch", "transformer_dataset")
+        self.logger.info(f"Using {cfg.get('name', 'synthetic')} dataset.")
+        if arch in ("synthetic", "synthetic_pairs"):
+            from ..dataset import build_synthetic_splits
+            train_data, query_data, retrieval_data = build_synthetic_splits(cfg, train_num, query_num)
+        else:
+            builder = registry.get_dataset_class(arch)
+            if builder is None:
+                raise NotImplementedError(
+                    "dataset arch '%s': the reference's .mat/PIL/BPE pipeline is host I/O outside this path (SURVEY 8f-2); "
+                    "register a dataset class yielding (image, caption, key_padding_mask, label, index) under that name, "
+                    "or call build_loader() with your own datasets" % arch)
+            train_data, query_data, retrieval_data = builder.build(cfg, train_num=train_num, query_num=query_num)
+        self.build_loader(train_data, query_data, retrieval_data, batch_size, num_workers, pin_memory, shuffle)
+
+    def build_loader(self, train_data, query_data, retrieval_data, batch_size, num_workers, pin_memory, shuffle, drop_last=False):
+        self.train_labels = train_data.get_all_label()
+        self.query_labels = query_data.get_all_label()
+        self.retrieval_labels = retrieval_data.get_all_label()
+        self.retrieval_num = len(self.retrieval_labels)
+        for nm, t in (("train", self.train_labels), ("query", self.query_labels), ("retrieval", self.retrieval_labels)):
+            self.logger.info(f"{nm} shape: {tuple(t.shape)}")
+        qs = rs = None
+        if self.distributed:
+            qs = ContiguousShardSampler(len(query_data), self.rank, self.world_size)
+            rs = ContiguousShardSampler(len(retrieval_data), self.rank, self.world_size)
+            batch_size = max(1, batch_size // self.world_size)
+        mk = lambda d, s, sh: DataLoader(d, batch_size=batch_size, num_workers=num_workers, pin_memory=pin_memory, sampler=s,   # noqa: E731
+                                         shuffle=sh, drop_last=False)
+        self.train_loader = mk(train_data, None, shuffle and not self.distributed)
+        self.query_loader = mk(query_data, qs, False)
+        self.retrieval_loader = mk(retrieval_data, rs, False)
+
+    # ---- run --------------------------------------------------------------------------------------------
+    def run(self):
+        if self.is_train:
+            self.train()
+        else:
+            self.test()
+
+    def train(self):
+        for epoch in range(self.epochs):
+            self.train_epoch(epoch=epoch)
+            self.valid(epoch, k=self.top_k)
+        self.logger.info(f">>>>>>> FINISHED >>>>>> Best epoch, I-T: {self.best_epoch_i}, mAP: {self.max_mapi2t}, T-I: {self.best_epoch_t}, mAP: {self.max_mapt2i}")
+
+    def train_epoch(self, epoch: int):
+        raise NotImplementedError("training is outside the encode-and-retrieve path this package implements")
+
+    def compute_loss(self, *a, **k):
+        raise NotImplementedError("training is outside the encode-and-retrieve path this package implements")
+
+    def change_state(self, mode):
+        if mode == "train":
+            self.model.train()
+            self.model.unfreezen()
+        else:
+            self.model.eval()
+            self.model.freezen()
+
+    # ---- encode ------------------------------------------------------------------------------------------
+    def generate_hash(self, image, text, key_padding_mask=None):
+        return self.model.encode_image(image), self.model.encode_text(text)
+
+    @classmethod
+    def make_hash_code(cls, code):
+        """reference :407-410 -- sign -> -1/0/+1 fp32 (computed by xmh_pack_sign + xmh_unpack_pm1)."""
+        return R.pack_sign(code).unpack()
+
+    @classmethod
+    def pack_hash_code(cls, code, out, row_index, flags):
+        """quantise a batch of model outputs straight into packed rows ``row_index`` of ``out``."""
+        R.pack_sign(code, out=out, row_index=row_index, flags=flags)
+
+    def _shard(self, length):
+        if not self.distributed:
+            return 0, length
+        b = sharded.shard_bounds(length, self.world_size)
+        return b[self.rank], b[self.rank + 1]
+
+    def encode_shard(self, data_loader, length: int):
+        """HOT LOOP 1 (runners/base.py:250-257): returns this rank's packed (image, text) code rows + flags."""
+        self.change_state(mode="valid")
+        lo, hi = self._shard(length)
+        dev = torch.device("cuda", self.device) if isinstance(self.device, int) else torch.device(self.device)
+        img = R.empty_packed(hi - lo, self.output_dim, dev, with_zero=True)
+        txt = R.empty_packed(hi - lo, self.output_dim, dev, with_zero=True)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            for image, text, key_padding_mask, label, index in data_loader:
+                image = image.to(dev, non_blocking=True)
+                text = text.to(dev, non_blocking=True)
+                rows = (index.to(dev, non_blocking=True) - lo).to(torch.int64)
+                image_hash, text_hash = self.generate_hash(image=image, text=text, key_padding_mask=key_padding_mask)
+                self.pack_hash_code(image_hash, img, rows, flags)
+                self.pack_hash_code(text_hash, txt, rows, flags)
+        if not (int(flags.item()) & 1):                      # no exact zero anywhere: drop the zero planes
+            img.zero = txt.zero = None
+        return img, txt
+
+    def _gather_packed(self, p: R.PackedCodes, length: int) -> R.PackedCodes:
+        if not self.distributed:
+            return p
+        b = sharded.shard_bounds(length, self.world_size)
+        counts = [b[r + 1] - b[r] for r in range(self.world_size)]
+        has_zero = torch.tensor([0 if p.zero is None else 1], device=p.bits.device)
+        dist.all_reduce(has_zero, op=dist.ReduceOp.MAX)
+        bits = sharded.all_gather_rows(p.bits, counts)
+        zero = None
+        if int(has_zero.item()):
+            zero = sharded.all_gather_rows(R.zero_plane_or_default(p), counts)
+        return R.PackedCodes(bits, zero, p.K)
+
+    def get_code(self, data_loader, length: int):
+        """reference :242-266 -- two [length, K] fp32 buffers of -1/0/+1, complete on every rank."""
+        img, txt = self.encode_shard(data_loader, length)
+        return self._gather_packed(img, length).unpack(), self._gather_packed(txt, length).unpack()
+
+    # ---- retrieve ----------------------------------------------------------------------------------------
+    def _map(self, q: R.PackedCodes, r_shard: R.PackedCodes, k):
+        """one calc_map_k: full query set against this rank's gallery shard (all of it when not distributed)."""
+        C = self.query_labels.shape[1]
+        dev = q.bits.device
+        if self._qlab is None:
+            self._qlab = R.pack_labels(self.query_labels.to(dev))
+            lo, hi = self._shard(self.retrieval_num)
+            self._rlab = R.pack_labels(self.retrieval_labels[lo:hi].to(dev))
+        if not self.distributed:
+            if self.calc_map_k is calc_map_k:
+                return float(R.map_k_packed(q, r_shard, self._qlab, self._rlab, C, k).item())
+            return float(self.calc_map_k(q.unpack(), r_shard.unpack(), self.query_labels, self.retrieval_labels, k))
+        ops = sharded.HipShardOps(q, self._qlab, r_shard, self._rlab, C)
+        return float(sharded.map_k_sharded(ops, k)[0].item())
+
+    def _evaluate(self, k):
+        self._qlab = self._rlab = None
+        q_img, q_txt = self.encode_shard(self.query_loader, self.query_num)
+        r_img, r_txt = self.encode_shard(self.retrieval_loader, self.retrieval_num)
+        q_img, q_txt = self._gather_packed(q_img, self.query_num), self._gather_packed(q_txt, self.query_num)
+        maps = (self._map(q_img, r_txt, k), self._map(q_txt, r_img, k), self._map(q_img, r_img, k), self._map(q_txt, r_txt, k))
+        return maps, (q_img, q_txt, r_img, r_txt)
+
+    def _is_writer(self):
+        return not self.distributed or self.rank == 0
+
+    def _save_codes(self, codes, save_file):
+        q_img, q_txt, r_img, r_txt = codes
+        r_img, r_txt = self._gather_packed(r_img, self.retrieval_num), self._gather_packed(r_txt, self.retrieval_num)
+        if self._is_writer():
+            self.save_mat(q_img.unpack(), q_txt.unpack(), self.query_labels, r_img.unpack(), r_txt.unpack(), self.retrieval_labels, save_file=save_file)
+
+    def valid(self, epoch, k=None):
+        assert self.query_loader is not None and self.retrieval_loader is not None
+        save_dir = os.path.join(self.save_dir, "mat_files")
+        os.makedirs(save_dir, exist_ok=True)
+        self.logger.info("Valid.")
+        (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(k)
+        if self.max_mapi2t < mAPi2t:
+            self.best_epoch_i = epoch
+            self._save_codes(codes, os.path.join(save_dir, "i2t-best.mat"))
+            if self._is_writer():
+                self.save_model(save_dir=self.save_dir, epoch=epoch)
+        self.max_mapi2t = max(self.max_mapi2t, mAPi2t)
+        if self.max_mapt2i < mAPt2i:
+            self.best_epoch_t = epoch
+            self._save_codes(codes, os.path.join(save_dir, "t2i-best.mat"))
+            if self._is_writer():
+                self.save_model(save_dir=self.save_dir, epoch=epoch)
+        self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
+        self._save_codes(codes, os.path.join(save_dir, "last.mat"))
+        self.logger.info(f">>>>>> [{epoch}/{self.epochs}], MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}, "
+                         f"MAX MAP(i->t): {self.max_mapi2t}, epoch: {self.best_epoch_i}, MAX MAP(t->i): {self.max_mapt2i}, epoch: {self.best_epoch_t}")
+        return mAPi2t, mAPt2i, mAPi2i, mAPt2t
+
+    def test(self):
+        assert not self.model_state == "", "test step must provide the model file!"
+        self.logger.info("Test.")
+        save_dir = os.path.join(self.save_dir, "mat_files")
+        os.makedirs(save_dir, exist_ok=True)
+        (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(self.top_k)
+        self._save_codes(codes, os.path.join(save_dir, "test.mat"))
+        self.logger.info(f">>>>>> TEST, MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}")
+        return mAPi2t, mAPt2i, mAPi2i, mAPt2t
+
+    # ---- outputs -----------------------------------------------------------------------------------------
+    def save_model(self, save_dir, epoch, other=""):
+        path = os.path.join(save_dir, "model-" + other + str(epoch) + ".pth")
+        torch.save(self.model.state_dict(), path)
+        self.logger.info("save mode to {}".format(path))
+
+    @classmethod
+    def save_mat(cls, query_img, query_txt, query_labels, retrieval_img, retrieval_txt, retrieval_labels, save_file="i2t"):
+        """reference :386-405 -- same keys; codes fp32 [N,K], labels as stored by the dataset (int64)."""
+        import scipy.io as scio
+
+        def arr(t):
+            return t.cpu().detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        scio.savemat(os.path.join(save_file), {"q_img": arr(query_img), "q_txt": arr(query_txt), "r_img": arr(retrieval_img),
+                                               "r_txt": arr(retrieval_txt), "q_l": arr(query_labels), "r_l": arr(retrieval_labels)})
+
+    @classmethod
+    def from_config(cls, cfg, logger=None):
+        raise NotImplementedError()

@@ -183,6 +183,16 @@ int xmh_affine_cols(const float* x, const float* mean, const float* var, const f
 /* softmax over each consecutive pair: softmax_hash (models/common/hash.py:21-31); x, y [rows, 2K] */
 int xmh_pair_softmax(const float* x, float* y, int64_t rows, int K, xmh_stream_t stream);
 
+/* MITH LocalizedTokenAggregation (models/MITH/hash/hash.py:109-169) + sin/cos positional encoding (:41-65):
+ * scores [B,L,K] (tanh concept scores of every token), tokens [B,L,D] (raw CLIP tokens), token_mask [B,L] bytes
+ * (non-zero = padded / EOS token, may be NULL), pos_enc [K,D] or NULL -> out [B,K,D]. */
+int xmh_lta_aggregate(const float* scores, const float* tokens, const uint8_t* token_mask, const float* pos_enc,
+                      float* out, int64_t B, int L, int K, int D, int top_k, xmh_stream_t stream);
+/* MITH BitwiseHashing (models/MITH/hash/hash.py:68-85): out[b,k] = tanh(w[k,:] . z[b,k,:] + bias[k]) (+ addend[b,k],
+ * the cls_hash + tokens_hash sum of runners/MITH/runner.py:129-130 when given). */
+int xmh_bitwise_hash(const float* z, const float* w, const float* bias, const float* addend, float* out, int64_t B,
+                     int K, int D, xmh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,38 @@ def dcmht_head(hp, e, image: bool):
 
 def dsph_head(hp, e):
     return torch.tanh(F.linear(e, hp["fc.weight"], hp["fc.bias"]))
+
+
+def _mith_gcl(hp, x):
+    """GlobalConceptLearning (models/MITH/hash/hash.py:88-106) with ResidualMLPs (:9-38): -> (mlp(x), tanh(Wc mlp(x)))."""
+    i = 0
+    while "gcl_i.mlp.lns.%d.weight" % i in hp:
+        p = "gcl_i.mlp."
+        h = F.layer_norm(x, (x.shape[-1],), hp[p + "lns.%d.weight" % i], hp[p + "lns.%d.bias" % i], 1e-5)
+        f = F.gelu(F.linear(h, hp[p + "mlps.%d.0.weight" % i], hp[p + "mlps.%d.0.bias" % i]))
+        x = x + F.linear(f, hp[p + "mlps.%d.3.weight" % i], hp[p + "mlps.%d.3.bias" % i])
+        i += 1
+    return x, torch.tanh(F.linear(x, hp["gcl_i.common_concept_embedding.weight"]))
+
+
+def mith_head(hp, cls, tokens_lnd, mask, modality: str, top_k: int = 8):
+    """Eval path of models/MITH/hash/hash.py:231-247 for one modality ('i' or 't'): -> (cls_hash [B,K], tokens_hash [B,K]).
+    tokens_lnd [L,B,D]; mask [B,L] bool or None (text: padding | EOS)."""
+    _, cls_hash = _mith_gcl(hp, cls)
+    _, sim = _mith_gcl(hp, tokens_lnd)                                   # [L,B,K]
+    sim = sim.clone()
+    L, B, K = sim.shape
+    if mask is not None:
+        sim = sim + torch.where(mask, float("-inf"), 0.0).t()[:, :, None]
+    sim = torch.where(sim > 0, sim, torch.full_like(sim, float("-inf")))
+    kth = torch.topk(sim, k=top_k, dim=-1).values.min(dim=-1, keepdim=True).values
+    sim = torch.where(sim >= kth, sim, torch.full_like(sim, float("-inf")))
+    att = torch.softmax(sim, dim=0)
+    att = torch.where(torch.isnan(att), torch.zeros_like(att), att)
+    merged = torch.bmm(att.permute(1, 2, 0), tokens_lnd.permute(1, 0, 2)).permute(1, 0, 2)       # [K,B,D]
+    pre = "lct_%s." % modality
+    x = merged + hp[pre + "position.pe"][:K]
+    sd = {k[len(pre + "transformer."):]: v for k, v in hp.items() if k.startswith(pre + "transformer.")}
+    x = _blocks(x, sd, "", _count_layers(sd, ""), x.shape[-1] // 64, None)
+    bits = torch.stack([F.linear(x[k], hp[pre + "hashing.fc_list.%d.weight" % k], hp[pre + "hashing.fc_list.%d.bias" % k]) for k in range(K)])
+    return cls_hash, torch.tanh(bits.permute(1, 0, 2).squeeze(-1))

@@ -1,0 +1,68 @@
+"""Host-side boundary logic that needs no GPU: registry semantics, config objects, synthetic dataset contract,
+shard arithmetic."""
+import os
+
+import pytest
+import torch
+
+from xmh.common.register import registry
+from xmh.utils.config import Config, load_yaml
+
+
+def test_registry_contract():
+    import xmh.models  # noqa: F401  (registers DCMHT / DSPH / MITH)
+    import xmh.runners  # noqa: F401
+    from xmh.models.base import BaseModel
+    from xmh.runners.base import BaseTrainer
+    for name in ("DCMHT", "DSPH", "MITH"):
+        assert issubclass(registry.get_model_class(name), BaseModel)
+    for name in ("DCMHTTrainer", "DSPHTrainer", "MITHTrainer"):
+        assert issubclass(registry.get_runner_class(name), BaseTrainer)
+    assert registry.get_model_class("nope") is None and registry.get_runner_class("nope") is None
+    with pytest.raises(KeyError):
+        registry.register_model("DCMHT")(registry.get_model_class("DCMHT"))
+    with pytest.raises(AssertionError):
+        registry.register_model("NotAModel")(dict)
+    with pytest.raises(AssertionError):
+        registry.register_runner("NotARunner")(dict)
+
+    @registry.register_tokenizer("unit_test_tokenizer")
+    class Tok:
+        pass
+    assert isinstance(registry.get_tokenizer_class("unit_test_tokenizer")(), Tok)
+    assert "DCMHT" in registry.list_models() and "DCMHTTrainer" in registry.list_runners()
+
+
+def test_config_object(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text("model:\n  arch: DCMHT\n  clip_path: synthetic\nrun:\n  output_dim: 64\n  save_dir: ./x\ndataset:\n  name: coco\n")
+    cfg = load_yaml(str(p), save_dir=str(tmp_path))
+    assert cfg.model.arch == "DCMHT" and cfg.run.get("top_k", None) is None and cfg.run.output_dim == 64
+    assert cfg.run.save_dir == str(tmp_path) and cfg.run.log_dir == str(tmp_path)
+    assert isinstance(cfg.dataset, Config) and cfg["dataset"]["name"] == "coco"
+
+
+def test_synthetic_dataset_tuple_contract():
+    from xmh.dataset import SyntheticPairs
+    d = SyntheticPairs(7, num_classes=24, resolution=32, max_words=32, seed=3)
+    image, ids, mask, label, index = d[4]
+    assert image.shape == (3, 32, 32) and image.dtype == torch.float32
+    assert ids.shape == (32,) and ids.dtype == torch.int64 and ids[0] == 49406 and ids.max() == 49407
+    assert mask.dtype == torch.bool and torch.equal(mask, ids == 0)
+    assert label.shape == (24,) and label.dtype == torch.int64 and label.sum() >= 1 and index == 4
+    assert d.get_all_label().shape == (7, 24)
+    again = d[4]
+    assert torch.equal(again[0], image) and torch.equal(again[1], ids)          # deterministic
+
+
+def test_shard_bounds_and_rank_offsets():
+    from xmh import sharded
+    assert sharded.shard_bounds(10, 3) == [0, 4, 7, 10]
+    assert sharded.shard_bounds(8, 8) == list(range(9))
+    ha = torch.tensor([[[1, 2, 0]], [[0, 1, 3]]])        # [world=2, Q=1, nb=3]
+    hr = torch.tensor([[[1, 0, 0]], [[0, 1, 1]]])
+    b0 = sharded.rank_offsets(ha, hr, 0)
+    b1 = sharded.rank_offsets(ha, hr, 1)
+    assert b0[0].tolist() == [[0, 1, 4]] and b1[0].tolist() == [[1, 3, 4]]
+    assert b0[1].tolist() == [[0, 1, 2]] and b1[1].tolist() == [[1, 1, 2]]
+    assert b0[2].tolist() == [3] and b1[2].tolist() == [3]

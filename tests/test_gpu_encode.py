@@ -40,16 +40,16 @@ def test_gemm_f32_matches_torch(ops, M, N, K):
     bias, res = torch.randn(N, generator=g_(3)), torch.randn(M, N, generator=g_(4))
     want = A.double() @ W.double().t()
     got = ops.gemm_nt(A.cuda(), W.cuda())
-    assert rel(got, want) < 2e-6
+    assert rel(got, want) < 5e-6
     for act, fn in ((ops.ACT_QUICKGELU, lambda x: x * torch.sigmoid(1.702 * x)), (ops.ACT_GELU_ERF, F.gelu), (ops.ACT_TANH, torch.tanh),
                     (ops.ACT_RELU, torch.relu)):
         got = ops.gemm_nt(A.cuda(), W.cuda(), bias.cuda(), residual=res.cuda(), act=act)
-        assert rel(got, fn((want + bias.double()).float()).double() + res.double()) < 5e-6
+        assert rel(got, fn((want + bias.double()).float()).double() + res.double()) < 1e-5
     # strided views (leading dimension > K) and in-place residual
     Abig = torch.randn(M, K + 8, generator=g_(5)).cuda()
     out = res.clone().cuda()
     ops.gemm_nt(Abig[:, :K], W.cuda(), residual=out, out=out)
-    assert rel(out, Abig[:, :K].cpu().double() @ W.double().t() + res.double()) < 2e-6
+    assert rel(out, Abig[:, :K].cpu().double() @ W.double().t() + res.double()) < 5e-6   # fp32 chain over K<=3072
 
 
 def test_gemm_f32_transpose_detecting(ops):
@@ -220,3 +220,52 @@ def test_fast_mode_fp16_error_and_bit_agreement(ops, clip_models):
     proj = torch.randn(512, 64, generator=g_(1)).cuda()
     flips = ((ref @ proj).sign() != (fast @ proj).sign()).float().mean().item()
     assert flips < 0.01
+
+
+def test_mith_head_matches_reference_goldens(ops):
+    from test_oracle_encode import mith_inputs, mith_params
+    from xmh.models import weights as W
+    from xmh.models.mith import MITHHashLayer
+    g = np.load(os.path.join(GOLDEN, "encode_mith.npz"))
+    seed = int(g["seed"])
+    cls_i, tok_i, cls_t, tok_t, mask = mith_inputs(W, seed)
+    for K in (16, 64):
+        head = MITHHashLayer(512, K)
+        hp = mith_params(W, seed, K)
+        sd = head.state_dict()
+        for k in sd:
+            src = k.replace("gcl_t.", "gcl_i.")
+            assert src in hp, k
+            sd[k] = hp[src]
+        head.load_state_dict(sd)
+        head = head.cuda().eval()
+        _, ch_i, th_i, _ = head.encode_img(cls_i.cuda(), tok_i.cuda())
+        _, ch_t, th_t, _ = head.encode_txt(cls_t.cuda(), tok_t.cuda(), mask.cuda())
+        for got, key in ((ch_i, "cls_hash_i"), (th_i, "tok_hash_i"), (ch_t, "cls_hash_t"), (th_t, "tok_hash_t")):
+            assert (got.cpu() - torch.from_numpy(g["k%d_%s" % (K, key)])).abs().max() < 2e-5, (K, key)
+        assert ((ch_i + th_i).sign().cpu().numpy() != g["k%d_code_i" % K]).mean() < 0.01
+        assert ((ch_t + th_t).sign().cpu().numpy() != g["k%d_code_t" % K]).mean() < 0.01
+
+
+def test_lta_edge_cases_against_oracle(ops):
+    """tokens with fewer than top-k positive concepts, fully masked concepts (NaN -> 0), exact ties."""
+    from oracle import encode as enc
+    B, L, K, D = 2, 9, 16, 64
+    gen = torch.Generator().manual_seed(4)
+    S = torch.tanh(torch.randn(B, L, K, generator=gen))
+    S[0, :, 3] = -0.5                   # concept 3 never positive for sample 0 -> all-zero aggregate row
+    S[1, 2, :] = 0.25                   # a token whose scores all tie
+    S[1, 4, :] = -0.1                   # a token with no positive concept at all
+    X = torch.randn(B, L, D, generator=gen)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[0, 7:] = True
+    got = ops.lta_aggregate(S.cuda(), X.cuda(), mask.cuda(), None, 8).cpu()
+    sim = S.permute(1, 0, 2).clone() + torch.where(mask, float("-inf"), 0.0).t()[:, :, None]
+    sim = torch.where(sim > 0, sim, torch.full_like(sim, float("-inf")))
+    kth = torch.topk(sim, k=8, dim=-1).values.min(dim=-1, keepdim=True).values
+    sim = torch.where(sim >= kth, sim, torch.full_like(sim, float("-inf")))
+    att = torch.softmax(sim, dim=0)
+    att = torch.where(torch.isnan(att), torch.zeros_like(att), att)
+    want = torch.bmm(att.permute(1, 2, 0), X)
+    assert (got - want).abs().max() < 1e-5 and got[0, 3].abs().max() == 0
+    del enc

@@ -1,0 +1,69 @@
+"""End-to-end drop-in check on the GPU: a registered runner built from a config runs get_code + valid and writes
+the reference's artefacts; its mAP equals the oracle's calc_map_k port on the codes it produced."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(tmp_path, arch, runner, K, layers=2):
+    from xmh.utils.config import Config
+    return Config({
+        "model": {"arch": arch, "clip_path": "synthetic:1814:vision_layers=%d,transformer_layers=%d" % (layers, layers)},
+        "dataset": {"arch": "synthetic", "name": "synth", "num_classes": 24, "retrieval_num": 230, "max_word": 32, "image_resolution": 224},
+        "run": {"arch": runner, "output_dim": K, "device": 0, "batch_size": 32, "num_workers": 0, "is_train": False, "query_num": 50,
+                "train_num": 60, "save_dir": str(tmp_path), "log_dir": str(tmp_path), "seed": 1814},
+    })
+
+
+@pytest.mark.parametrize("arch,runner,K", [("DCMHT", "DCMHTTrainer", 16), ("DSPH", "DSPHTrainer", 128), ("MITH", "MITHTrainer", 64)])
+def test_runner_valid_matches_oracle(tmp_path, arch, runner, K):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import scipy.io as scio
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from oracle import retrieval as orc
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, arch, runner, K)
+    trainer = registry.get_runner_class(runner).from_config(cfg=cfg, autorun=False)
+    q_img, q_txt = trainer.get_code(trainer.query_loader, trainer.query_num)
+    r_img, r_txt = trainer.get_code(trainer.retrieval_loader, trainer.retrieval_num)
+    assert q_img.shape == (50, K) and r_txt.shape == (230, K) and q_img.dtype == torch.float32
+    assert set(np.unique(q_img.cpu().numpy())) <= {-1.0, 0.0, 1.0}
+    maps = trainer.valid(0, k=None)
+    qL, rL = trainer.query_labels, trainer.retrieval_labels
+    want = [orc.map_k(a.cpu(), b.cpu(), qL, rL, None, stable=True) for a, b in ((q_img, r_txt), (q_txt, r_img), (q_img, r_img), (q_txt, r_txt))]
+    for got, w in zip(maps, want):
+        assert abs(got - float(w)) < 1e-6
+    # artefacts (runners/base.py:322-336, :379-405)
+    mat = scio.loadmat(os.path.join(str(tmp_path), "mat_files", "last.mat"))
+    assert set(["q_img", "q_txt", "r_img", "r_txt", "q_l", "r_l"]) <= set(mat)
+    assert mat["q_img"].dtype == np.float32 and mat["q_img"].shape == (50, K) and np.array_equal(mat["r_txt"], r_txt.cpu().numpy())
+    assert mat["q_l"].dtype == np.int64 and np.array_equal(mat["r_l"], rL.numpy())
+    assert os.path.exists(os.path.join(str(tmp_path), "mat_files", "i2t-best.mat"))
+    pth = os.path.join(str(tmp_path), "model-0.pth")
+    assert os.path.exists(pth)
+    sd = torch.load(pth, map_location="cpu")
+    assert any(k.startswith("backbone.visual.transformer.resblocks.0.attn.in_proj_weight") for k in sd)
+    assert any(k.startswith("hash.") for k in sd)
+    # mAP@k path and the calc_map_k injection seam
+    m50 = trainer.valid(1, k=50)
+    assert abs(m50[0] - float(orc.map_k(q_img.cpu(), r_txt.cpu(), qL, rL, 50, stable=True))) < 1e-6
+    calls = []
+
+    def spy(qB, rB, qLx, rLx, k=None):
+        calls.append(qB.shape)
+        return orc.map_k(qB.cpu(), rB.cpu(), qLx, rLx, k, stable=True)
+    trainer.calc_map_k = spy
+    m_spy = trainer.valid(2, k=None)
+    assert len(calls) == 4 and abs(m_spy[0] - maps[0]) < 1e-6
+    # a saved checkpoint round-trips through resume_model -> test()
+    cfg.run.resume_model = pth
+    t2 = registry.get_runner_class(runner).from_config(cfg=cfg, autorun=False)
+    t2.top_k = None
+    assert abs(t2.test()[0] - maps[0]) < 1e-6
+    assert os.path.exists(os.path.join(str(tmp_path), "mat_files", "test.mat"))

@@ -86,3 +86,74 @@ def test_heads_match_reference_goldens():
         out = enc.dsph_head(dsph_params(W, seed, 128, mod), emb)
         assert np.abs(out.numpy() - g["dsph128_%s" % mod]).max() < 2e-6
         assert (np.sign(out.numpy()) != g["dsph128_%s_code" % mod]).mean() < 0.002
+
+
+def mith_params(W, seed, K):
+    """named tensors identical to the ones oracle/make_golden_mith.py loaded into the reference HashLayer; keys are the
+    reference head's state_dict keys (gcl_t.* aliases gcl_i.*)."""
+    import math
+    p = {}
+
+    def t(name, shape, std, plus=0.0):
+        p[name] = plus + W.synth_tensor(seed, "mith%d." % K + name, shape, std)
+    for i in range(2):
+        t("gcl_i.mlp.mlps.%d.0.weight" % i, (2048, 512), 0.04)
+        t("gcl_i.mlp.mlps.%d.0.bias" % i, (2048,), 0.02)
+        t("gcl_i.mlp.mlps.%d.3.weight" % i, (512, 2048), 0.04)
+        t("gcl_i.mlp.mlps.%d.3.bias" % i, (512,), 0.02)
+        t("gcl_i.mlp.lns.%d.weight" % i, (512,), 0.05, 1.0)
+        t("gcl_i.mlp.lns.%d.bias" % i, (512,), 0.02)
+    t("gcl_i.common_concept_embedding.weight", (K, 512), 0.04)
+    for m in ("i", "t"):
+        pre = "lct_%s." % m
+        pe = torch.zeros(K, 512)
+        pos = torch.arange(0, K, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, 512, 2).float() * (-math.log(10000.0) / 512))
+        pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
+        p[pre + "position.pe"] = pe.unsqueeze(0).transpose(0, 1) / (512 ** 0.5)
+        for i in range(2):
+            b = pre + "transformer.resblocks.%d." % i
+            t(b + "attn.in_proj_weight", (1536, 512), 0.04)
+            t(b + "attn.in_proj_bias", (1536,), 0.02)
+            t(b + "attn.out_proj.weight", (512, 512), 0.04)
+            t(b + "attn.out_proj.bias", (512,), 0.02)
+            t(b + "ln_1.weight", (512,), 0.05, 1.0)
+            t(b + "ln_1.bias", (512,), 0.02)
+            t(b + "mlp.c_fc.weight", (2048, 512), 0.04)
+            t(b + "mlp.c_fc.bias", (2048,), 0.02)
+            t(b + "mlp.c_proj.weight", (512, 2048), 0.04)
+            t(b + "mlp.c_proj.bias", (512,), 0.02)
+            t(b + "ln_2.weight", (512,), 0.05, 1.0)
+            t(b + "ln_2.bias", (512,), 0.02)
+        for k in range(K):
+            t(pre + "hashing.fc_list.%d.weight" % k, (1, 512), 0.04)
+            t(pre + "hashing.fc_list.%d.bias" % k, (1,), 0.02)
+    for m in ("img", "txt"):
+        t("%s_concept_proj.weight" % m, (512, 512), 0.04)
+        t("%s_concept_proj.bias" % m, (512,), 0.02)
+    return p
+
+
+def mith_inputs(W, seed):
+    B = 3
+    mask = torch.zeros(B, 32, dtype=torch.bool)
+    mask[0, 9:], mask[1, 20:], mask[2, 4:] = True, True, True
+    return (W.synth_tensor(seed, "mith_in.cls_i", (B, 512), 0.6), W.synth_tensor(seed, "mith_in.tok_i", (49, B, 512), 0.6),
+            W.synth_tensor(seed, "mith_in.cls_t", (B, 512), 0.6), W.synth_tensor(seed, "mith_in.tok_t", (32, B, 512), 0.6), mask)
+
+
+def test_mith_head_matches_reference_goldens():
+    g = np.load(os.path.join(GOLDEN, "encode_mith.npz"))
+    W = _weights()
+    seed = int(g["seed"])
+    cls_i, tok_i, cls_t, tok_t, mask = mith_inputs(W, seed)
+    assert np.array_equal(mask.numpy(), g["mask"])
+    for K in (16, 64):
+        hp = mith_params(W, seed, K)
+        with torch.no_grad():
+            ch_i, th_i = enc.mith_head(hp, cls_i, tok_i, None, "i")
+            ch_t, th_t = enc.mith_head(hp, cls_t, tok_t, mask, "t")
+        for got, key in ((ch_i, "cls_hash_i"), (th_i, "tok_hash_i"), (ch_t, "cls_hash_t"), (th_t, "tok_hash_t")):
+            assert np.abs(got.numpy() - g["k%d_%s" % (K, key)]).max() < 5e-6, (K, key)
+        assert np.array_equal((ch_i + th_i).sign().numpy(), g["k%d_code_i" % K])
+        assert np.array_equal((ch_t + th_t).sign().numpy(), g["k%d_code_t" % K])
