@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--C", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-regime", action="store_true")
+    ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -182,6 +183,12 @@ def main():
             out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and not args.no_encode:
+        try:
+            import bench_encode
+            out["encode"] = bench_encode.measure()
+        except Exception as exc:
+            out["encode"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _, _, rB0, rL0 = rB, rL, rB, rL
         out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, args.cpu_seconds)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""CLIP ViT-B/32 encode throughput on one MI355X (SURVEY 8d metric iii): images/s and captions/s of the HIP encoder +
+DCMHT 64-bit head on device-resident synthetic batches (B=100, random-init weights of the reference architecture),
+in parity mode (fp32 MFMA) and fast mode (fp16 operands, fp32 accumulate), with the MFMA roofline of the GEMM kernel.
+
+    python bench_encode.py [--batch 100 --steps 10]
+Called by bench.py (``measure()``)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FLOP_IMAGE = 8.86e9        # patch-embed 0.23 + 12 x 0.716 + proj 0.04 GFLOP (cls-only projection is ~0.04 less)
+FLOP_TEXT = 2.46e9         # 12 x 0.203 + 0.017 GFLOP at L=32
+PEAK = {"f32": 157.3, "f16": 2500.0}     # TFLOP/s dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def measure(batch=100, steps=10, warmup=2, K=64):
+    from xmh import _lib, ops
+    from xmh import retrieval as R
+    from xmh.models.dcmht import DCMHT
+    from xmh.utils.config import Config
+    model = DCMHT.from_config(Config({"clip_path": "synthetic:1814"}), output_dim=K).cuda().eval()
+    from xmh.models import weights as W
+    image = W.synth_images(5, batch).cuda()
+    ids, _ = W.synth_text(5, batch)
+    ids = ids.cuda()
+    out = {}
+    for mode in ("f32", "f16"):
+        ops.set_precision(mode)
+        try:
+            for what, fn, flop in (("images", lambda: R.pack_pair_argmax(model.encode_image(image)), FLOP_IMAGE),
+                                   ("captions", lambda: R.pack_pair_argmax(model.encode_text(ids)), FLOP_TEXT)):
+                for _ in range(warmup):
+                    fn()
+                torch.cuda.synchronize()
+                _lib.prof_enable(True)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                gemm_ms, launches = _lib.prof_read("gemm_" + mode)
+                _lib.prof_enable(False)
+                gemm_total = gemm_ms * 1e-3 * launches / steps          # seconds of GEMM kernels per forward
+                out["%s_per_s_%s" % (what, mode)] = batch / dt
+                out["%s_ms_per_batch_%s" % (what, mode)] = dt * 1e3
+                out["%s_gemm_tflops_%s" % (what, mode)] = flop * batch / gemm_total / 1e12
+                out["%s_gemm_share_%s" % (what, mode)] = gemm_total / dt
+        finally:
+            ops.set_precision("f32")
+    ach = out["images_gemm_tflops_f32"]
+    out["roofline"] = {"kernel": "k_gemm_nt_f32 (all GEMM launches of one image forward, HIP events per launch)", "bound": "mfma",
+                       "achieved": ach, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": ach / PEAK["f32"], "traffic": None,
+                       "fast_mode": {"kernel": "k_gemm_nt_f16", "achieved": out["images_gemm_tflops_f16"], "peak": PEAK["f16"],
+                                     "frac": out["images_gemm_tflops_f16"] / PEAK["f16"]}}
+    out["config"] = {"workload": "CLIP ViT-B/32 + DCMHT %d-bit head, batch %d, 224x224 / 32 tokens, random-init weights" % (K, batch)}
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.batch, a.steps)))

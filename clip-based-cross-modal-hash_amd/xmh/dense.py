@@ -1,0 +1,53 @@
+"""calc_utils on un-quantised float inputs: GEMM + row-wise kernels from libxmh.so."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from . import retrieval as R
+from ._lib import check, current_stream, lib, ptr
+
+
+def _sqnorm(x: torch.Tensor) -> torch.Tensor:
+    n = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib.xmh_row_l2normalize(ptr(x), x.shape[0], x.shape[1], None, ptr(n), current_stream()), "xmh_row_l2normalize")
+    return n
+
+
+def _normalize(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty_like(x)
+    check(lib.xmh_row_l2normalize(ptr(x), x.shape[0], x.shape[1], ptr(y), None, current_stream()), "xmh_row_l2normalize")
+    return y
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = a.contiguous(), b.contiguous()
+    return ops.gemm_nt(_normalize(a), _normalize(b), precision=ops.PREC_F32)
+
+
+def pairwise_l2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = a.contiguous(), b.contiguous()
+    g = ops.gemm_nt(a, b, precision=ops.PREC_F32)
+    check(lib.xmh_pairwise_l2_from_gram(ptr(g), ptr(_sqnorm(a)), ptr(_sqnorm(b)), a.shape[0], b.shape[0], current_stream()),
+          "xmh_pairwise_l2_from_gram")
+    return g
+
+
+def hamming_dist_float(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
+    """0.5 * (K - B1 @ B2^T) for arbitrary float 'codes'."""
+    B1, B2 = B1.contiguous(), B2.contiguous()
+    g = ops.gemm_nt(B1, B2, precision=ops.PREC_F32)
+    check(lib.xmh_affine_inplace(ptr(g), g.numel(), -0.5, 0.5 * B2.shape[1], current_stream()), "xmh_affine_inplace")
+    return g
+
+
+def map_k_float(qB, rB, qlab, rlab, C: int, k: Optional[int]) -> torch.Tensor:
+    d = hamming_dist_float(qB, rB)
+    Q, Rn = d.shape
+    ap = torch.empty(Q, dtype=torch.float64, device=d.device)
+    cap = torch.empty(Q, dtype=torch.int32, device=d.device)
+    check(lib.xmh_float_rank_ap(ptr(d), ptr(qlab), ptr(rlab), Q, Rn, C, 0 if k is None else int(k), ptr(ap), ptr(cap), current_stream()),
+          "xmh_float_rank_ap")
+    return R.map_finalize(ap, cap)

@@ -193,6 +193,21 @@ int xmh_lta_aggregate(const float* scores, const float* tokens, const uint8_t* t
 int xmh_bitwise_hash(const float* z, const float* w, const float* bias, const float* addend, float* out, int64_t B,
                      int K, int D, xmh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Float similarities of common/calc_utils.py on un-quantised inputs (a-3, a-4).
+ * ------------------------------------------------------------------------------------------- */
+/* y = x / ||x|| row-wise (cosine_similarity :38-49, no eps) and/or sqnorm[r] = ||x_r||^2; y or sqnorm may be NULL */
+int xmh_row_l2normalize(const float* x, int64_t rows, int D, float* y, float* sqnorm, xmh_stream_t stream);
+/* in place: gram[i][j] = sqrt(max(|a_i|^2 + |b_j|^2 - 2 gram[i][j], 0))   (euclidean_similarity :28-36) */
+int xmh_pairwise_l2_from_gram(float* gram_inout, const float* sqnorm_a, const float* sqnorm_b, int64_t M, int64_t N,
+                              xmh_stream_t stream);
+/* in place: x = alpha * x + beta   (0.5 * (K - q.r) on float codes, calc_hammingDist :51-56) */
+int xmh_affine_inplace(float* x, int64_t n, float alpha, float beta, xmh_stream_t stream);
+/* calc_map_k ranking for FLOAT distances dist[Q][R] under (distance, index) order; same outputs as xmh_hamming_ap.
+ * Direct counting, O(R * n_rel) per query: the small-set fallback for non-binary "codes". */
+int xmh_float_rank_ap(const float* dist, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C,
+                      int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

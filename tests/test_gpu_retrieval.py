@@ -343,3 +343,23 @@ def test_topk_full_size_sample_path(xr):
     """a gallery large enough that the threshold comes from a 2.6 % sample (fast path proper)."""
     _topk_check(xr, 8, 2_000_000, 64, 100, seed=21)
     _topk_check(xr, 4, 1_500_000, 256, 10, seed=22)
+
+
+def test_float_similarities_and_float_code_fallback(cu):
+    """cosine / euclidean / calc_hammingDist / calc_map_k on un-quantised float inputs vs the goldens."""
+    g = np.load(os.path.join(GOLDEN, "calc_utils_ternary_float.npz"))
+    fa, fb = dev(g["fa"]), dev(g["fb"])
+    assert np.allclose(cu.cosine_similarity(fa, fb).cpu().numpy(), g["cos"], atol=2e-6)
+    assert np.allclose(cu.cosine_similarity(g["fa"], g["fb"]), g["cos_np"], atol=2e-6)          # numpy in -> numpy out
+    assert np.allclose(cu.euclidean_similarity(fa, fb).cpu().numpy(), g["euc"], atol=2e-5)
+    assert np.allclose(cu.euclidean_similarity(g["fa"], g["fb"]), g["euc_np"], atol=2e-5)
+    with pytest.raises(ValueError):
+        cu.cosine_similarity(fa, g["fb"])
+    with pytest.raises(ValueError):
+        cu.euclidean_similarity(g["fa"], fb)
+    fq, fr = dev(g["fq"]), dev(g["fr"])
+    assert np.allclose(cu.calc_hammingDist(fq, fr).cpu().numpy(), g["float_dist"], atol=1e-5)
+    got = cu.calc_map_k(fq, fr, dev(g["fqL"], torch.int64), dev(g["frL"], torch.int64))
+    assert abs(float(got) - float(g["float_map_stable"])) < 1e-6
+    kat = np.load(os.path.join(GOLDEN, "calc_utils_kat.npz"))
+    assert float(cu.calc_hammingDist(dev(kat["kat4_a"]), dev(kat["kat4_b"])).cpu().reshape(-1)[0]) == 1.0     # KAT-4

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_scan
 mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-regime"
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-regime --no-encode"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o scan -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc1 -o scan -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc2 -o scan -- $CMD > $OUT/pmc2.log 2>&1
