@@ -61,13 +61,15 @@ __device__ __forceinline__ void tile_of_block(int nbm, int nbn, int& tm, int& tn
 }
 
 // ---------------------------------------------------------------------------------------------------
-// f32 path: BK = 16, LDS row = 16 floats + 4 pad (80 B)
+// f32 path: BK = 32, LDS row = 32 floats + 4 pad (144 B: a 16-lane ds_read_b128 group covers 16 distinct slots)
 // ---------------------------------------------------------------------------------------------------
-constexpr int BK32 = 16, LD32 = 20;
+constexpr int BK32 = 32, LD32 = 36;
 
+template <bool FAST>
 __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * LD32];
-    __shared__ __attribute__((aligned(16))) float sW[2][BN * LD32];
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* sA = smem32;                        // [2][BM * LD32]
+    float* sW = smem32 + 2 * BM * LD32;        // [2][BN * LD32]
     const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
     int tm, tn;
     tile_of_block(nbm, nbn, tm, tn);
@@ -75,48 +77,63 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
-    // staging: 128 rows x 16 floats = 512 float4 per operand -> 2 per thread
-    const int srow = tid >> 2, scol = (tid & 3) * 4;          // rows srow and srow+64
+    // staging: 128 rows x 32 floats = 1024 float4 per operand -> 4 per thread (rows srow + 32*h)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
     const bool k_vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldw % 4 == 0);
-    float4 ra[2], rw[2];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = srow + h * 64;
-            const int k = k0 + scol;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
-            if (m0 + r < g.M) {
-                const float* p = g.A + (int64_t)(m0 + r) * g.lda + k;
-                if (k_vec && k + 3 < g.K) va = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (k < g.K) va.x = p[0];
-                    if (k + 1 < g.K) va.y = p[1];
-                    if (k + 2 < g.K) va.z = p[2];
-                    if (k + 3 < g.K) va.w = p[3];
-                }
-            }
-            if (n0 + r < g.N) {
-                const float* p = g.W + (int64_t)(n0 + r) * g.ldw + k;
-                if (k_vec && k + 3 < g.K) vw = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (k < g.K) vw.x = p[0];
-                    if (k + 1 < g.K) vw.y = p[1];
-                    if (k + 2 < g.K) vw.z = p[2];
-                    if (k + 3 < g.K) vw.w = p[3];
-                }
-            }
-            ra[h] = va;
-            rw[h] = vw;
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+
+    auto load_a = [&](int h, int k0) -> float4 {
+        const int r = srow + h * 32;
+        if (FAST) {       // K % BK == 0, 16-byte aligned rows: branch-free, rows clamped (clamped rows are never stored)
+            const int rr = m0 + r < g.M ? m0 + r : g.M - 1;
+            return *reinterpret_cast<const float4*>(g.A + (int64_t)rr * g.lda + k0 + scol);
         }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = srow + h * 64;
-            *reinterpret_cast<float4*>(&sA[buf][r * LD32 + scol]) = ra[h];
-            *reinterpret_cast<float4*>(&sW[buf][r * LD32 + scol]) = rw[h];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = k0 + scol;
+        if (m0 + r < g.M) {
+            const float* p = g.A + (int64_t)(m0 + r) * g.lda + k;
+            if (k_vec && k + 3 < g.K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k < g.K) v.x = p[0];
+                if (k + 1 < g.K) v.y = p[1];
+                if (k + 2 < g.K) v.z = p[2];
+                if (k + 3 < g.K) v.w = p[3];
+            }
         }
+        return v;
     };
+    auto load_w = [&](int h, int k0) -> float4 {
+        const int r = srow + h * 32;
+        if (FAST) {
+            const int rr = n0 + r < g.N ? n0 + r : g.N - 1;
+            return *reinterpret_cast<const float4*>(g.W + (int64_t)rr * g.ldw + k0 + scol);
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = k0 + scol;
+        if (n0 + r < g.N) {
+            const float* p = g.W + (int64_t)(n0 + r) * g.ldw + k;
+            if (k_vec && k + 3 < g.K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k < g.K) v.x = p[0];
+                if (k + 1 < g.K) v.y = p[1];
+                if (k + 2 < g.K) v.z = p[2];
+                if (k + 3 < g.K) v.w = p[3];
+            }
+        }
+        return v;
+    };
+#define XMH_GLOAD(k0)                                                       \
+    ra0 = load_a(0, k0); ra1 = load_a(1, k0); ra2 = load_a(2, k0); ra3 = load_a(3, k0); \
+    rw0 = load_w(0, k0); rw1 = load_w(1, k0); rw2 = load_w(2, k0); rw3 = load_w(3, k0);
+#define XMH_SWRITE(buf)                                                                              \
+    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 0) * LD32 + scol]) = ra0;             \
+    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 32) * LD32 + scol]) = ra1;            \
+    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 64) * LD32 + scol]) = ra2;            \
+    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 96) * LD32 + scol]) = ra3;            \
+    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 0) * LD32 + scol]) = rw0;             \
+    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 32) * LD32 + scol]) = rw1;            \
+    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 64) * LD32 + scol]) = rw2;            \
+    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 96) * LD32 + scol]) = rw3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -127,40 +144,45 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = (g.K + BK32 - 1) / BK32;
-    gload(0);
-    swrite(0);
+    XMH_GLOAD(0)
+    XMH_SWRITE(0)
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;                  // fragment row/col, k half
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK32);               // global loads fly under the MFMAs below
-        float4 a[2][2], b[2][2];
+        if (kt + 1 < nk) { XMH_GLOAD((kt + 1) * BK32) }        // global loads fly under the MFMAs below
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* pa = &sA[buf][(wm + i * 32 + fr) * LD32 + fh * 8];
-            const float* pb = &sW[buf][(wn + i * 32 + fr) * LD32 + fh * 8];
-            a[i][0] = *reinterpret_cast<const float4*>(pa);
-            a[i][1] = *reinterpret_cast<const float4*>(pa + 4);
-            b[i][0] = *reinterpret_cast<const float4*>(pb);
-            b[i][1] = *reinterpret_cast<const float4*>(pb + 4);
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int half = 0; half < 2; ++half) {                 // two k-slabs of 16: lane half fh reads k = half*16 + fh*8 ..+7
+            float4 a[2][2], b[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float av = reinterpret_cast<const float*>(&a[i][0])[s];
+                const float* pa = &sA[buf * BM * LD32 + (wm + i * 32 + fr) * LD32 + half * 16 + fh * 8];
+                const float* pb = &sW[buf * BN * LD32 + (wn + i * 32 + fr) * LD32 + half * 16 + fh * 8];
+                a[i][0] = *reinterpret_cast<const float4*>(pa);
+                a[i][1] = *reinterpret_cast<const float4*>(pa + 4);
+                b[i][0] = *reinterpret_cast<const float4*>(pb);
+                b[i][1] = *reinterpret_cast<const float4*>(pb + 4);
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float bv = reinterpret_cast<const float*>(&b[j][0])[s];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float av = reinterpret_cast<const float*>(&a[i][0])[s];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float bv = reinterpret_cast<const float*>(&b[j][0])[s];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
         if (kt + 1 < nk) {
-            swrite(buf ^ 1);
+            XMH_SWRITE(buf ^ 1)
             __syncthreads();
         }
     }
+#undef XMH_GLOAD
+#undef XMH_SWRITE
 
     // epilogue: lane holds column (lane&31) and rows (e&3) + 8*(e>>2) + 4*(lane>>5) of each 32x32 tile
 #pragma unroll
@@ -189,6 +211,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int BK16 = 32, LD16 = 40;
 
+template <bool FAST>
 __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LD16];
     __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LD16];
@@ -204,6 +227,17 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
     const bool k_vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldw % 4 == 0);
     float4 ra[4], rw[4];
     auto gload = [&](int k0) {
+        if (FAST) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int r = srow + h * 32;
+                const int ra_ = m0 + r < g.M ? m0 + r : g.M - 1;
+                const int rw_ = n0 + r < g.N ? n0 + r : g.N - 1;
+                ra[h] = *reinterpret_cast<const float4*>(g.A + (int64_t)ra_ * g.lda + k0 + scol);
+                rw[h] = *reinterpret_cast<const float4*>(g.W + (int64_t)rw_ * g.ldw + k0 + scol);
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int r = srow + h * 32;
@@ -318,9 +352,22 @@ extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int6
     const int64_t nblk = xmh::ceil_div(M, BM) * xmh::ceil_div(N, BN);
     hipStream_t st = xmh::as_stream(stream);
     xmh::ProfScope prof(precision == 1 ? "gemm_f16" : "gemm_f32", st);
-    if (precision == 0) hipLaunchKernelGGL(k_gemm_nt_f32, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    else if (precision == 1) hipLaunchKernelGGL(k_gemm_nt_f16, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    else return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: precision must be 0 (f32 MFMA) or 1 (f16 MFMA, f32 accumulate)");
+    const bool aligned = (lda % 4 == 0) && (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
+    if (precision == 0) {
+        const size_t lds = (size_t)2 * (BM + BN) * LD32 * 4;          // 73,728 B: above the 64 KB default, opt in once per kernel
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e1 != hipSuccess || e2 != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_gemm_nt_f32: cannot raise dynamic LDS to %zu", lds);
+            raised = true;
+        }
+        if (aligned && K % BK32 == 0) hipLaunchKernelGGL(k_gemm_nt_f32<true>, dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+        else hipLaunchKernelGGL(k_gemm_nt_f32<false>, dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+    } else if (precision == 1) {
+        if (aligned && K % BK16 == 0) hipLaunchKernelGGL(k_gemm_nt_f16<true>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+        else hipLaunchKernelGGL(k_gemm_nt_f16<false>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    } else return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: precision must be 0 (f32 MFMA) or 1 (f16 MFMA, f32 accumulate)");
     XMH_LAUNCH_CHECK("xmh_gemm_nt_f32");
     return XMH_OK;
 }

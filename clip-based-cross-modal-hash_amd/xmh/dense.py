@@ -30,8 +30,8 @@ def cosine(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def pairwise_l2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = a.contiguous(), b.contiguous()
     g = ops.gemm_nt(a, b, precision=ops.PREC_F32)
-    check(lib.xmh_pairwise_l2_from_gram(ptr(g), ptr(_sqnorm(a)), ptr(_sqnorm(b)), a.shape[0], b.shape[0], current_stream()),
-          "xmh_pairwise_l2_from_gram")
+    na, nb = _sqnorm(a), _sqnorm(b)          # keep both alive until the launch is enqueued (a freed temporary's block can be re-used)
+    check(lib.xmh_pairwise_l2_from_gram(ptr(g), ptr(na), ptr(nb), a.shape[0], b.shape[0], current_stream()), "xmh_pairwise_l2_from_gram")
     return g
 
 

@@ -60,9 +60,9 @@ def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    x2 = _rows(x)
+    x2, gm, bt = _rows(x), _f32c(gamma), _f32c(beta)       # locals keep any converted temporaries alive past the launch
     y = torch.empty_like(x2)
-    check(lib.xmh_layernorm_f32(ptr(x2), x2.stride(0), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps, ptr(y), y.stride(0), x2.shape[0],
+    check(lib.xmh_layernorm_f32(ptr(x2), x2.stride(0), ptr(gm), ptr(bt), eps, ptr(y), y.stride(0), x2.shape[0],
                                 x2.shape[1], current_stream()), "xmh_layernorm_f32")
     return y.reshape(x.shape)
 
@@ -94,8 +94,8 @@ def im2col_patch(image: torch.Tensor, patch: int) -> torch.Tensor:
 def vit_assemble(patch_out, cls, pos, gamma, beta, B: int, n_patches: int, eps: float = 1e-5) -> torch.Tensor:
     D = patch_out.shape[-1]
     x = torch.empty(B, n_patches + 1, D, dtype=torch.float32, device=patch_out.device)
-    check(lib.xmh_vit_assemble(ptr(_rows(patch_out)), ptr(_f32c(cls)), ptr(_f32c(pos).contiguous()), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps,
-                               ptr(x), B, n_patches, D, current_stream()), "xmh_vit_assemble")
+    po, c, p, gm, bt = _rows(patch_out), _f32c(cls), _f32c(pos).contiguous(), _f32c(gamma), _f32c(beta)
+    check(lib.xmh_vit_assemble(ptr(po), ptr(c), ptr(p), ptr(gm), ptr(bt), eps, ptr(x), B, n_patches, D, current_stream()), "xmh_vit_assemble")
     return x
 
 
@@ -124,8 +124,9 @@ def gather_rows(x: torch.Tensor, group: int, idx: Optional[torch.Tensor] = None,
 def affine_cols(x, mean, var, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
     x2 = _rows(x).contiguous()
     y = torch.empty_like(x2)
-    check(lib.xmh_affine_cols(ptr(x2), ptr(_f32c(mean)), ptr(_f32c(var)), ptr(_f32c(gamma)), ptr(_f32c(beta)), eps, ptr(y), x2.shape[0],
-                              x2.shape[1], current_stream()), "xmh_affine_cols")
+    mn, vr, gm, bt = _f32c(mean), _f32c(var), _f32c(gamma), _f32c(beta)
+    check(lib.xmh_affine_cols(ptr(x2), ptr(mn), ptr(vr), ptr(gm), ptr(bt), eps, ptr(y), x2.shape[0], x2.shape[1], current_stream()),
+          "xmh_affine_cols")
     return y
 
 
@@ -155,6 +156,6 @@ def bitwise_hash(z: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, addend: O
     B, K, D = z.shape
     out = torch.empty(B, K, dtype=torch.float32, device=z.device)
     a = None if addend is None else _f32c(addend).contiguous()
-    check(lib.xmh_bitwise_hash(ptr(z), ptr(_f32c(w).contiguous()), ptr(_f32c(bias).contiguous()), ptr(a), ptr(out), B, K, D, current_stream()),
-          "xmh_bitwise_hash")
+    w2, b2 = _f32c(w).contiguous(), _f32c(bias).contiguous()
+    check(lib.xmh_bitwise_hash(ptr(z), ptr(w2), ptr(b2), ptr(a), ptr(out), B, K, D, current_stream()), "xmh_bitwise_hash")
     return out
