@@ -67,8 +67,23 @@ def cpu_baseline(qB, qL, rB, rL, budget_s=20.0):
                       % (qsub, qB.shape[0], rB.shape[0], threads, dt), "map": float(m)}
 
 
-def ev():
-    return torch.cuda.Event(enable_timing=True)
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary under profiles/ (collected by
+    tools/profile_round.sh with separate FETCH_SIZE / WRITE_SIZE passes and the gfx950 corrections of
+    MI355X_MICROARCH.md); None if no profile has been committed for it."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, e in d.get("pmc", {}).items():
+            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+                best = {"bytes": e["hbm_bytes_per_launch"]["total"], "fetch_raw": e["hbm_bytes_per_launch"]["fetch_raw"],
+                        "write_raw": e["hbm_bytes_per_launch"]["write_raw"], "fetch_correction": e["hbm_bytes_per_launch"]["fetch_correction"],
+                        "source": os.path.relpath(f, ROOT)}
+    return best
 
 
 def main():
@@ -156,7 +171,8 @@ def main():
     roofline = {
         "kernel": "k_scan_ap (pass 2 of the fused mAP scan), HIP events around the launch, %d launches" % n_ap,
         "bound": "hbm", "achieved": alg_bytes / t_ap / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": None,
+        "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_scan_ap") or {}).get("bytes"),
+        "traffic_detail": pmc_traffic("k_scan_ap"),
         "algorithmic_bytes": alg_bytes, "avg_launch_ms": t_ap * 1e3,
         "valu": {"lane_ops_per_pair": ops_pair_ap, "achieved": Q * Rn * ops_pair_ap / t_ap / 1e9,
                  "peak": VALU_PEAK_GLOPS, "unit": "G lane-ops/s", "frac": Q * Rn * ops_pair_ap / t_ap / 1e9 / VALU_PEAK_GLOPS},

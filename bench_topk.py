@@ -21,6 +21,15 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
+def _traffic():
+    try:
+        import bench
+        t = bench.pmc_traffic("k_topk_filter")
+        return None if t is None else t["bytes"]
+    except Exception:
+        return None
+
+
 def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3):
     from xmh import retrieval as X
     from xmh._lib import lib
@@ -47,7 +56,7 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3):
     alg = R * W * 4 + Q * W * 4 + Q * 4                 # gallery read once + queries + thresholds
     return {"kernel": "k_topk_filter (streaming pass of xmh_hamming_topk), HIP events around the launch, %d launches" % launches,
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
+            "traffic": _traffic(), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
             "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9,
             "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU" % (k, Q, R, K),
             "pairs_per_s_whole_call": Q * R / t_call}

@@ -534,7 +534,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     // pass 2 runs `rounds` resident sets of waves; pass 1 (half the LDS) then gets 2 waves per SIMD
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
-    const int64_t rounds = rounds_env > 0 ? rounds_env : 4;
+    const int64_t rounds = rounds_env > 0 ? rounds_env : 2;
     int64_t nchunk = rounds * slots / nqt;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile: rocprofv3 kernel trace + stats of the default bench command, then separate PMC passes
+# (FETCH_SIZE / WRITE_SIZE cannot share a pass: TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2).
+# Run on the GPU box:  gpurun -- ./tools/profile_round.sh r01      -> gpurun_out/profile_<tag>/..., summary JSON/MD
+TAG=${1:-r01}
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/profile_$TAG
+rm -rf $OUT; mkdir -p $OUT
+CMD="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o b -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- $CMD > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o b -- $CMD > $OUT/pmc_write.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc_sq1 -o b -- $CMD > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq2 -o b -- $CMD > $OUT/pmc_sq2.log 2>&1
+python tools/summarize_profile.py $OUT $TAG

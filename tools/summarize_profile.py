@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into small, committable summaries: <out>/summary_<tag>.md and .json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+res = {"tag": tag, "kernel_stats": [], "pmc": {}}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        res["kernel_stats"].append({"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                    "total_ns": float(r["TotalDurationNs"]), "pct": float(r["Percentage"]), "min_ns": float(r["MinNs"]),
+                                    "max_ns": float(r["MaxNs"])})
+res["kernel_stats"].sort(key=lambda r: -r["total_ns"])
+res["kernel_stats"] = res["kernel_stats"][:30]
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[k].add(r["Dispatch_Id"])
+        for k, v in agg.items():
+            e = res["pmc"].setdefault(k, {"per_launch": {}})
+            n = max(1, len(disp[k]))
+            e["launches_seen"] = n
+            for c, val in v.items():
+                e["per_launch"][c] = val / n
+# HBM traffic per launch as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
+# the bytes of a wide (16 B/lane) coalesced streaming read -> doubled for the kernels whose reads are of that kind.
+WIDE = ("k_topk_filter", "k_gemm_nt", "k_topk_stream", "k_im2col_patch")
+for k, e in res["pmc"].items():
+    pl = e["per_launch"]
+    if "FETCH_SIZE" in pl or "WRITE_SIZE" in pl:
+        f = pl.get("FETCH_SIZE", 0.0) * 1024.0
+        w = pl.get("WRITE_SIZE", 0.0) * 1024.0
+        corr = 2.0 if any(k.startswith(x) for x in WIDE) else 1.0
+        e["hbm_bytes_per_launch"] = {"fetch_raw": f, "write_raw": w, "fetch_correction": corr, "total": f * corr + w}
+json.dump(res, open(os.path.join(out, "summary_%s.json" % tag), "w"), indent=1)
+with open(os.path.join(out, "summary_%s.md" % tag), "w") as md:
+    md.write("# rocprofv3 summary %s\n\ncommand: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes\n\n" % tag)
+    md.write("## kernel stats (top by total time)\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+    for r in res["kernel_stats"]:
+        md.write("| %s | %d | %.2f | %.2f | %.2f | %.2f |\n" % (r["name"], r["calls"], r["avg_ns"] / 1e3, r["min_ns"] / 1e3, r["max_ns"] / 1e3, r["pct"]))
+    md.write("\n## PMC per launch (averaged over the launches seen)\n\n")
+    for k, e in sorted(res["pmc"].items()):
+        if not any(s in k for s in ("k_scan", "k_topk", "k_gemm", "k_attention", "k_layernorm", "k_pack")):
+            continue
+        md.write("### %s (%d launches)\n\n" % (k, e["launches_seen"]))
+        for c, v in sorted(e["per_launch"].items()):
+            md.write("- %s = %.4g\n" % (c, v))
+        if "hbm_bytes_per_launch" in e:
+            h = e["hbm_bytes_per_launch"]
+            md.write("- **HBM bytes/launch** = %.4g (FETCH_SIZE*1024*%g + WRITE_SIZE*1024)\n" % (h["total"], h["fetch_correction"]))
+        md.write("\n")
+print(open(os.path.join(out, "summary_%s.md" % tag)).read()[:6000])
