@@ -98,8 +98,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-regime", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU exchange path even with one rank (RCCL smoke test)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
+
+    # stdout must carry exactly ONE JSON line: route everything else (RCCL banners printed from C, warnings) to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,9 +115,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_sharded
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
 
     from xmh import retrieval as R
     from xmh import sharded
@@ -128,14 +136,14 @@ def main():
     scan = ops.scan
 
     def step():
-        if world == 1:
+        if not use_dist:
             scan.histograms(False)
             a, c = scan.ap_sums(None)
             return R.map_finalize(a, c)
         return sharded.map_k_sharded(ops, None)[0]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +155,7 @@ def main():
         m = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,10 +217,12 @@ def main():
         _, _, rB0, rL0 = rB, rL, rB, rL
         out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, args.cpu_seconds)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -67,3 +67,24 @@ def test_runner_valid_matches_oracle(tmp_path, arch, runner, K):
     t2.top_k = None
     assert abs(t2.test()[0] - maps[0]) < 1e-6
     assert os.path.exists(os.path.join(str(tmp_path), "mat_files", "test.mat"))
+
+
+def test_bench_sharded_path_over_rccl_single_rank():
+    """bench.py's multi-GPU exchange path (all_gather of histograms, all_reduce of AP sums over RCCL) on one rank:
+    must run and give the same mAP as the single-process path."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--Q", "300", "--R", "20000", "--no-cpu-baseline",
+            "--no-hbm-regime", "--no-encode"]
+    a = json.loads(subprocess.run(base, capture_output=True, text=True, check=True, timeout=600).stdout.strip().splitlines()[-1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    b = json.loads(subprocess.run(base + ["--force-sharded"], capture_output=True, text=True, check=True, timeout=600, env=env).stdout.strip().splitlines()[-1])
+    assert abs(a["mAP"] - b["mAP"]) < 1e-9 and b["n_gpus"] == 1 and b["value"] > 0
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in a
+    assert a["roofline"]["bound"] in ("hbm", "mfma") and "frac" in a["roofline"] and "workload" in a["config"]
