@@ -65,33 +65,36 @@ __device__ __forceinline__ void tile_of_block(int nbm, int nbn, int& tm, int& tn
 // ---------------------------------------------------------------------------------------------------
 constexpr int BK32 = 32, LD32 = 36;
 
-template <bool FAST>
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128x128 block tile (large grids), 1 -> 64x128 block tile, chosen
+// by the launcher when the 128x128 grid would leave less than two waves per SIMD (text tower, N = 768 GEMMs).
+template <bool FAST, int MI>
 __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
+    constexpr int TBM = 64 * MI;                               // block rows
+    constexpr int AH = MI * 2;                                 // float4 of A staged per thread (TBM rows / 32 rows per pass)
     extern __shared__ __attribute__((aligned(16))) float smem32[];
-    float* sA = smem32;                        // [2][BM * LD32]
-    float* sW = smem32 + 2 * BM * LD32;        // [2][BN * LD32]
-    const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+    float* sA = smem32;                        // [2][TBM * LD32]
+    float* sW = smem32 + 2 * TBM * LD32;       // [2][BN * LD32]
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
     int tm, tn;
     tile_of_block(nbm, nbn, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
 
-    // staging: 128 rows x 32 floats = 1024 float4 per operand -> 4 per thread (rows srow + 32*h)
+    // staging: rows srow + 32*h, 8 float4 columns per row
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     const bool k_vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldw % 4 == 0);
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    float4 ra[AH], rw[4];
 
-    auto load_a = [&](int h, int k0) -> float4 {
-        const int r = srow + h * 32;
+    auto load_row = [&](const float* base, int64_t ld, int row0, int nrows, int r, int k0) -> float4 {
         if (FAST) {       // K % BK == 0, 16-byte aligned rows: branch-free, rows clamped (clamped rows are never stored)
-            const int rr = m0 + r < g.M ? m0 + r : g.M - 1;
-            return *reinterpret_cast<const float4*>(g.A + (int64_t)rr * g.lda + k0 + scol);
+            const int rr = row0 + r < nrows ? row0 + r : nrows - 1;
+            return *reinterpret_cast<const float4*>(base + (int64_t)rr * ld + k0 + scol);
         }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int k = k0 + scol;
-        if (m0 + r < g.M) {
-            const float* p = g.A + (int64_t)(m0 + r) * g.lda + k;
+        if (row0 + r < nrows) {
+            const float* p = base + (int64_t)(row0 + r) * ld + k;
             if (k_vec && k + 3 < g.K) v = *reinterpret_cast<const float4*>(p);
             else {
                 if (k < g.K) v.x = p[0];
@@ -102,71 +105,54 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
         }
         return v;
     };
-    auto load_w = [&](int h, int k0) -> float4 {
-        const int r = srow + h * 32;
-        if (FAST) {
-            const int rr = n0 + r < g.N ? n0 + r : g.N - 1;
-            return *reinterpret_cast<const float4*>(g.W + (int64_t)rr * g.ldw + k0 + scol);
-        }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int k = k0 + scol;
-        if (n0 + r < g.N) {
-            const float* p = g.W + (int64_t)(n0 + r) * g.ldw + k;
-            if (k_vec && k + 3 < g.K) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (k < g.K) v.x = p[0];
-                if (k + 1 < g.K) v.y = p[1];
-                if (k + 2 < g.K) v.z = p[2];
-                if (k + 3 < g.K) v.w = p[3];
-            }
-        }
-        return v;
-    };
-#define XMH_GLOAD(k0)                                                       \
-    ra0 = load_a(0, k0); ra1 = load_a(1, k0); ra2 = load_a(2, k0); ra3 = load_a(3, k0); \
-    rw0 = load_w(0, k0); rw1 = load_w(1, k0); rw2 = load_w(2, k0); rw3 = load_w(3, k0);
-#define XMH_SWRITE(buf)                                                                              \
-    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 0) * LD32 + scol]) = ra0;             \
-    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 32) * LD32 + scol]) = ra1;            \
-    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 64) * LD32 + scol]) = ra2;            \
-    *reinterpret_cast<float4*>(&sA[(buf) * BM * LD32 + (srow + 96) * LD32 + scol]) = ra3;            \
-    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 0) * LD32 + scol]) = rw0;             \
-    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 32) * LD32 + scol]) = rw1;            \
-    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 64) * LD32 + scol]) = rw2;            \
-    *reinterpret_cast<float4*>(&sW[(buf) * BN * LD32 + (srow + 96) * LD32 + scol]) = rw3;
-
-    f32x16 acc[2][2];
+    auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int h = 0; h < AH; ++h) ra[h] = load_row(g.A, g.lda, m0, g.M, srow + 32 * h, k0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rw[h] = load_row(g.W, g.ldw, n0, g.N, srow + 32 * h, k0);
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < AH; ++h) *reinterpret_cast<float4*>(&sA[buf * TBM * LD32 + (srow + 32 * h) * LD32 + scol]) = ra[h];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(&sW[buf * BN * LD32 + (srow + 32 * h) * LD32 + scol]) = rw[h];
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = (g.K + BK32 - 1) / BK32;
-    XMH_GLOAD(0)
-    XMH_SWRITE(0)
+    gload(0);
+    swrite(0);
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;                  // fragment row/col, k half
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) { XMH_GLOAD((kt + 1) * BK32) }        // global loads fly under the MFMAs below
+        if (kt + 1 < nk) gload((kt + 1) * BK32);               // global loads fly under the MFMAs below
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                 // two k-slabs of 16: lane half fh reads k = half*16 + fh*8 ..+7
-            float4 a[2][2], b[2][2];
+            float4 a[MI][2], b[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float* pa = &sA[buf * BM * LD32 + (wm + i * 32 + fr) * LD32 + half * 16 + fh * 8];
-                const float* pb = &sW[buf * BN * LD32 + (wn + i * 32 + fr) * LD32 + half * 16 + fh * 8];
+            for (int i = 0; i < MI; ++i) {
+                const float* pa = &sA[buf * TBM * LD32 + (wm + i * 32 + fr) * LD32 + half * 16 + fh * 8];
                 a[i][0] = *reinterpret_cast<const float4*>(pa);
                 a[i][1] = *reinterpret_cast<const float4*>(pa + 4);
-                b[i][0] = *reinterpret_cast<const float4*>(pb);
-                b[i][1] = *reinterpret_cast<const float4*>(pb + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* pb = &sW[buf * BN * LD32 + (wn + j * 32 + fr) * LD32 + half * 16 + fh * 8];
+                b[j][0] = *reinterpret_cast<const float4*>(pb);
+                b[j][1] = *reinterpret_cast<const float4*>(pb + 4);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     const float av = reinterpret_cast<const float*>(&a[i][0])[s];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -177,16 +163,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f32(GemmArgs g) {
             }
         }
         if (kt + 1 < nk) {
-            XMH_SWRITE(buf ^ 1)
+            swrite(buf ^ 1);
             __syncthreads();
         }
     }
-#undef XMH_GLOAD
-#undef XMH_SWRITE
 
     // epilogue: lane holds column (lane&31) and rows (e&3) + 8*(e>>2) + 4*(lane>>5) of each 32x32 tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn + j * 32 + fr;
@@ -349,21 +333,30 @@ extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int6
     g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
-    const int64_t nblk = xmh::ceil_div(M, BM) * xmh::ceil_div(N, BN);
+    int64_t nblk = xmh::ceil_div(M, BM) * xmh::ceil_div(N, BN);
     hipStream_t st = xmh::as_stream(stream);
     xmh::ProfScope prof(precision == 1 ? "gemm_f16" : "gemm_f32", st);
     const bool aligned = (lda % 4 == 0) && (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
     if (precision == 0) {
-        const size_t lds = (size_t)2 * (BM + BN) * LD32 * 4;          // 73,728 B: above the 64 KB default, opt in once per kernel
+        const bool fast = aligned && K % BK32 == 0;
+        const bool small = nblk < 2ll * xmh::device_cu_count();          // fewer than two 128x128 blocks per CU -> 64x128 tiles
+        const size_t lds = (size_t)2 * ((small ? 64 : 128) + BN) * LD32 * 4;
         static bool raised = false;
         if (!raised) {
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e1 != hipSuccess || e2 != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_gemm_nt_f32: cannot raise dynamic LDS to %zu", lds);
+            const size_t big = (size_t)2 * (128 + BN) * LD32 * 4;        // 73,728 B: above the 64 KB default, opt in once
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+            if (e1 != hipSuccess || e2 != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_gemm_nt_f32: cannot raise dynamic LDS to %zu", big);
             raised = true;
         }
-        if (aligned && K % BK32 == 0) hipLaunchKernelGGL(k_gemm_nt_f32<true>, dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
-        else hipLaunchKernelGGL(k_gemm_nt_f32<false>, dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+        if (small) {
+            nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
+            if (fast) hipLaunchKernelGGL((k_gemm_nt_f32<true, 1>), dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+            else hipLaunchKernelGGL((k_gemm_nt_f32<false, 1>), dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_gemm_nt_f32<true, 2>), dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+            else hipLaunchKernelGGL((k_gemm_nt_f32<false, 2>), dim3((unsigned)nblk), dim3(kThreads), lds, st, g);
+        }
     } else if (precision == 1) {
         if (aligned && K % BK16 == 0) hipLaunchKernelGGL(k_gemm_nt_f16<true>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
         else hipLaunchKernelGGL(k_gemm_nt_f16<false>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);

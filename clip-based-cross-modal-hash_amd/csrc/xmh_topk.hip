@@ -508,14 +508,43 @@ __global__ __launch_bounds__(64) void k_topk_pick(const uint32_t* __restrict__ h
     t_est[q] = (uint32_t)t;
 }
 
-template <int W, int IPT>
+// rare path of the filter, kept out of line so the streaming loop stays small: wave-aggregated append
+__device__ __noinline__ void append_candidates(int64_t it, int d, bool hit, uint32_t* cnt_q, unsigned long long* cand_q) {
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = lane_id();
+    const int lead = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == lead) base = atomicAdd(cnt_q, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, lead);
+    if (hit) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < (uint32_t)kCandCap) cand_q[pos] = ((unsigned long long)d << 32) | (uint32_t)it;
+    }
+}
+
+// queries are processed in groups of QN (blockIdx.y): their words and thresholds are loaded ONCE per block
+// (wave-uniform -> SGPRs) and stay resident over the whole stream, so the tile loop is loads + XOR/popcount only.
+template <int W, int IPT, int QN>
 __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
                                                           int Q, int64_t R, const uint32_t* __restrict__ t_est,
                                                           uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     constexpr int TILE = kThreads * IPT;
-    const int lane = lane_id();
+    const int q0 = blockIdx.y * QN;
     const int64_t ntiles = (R + TILE - 1) / TILE;
     auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    uint32_t qw[QN][W];
+    int thr[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // clamp: surplus slots repeat the last query and are ignored below
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            qw[q][x] = qbits[(int64_t)qq * W + x];
+            asm volatile("" : "+v"(qw[q][x]));              // keep the 8x8 query words in VGPRs: 64+ SGPRs would spill through v_readlane
+        }
+        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+    }
     Rec<W> cur[IPT], nxt[IPT];
     int64_t tile = blockIdx.x;
     if (tile < ntiles) {
@@ -534,26 +563,22 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
                 load_rec<W>(nxt[j], rbits, it, it < R);
             }
         }
-        for (int q = 0; q < Q; ++q) {
-            const uint32_t* __restrict__ qw = qbits + (int64_t)q * W;     // uniform -> SGPRs
-            const int t = (int)t_est[q];
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const int64_t it = item_of(tile, j);
-                const int d = dist_words<W>(cur[j], qw);
-                const bool hit = it < R && d <= t;
-                const unsigned long long m = __ballot(hit);
-                if (m) {                                               // rare: a few hundred items per query per pass
-                    const int lead = __ffsll((long long)m) - 1;
-                    uint32_t base = 0;
-                    if (lane == lead) base = atomicAdd(&cnt[q], (uint32_t)__popcll(m));
-                    base = (uint32_t)__shfl((int)base, lead);
-                    if (hit) {
-                        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)d << 32) | (uint32_t)it;
-                    }
-                }
-            }
+        for (int q = 0; q < QN; ++q) {
+            int dd[IPT];                                   // word-major: IPT independent popcount chains interleave
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) dd[j] = 0;
+#pragma unroll
+            for (int x = 0; x < W; ++x)
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) dd[j] += __popc(cur[j].w[x] ^ qw[q][x]);
+            unsigned long long any = 0;
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) any |= __ballot(item_of(tile, j) < R && dd[j] <= thr[q]);
+            if (!any) continue;                            // common case: no candidate in this tile for this query
+#pragma unroll
+            for (int j = 0; j < IPT; ++j)
+                append_candidates(item_of(tile, j), dd[j], item_of(tile, j) < R && dd[j] <= thr[q], cnt + q0 + q, cand + (int64_t)(q0 + q) * kCandCap);
         }
         if (tn < ntiles) {
 #pragma unroll
@@ -710,11 +735,16 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
             hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)xmh::ceil_div(Q, 64)), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
                                target, f.t_est);                                                                           \
             const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
-            int64_t fb = (int64_t)xmh::device_cu_count() * 8;                                                              \
+            const int qn = Q >= 8 ? 8 : (Q >= 4 ? 4 : (Q >= 2 ? 2 : 1));                                                   \
+            const unsigned gy = (unsigned)xmh::ceil_div(Q, qn);                                                            \
+            int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;                                                         \
+            if (fb < xmh::device_cu_count()) fb = xmh::device_cu_count();                                                  \
             if (fb > ft) fb = ft;                                                                                          \
             xmh::ProfScope prof("topk_filter", st);                                                                        \
-            hipLaunchKernelGGL((k_topk_filter<WW, II>), dim3((unsigned)fb), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
-                               (const uint32_t*)f.t_est, f.cnt, f.cand);                                                   \
+            if (qn == 8) hipLaunchKernelGGL((k_topk_filter<WW, II, 8>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            else if (qn == 4) hipLaunchKernelGGL((k_topk_filter<WW, II, 4>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            else if (qn == 2) hipLaunchKernelGGL((k_topk_filter<WW, II, 2>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            else hipLaunchKernelGGL((k_topk_filter<WW, II, 1>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
         }
         switch (p.W) {
             case 1: XMH_FAST(1, 8) break;
