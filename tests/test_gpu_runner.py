@@ -88,3 +88,29 @@ def test_bench_sharded_path_over_rccl_single_rank():
                 "data", "config", "roofline"):
         assert key in a
     assert a["roofline"]["bound"] in ("hbm", "mfma") and "frac" in a["roofline"] and "workload" in a["config"]
+
+
+def test_runner_distributed_code_path_world_size_1(tmp_path):
+    """the sharded eval path of the runner (contiguous shard sampler, RCCL all-gather of packed query codes, histogram
+    exchange, all-reduce) with a 1-rank process group must reproduce the single-process result."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.distributed as dist
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, "DSPH", "DSPHTrainer", 64, layers=1)
+    single = registry.get_runner_class("DSPHTrainer").from_config(cfg=cfg, autorun=False)
+    want = single.valid(0, k=None)
+    cfg.run.distributed_addr, cfg.run.distributed_port = "127.0.0.1", 29577
+    cfg.run.save_dir = cfg.run.log_dir = str(tmp_path / "dist")
+    try:
+        shard = registry.get_runner_class("DSPHTrainer").from_config(0, 1, True, cfg, None, autorun=False)
+        got = shard.valid(0, k=None)
+        q_img, _ = shard.get_code(shard.query_loader, shard.query_num)
+        assert q_img.shape == (50, 64)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    for a, b in zip(got, want):
+        assert abs(a - b) < 1e-9
