@@ -61,35 +61,46 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 
 // ---- small-sequence attention: one block per (batch, head), one thread per query row -------------------
 // qkv: [B, L, 3*H*dh] rows = tokens, columns [q | k | v] each H*dh wide (nn.MultiheadAttention in_proj order).
-// LDS: K and V of this head [L][dh+1], scores [L][L+1].
+// LDS: K and V of this head [L][dh] (float4 rows), scores [L][L+1].
 template <int DH>
 __global__ void k_attention(const float* __restrict__ qkv, int L, int H, int causal, const uint8_t* __restrict__ kpm,
                             float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * DH;
-    float* sK = smem;                          // [L][DH+1]
-    float* sV = sK + L * (DH + 1);             // [L][DH+1]
-    float* sS = sV + L * (DH + 1);             // [L][L+1]
+    // K and V rows are read by all lanes at the same address (LDS broadcast: no bank conflicts whatever the stride), so
+    // they stay unpadded and 16-byte aligned for ds_read_b128; the score rows are per-lane and padded by one float.
+    float4* sK = reinterpret_cast<float4*>(smem);                    // [L][DH/4]
+    float4* sV = sK + L * (DH / 4);                                  // [L][DH/4]
+    float* sS = reinterpret_cast<float*>(sV + L * (DH / 4));         // [L][L+1]
     const float* base = qkv + (int64_t)b * L * 3 * D;
-    for (int e = threadIdx.x; e < L * DH; e += blockDim.x) {
-        const int j = e / DH, c = e % DH;
-        sK[j * (DH + 1) + c] = base[(int64_t)j * 3 * D + D + h * DH + c];
-        sV[j * (DH + 1) + c] = base[(int64_t)j * 3 * D + 2 * D + h * DH + c];
+    for (int e = threadIdx.x; e < L * (DH / 4); e += blockDim.x) {
+        const int j = e / (DH / 4), c4 = e % (DH / 4);
+        sK[e] = *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + D + h * DH + c4 * 4);
+        sV[e] = *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + 2 * D + h * DH + c4 * 4);
     }
     __syncthreads();
     const int i = threadIdx.x;
     if (i >= L) return;
-    float q[DH];
+    float4 q[DH / 4];
     const float scale = rsqrtf((float)DH);
 #pragma unroll
-    for (int c = 0; c < DH; ++c) q[c] = base[(int64_t)i * 3 * D + h * DH + c] * scale;   // PyTorch scales q before QK^T
+    for (int c = 0; c < DH / 4; ++c) {                               // PyTorch scales q before QK^T
+        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * 3 * D + h * DH + c * 4);
+        q[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
     float* srow = sS + i * (L + 1);
     float mx = -INFINITY;
     for (int j = 0; j < L; ++j) {
         float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < DH; ++c) s = fmaf(q[c], sK[j * (DH + 1) + c], s);
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 kv = sK[j * (DH / 4) + c];
+            s = fmaf(q[c].x, kv.x, s);
+            s = fmaf(q[c].y, kv.y, s);
+            s = fmaf(q[c].z, kv.z, s);
+            s = fmaf(q[c].w, kv.w, s);
+        }
         if ((causal && j > i) || (kpm && kpm[(int64_t)b * L + j])) s = -INFINITY;
         srow[j] = s;
         mx = fmaxf(mx, s);
@@ -101,17 +112,23 @@ __global__ void k_attention(const float* __restrict__ qkv, int L, int H, int cau
         sum += p;
     }
     const float inv = 1.0f / sum;
-    float o[DH];
+    float4 o[DH / 4];
 #pragma unroll
-    for (int c = 0; c < DH; ++c) o[c] = 0.0f;
+    for (int c = 0; c < DH / 4; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < L; ++j) {
         const float p = srow[j] * inv;
 #pragma unroll
-        for (int c = 0; c < DH; ++c) o[c] = fmaf(p, sV[j * (DH + 1) + c], o[c]);
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 vv = sV[j * (DH / 4) + c];
+            o[c].x = fmaf(p, vv.x, o[c].x);
+            o[c].y = fmaf(p, vv.y, o[c].y);
+            o[c].z = fmaf(p, vv.z, o[c].z);
+            o[c].w = fmaf(p, vv.w, o[c].w);
+        }
     }
     float* orow = out + ((int64_t)b * L + i) * D + h * DH;
 #pragma unroll
-    for (int c = 0; c < DH; ++c) orow[c] = o[c];
+    for (int c = 0; c < DH / 4; ++c) *reinterpret_cast<float4*>(orow + c * 4) = o[c];
 }
 
 // ---- patch gather: cols[(b*G*G + gy*G + gx)][c*P*P + dy*P + dx] = image[b][c][gy*P+dy][gx*P+dx] --------
@@ -345,7 +362,7 @@ extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int 
     if (dh != 64) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
     if (L > 128) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
     if (!qkv || !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
-    const size_t lds = ((size_t)2 * L * (dh + 1) + (size_t)L * (L + 1)) * 4;
+    const size_t lds = ((size_t)2 * L * dh + (size_t)L * (L + 1)) * 4;
     const int threads = L <= 64 ? 64 : 128;
     auto kern = k_attention<64>;
     if (lds > 64 * 1024) {
