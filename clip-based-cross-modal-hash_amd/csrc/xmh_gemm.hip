@@ -318,6 +318,113 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// h16 path: A and W already fp16 in memory (fast mode proper: weights are converted once and cached by the host,
+// activations by one HBM-bound cast pass), BK = 64, LDS row = 64 halves + 8 pad (144 B), no conversion in the loop.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BKH = 32, LDH = 40;          // 32 halves + 8 pad = 80 B rows: 16-lane ds_read_b128 groups hit 16 distinct slots
+
+struct GemmArgsH {
+    const _Float16* A;
+    const _Float16* W;
+    const float* bias;
+    const float* residual;
+    float* C;
+    int64_t lda, ldw, ldr, ldc;
+    int M, N, K, act;
+};
+
+template <int MI>
+__global__ __launch_bounds__(kThreads) void k_gemm_nt_h16(GemmArgsH g) {
+    constexpr int TBM = 64 * MI;
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][TBM * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LDH];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
+    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 halves = 16 B per thread
+    // named registers (not arrays captured by a lambda): hipcc sends such arrays to scratch, one round trip per K step
+    uint4 ra0, ra1, rw0, rw1;
+    ra0 = ra1 = rw0 = rw1 = make_uint4(0u, 0u, 0u, 0u);
+    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
+    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
+#define XMH_HLOAD(k0)                                                                                               \
+    ra0 = *reinterpret_cast<const uint4*>(g.A + (int64_t)row_a(srow) * g.lda + (k0) + scol);                         \
+    if (MI == 2) ra1 = *reinterpret_cast<const uint4*>(g.A + (int64_t)row_a(srow + 64) * g.lda + (k0) + scol);       \
+    rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                         \
+    rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);
+#define XMH_HWRITE(buf)                                                                                             \
+    *reinterpret_cast<uint4*>(&sA[buf][srow * LDH + scol]) = ra0;                                                    \
+    if (MI == 2) *reinterpret_cast<uint4*>(&sA[buf][(srow + 64) * LDH + scol]) = ra1;                                \
+    *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                    \
+    *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int nk = g.K / BKH;
+    XMH_HLOAD(0)
+    XMH_HWRITE(0)
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { XMH_HLOAD((kt + 1) * BKH) }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {                       // two k-slabs of 16 per BK
+            f16x8 a[MI], b[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(&sA[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            XMH_HWRITE(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef XMH_HLOAD
+#undef XMH_HWRITE
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][e] + bv, g.act);
+                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cast_f32_h16(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n8) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * e], b = reinterpret_cast<const float4*>(x)[2 * e + 1];
+        f16x8 h;
+        h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+        h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+        reinterpret_cast<f16x8*>(y)[e] = h;
+    }
+}
+
 }  // namespace
 
 extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
@@ -362,5 +469,47 @@ extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int6
         else hipLaunchKernelGGL(k_gemm_nt_f16<false>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
     } else return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_f32: precision must be 0 (f32 MFMA) or 1 (f16 MFMA, f32 accumulate)");
     XMH_LAUNCH_CHECK("xmh_gemm_nt_f32");
+    return XMH_OK;
+}
+
+extern "C" int xmh_cast_f32_to_f16(const float* x, void* y_half, int64_t n, xmh_stream_t stream) {
+    if (n < 0 || n % 8) return xmh::fail(XMH_EINVAL, "xmh_cast_f32_to_f16: n=%lld must be a non-negative multiple of 8", (long long)n);
+    if (n == 0) return XMH_OK;
+    if (!x || !y_half) return xmh::fail(XMH_EINVAL, "xmh_cast_f32_to_f16: null pointer");
+    int64_t grid = xmh::ceil_div(n / 8, 256);
+    const int64_t cap = (int64_t)xmh::device_cu_count() * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_cast_f32_h16, dim3((unsigned)grid), dim3(256), 0, xmh::as_stream(stream), x, static_cast<_Float16*>(y_half), n / 8);
+    XMH_LAUNCH_CHECK("xmh_cast_f32_to_f16");
+    return XMH_OK;
+}
+
+extern "C" int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
+                               const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                               int act, xmh_stream_t stream) {
+    if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: bad shape");
+    if (M == 0 || N == 0) return XMH_OK;
+    if (!A_half || !W_half || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: null pointer");
+    if (K % BKH || lda % 8 || ldw % 8 || ((reinterpret_cast<uintptr_t>(A_half) | reinterpret_cast<uintptr_t>(W_half)) % 16))
+        return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_h16: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)K, (long long)lda, (long long)ldw);
+    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: leading dimension too small");
+    if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: unknown activation %d", act);
+    if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_h16: dimension >= 2^31");
+    GemmArgsH g;
+    g.A = static_cast<const _Float16*>(A_half); g.W = static_cast<const _Float16*>(W_half);
+    g.bias = bias; g.residual = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
+    hipStream_t st = xmh::as_stream(stream);
+    int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
+    const bool small = nblk < 3ll * xmh::device_cu_count();
+    xmh::ProfScope prof("gemm_f16", st);
+    if (small) {
+        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
+        hipLaunchKernelGGL(k_gemm_nt_h16<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(k_gemm_nt_h16<2>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    }
+    XMH_LAUNCH_CHECK("xmh_gemm_nt_h16");
     return XMH_OK;
 }

@@ -39,6 +39,28 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t2 if t2.stride(-1) == 1 else t2.contiguous()
 
 
+_half_weights = {}          # (data_ptr, version, shape) -> fp16 copy of a weight tensor (fast mode converts weights once)
+
+
+def cast_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, D] (D % 8 == 0, contiguous) -> fp16 through the HIP cast kernel."""
+    x = _f32c(x).contiguous()
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(lib.xmh_cast_f32_to_f16(ptr(x), ptr(y), x.numel(), current_stream()), "xmh_cast_f32_to_f16")
+    return y
+
+
+def _half_weight(W: torch.Tensor) -> torch.Tensor:
+    key = (W.data_ptr(), W._version, tuple(W.shape))
+    h = _half_weights.get(key)
+    if h is None:
+        if len(_half_weights) > 512:
+            _half_weights.clear()
+        h = cast_f16(W.detach())
+        _half_weights[key] = h
+    return h
+
+
 def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             act: int = ACT_NONE, out: Optional[torch.Tensor] = None, precision: Optional[int] = None) -> torch.Tensor:
     """act(A @ W^T + bias) (+ residual); A [..., K], W [N, K] (nn.Linear layout) -> [..., N]."""
@@ -53,6 +75,14 @@ def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
     out2 = out.reshape(-1, N)
     res2 = None if residual is None else _rows(residual)
     b = None if bias is None else _f32c(bias)
+    prec = _precision if precision is None else precision
+    if prec == PREC_F16 and K % 32 == 0 and W2.is_contiguous() and M * K % 8 == 0:
+        # fast mode proper: fp16 operands in memory (weights converted once, activations by one cast pass), fp32 accumulate
+        Ah = cast_f16(A2) if A2.is_contiguous() else cast_f16(A2.contiguous())
+        Wh = _half_weight(W2)
+        check(lib.xmh_gemm_nt_h16(ptr(Ah), K, ptr(Wh), K, ptr(b), ptr(res2), 0 if res2 is None else res2.stride(0), ptr(out2),
+                                  out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_h16")
+        return out2.reshape(*lead, N)
     check(lib.xmh_gemm_nt_f32(ptr(A2), A2.stride(0), ptr(W2), W2.stride(0), ptr(b), ptr(res2), 0 if res2 is None else res2.stride(0),
                               ptr(out2), out2.stride(0), M, N, K, act, _precision if precision is None else precision,
                               current_stream()), "xmh_gemm_nt_f32")

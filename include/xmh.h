@@ -157,6 +157,12 @@ int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, in
 int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                     const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                     int act, int precision, xmh_stream_t stream);
+/* Fast mode proper: the same contraction with A and W already stored as IEEE fp16 (K % 32 == 0, 16-byte aligned rows);
+ * fp32 accumulate, fp32 bias/residual/output.  xmh_cast_f32_to_f16 is the HBM-bound conversion pass (n % 8 == 0). */
+int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
+                    const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                    int act, xmh_stream_t stream);
+int xmh_cast_f32_to_f16(const float* x, void* y_half, int64_t n, xmh_stream_t stream);
 /* models/CLIP/model.py:153-159 (fp32 LayerNorm) */
 int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
                       int64_t ldy, int64_t rows, int D, xmh_stream_t stream);
