@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 // qkv: [B, L, 3*H*dh] rows = tokens, columns [q | k | v] each H*dh wide (nn.MultiheadAttention in_proj order).
 // LDS: K and V of this head [L][dh] (float4 rows), scores [L][L+1].
 template <int DH>
-__global__ void k_attention(const float* __restrict__ qkv, int L, int H, int causal, const uint8_t* __restrict__ kpm,
+__global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv, int L, int H, int causal, const uint8_t* __restrict__ kpm,
                             float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -82,25 +82,29 @@ __global__ void k_attention(const float* __restrict__ qkv, int L, int H, int cau
     __syncthreads();
     const int i = threadIdx.x;
     if (i >= L) return;
-    float4 q[DH / 4];
+    float q[DH];
     const float scale = rsqrtf((float)DH);
 #pragma unroll
     for (int c = 0; c < DH / 4; ++c) {                               // PyTorch scales q before QK^T
-        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * 3 * D + h * DH + c * 4);
-        q[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * 3 * D + h * DH + c * 4);
+        q[4 * c + 0] = v.x * scale;
+        q[4 * c + 1] = v.y * scale;
+        q[4 * c + 2] = v.z * scale;
+        q[4 * c + 3] = v.w * scale;
     }
     float* srow = sS + i * (L + 1);
     float mx = -INFINITY;
     for (int j = 0; j < L; ++j) {
-        float s = 0.0f;
+        float s0 = 0.0f, s1 = 0.0f;                                  // two chains: shorter dependent-FMA latency
 #pragma unroll
         for (int c = 0; c < DH / 4; ++c) {
             const float4 kv = sK[j * (DH / 4) + c];
-            s = fmaf(q[c].x, kv.x, s);
-            s = fmaf(q[c].y, kv.y, s);
-            s = fmaf(q[c].z, kv.z, s);
-            s = fmaf(q[c].w, kv.w, s);
+            s0 = fmaf(q[4 * c + 0], kv.x, s0);
+            s1 = fmaf(q[4 * c + 1], kv.y, s1);
+            s0 = fmaf(q[4 * c + 2], kv.z, s0);
+            s1 = fmaf(q[4 * c + 3], kv.w, s1);
         }
+        float s = s0 + s1;
         if ((causal && j > i) || (kpm && kpm[(int64_t)b * L + j])) s = -INFINITY;
         srow[j] = s;
         mx = fmaxf(mx, s);
@@ -112,23 +116,24 @@ __global__ void k_attention(const float* __restrict__ qkv, int L, int H, int cau
         sum += p;
     }
     const float inv = 1.0f / sum;
-    float4 o[DH / 4];
+    float o[DH];
 #pragma unroll
-    for (int c = 0; c < DH / 4; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < DH; ++c) o[c] = 0.0f;
     for (int j = 0; j < L; ++j) {
         const float p = srow[j] * inv;
 #pragma unroll
         for (int c = 0; c < DH / 4; ++c) {
             const float4 vv = sV[j * (DH / 4) + c];
-            o[c].x = fmaf(p, vv.x, o[c].x);
-            o[c].y = fmaf(p, vv.y, o[c].y);
-            o[c].z = fmaf(p, vv.z, o[c].z);
-            o[c].w = fmaf(p, vv.w, o[c].w);
+            o[4 * c + 0] = fmaf(p, vv.x, o[4 * c + 0]);
+            o[4 * c + 1] = fmaf(p, vv.y, o[4 * c + 1]);
+            o[4 * c + 2] = fmaf(p, vv.z, o[4 * c + 2]);
+            o[4 * c + 3] = fmaf(p, vv.w, o[4 * c + 3]);
         }
     }
     float* orow = out + ((int64_t)b * L + i) * D + h * DH;
 #pragma unroll
-    for (int c = 0; c < DH / 4; ++c) *reinterpret_cast<float4*>(orow + c * 4) = o[c];
+    for (int c = 0; c < DH / 4; ++c)
+        *reinterpret_cast<float4*>(orow + c * 4) = make_float4(o[4 * c + 0], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
 }
 
 // ---- patch gather: cols[(b*G*G + gy*G + gx)][c*P*P + dy*P + dx] = image[b][c][gy*P+dy][gx*P+dx] --------
