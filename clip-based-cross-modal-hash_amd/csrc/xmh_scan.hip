@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot,
                                                   const uint32_t* __restrict__ nrel_total, int64_t kcap,
                                                   uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
                                                   int32_t* __restrict__ cap_out, uint32_t* __restrict__ hist_all,
-                                                  uint32_t* __restrict__ hist_rel) {
+                                                  uint32_t* __restrict__ hist_rel, uint32_t* __restrict__ nrel_max) {
     const int q = blockIdx.x * 64 + threadIdx.x;
     const bool qok = q < Q;
     uint32_t ra = 0, rr = 0;
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot,
         const uint32_t cap = (kcap > 0 && (uint64_t)kcap < (uint64_t)nrel) ? (uint32_t)kcap : nrel;
         cap_ws[q] = cap;
         if (qok) cap_out[q] = (int32_t)cap;
+        if (qok && nrel_max) atomicMax(nrel_max, nrel);
     }
 }
 
@@ -331,10 +332,13 @@ __global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot,
 // ---------------------------------------------------------------------------------------------------
 template <int W, int LW, bool TERN, bool CAPPED, int GM>
 __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
-                                                const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part) {
+                                                const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
+                                                const uint32_t* __restrict__ nrel_max, int rank_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long cnt[];   // [nb][64]
     int chunk_id, qtile;
     if (!map_block(a, chunk_id, qtile)) return;
+    // the 32-bit packed variant (k_scan_ap32) handles this call when rank and ordinal fit one word together
+    if (rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits))) return;
     const int lane = threadIdx.x;
     const int q = qtile * 64 + lane;
     {
@@ -473,6 +477,116 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
     ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// pass 2, packed variant: when (rank bits) + (ordinal bits) <= 32 -- known on the device after pass 1 -- the two
+// running numbers share ONE 32-bit counter {lo rank_bits: rank, hi: ordinal}.  Half the LDS (two waves per SIMD at
+// K = 64) and a 32-bit returning add per pair.  Gated against k_scan_ap by the same device word, no host sync.
+// ---------------------------------------------------------------------------------------------------
+template <int W, int LW, bool TERN, bool CAPPED>
+__global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+                                                  const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
+                                                  const uint32_t* __restrict__ nrel_max, int rank_bits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt32[];            // [nb][64]
+    int chunk_id, qtile;
+    if (!map_block(a, chunk_id, qtile)) return;
+    if (!((uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits)))) return;       // k_scan_ap takes this call
+    const int lane = threadIdx.x;
+    const int q = qtile * 64 + lane;
+    {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q;
+        const uint2* __restrict__ pd = dpre + q;
+        int d = 0;
+        for (; d + 8 <= a.nb; d += 8) {
+            uint2 x[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] = pb[(int64_t)(d + j) * a.qpad];
+                y[j] = pd[(int64_t)(d + j) * a.qpad];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt32[(d + j) * 64 + lane] = (x[j].x + y[j].x + 1u) | ((x[j].y + y[j].y + 1u) << rank_bits);
+        }
+        for (; d < a.nb; ++d) {
+            const uint2 x = pb[(int64_t)d * a.qpad], y = pd[(int64_t)d * a.qpad];
+            cnt32[d * 64 + lane] = (x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits);
+        }
+    }
+    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
+    const uint32_t rmask = (1u << rank_bits) - 1u;
+    const uint32_t one_rel = 1u << rank_bits;
+
+    QueryRegs<W, LW, TERN> qr;
+    qr.load(a, q);
+    using R = Rec<W, LW, TERN>;
+    constexpr int U = Unroll<W, LW, TERN>::value;
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    float acc = 0.0f;
+    auto credit = [&](uint32_t old, uint32_t hit) {
+        const uint32_t rank = old & rmask;
+        uint32_t ord = old >> rank_bits;
+        if (CAPPED) hit = ord <= cap ? hit : 0u;
+        const float of = (float)__umul24(ord, hit);
+        acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
+    };
+    uint32_t old[U], hitp[U];
+    auto eval_issue = [&](const R (&g)[U], bool have_prev) {
+        int d[U];
+        bool rel[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
+        if (have_prev) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            hitp[u] = rel[u] ? 1u : 0u;
+            old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], rel[u] ? one_rel + 1u : 1u);
+        }
+    };
+    R ga[U], gb[U];
+    int64_t i = lo;
+    const int64_t ngroups = (hi - lo) / U;
+    if (ngroups > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
+    }
+    int64_t g = 0;
+    bool prev = false;
+    for (; g + 2 <= ngroups; g += 2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
+        eval_issue(ga, prev);
+        if (g + 2 < ngroups) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
+        }
+        eval_issue(gb, true);
+        prev = true;
+        i += 2 * U;
+    }
+    if (g < ngroups) {
+        eval_issue(ga, prev);
+        prev = true;
+        i += U;
+    }
+    if (prev) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+    }
+    for (; i < hi; ++i) {
+        R r;
+        rec_load_uniform<W, LW, TERN>(r, a, i);
+        int d;
+        bool rel;
+        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
+        const uint32_t hit = rel ? 1u : 0u;
+        credit(atomicAdd(&cnt32[d * 64 + lane], rel ? one_rel + 1u : 1u), hit);
+    }
+    ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
                                                    double* __restrict__ ap_sum) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -500,7 +614,7 @@ __global__ __launch_bounds__(256) void k_map_finalize(const double* __restrict__
 // host side
 // ---------------------------------------------------------------------------------------------------
 struct WsLayout {
-    size_t chunk_hist, below, tot, dpre, cap, ap_part, total;
+    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, total;
 };
 
 WsLayout ws_layout(const xmh_scan_plan& p) {
@@ -517,6 +631,7 @@ WsLayout ws_layout(const xmh_scan_plan& p) {
     L.tot = take((size_t)p.nbuckets * p.qpad * 8);
     L.dpre = take((size_t)p.nbuckets * p.qpad * 8);
     L.cap = take((size_t)p.qpad * 4);
+    L.gate = take(256);
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
     L.total = o;
     return L;
@@ -529,12 +644,12 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const int64_t lds_ap = nb * 64 * 8;
     if (lds_ap > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave (max 163840); K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const int64_t nqt = xmh::ceil_div(Q, 64);
-    int64_t wpc = (160 * 1024) / lds_ap;          // waves per CU the pass-2 LDS footprint admits
+    int64_t wpc = (160 * 1024) / (lds_ap / 2);    // waves per CU of the packed pass-2 variant (the 64-bit one fits half)
     if (wpc > 8) wpc = 8;
     // pass 2 runs `rounds` resident sets of waves; pass 1 (half the LDS) then gets 2 waves per SIMD
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
-    const int64_t rounds = rounds_env > 0 ? rounds_env : 2;
+    const int64_t rounds = rounds_env > 0 ? rounds_env : 1;
     int64_t nchunk = rounds * slots / nqt;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
@@ -654,7 +769,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     if (hist_all || hist_rel) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
                            (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int64_t)0,
-                           (uint2*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, hist_all, hist_rel);
+                           (uint2*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, hist_all, hist_rel, (uint32_t*)nullptr);
         XMH_LAUNCH_CHECK("xmh_hamming_hist totals");
     }
     return XMH_OK;
@@ -682,8 +797,16 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     uint32_t* cap_ws = reinterpret_cast<uint32_t*>(base + L.cap);
     float* ap_part = reinterpret_cast<float*>(base + L.ap_part);
     hipStream_t st = xmh::as_stream(stream);
+    uint32_t* nrel_max = reinterpret_cast<uint32_t*>(base + L.gate);
+    // packed 32-bit counters apply to a single shard when rank fits rank_bits and the largest relevant count fits the rest
+    int rank_bits = 0;
+    if (!base_all && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
+        while ((1ll << rank_bits) < R + 2) ++rank_bits;
+        if (rank_bits > 24) rank_bits = 0;
+    }
+    if (rank_bits) XMH_HIP(hipMemsetAsync(nrel_max, 0, 4, st));
     hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
-                       base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
     XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
     const size_t lds = (size_t)p.nbuckets * 64 * 8;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
@@ -697,7 +820,8 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
             xmh::ProfScope prof("scan_ap", st);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part);
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+                               (const uint32_t*)nrel_max, rank_bits);
             return (int)XMH_OK;
         });
     };
@@ -706,6 +830,26 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     using GS = std::integral_constant<int, GM_SCALAR>;
     using GL = std::integral_constant<int, GM_LANE>;
     const bool capped = k > 0;
+    if (rank_bits) {
+        const size_t lds32 = (size_t)p.nbuckets * 64 * 4;
+        auto launch32 = [&](auto tern_c, auto cap_c) {
+            constexpr bool T = decltype(tern_c)::value;
+            constexpr bool CP = decltype(cap_c)::value;
+            return dispatch_shape(W, LW, [&](auto w, auto l) {
+                auto kern = k_scan_ap32<decltype(w)::value, decltype(l)::value, T, CP>;
+                const int r2 = raise_lds(kern, lds32, "xmh_hamming_ap");
+                if (r2) return r2;
+                xmh::ProfScope prof("scan_ap32", st);
+                hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds32, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+                                   (const uint32_t*)nrel_max, rank_bits);
+                return (int)XMH_OK;
+            });
+        };
+        if (tern) rc = capped ? launch32(T1{}, T1{}) : launch32(T1{}, T0{});
+        else rc = capped ? launch32(T0{}, T1{}) : launch32(T0{}, T0{});
+        if (rc) return rc;
+        XMH_LAUNCH_CHECK("xmh_hamming_ap packed");
+    }
     if (gm == GM_SCALAR) {
         if (tern) rc = capped ? launch(T1{}, T1{}, GS{}) : launch(T1{}, T0{}, GS{});
         else rc = capped ? launch(T0{}, T1{}, GS{}) : launch(T0{}, T0{}, GS{});
