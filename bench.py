@@ -212,6 +212,17 @@ def main():
             out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}
+    if rank == 0 and world == 1:
+        # boundary-inclusive rate: the drop-in calc_map_k handed HOST fp32 [N,K] codes and int64 labels like the reference's
+        # callers do (H2D over PCIe + pack + both passes + D2H of the scalar); reported next to `value`, never as `value`
+        from xmh.common import calc_utils as cu
+        cu.calc_map_k(qB, rB, qL, rL)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m_host = cu.calc_map_k(qB, rB, qL, rL)
+        t_host = (time.perf_counter() - t0) / 3
+        out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
+                                     "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
     if rank == 0 and world == 1 and not args.no_encode:
         try:
             import bench_encode

@@ -66,3 +66,30 @@ def test_shard_bounds_and_rank_offsets():
     assert b0[0].tolist() == [[0, 1, 4]] and b1[0].tolist() == [[1, 3, 4]]
     assert b0[1].tolist() == [[0, 1, 2]] and b1[1].tolist() == [[1, 1, 2]]
     assert b0[2].tolist() == [3] and b1[2].tolist() == [3]
+
+
+def test_load_backbone_from_checkpoint_file_and_weight_rounding(tmp_path):
+    """models/base.py:18-31 file branch (torch.jit.load fails on a plain state_dict -> torch.load), architecture
+    inference from shapes (model.py:438-489) and the fp16 rounding of convert_weights (:415-436)."""
+    import xmh.models  # noqa: F401
+    from xmh.models import weights as W
+    sd = W.synth_clip_state_dict(3, vision_layers=1, transformer_layers=2, vocab_size=1000)
+    sd["input_resolution"], sd["context_length"], sd["vocab_size"] = torch.tensor(224), torch.tensor(77), torch.tensor(1000)
+    path = str(tmp_path / "clip_small.pt")
+    torch.save(dict(sd), path)
+    model = registry.get_model_class("DCMHT").from_config(Config({"clip_path": path}), output_dim=32)
+    bb = model.backbone
+    assert len(bb.visual.transformer.resblocks) == 1 and len(bb.transformer.resblocks) == 2 and bb.vocab_size == 1000
+    w = bb.visual.transformer.resblocks[0].attn.in_proj_weight.detach()
+    assert torch.equal(w, sd["visual.transformer.resblocks.0.attn.in_proj_weight"].half().float())      # fp16-rounded
+    ln = bb.visual.ln_pre.weight.detach()
+    assert torch.equal(ln, sd["visual.ln_pre.weight"])                                                    # LayerNorm stays fp32
+    keys = set(model.state_dict().keys())
+    assert "backbone.visual.conv1.weight" in keys and "hash.img_hash.fc2.weight" in keys and "hash.txt_hash.norm.weight" in keys
+    assert model.hash.img_hash.fc2.weight.shape == (64, 512)                                             # 2K outputs (hash_scale = 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.encode_image(torch.zeros(1, 3, 224, 224))                                                  # product path needs the GPU
+    model.freezen()
+    assert not any(p.requires_grad for p in model.parameters())
+    model.unfreezen()
+    assert all(p.requires_grad for p in model.parameters())

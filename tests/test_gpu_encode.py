@@ -269,3 +269,15 @@ def test_lta_edge_cases_against_oracle(ops):
     want = torch.bmm(att.permute(1, 2, 0), X)
     assert (got - want).abs().max() < 1e-5 and got[0, 3].abs().max() == 0
     del enc
+
+
+def test_fast_mode_gemm_paths_and_cast(ops):
+    """fp16-input MFMA GEMM (K % 32 == 0) and its fp32-operand fallback (other K) agree with an fp16-rounded reference."""
+    for M, N, K in ((300, 200, 768), (77, 130, 96), (64, 64, 40), (5, 512, 3072)):
+        A, W = torch.randn(M, K, generator=g_(M)), (torch.randn(N, K, generator=g_(N)) * 0.05).half().float()
+        b = torch.randn(N, generator=g_(K))
+        want = A.half().double() @ W.double().t() + b.double()
+        got = ops.gemm_nt(A.cuda(), W.cuda(), b.cuda(), precision=ops.PREC_F16)
+        assert rel(got, want) < 5e-6, (M, N, K)
+    x = torch.randn(33, 64, generator=g_(9))
+    assert torch.equal(ops.cast_f16(x.cuda()).cpu(), x.half())

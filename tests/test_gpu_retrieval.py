@@ -363,3 +363,32 @@ def test_float_similarities_and_float_code_fallback(cu):
     assert abs(float(got) - float(g["float_map_stable"])) < 1e-6
     kat = np.load(os.path.join(GOLDEN, "calc_utils_kat.npz"))
     assert float(cu.calc_hammingDist(dev(kat["kat4_a"]), dev(kat["kat4_b"])).cpu().reshape(-1)[0]) == 1.0     # KAT-4
+
+
+@pytest.mark.parametrize("K", [512, 2048, 96])
+def test_long_and_odd_code_lengths_distance(xr, cu, K):
+    """TwDH-style long codes (up to 2048 bits) and a non-power-of-two word count go through the generic
+    distance kernel; the ranking scan reports its LDS limit instead of failing silently."""
+    orc = _orc()
+    gen = torch.Generator().manual_seed(K)
+    qB, rB = torch.randn(9, K, generator=gen).sign(), torch.randn(301, K, generator=gen).sign()
+    assert torch.equal(cu.calc_hammingDist(qB.cuda(), rB.cuda()).cpu(), orc.hamming_dist(qB, rB))
+    q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+    assert np.array_equal(xr.hamming_dist(q, r, as_u16=True).cpu().numpy().view(np.uint16), orc.hamming_packed(_u32(q.bits), _u32(r.bits)))
+    assert torch.equal(q.unpack().cpu(), qB)
+    if K > 256:
+        L = torch.ones(9, 3, dtype=torch.int64)
+        with pytest.raises(RuntimeError, match="LDS|unsupported"):
+            cu.calc_map_k(qB.cuda(), rB.cuda(), L.cuda(), torch.ones(301, 3, dtype=torch.int64).cuda())
+
+
+def test_error_paths_report_through_last_error(xr):
+    from xmh import _lib
+    q = xr.PackedCodes(torch.zeros(4, 2, dtype=torch.int32, device="cuda"), None, 64)
+    r = xr.PackedCodes(torch.zeros(10, 4, dtype=torch.int32, device="cuda"), None, 128)
+    with pytest.raises(ValueError):
+        xr.hamming_dist(q, r)
+    with pytest.raises(_lib.XmhError, match="k=0"):
+        xr.hamming_topk(q, xr.PackedCodes(torch.zeros(10, 2, dtype=torch.int32, device="cuda"), None, 64), 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        xr.pack_sign(torch.zeros(3, 64))
