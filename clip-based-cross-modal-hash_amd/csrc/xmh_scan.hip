@@ -31,6 +31,7 @@ constexpr int kMaxChunk = 32768;   // u16 halves of the packed pass-1 counters m
 constexpr int kMinChunk = 256;
 constexpr int GM_SCALAR = 0;
 constexpr int GM_LANE = 1;
+constexpr int GM_LDS = 2;
 
 struct ScanArgs {
     const uint32_t* qbits;
@@ -80,8 +81,9 @@ struct Rec {
     uint32_t l[LW];
 };
 
+// distance bucket d and relevance (as 0/1 in `hit01`) of (this lane's query, record r)
 template <int W, int LW, bool TERN>
-__device__ __forceinline__ void rec_eval(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, bool& rel) {
+__device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, uint32_t& hit01) {
     if (!TERN) {
         int acc = 0;
 #pragma unroll
@@ -100,7 +102,14 @@ __device__ __forceinline__ void rec_eval(const QueryRegs<W, LW, TERN>& qr, const
     uint32_t hit = 0;
 #pragma unroll
     for (int w = 0; w < LW; ++w) hit |= qr.l[w] & r.l[w];
-    rel = hit != 0;
+    hit01 = hit != 0 ? 1u : 0u;
+}
+
+template <int W, int LW, bool TERN>
+__device__ __forceinline__ void rec_eval(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, bool& rel) {
+    uint32_t h;
+    rec_eval01<W, LW, TERN>(qr, r, K, d, h);
+    rel = h != 0;
 }
 
 // GM_SCALAR: record i through a wave-uniform address (the compiler emits s_load_dwordxN)
@@ -144,6 +153,51 @@ struct LaneBatch {
         }
 #pragma unroll
         for (int w = 0; w < LW; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.l[w], u);
+    }
+};
+
+// GM_LDS: the same 64-record batch, but staged through a small LDS ring: lane i writes its record once
+// (16-byte ds_writes), every item is then fetched with wave-uniform ds_read_b128s (an LDS broadcast: one address,
+// no bank conflict).  No v_readlane on the VALU pipe, no SGPR pressure, and -- LDS being in-order per wave -- every
+// wait in the loop is a counted lgkmcnt.  Record stride is padded to a multiple of 4 dwords.
+template <int W, int LW, bool TERN>
+struct LdsBatch {
+    static constexpr int RW = W * (TERN ? 2 : 1) + LW;
+    static constexpr int RS = (RW + 3) / 4 * 4;
+    uint32_t w[RS];
+    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
+        const int64_t i = base + lane;
+        const bool ok = i < hi;
+#pragma unroll
+        for (int x = 0; x < W; ++x) w[x] = ok ? a.rbits[i * W + x] : 0u;
+        if (TERN) {
+#pragma unroll
+            for (int x = 0; x < W; ++x) w[W + x] = ok ? a.rzero[i * W + x] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
+#pragma unroll
+        for (int x = RW; x < RS; ++x) w[x] = 0u;
+    }
+    __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
+#pragma unroll
+        for (int x = 0; x < RS; x += 4) *reinterpret_cast<uint4*>(ring + lane * RS + x) = make_uint4(w[x], w[x + 1], w[x + 2], w[x + 3]);
+    }
+    static __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, const uint32_t* ring, int u) {
+        uint32_t t[RS];
+#pragma unroll
+        for (int x = 0; x < RS; x += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ring + u * RS + x);       // wave-uniform address
+            t[x] = v.x; t[x + 1] = v.y; t[x + 2] = v.z; t[x + 3] = v.w;
+        }
+#pragma unroll
+        for (int x = 0; x < W; ++x) r.b[x] = t[x];
+        if (TERN) {
+#pragma unroll
+            for (int x = 0; x < W; ++x) r.z[x] = t[W + x];
+        }
+#pragma unroll
+        for (int x = 0; x < LW; ++x) r.l[x] = t[W * (TERN ? 2 : 1) + x];
     }
 };
 
@@ -216,6 +270,29 @@ __global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restri
             R r;
             rec_load_uniform<W, LW, TERN>(r, a, i);
             count_one(r);
+        }
+    } else if (GM == GM_LDS) {
+        using LB = LdsBatch<W, LW, TERN>;
+        uint32_t* ring = lds + a.nb * 64;                          // [64][RS] after the counters
+        LB cur, nxt;
+        cur.load(a, lo, hi, lane);
+        for (int64_t base = lo; base < hi; base += 64) {
+            cur.publish(ring, lane);
+            nxt.load(a, base + 64, hi, lane);                      // prefetch (vmcnt) while this batch is consumed from LDS
+            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
+            int u0 = 0;
+            for (; u0 + U <= cnt; u0 += U) {
+                R g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
+                count_group(g);
+            }
+            for (; u0 < cnt; ++u0) {
+                R r;
+                LB::get(r, ring, u0);
+                count_one(r);
+            }
+            cur = nxt;
         }
     } else {
         LaneBatch<W, LW, TERN> cur, nxt;
@@ -386,17 +463,17 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
     uint32_t hitp[U];
     auto eval_issue = [&](const R (&g)[U], bool have_prev) {
         int d[U];
-        bool rel[U];
+        uint32_t hit[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
+        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
             for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);              // previous group's returns
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            hitp[u] = rel[u] ? 1u : 0u;
-            old[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)hitp[u] << 32));
+            hitp[u] = hit[u];
+            old[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)hit[u] << 32));
         }
     };
     auto drain = [&]() {
@@ -446,6 +523,40 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
             rec_load_uniform<W, LW, TERN>(r, a, i);
             one(r);
         }
+    } else if (GM == GM_LDS) {
+        // Batches of 64 records are staged through an LDS ring slot by the wave itself and read back with wave-uniform
+        // ds_read_b128s (broadcast); the next batch's global loads are in flight (vmcnt) during the whole current batch.
+        // LDS is in-order per wave, so every wait in the loop is a counted lgkmcnt.  (A one-group LDS read-ahead with a
+        // two-slot ring was measured and bought nothing: 0.69 vs 0.67 ms.)
+        using LB = LdsBatch<W, LW, TERN>;
+        uint32_t* ring = reinterpret_cast<uint32_t*>(cnt + a.nb * 64);   // [64][RS] after the counters
+        LB cur, nxt;
+        cur.load(a, lo, hi, lane);
+        bool prev = false;
+        for (int64_t base = lo; base < hi; base += 64) {
+            cur.publish(ring, lane);
+            nxt.load(a, base + 64, hi, lane);
+            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+            int u0 = 0;
+            for (; u0 + U <= cntb; u0 += U) {
+                R g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
+                eval_issue(g, prev);
+                prev = true;
+            }
+            if (u0 < cntb) {
+                if (prev) drain();
+                prev = false;
+                for (; u0 < cntb; ++u0) {
+                    R r;
+                    LB::get(r, ring, u0);
+                    one(r);
+                }
+            }
+            cur = nxt;
+        }
+        if (prev) drain();
     } else {
         LaneBatch<W, LW, TERN> cur, nxt;
         cur.load(a, lo, hi, lane);
@@ -545,44 +656,45 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
             old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], rel[u] ? one_rel + 1u : 1u);
         }
     };
-    R ga[U], gb[U];
-    int64_t i = lo;
-    const int64_t ngroups = (hi - lo) / U;
-    if (ngroups > 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
-    }
-    int64_t g = 0;
+    // gallery through the LDS ring (see k_scan_ap, GM_LDS)
+    using LB = LdsBatch<W, LW, TERN>;
+    uint32_t* ring = cnt32 + a.nb * 64;                              // [64][RS] after the counters
+    LB cur, nxt;
+    cur.load(a, lo, hi, lane);
     bool prev = false;
-    for (; g + 2 <= ngroups; g += 2) {
+    for (int64_t base = lo; base < hi; base += 64) {
+        cur.publish(ring, lane);
+        nxt.load(a, base + 64, hi, lane);
+        const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+        int u0 = 0;
+        for (; u0 + U <= cntb; u0 += U) {
+            R g[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
-        eval_issue(ga, prev);
-        if (g + 2 < ngroups) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
+            for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
+            eval_issue(g, prev);
+            prev = true;
         }
-        eval_issue(gb, true);
-        prev = true;
-        i += 2 * U;
-    }
-    if (g < ngroups) {
-        eval_issue(ga, prev);
-        prev = true;
-        i += U;
+        if (u0 < cntb) {
+            if (prev) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+            }
+            prev = false;
+            for (; u0 < cntb; ++u0) {
+                R r;
+                LB::get(r, ring, u0);
+                int d;
+                bool rel;
+                rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
+                const uint32_t hit = rel ? 1u : 0u;
+                credit(atomicAdd(&cnt32[d * 64 + lane], rel ? one_rel + 1u : 1u), hit);
+            }
+        }
+        cur = nxt;
     }
     if (prev) {
 #pragma unroll
         for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
-    }
-    for (; i < hi; ++i) {
-        R r;
-        rec_load_uniform<W, LW, TERN>(r, a, i);
-        int d;
-        bool rel;
-        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
-        const uint32_t hit = rel ? 1u : 0u;
-        credit(atomicAdd(&cnt32[d * 64 + lane], rel ? one_rel + 1u : 1u), hit);
     }
     ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
@@ -670,7 +782,8 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
 int gallery_mode(const char* env, int dflt) {
     const char* v = getenv(env);
     if (!v) return dflt;
-    return atoi(v) ? GM_LANE : GM_SCALAR;
+    const int m = atoi(v);
+    return m == 2 ? GM_LDS : (m == 1 ? GM_LANE : GM_SCALAR);
 }
 
 template <typename F>
@@ -740,9 +853,10 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     uint2* below = reinterpret_cast<uint2*>(base + L.below);
     uint2* tot = reinterpret_cast<uint2*>(base + L.tot);
     hipStream_t st = xmh::as_stream(stream);
-    const size_t lds = (size_t)p.nbuckets * 64 * 4;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const int gm = gallery_mode("XMH_SCAN_GM_HIST", GM_SCALAR);
+    const size_t ring = (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4;     // GM_LDS staging ring
+    const size_t lds = (size_t)p.nbuckets * 64 * 4 + (gm == GM_LDS ? ring : 0);
     auto launch = [&](auto tern_c, auto gm_c) {
         constexpr bool T = decltype(tern_c)::value;
         constexpr int G = decltype(gm_c)::value;
@@ -759,8 +873,9 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     using T0 = std::false_type;
     using GS = std::integral_constant<int, GM_SCALAR>;
     using GL = std::integral_constant<int, GM_LANE>;
-    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : launch(T1{}, GL{});
-    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : launch(T0{}, GL{});
+    using GD = std::integral_constant<int, GM_LDS>;
+    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : (gm == GM_LANE ? launch(T1{}, GL{}) : launch(T1{}, GD{}));
+    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : (gm == GM_LANE ? launch(T0{}, GL{}) : launch(T0{}, GD{}));
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
@@ -808,9 +923,10 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
                        base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
     XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
-    const size_t lds = (size_t)p.nbuckets * 64 * 8;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    const int gm = gallery_mode("XMH_SCAN_GM_AP", GM_SCALAR);
+    const int gm = gallery_mode("XMH_SCAN_GM_AP", GM_LDS);
+    const size_t ring = (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4;     // GM_LDS staging ring
+    const size_t lds = (size_t)p.nbuckets * 64 * 8 + (gm == GM_LDS ? ring : 0);
     auto launch = [&](auto tern_c, auto cap_c, auto gm_c) {
         constexpr bool T = decltype(tern_c)::value;
         constexpr bool CP = decltype(cap_c)::value;
@@ -831,7 +947,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     using GL = std::integral_constant<int, GM_LANE>;
     const bool capped = k > 0;
     if (rank_bits) {
-        const size_t lds32 = (size_t)p.nbuckets * 64 * 4;
+        const size_t lds32 = (size_t)p.nbuckets * 64 * 4 + ring;
         auto launch32 = [&](auto tern_c, auto cap_c) {
             constexpr bool T = decltype(tern_c)::value;
             constexpr bool CP = decltype(cap_c)::value;
@@ -853,9 +969,13 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     if (gm == GM_SCALAR) {
         if (tern) rc = capped ? launch(T1{}, T1{}, GS{}) : launch(T1{}, T0{}, GS{});
         else rc = capped ? launch(T0{}, T1{}, GS{}) : launch(T0{}, T0{}, GS{});
-    } else {
+    } else if (gm == GM_LANE) {
         if (tern) rc = capped ? launch(T1{}, T1{}, GL{}) : launch(T1{}, T0{}, GL{});
         else rc = capped ? launch(T0{}, T1{}, GL{}) : launch(T0{}, T0{}, GL{});
+    } else {
+        using GD = std::integral_constant<int, GM_LDS>;
+        if (tern) rc = capped ? launch(T1{}, T1{}, GD{}) : launch(T1{}, T0{}, GD{});
+        else rc = capped ? launch(T0{}, T1{}, GD{}) : launch(T0{}, T0{}, GD{});
     }
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
