@@ -82,7 +82,9 @@ struct Rec {
 };
 
 // distance bucket d and relevance (as 0/1 in `hit01`) of (this lane's query, record r)
-template <int W, int LW, bool TERN>
+// VREC = the record words live in VGPRs (GM_LDS): relevance then uses v_and_or_b32 / v_min_u32 (one op per label word
+// + one) through inline asm -- hipcc does not form them -- which would cost extra v_movs on SGPR-resident records.
+template <int W, int LW, bool TERN, bool VREC = false>
 __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, uint32_t& hit01) {
     if (!TERN) {
         int acc = 0;
@@ -99,10 +101,17 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
         }
         d = K - live_n + 2 * diff_n;                           // 2 * (0.5 * (K - q.r)), in [0, 2K]
     }
-    uint32_t hit = 0;
+    if (VREC) {
+        uint32_t hit = qr.l[0] & r.l[0];
 #pragma unroll
-    for (int w = 0; w < LW; ++w) hit |= qr.l[w] & r.l[w];
-    hit01 = hit != 0 ? 1u : 0u;
+        for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "v"(qr.l[w]), "v"(r.l[w]));
+        asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
+    } else {
+        uint32_t hit = 0;
+#pragma unroll
+        for (int w = 0; w < LW; ++w) hit |= qr.l[w] & r.l[w];
+        hit01 = hit != 0 ? 1u : 0u;
+    }
 }
 
 template <int W, int LW, bool TERN>
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
         int d[U];
         uint32_t hit[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
+        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN, GM == GM_LDS>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
             for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);              // previous group's returns
@@ -643,17 +652,17 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
     uint32_t old[U], hitp[U];
     auto eval_issue = [&](const R (&g)[U], bool have_prev) {
         int d[U];
-        bool rel[U];
+        uint32_t hit[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
+        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN, true>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
             for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            hitp[u] = rel[u] ? 1u : 0u;
-            old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], rel[u] ? one_rel + 1u : 1u);
+            hitp[u] = hit[u];
+            old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], (hit[u] << rank_bits) + 1u);      // v_lshl_add_u32
         }
     };
     // gallery through the LDS ring (see k_scan_ap, GM_LDS)
