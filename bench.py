@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_GLOPS = 39321.6         # integer VALU: 256 CU x 4 SIMD x 64 lanes / 4 cycles x 2.4 GHz (SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU = 4)
+VALU_PEAK_GLOPS = 39321.6         # VALU issue: 256 CU x 4 SIMD x 64 lanes / 4 cycles x 2.4 GHz (tools/ubench_valu.hip: 4.0-4.4 cycles per wave64 op for this mix)
 
 
 def synth(Q, R, K, C, seed, p=0.04, device="cuda"):
@@ -180,7 +180,9 @@ def main():
 
     W, Lw = (K + 31) // 32, (C + 31) // 32
     alg_bytes = Rn * 4 * (W + Lw) + Q * 4 * (W + Lw) + Q * 12          # gallery once + queries + ap_sum/cap out
-    ops_pair_ap = 2 * W + (Lw + 1) + 1 + 3 + 7                         # xor+bcnt, and/or3, cmp, cndmask/or/addr, credit (VALU instr per wave-item)
+    # VALU instructions per wave-item of pass 2 (ISA count): xor+bcnt per code word, and + and_or per further label word,
+    # min, address, (64-bit variant: hi-word mov), credit = 2 cvt + rcp + mul24 + fmac
+    ops_pair_ap = 2 * W + Lw + 1 + 1 + (0 if ap_kernel == "k_scan_ap32" else 1) + 5
     roofline = {
         "kernel": "%s (pass 2 of the fused mAP scan), HIP events around the launch, %d launches" % (ap_kernel, n_ap),
         "bound": "hbm", "achieved": alg_bytes / t_ap / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

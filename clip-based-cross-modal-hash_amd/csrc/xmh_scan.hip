@@ -8,17 +8,22 @@
 // Walking in index order makes "number of same-distance items with a smaller index" a running counter,
 // which is exactly the tie-break of the canonical (distance, index) order.
 //
-// The gallery record is wave-uniform.  Two ways to broadcast it, chosen per pass from measurements
-// (tools/ubench_lds.hip):
-//   GM_SCALAR  s_load_dwordxN into SGPRs, used directly as the scalar operand of v_xor/v_and; zero VALU cost.
-//              Scalar loads share the lgkm counter with LDS returns, so both passes ping-pong two SGPR
-//              groups and issue the loads of group g+1 before group g is evaluated (default for both passes);
-//   GM_LANE    lane i loads record base+i (coalesced, vmcnt), record u is broadcast with v_readlane; costs
-//              W+LW VALU issues per item (kept for experiments: XMH_SCAN_GM_HIST / XMH_SCAN_GM_AP = 1).
+// The gallery record is wave-uniform.  Two ways to broadcast it (XMH_SCAN_GM_HIST / XMH_SCAN_GM_AP; both measured
+// within a few percent of each other on MI355X):
+//   GM_LDS (2, default)  the wave stages 64 records at a time into a small word-major LDS ring and fetches word x of
+//              four consecutive items with ONE wave-uniform ds_read_b128 (LDS broadcast).  LDS ops of a wave
+//              complete in order, so every wait in the loop is a counted lgkmcnt; the next batch's global loads
+//              (vmcnt) fly during the whole batch.  Record words arrive in VGPRs.
+//   GM_SCALAR (0)  hand-issued s_load_dwordxN into SGPRs (inline asm, invisible to the compiler's waitcnt pass), used
+//              directly as the scalar operand of v_xor / v_and_or.  SMEM returns out of order and shares lgkmcnt
+//              with LDS, so each group has exactly one explicit lgkmcnt(0); the next group's loads and the previous
+//              group's atomics are issued right after it and complete under the current group's VALU work.
 //
-// Bound: integer VALU issue (a wave64 integer op occupies its SIMD for 4 cycles = 39.3 T lane-ops/s
-// per chip, measured with SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU): ~11 (pass 1) / ~19 (pass 2) VALU instructions
-// per wave-item at K=64, C=80, against K/8+4*Lw gallery bytes shared by the 64 queries of a wave.
+// Bound: VALU issue.  tools/ubench_valu.hip measures ~4.0-4.4 cycles per wave64 instruction per SIMD for
+// the instruction mix of these loops at any occupancy (v_xor/v_and/v_add alone reach 2.4, VOP3 ops such as
+// v_bcnt_u32_b32 / v_and_or_b32 / v_lshl_add_u32 4.2, v_rcp_f32 8.2): 10 (pass 1) / 14 (pass 2) VALU instructions per
+// wave-item at K=64, C=80, against K/8+4*Lw gallery bytes shared by the 64 queries of a wave.  The relevance test
+// is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does not form them).
 // Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
 
@@ -30,7 +35,6 @@ namespace {
 constexpr int kMaxChunk = 32768;   // u16 halves of the packed pass-1 counters must not overflow
 constexpr int kMinChunk = 256;
 constexpr int GM_SCALAR = 0;
-constexpr int GM_LANE = 1;
 constexpr int GM_LDS = 2;
 
 struct ScanArgs {
@@ -84,7 +88,7 @@ struct Rec {
 // distance bucket d and relevance (as 0/1 in `hit01`) of (this lane's query, record r)
 // VREC = the record words live in VGPRs (GM_LDS): relevance then uses v_and_or_b32 / v_min_u32 (one op per label word
 // + one) through inline asm -- hipcc does not form them -- which would cost extra v_movs on SGPR-resident records.
-template <int W, int LW, bool TERN, bool VREC = false>
+template <int W, int LW, bool TERN, int VREC = 0>
 __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, uint32_t& hit01) {
     if (!TERN) {
         int acc = 0;
@@ -101,10 +105,15 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
         }
         d = K - live_n + 2 * diff_n;                           // 2 * (0.5 * (K - q.r)), in [0, 2K]
     }
-    if (VREC) {
+    if (VREC == 1) {
         uint32_t hit = qr.l[0] & r.l[0];
 #pragma unroll
         for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "v"(qr.l[w]), "v"(r.l[w]));
+        asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
+    } else if (VREC == 2) {                                      // record words wave-uniform in SGPRs (one SGPR per VOP3)
+        uint32_t hit = qr.l[0] & r.l[0];
+#pragma unroll
+        for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "s"(r.l[w]), "v"(qr.l[w]));
         asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
     } else {
         uint32_t hit = 0;
@@ -137,43 +146,91 @@ __device__ __forceinline__ void rec_load_uniform(Rec<W, LW, TERN>& r, const Scan
     for (int w = 0; w < LW; ++w) r.l[w] = pl[w];
 }
 
-// GM_LANE: a batch of 64 consecutive records, one per lane (coalesced, vmcnt-tracked); broadcast by readlane
-template <int W, int LW, bool TERN>
-struct LaneBatch {
-    Rec<W, LW, TERN> mine;
-    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
-        const int64_t i = base + lane;
-        const bool ok = i < hi;
-#pragma unroll
-        for (int w = 0; w < W; ++w) mine.b[w] = ok ? a.rbits[i * W + w] : 0u;
-        if (TERN) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) mine.z[w] = ok ? a.rzero[i * W + w] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int w = 0; w < LW; ++w) mine.l[w] = ok ? a.rlab[i * LW + w] : 0u;
+// GM_SCALAR, explicit form: N consecutive dwords fetched into SGPRs by hand-issued s_load_dwordxN.  The compiler's
+// waitcnt pass does not see these loads, which is the point: the kernel decides where the one lgkmcnt(0) per group goes
+// (see k_scan_hist).  Protocol: issue() ... __builtin_amdgcn_s_waitcnt(lgkmcnt 0) ... fence() ... word(i).  fence() is
+// an empty asm that makes every later use depend on a point after the wait.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <int P> struct SPiece;
+template <> struct SPiece<1> {
+    uint32_t v;
+    template <int OFF> __device__ __forceinline__ void issue(const uint32_t* p) { asm volatile("s_load_dword %0, %1, %2" : "=&s"(v) : "s"(p), "n"(OFF)); }
+    __device__ __forceinline__ void fence() { asm volatile("" : "+s"(v)); }
+    __device__ __forceinline__ uint32_t word(int) const { return v; }
+};
+#define XMH_SPIECE(P, T, INSN)                                                                                              \
+    template <> struct SPiece<P> {                                                                                          \
+        T v;                                                                                                                \
+        template <int OFF> __device__ __forceinline__ void issue(const uint32_t* p) {                                       \
+            asm volatile(INSN " %0, %1, %2" : "=&s"(v) : "s"(p), "n"(OFF));                                                 \
+        }                                                                                                                   \
+        __device__ __forceinline__ void fence() { asm volatile("" : "+s"(v)); }                                             \
+        __device__ __forceinline__ uint32_t word(int i) const { return v[i]; }                                              \
+    };
+XMH_SPIECE(2, u32x2, "s_load_dwordx2")
+XMH_SPIECE(4, u32x4, "s_load_dwordx4")
+XMH_SPIECE(8, u32x8, "s_load_dwordx8")
+XMH_SPIECE(16, u32x16, "s_load_dwordx16")
+#undef XMH_SPIECE
+
+template <int N>
+struct SRun {
+    static constexpr int P = N >= 16 ? 16 : (N >= 8 ? 8 : (N >= 4 ? 4 : (N >= 2 ? 2 : 1)));
+    SPiece<P> head;
+    SRun<N - P> tail;
+    template <int OFF = 0> __device__ __forceinline__ void issue(const uint32_t* p) {
+        head.template issue<OFF>(p);
+        tail.template issue<OFF + 4 * P>(p);
     }
-    __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, int u) const {
+    __device__ __forceinline__ void fence() { head.fence(); tail.fence(); }
+    __device__ __forceinline__ uint32_t word(int i) const { return i < P ? head.word(i < P ? i : 0) : tail.word(i - P); }
+};
+template <>
+struct SRun<0> {
+    template <int OFF = 0> __device__ __forceinline__ void issue(const uint32_t*) {}
+    __device__ __forceinline__ void fence() {}
+    __device__ __forceinline__ uint32_t word(int) const { return 0u; }
+};
+
+// U consecutive records in SGPRs
+template <int W, int LW, bool TERN, int U>
+struct ScalarGroup {
+    SRun<U * W> b;
+    SRun<TERN ? U * W : 0> z;
+    SRun<U * LW> l;
+    __device__ __forceinline__ void issue(const ScanArgs& a, int64_t at) {
+        b.issue(a.rbits + at * W);
+        if (TERN) z.issue(a.rzero + at * W);
+        l.issue(a.rlab + at * LW);
+    }
+    __device__ __forceinline__ void fence() { b.fence(); z.fence(); l.fence(); }
+    __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, int u) const {           // u is a constant after unrolling
 #pragma unroll
-        for (int w = 0; w < W; ++w) r.b[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.b[w], u);
+        for (int w = 0; w < W; ++w) r.b[w] = b.word(u * W + w);
         if (TERN) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) r.z[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.z[w], u);
+            for (int w = 0; w < W; ++w) r.z[w] = z.word(u * W + w);
         }
 #pragma unroll
-        for (int w = 0; w < LW; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_readlane((int)mine.l[w], u);
+        for (int w = 0; w < LW; ++w) r.l[w] = l.word(u * LW + w);
     }
 };
 
-// GM_LDS: the same 64-record batch, but staged through a small LDS ring: lane i writes its record once
-// (16-byte ds_writes), every item is then fetched with wave-uniform ds_read_b128s (an LDS broadcast: one address,
-// no bank conflict).  No v_readlane on the VALU pipe, no SGPR pressure, and -- LDS being in-order per wave -- every
-// wait in the loop is a counted lgkmcnt.  Record stride is padded to a multiple of 4 dwords.
+// GM_LDS: the same 64-record batch, but staged through a small LDS ring, word-major: ring[word][item].  Lane i writes
+// the words of record base+i (conflict-free ds_write_b32s); word x of four consecutive items is then ONE wave-uniform
+// ds_read_b128 (an LDS broadcast: one address, no bank conflict), i.e. RW reads per 4 items with no padding.  No
+// v_readlane on the VALU pipe, no SGPR pressure, and -- LDS being in-order per wave -- every wait in the loop is a
+// counted lgkmcnt.  lgkmcnt has 4 bits on gfx9: the loops below keep <= 15 LDS ops between a read and its use so a
+// wait never has to drain the atomics issued after it.
 template <int W, int LW, bool TERN>
 struct LdsBatch {
     static constexpr int RW = W * (TERN ? 2 : 1) + LW;
-    static constexpr int RS = (RW + 3) / 4 * 4;
-    uint32_t w[RS];
+    static constexpr int RS = (RW + 3) / 4 * 4;                    // host sizes the ring as 64 * RS dwords
+    using R = Rec<W, LW, TERN>;
+    uint32_t w[RW];
     __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
         const int64_t i = base + lane;
         const bool ok = i < hi;
@@ -185,28 +242,30 @@ struct LdsBatch {
         }
 #pragma unroll
         for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
-#pragma unroll
-        for (int x = RW; x < RS; ++x) w[x] = 0u;
     }
     __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
 #pragma unroll
-        for (int x = 0; x < RS; x += 4) *reinterpret_cast<uint4*>(ring + lane * RS + x) = make_uint4(w[x], w[x + 1], w[x + 2], w[x + 3]);
+        for (int x = 0; x < RW; ++x) ring[x * 64 + lane] = w[x];
     }
-    static __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, const uint32_t* ring, int u) {
-        uint32_t t[RS];
+    static __device__ __forceinline__ void set_word(R& r, int x, uint32_t v) {      // x is a constant after unrolling
+        if (x < W) r.b[x] = v;
+        else if (TERN && x < 2 * W) r.z[TERN ? x - W : 0] = v;
+        else r.l[x - W * (TERN ? 2 : 1)] = v;
+    }
+    static __device__ __forceinline__ void get(R& r, const uint32_t* ring, int u) {
 #pragma unroll
-        for (int x = 0; x < RS; x += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(ring + u * RS + x);       // wave-uniform address
-            t[x] = v.x; t[x + 1] = v.y; t[x + 2] = v.z; t[x + 3] = v.w;
+        for (int x = 0; x < RW; ++x) set_word(r, x, ring[x * 64 + u]);              // wave-uniform address
+    }
+    // items u0 .. u0+3 (u0 % 4 == 0)
+    static __device__ __forceinline__ void get4(R (&g)[4], const uint32_t* ring, int u0) {
+#pragma unroll
+        for (int x = 0; x < RW; ++x) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ring + x * 64 + u0);    // wave-uniform address
+            set_word(g[0], x, v.x);
+            set_word(g[1], x, v.y);
+            set_word(g[2], x, v.z);
+            set_word(g[3], x, v.w);
         }
-#pragma unroll
-        for (int x = 0; x < W; ++x) r.b[x] = t[x];
-        if (TERN) {
-#pragma unroll
-            for (int x = 0; x < W; ++x) r.z[x] = t[W + x];
-        }
-#pragma unroll
-        for (int x = 0; x < LW; ++x) r.l[x] = t[W * (TERN ? 2 : 1) + x];
     }
 };
 
@@ -235,52 +294,75 @@ __global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restri
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
 
-    auto count_group = [&](const R (&g)[U]) {
-        int d[U];
-        bool rel[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval<W, LW, TERN>(qr, g[u], a.K, d[u], rel[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) atomicAdd(&lds[d[u] * 64 + lane], rel[u] ? 0x10001u : 1u);
-    };
     auto count_one = [&](const R& r) {
         int d;
         bool rel;
         rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
         atomicAdd(&lds[d * 64 + lane], rel ? 0x10001u : 1u);
     };
+    auto count_four = [&](const R (&g)[4]) {                         // records in VGPRs (LDS mode): one-op-per-word relevance
+        int d[4];
+        uint32_t hit[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rec_eval01<W, LW, TERN, 1>(qr, g[u], a.K, d[u], hit[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            atomicAdd(&lds[d[u] * 64 + lane], (hit[u] << 16) + 1u);
+        }
+    };
 
-    if (GM == GM_SCALAR) {
-        // ping-pong two SGPR-resident groups: group g+1 is in flight while group g is counted
-        R ga[U], gb[U];
-        int64_t i = lo;
+    if constexpr (GM == GM_SCALAR) {
+        // Two SGPR-resident groups, ping-pong.  SMEM returns out of order, so the only wait that makes a group usable
+        // is lgkmcnt(0) -- which also drains every LDS op in flight.  The loop therefore puts ONE explicit wait at the
+        // top of each half-iteration and issues, right after it, the next group's s_loads AND the previous group's
+        // atomics (their operands are held in VGPRs for one stage): both then have the whole evaluation of the current
+        // group (~10 VALU/item) to complete, and the next wait finds the counters already at zero.
+        using SG = ScalarGroup<W, LW, TERN, U>;
+        SG ga, gb;
+        int dA[U], dB[U];
+        uint32_t vA[U], vB[U];
         const int64_t ngroups = (hi - lo) / U;
-        if (ngroups > 0) {
+        auto load = [&](SG& g, int64_t at) { g.issue(a, at); };
+        auto eval = [&](SG& g, int (&d)[U], uint32_t (&v)[U]) {
+            g.fence();
 #pragma unroll
-            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
-        }
-        int64_t g = 0;
-        for (; g + 2 <= ngroups; g += 2) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
-            count_group(ga);
-            if (g + 2 < ngroups) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
+            for (int u = 0; u < U; ++u) {
+                R r;
+                g.get(r, u);
+                uint32_t hit;
+                rec_eval01<W, LW, TERN, 2>(qr, r, a.K, d[u], hit);
+                v[u] = (hit << 16) + 1u;
             }
-            count_group(gb);
-            i += 2 * U;
+        };
+        auto issue = [&](const int (&d)[U], const uint32_t (&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) atomicAdd(&lds[d[u] * 64 + lane], v[u]);
+        };
+        int64_t g = 0;
+        bool eA = false, eB = false;
+        if (ngroups > 0) load(ga, lo);
+        while (g < ngroups) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): ga landed
+            if (g + 1 < ngroups) load(gb, lo + (g + 1) * U);
+            if (eB) issue(dB, vB);
+            eval(ga, dA, vA);
+            eA = true; eB = false;
+            if (++g >= ngroups) break;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // gb landed
+            if (g + 1 < ngroups) load(ga, lo + (g + 1) * U);
+            issue(dA, vA);
+            eval(gb, dB, vB);
+            eB = true; eA = false;
+            ++g;
         }
-        if (g < ngroups) {
-            count_group(ga);
-            i += U;
-        }
-        for (; i < hi; ++i) {
+        if (eA) issue(dA, vA);
+        if (eB) issue(dB, vB);
+        for (int64_t i = lo + ngroups * U; i < hi; ++i) {
             R r;
             rec_load_uniform<W, LW, TERN>(r, a, i);
             count_one(r);
         }
-    } else if (GM == GM_LDS) {
+    } else if constexpr (GM == GM_LDS) {
         using LB = LdsBatch<W, LW, TERN>;
         uint32_t* ring = lds + a.nb * 64;                          // [64][RS] after the counters
         LB cur, nxt;
@@ -290,35 +372,26 @@ __global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restri
             nxt.load(a, base + 64, hi, lane);                      // prefetch (vmcnt) while this batch is consumed from LDS
             const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
             int u0 = 0;
-            for (; u0 + U <= cnt; u0 += U) {
-                R g[U];
+            if (cnt == 64) {                                         // full batch: unrolled, one-group LDS read-ahead
+                R ga[4], gb[4];
+                LB::get4(ga, ring, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
-                count_group(g);
+                for (int g = 0; g < 16; g += 2) {
+                    LB::get4(gb, ring, (g + 1) * 4);
+                    count_four(ga);
+                    if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
+                    count_four(gb);
+                }
+                u0 = 64;
+            }
+            for (; u0 + 4 <= cnt; u0 += 4) {
+                R g[4];
+                LB::get4(g, ring, u0);
+                count_four(g);
             }
             for (; u0 < cnt; ++u0) {
                 R r;
                 LB::get(r, ring, u0);
-                count_one(r);
-            }
-            cur = nxt;
-        }
-    } else {
-        LaneBatch<W, LW, TERN> cur, nxt;
-        cur.load(a, lo, hi, lane);
-        for (int64_t base = lo; base < hi; base += 64) {
-            nxt.load(a, base + 64, hi, lane);                  // prefetch (all-zero past the end)
-            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
-            int u0 = 0;
-            for (; u0 + U <= cnt; u0 += U) {
-                R g[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) cur.get(g[u], u0 + u);
-                count_group(g);
-            }
-            for (; u0 < cnt; ++u0) {
-                R r;
-                cur.get(r, u0);
                 count_one(r);
             }
             cur = nxt;
@@ -468,26 +541,27 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
         const float of = (float)__umul24(ord, hit);            // ordinals < 2^24 (R < 16.7 M per shard checked in the plan)
         acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
     };
-    unsigned long long old[U];
-    uint32_t hitp[U];
-    auto eval_issue = [&](const R (&g)[U], bool have_prev) {
-        int d[U];
-        uint32_t hit[U];
+    constexpr int UG = (GM == GM_LDS) ? 4 : U;                       // items per pipelined group
+    unsigned long long old[UG];
+    uint32_t hitp[UG];
+    auto eval_issue = [&](const R (&g)[UG], bool have_prev) {
+        int d[UG];
+        uint32_t hit[UG];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN, GM == GM_LDS>(qr, g[u], a.K, d[u], hit[u]);
+        for (int u = 0; u < UG; ++u) rec_eval01<W, LW, TERN, (GM == GM_LDS ? 1 : (GM == GM_SCALAR ? 2 : 0))>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);              // previous group's returns
+            for (int u = 0; u < UG; ++u) credit(old[u], hitp[u]);             // previous group's returns
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UG; ++u) {
             hitp[u] = hit[u];
             old[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)hit[u] << 32));
         }
     };
     auto drain = [&]() {
 #pragma unroll
-        for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+        for (int u = 0; u < UG; ++u) credit(old[u], hitp[u]);
     };
     auto one = [&](const R& r) {
         int d;
@@ -497,42 +571,68 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
         credit(atomicAdd(&cnt[d * 64 + lane], 1ull | ((unsigned long long)hit << 32)), hit);
     };
 
-    if (GM == GM_SCALAR) {
-        // ping-pong two SGPR-resident groups; the scalar loads of group g+1 are issued before group g is
-        // evaluated, so by the time the LDS returns force an lgkmcnt(0) they have long landed
-        R ga[U], gb[U];
-        int64_t i = lo;
+    if constexpr (GM == GM_SCALAR) {
+        // Same one-wait-per-group pipeline as k_scan_hist (GM_SCALAR), one stage deeper: after the lgkmcnt(0) at the top
+        // of a half-iteration the wave issues the next group's s_loads and the atomics of the group evaluated in the
+        // PREVIOUS half, credits the group whose returns that wait has just made valid, and evaluates the current one.
+        // Atomics are issued in item order (A0 B0 A1 B1 ...), which is what the running counters need.
+        using SG = ScalarGroup<W, LW, TERN, U>;
+        SG ga, gb;
+        int dA[U], dB[U];
+        uint32_t hA[U], hB[U], cA[U], cB[U];
+        unsigned long long oA[U], oB[U];
         const int64_t ngroups = (hi - lo) / U;
-        if (ngroups > 0) {
+        auto load = [&](SG& g, int64_t at) { g.issue(a, at); };
+        auto eval = [&](SG& g, int (&d)[U], uint32_t (&h)[U]) {
+            g.fence();
 #pragma unroll
-            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + u);
-        }
-        int64_t g = 0;
-        bool prev = false;
-        for (; g + 2 <= ngroups; g += 2) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(gb[u], a, i + U + u);
-            eval_issue(ga, prev);
-            if (g + 2 < ngroups) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) rec_load_uniform<W, LW, TERN>(ga[u], a, i + 2 * U + u);
+            for (int u = 0; u < U; ++u) {
+                R r;
+                g.get(r, u);
+                rec_eval01<W, LW, TERN, 2>(qr, r, a.K, d[u], h[u]);
             }
-            eval_issue(gb, true);
-            prev = true;
-            i += 2 * U;
+        };
+        auto issue = [&](const int (&d)[U], const uint32_t (&h)[U], unsigned long long (&o)[U], uint32_t (&c)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c[u] = h[u];
+                o[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)h[u] << 32));
+            }
+        };
+        auto settle = [&](const unsigned long long (&o)[U], const uint32_t (&c)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) credit(o[u], c[u]);
+        };
+        int64_t g = 0;
+        bool eA = false, eB = false, iA = false, iB = false;   // e: evaluated, not yet issued; i: issued, not yet credited
+        if (ngroups > 0) load(ga, lo);
+        while (g < ngroups) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): ga landed, oA returned
+            if (g + 1 < ngroups) load(gb, lo + (g + 1) * U);
+            if (eB) { issue(dB, hB, oB, cB); iB = true; eB = false; }
+            if (iA) { settle(oA, cA); iA = false; }
+            eval(ga, dA, hA);
+            eA = true;
+            if (++g >= ngroups) break;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // gb landed, oB returned
+            if (g + 1 < ngroups) load(ga, lo + (g + 1) * U);
+            issue(dA, hA, oA, cA); iA = true; eA = false;
+            if (iB) { settle(oB, cB); iB = false; }
+            eval(gb, dB, hB);
+            eB = true;
+            ++g;
         }
-        if (g < ngroups) {
-            eval_issue(ga, prev);
-            prev = true;
-            i += U;
-        }
-        if (prev) drain();
-        for (; i < hi; ++i) {
+        // tail: at most one group evaluated-not-issued and one issued-not-credited (the older one)
+        if (eA) { if (iB) { settle(oB, cB); iB = false; } issue(dA, hA, oA, cA); iA = true; }
+        if (eB) { if (iA) { settle(oA, cA); iA = false; } issue(dB, hB, oB, cB); iB = true; }
+        if (iA) settle(oA, cA);
+        if (iB) settle(oB, cB);
+        for (int64_t i = lo + ngroups * U; i < hi; ++i) {
             R r;
             rec_load_uniform<W, LW, TERN>(r, a, i);
             one(r);
         }
-    } else if (GM == GM_LDS) {
+    } else if constexpr (GM == GM_LDS) {
         // Batches of 64 records are staged through an LDS ring slot by the wave itself and read back with wave-uniform
         // ds_read_b128s (broadcast); the next batch's global loads are in flight (vmcnt) during the whole current batch.
         // LDS is in-order per wave, so every wait in the loop is a counted lgkmcnt.  (A one-group LDS read-ahead with a
@@ -547,10 +647,24 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
             nxt.load(a, base + 64, hi, lane);
             const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
             int u0 = 0;
-            for (; u0 + U <= cntb; u0 += U) {
-                R g[U];
+            if (cntb == 64) {
+                // full batch, fully unrolled with a one-group LDS read-ahead: the ds_reads of group g+1 are issued
+                // before group g is evaluated (counted lgkmcnt waits: LDS returns in order)
+                R ga[4], gb[4];
+                LB::get4(ga, ring, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
+                for (int g = 0; g < 16; g += 2) {
+                    LB::get4(gb, ring, (g + 1) * 4);
+                    eval_issue(ga, prev);
+                    prev = true;
+                    if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
+                    eval_issue(gb, true);
+                }
+                u0 = 64;
+            }
+            for (; u0 + 4 <= cntb; u0 += 4) {
+                R g[4];
+                LB::get4(g, ring, u0);
                 eval_issue(g, prev);
                 prev = true;
             }
@@ -560,33 +674,6 @@ __global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restr
                 for (; u0 < cntb; ++u0) {
                     R r;
                     LB::get(r, ring, u0);
-                    one(r);
-                }
-            }
-            cur = nxt;
-        }
-        if (prev) drain();
-    } else {
-        LaneBatch<W, LW, TERN> cur, nxt;
-        cur.load(a, lo, hi, lane);
-        bool prev = false;
-        for (int64_t base = lo; base < hi; base += 64) {
-            nxt.load(a, base + 64, hi, lane);                  // prefetch (all-zero past the end)
-            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-            int u0 = 0;
-            for (; u0 + U <= cntb; u0 += U) {
-                R g[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) cur.get(g[u], u0 + u);
-                eval_issue(g, prev);
-                prev = true;
-            }
-            if (u0 < cntb) {
-                if (prev) drain();
-                prev = false;
-                for (; u0 < cntb; ++u0) {
-                    R r;
-                    cur.get(r, u0);
                     one(r);
                 }
             }
@@ -638,7 +725,6 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
     using R = Rec<W, LW, TERN>;
-    constexpr int U = Unroll<W, LW, TERN>::value;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     float acc = 0.0f;
@@ -649,18 +735,18 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
         const float of = (float)__umul24(ord, hit);
         acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
     };
-    uint32_t old[U], hitp[U];
-    auto eval_issue = [&](const R (&g)[U], bool have_prev) {
-        int d[U];
-        uint32_t hit[U];
+    uint32_t old[4], hitp[4];
+    auto eval_issue = [&](const R (&g)[4], bool have_prev) {
+        int d[4];
+        uint32_t hit[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rec_eval01<W, LW, TERN, true>(qr, g[u], a.K, d[u], hit[u]);
+        for (int u = 0; u < 4; ++u) rec_eval01<W, LW, TERN, 1>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+            for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < 4; ++u) {
             hitp[u] = hit[u];
             old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], (hit[u] << rank_bits) + 1u);      // v_lshl_add_u32
         }
@@ -676,17 +762,29 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
         nxt.load(a, base + 64, hi, lane);
         const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
         int u0 = 0;
-        for (; u0 + U <= cntb; u0 += U) {
-            R g[U];
+        if (cntb == 64) {                                            // full batch: unrolled, one-group LDS read-ahead
+            R ga[4], gb[4];
+            LB::get4(ga, ring, 0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) LB::get(g[u], ring, u0 + u);
+            for (int g = 0; g < 16; g += 2) {
+                LB::get4(gb, ring, (g + 1) * 4);
+                eval_issue(ga, prev);
+                prev = true;
+                if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
+                eval_issue(gb, true);
+            }
+            u0 = 64;
+        }
+        for (; u0 + 4 <= cntb; u0 += 4) {
+            R g[4];
+            LB::get4(g, ring, u0);
             eval_issue(g, prev);
             prev = true;
         }
         if (u0 < cntb) {
             if (prev) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+                for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
             }
             prev = false;
             for (; u0 < cntb; ++u0) {
@@ -703,7 +801,7 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
     }
     if (prev) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) credit(old[u], hitp[u]);
+        for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
     }
     ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
@@ -792,7 +890,7 @@ int gallery_mode(const char* env, int dflt) {
     const char* v = getenv(env);
     if (!v) return dflt;
     const int m = atoi(v);
-    return m == 2 ? GM_LDS : (m == 1 ? GM_LANE : GM_SCALAR);
+    return m == 0 ? GM_SCALAR : GM_LDS;
 }
 
 template <typename F>
@@ -863,7 +961,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     uint2* tot = reinterpret_cast<uint2*>(base + L.tot);
     hipStream_t st = xmh::as_stream(stream);
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    const int gm = gallery_mode("XMH_SCAN_GM_HIST", GM_SCALAR);
+    const int gm = gallery_mode("XMH_SCAN_GM_HIST", GM_LDS);
     const size_t ring = (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4;     // GM_LDS staging ring
     const size_t lds = (size_t)p.nbuckets * 64 * 4 + (gm == GM_LDS ? ring : 0);
     auto launch = [&](auto tern_c, auto gm_c) {
@@ -881,10 +979,9 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     using T1 = std::true_type;
     using T0 = std::false_type;
     using GS = std::integral_constant<int, GM_SCALAR>;
-    using GL = std::integral_constant<int, GM_LANE>;
     using GD = std::integral_constant<int, GM_LDS>;
-    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : (gm == GM_LANE ? launch(T1{}, GL{}) : launch(T1{}, GD{}));
-    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : (gm == GM_LANE ? launch(T0{}, GL{}) : launch(T0{}, GD{}));
+    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : launch(T1{}, GD{});
+    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : launch(T0{}, GD{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
@@ -953,7 +1050,6 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     using T1 = std::true_type;
     using T0 = std::false_type;
     using GS = std::integral_constant<int, GM_SCALAR>;
-    using GL = std::integral_constant<int, GM_LANE>;
     const bool capped = k > 0;
     if (rank_bits) {
         const size_t lds32 = (size_t)p.nbuckets * 64 * 4 + ring;
@@ -978,9 +1074,6 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     if (gm == GM_SCALAR) {
         if (tern) rc = capped ? launch(T1{}, T1{}, GS{}) : launch(T1{}, T0{}, GS{});
         else rc = capped ? launch(T0{}, T1{}, GS{}) : launch(T0{}, T0{}, GS{});
-    } else if (gm == GM_LANE) {
-        if (tern) rc = capped ? launch(T1{}, T1{}, GL{}) : launch(T1{}, T0{}, GL{});
-        else rc = capped ? launch(T0{}, T1{}, GL{}) : launch(T0{}, T0{}, GL{});
     } else {
         using GD = std::integral_constant<int, GM_LDS>;
         if (tern) rc = capped ? launch(T1{}, T1{}, GD{}) : launch(T1{}, T0{}, GD{});
