@@ -1,30 +1,33 @@
 // Fused ranking scan: calc_map_k (reference common/calc_utils.py:58-92) as two streaming passes over
 // bit-packed codes, no [Q,R] intermediate, no sort.
 //
-// Execution shape ("query per lane"): a wave owns 64 queries -- their code words and label masks live in
-// VGPRs -- and walks a contiguous gallery chunk in index order.  Per-lane bucket counters sit in LDS as
-// cnt[d][lane] (row stride = 64 lanes), so lane l always hits bank l%32: conflict-free for any distance
-// pattern, and because every lane owns its column the read-modify-write needs no cross-lane atomicity.
-// Walking in index order makes "number of same-distance items with a smaller index" a running counter,
-// which is exactly the tie-break of the canonical (distance, index) order.
+// Execution shape: a wave owns QW = 64/S queries and S "slots"; lane = slot * QW + ql holds query ql (code words and
+// label masks in VGPRs) and, at step t of a 64-item batch, works on gallery item t*S + slot.  Per-query bucket counters
+// sit in LDS as cnt[d][ql].  Walking the gallery in index order makes "number of same-distance items with a smaller
+// index" a running counter, which is exactly the tie-break of the canonical (distance, index) order:
+//   pass 1 (k_scan_hist_s)  histogram of (distance, relevant) per (chunk, query): one ds_add_u32 per pair;
+//   tables                  exclusive prefixes over chunks and over buckets (k_scan_below, k_scan_dpre);
+//   pass 2 (k_scan_ap_s)    counters start at the global base of (bucket, chunk); one returning ds_add per pair yields
+//                           (rank, ordinal) of the item, relevant items add ordinal/rank to the query's AP sum.
+// Why slots: with one query per lane (S = 1) the counters of a wave cost nb*64*{4,8} bytes -- 33 KB at K = 64 with
+// 64-bit counters (one wave per SIMD), 131 KB at K = 256 (one wave per CU).  S lanes per query shrink the footprint by
+// S: 3-4 waves per SIMD for every supported K, which is what hides the LDS round trips of this loop (measured at
+// K=64/128/256: 0.55/3.6/13.3 ms for S = 1 against 0.34/0.47/0.77 ms).
+// Ordering: the S lanes of a query may hit the same counter in one instruction.  Pass 1 only needs totals.  Pass 2 needs
+// the returns in item order; the LDS serialises same-address lanes in ascending lane order (= item order, slot being the
+// high lane bits).  That is observed behaviour, not an ISA promise, so xmh_hamming_ap probes it once per process
+// (k_probe_lane_order) and otherwise issues the add once per slot under an exec mask (MASKED, ~1.6x slower).
 //
-// The gallery record is wave-uniform.  Two ways to broadcast it (XMH_SCAN_GM_HIST / XMH_SCAN_GM_AP; both measured
-// within a few percent of each other on MI355X):
-//   GM_LDS (2, default)  the wave stages 64 records at a time into a small word-major LDS ring and fetches word x of
-//              four consecutive items with ONE wave-uniform ds_read_b128 (LDS broadcast).  LDS ops of a wave
-//              complete in order, so every wait in the loop is a counted lgkmcnt; the next batch's global loads
-//              (vmcnt) fly during the whole batch.  Record words arrive in VGPRs.
-//   GM_SCALAR (0)  hand-issued s_load_dwordxN into SGPRs (inline asm, invisible to the compiler's waitcnt pass), used
-//              directly as the scalar operand of v_xor / v_and_or.  SMEM returns out of order and shares lgkmcnt
-//              with LDS, so each group has exactly one explicit lgkmcnt(0); the next group's loads and the previous
-//              group's atomics are issued right after it and complete under the current group's VALU work.
+// The gallery batch: lane i loads record base+i (coalesced, vmcnt; the next batch is in flight during the current one),
+// the wave stages it record-major in a small LDS ring, and a lane reads the record of its own item with ds_read_b128s
+// (S distinct addresses per instruction, each broadcast to QW lanes).  LDS ops of a wave complete in order, so every
+// wait in the loop is a counted lgkmcnt; reads run one 4-step group ahead of their use.
 //
 // Bound: VALU issue.  tools/ubench_valu.hip measures ~4.0-4.4 cycles per wave64 instruction per SIMD for
-// the instruction mix of these loops at any occupancy (v_xor/v_and/v_add alone reach 2.4, VOP3 ops such as
-// v_bcnt_u32_b32 / v_and_or_b32 / v_lshl_add_u32 4.2, v_rcp_f32 8.2): 10 (pass 1) / 14 (pass 2) VALU instructions per
-// wave-item at K=64, C=80, against K/8+4*Lw gallery bytes shared by the 64 queries of a wave.  The relevance test
-// is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does not form them).
-// Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
+// the instruction mix of these loops (v_xor/v_and/v_add alone reach 2.4, VOP3 ops such as v_bcnt_u32_b32 /
+// v_and_or_b32 / v_lshl_add_u32 4.2, v_rcp_f32 8.2): 10 (pass 1) / 14 (pass 2) VALU instructions per pair-step of a
+// wave at K=64, C=80.  The relevance test is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does
+// not form them).  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
 
 #include <stdlib.h>
@@ -34,8 +37,6 @@ namespace {
 
 constexpr int kMaxChunk = 32768;   // u16 halves of the packed pass-1 counters must not overflow
 constexpr int kMinChunk = 256;
-constexpr int GM_SCALAR = 0;
-constexpr int GM_LDS = 2;
 
 struct ScanArgs {
     const uint32_t* qbits;
@@ -85,10 +86,8 @@ struct Rec {
     uint32_t l[LW];
 };
 
-// distance bucket d and relevance (as 0/1 in `hit01`) of (this lane's query, record r)
-// VREC = the record words live in VGPRs (GM_LDS): relevance then uses v_and_or_b32 / v_min_u32 (one op per label word
-// + one) through inline asm -- hipcc does not form them -- which would cost extra v_movs on SGPR-resident records.
-template <int W, int LW, bool TERN, int VREC = 0>
+// distance bucket d and relevance (as 0/1 in `hit01`) of (this lane's query, record r); all operands in VGPRs
+template <int W, int LW, bool TERN>
 __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, uint32_t& hit01) {
     if (!TERN) {
         int acc = 0;
@@ -105,300 +104,10 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
         }
         d = K - live_n + 2 * diff_n;                           // 2 * (0.5 * (K - q.r)), in [0, 2K]
     }
-    if (VREC == 1) {
-        uint32_t hit = qr.l[0] & r.l[0];
+    uint32_t hit = qr.l[0] & r.l[0];
 #pragma unroll
-        for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "v"(qr.l[w]), "v"(r.l[w]));
-        asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
-    } else if (VREC == 2) {                                      // record words wave-uniform in SGPRs (one SGPR per VOP3)
-        uint32_t hit = qr.l[0] & r.l[0];
-#pragma unroll
-        for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "s"(r.l[w]), "v"(qr.l[w]));
-        asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
-    } else {
-        uint32_t hit = 0;
-#pragma unroll
-        for (int w = 0; w < LW; ++w) hit |= qr.l[w] & r.l[w];
-        hit01 = hit != 0 ? 1u : 0u;
-    }
-}
-
-template <int W, int LW, bool TERN>
-__device__ __forceinline__ void rec_eval(const QueryRegs<W, LW, TERN>& qr, const Rec<W, LW, TERN>& r, int K, int& d, bool& rel) {
-    uint32_t h;
-    rec_eval01<W, LW, TERN>(qr, r, K, d, h);
-    rel = h != 0;
-}
-
-// GM_SCALAR: record i through a wave-uniform address (the compiler emits s_load_dwordxN)
-template <int W, int LW, bool TERN>
-__device__ __forceinline__ void rec_load_uniform(Rec<W, LW, TERN>& r, const ScanArgs& a, int64_t i) {
-    const uint32_t* __restrict__ pb = a.rbits + i * W;
-#pragma unroll
-    for (int w = 0; w < W; ++w) r.b[w] = pb[w];
-    if (TERN) {
-        const uint32_t* __restrict__ pz = a.rzero + i * W;
-#pragma unroll
-        for (int w = 0; w < W; ++w) r.z[w] = pz[w];
-    }
-    const uint32_t* __restrict__ pl = a.rlab + i * LW;
-#pragma unroll
-    for (int w = 0; w < LW; ++w) r.l[w] = pl[w];
-}
-
-// GM_SCALAR, explicit form: N consecutive dwords fetched into SGPRs by hand-issued s_load_dwordxN.  The compiler's
-// waitcnt pass does not see these loads, which is the point: the kernel decides where the one lgkmcnt(0) per group goes
-// (see k_scan_hist).  Protocol: issue() ... __builtin_amdgcn_s_waitcnt(lgkmcnt 0) ... fence() ... word(i).  fence() is
-// an empty asm that makes every later use depend on a point after the wait.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-template <int P> struct SPiece;
-template <> struct SPiece<1> {
-    uint32_t v;
-    template <int OFF> __device__ __forceinline__ void issue(const uint32_t* p) { asm volatile("s_load_dword %0, %1, %2" : "=&s"(v) : "s"(p), "n"(OFF)); }
-    __device__ __forceinline__ void fence() { asm volatile("" : "+s"(v)); }
-    __device__ __forceinline__ uint32_t word(int) const { return v; }
-};
-#define XMH_SPIECE(P, T, INSN)                                                                                              \
-    template <> struct SPiece<P> {                                                                                          \
-        T v;                                                                                                                \
-        template <int OFF> __device__ __forceinline__ void issue(const uint32_t* p) {                                       \
-            asm volatile(INSN " %0, %1, %2" : "=&s"(v) : "s"(p), "n"(OFF));                                                 \
-        }                                                                                                                   \
-        __device__ __forceinline__ void fence() { asm volatile("" : "+s"(v)); }                                             \
-        __device__ __forceinline__ uint32_t word(int i) const { return v[i]; }                                              \
-    };
-XMH_SPIECE(2, u32x2, "s_load_dwordx2")
-XMH_SPIECE(4, u32x4, "s_load_dwordx4")
-XMH_SPIECE(8, u32x8, "s_load_dwordx8")
-XMH_SPIECE(16, u32x16, "s_load_dwordx16")
-#undef XMH_SPIECE
-
-template <int N>
-struct SRun {
-    static constexpr int P = N >= 16 ? 16 : (N >= 8 ? 8 : (N >= 4 ? 4 : (N >= 2 ? 2 : 1)));
-    SPiece<P> head;
-    SRun<N - P> tail;
-    template <int OFF = 0> __device__ __forceinline__ void issue(const uint32_t* p) {
-        head.template issue<OFF>(p);
-        tail.template issue<OFF + 4 * P>(p);
-    }
-    __device__ __forceinline__ void fence() { head.fence(); tail.fence(); }
-    __device__ __forceinline__ uint32_t word(int i) const { return i < P ? head.word(i < P ? i : 0) : tail.word(i - P); }
-};
-template <>
-struct SRun<0> {
-    template <int OFF = 0> __device__ __forceinline__ void issue(const uint32_t*) {}
-    __device__ __forceinline__ void fence() {}
-    __device__ __forceinline__ uint32_t word(int) const { return 0u; }
-};
-
-// U consecutive records in SGPRs
-template <int W, int LW, bool TERN, int U>
-struct ScalarGroup {
-    SRun<U * W> b;
-    SRun<TERN ? U * W : 0> z;
-    SRun<U * LW> l;
-    __device__ __forceinline__ void issue(const ScanArgs& a, int64_t at) {
-        b.issue(a.rbits + at * W);
-        if (TERN) z.issue(a.rzero + at * W);
-        l.issue(a.rlab + at * LW);
-    }
-    __device__ __forceinline__ void fence() { b.fence(); z.fence(); l.fence(); }
-    __device__ __forceinline__ void get(Rec<W, LW, TERN>& r, int u) const {           // u is a constant after unrolling
-#pragma unroll
-        for (int w = 0; w < W; ++w) r.b[w] = b.word(u * W + w);
-        if (TERN) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) r.z[w] = z.word(u * W + w);
-        }
-#pragma unroll
-        for (int w = 0; w < LW; ++w) r.l[w] = l.word(u * LW + w);
-    }
-};
-
-// GM_LDS: the same 64-record batch, but staged through a small LDS ring, word-major: ring[word][item].  Lane i writes
-// the words of record base+i (conflict-free ds_write_b32s); word x of four consecutive items is then ONE wave-uniform
-// ds_read_b128 (an LDS broadcast: one address, no bank conflict), i.e. RW reads per 4 items with no padding.  No
-// v_readlane on the VALU pipe, no SGPR pressure, and -- LDS being in-order per wave -- every wait in the loop is a
-// counted lgkmcnt.  lgkmcnt has 4 bits on gfx9: the loops below keep <= 15 LDS ops between a read and its use so a
-// wait never has to drain the atomics issued after it.
-template <int W, int LW, bool TERN>
-struct LdsBatch {
-    static constexpr int RW = W * (TERN ? 2 : 1) + LW;
-    static constexpr int RS = (RW + 3) / 4 * 4;                    // host sizes the ring as 64 * RS dwords
-    using R = Rec<W, LW, TERN>;
-    uint32_t w[RW];
-    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
-        const int64_t i = base + lane;
-        const bool ok = i < hi;
-#pragma unroll
-        for (int x = 0; x < W; ++x) w[x] = ok ? a.rbits[i * W + x] : 0u;
-        if (TERN) {
-#pragma unroll
-            for (int x = 0; x < W; ++x) w[W + x] = ok ? a.rzero[i * W + x] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
-    }
-    __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
-#pragma unroll
-        for (int x = 0; x < RW; ++x) ring[x * 64 + lane] = w[x];
-    }
-    static __device__ __forceinline__ void set_word(R& r, int x, uint32_t v) {      // x is a constant after unrolling
-        if (x < W) r.b[x] = v;
-        else if (TERN && x < 2 * W) r.z[TERN ? x - W : 0] = v;
-        else r.l[x - W * (TERN ? 2 : 1)] = v;
-    }
-    static __device__ __forceinline__ void get(R& r, const uint32_t* ring, int u) {
-#pragma unroll
-        for (int x = 0; x < RW; ++x) set_word(r, x, ring[x * 64 + u]);              // wave-uniform address
-    }
-    // items u0 .. u0+3 (u0 % 4 == 0)
-    static __device__ __forceinline__ void get4(R (&g)[4], const uint32_t* ring, int u0) {
-#pragma unroll
-        for (int x = 0; x < RW; ++x) {
-            const uint4 v = *reinterpret_cast<const uint4*>(ring + x * 64 + u0);    // wave-uniform address
-            set_word(g[0], x, v.x);
-            set_word(g[1], x, v.y);
-            set_word(g[2], x, v.z);
-            set_word(g[3], x, v.w);
-        }
-    }
-};
-
-// items per unrolled group: two groups of records must fit the SGPR file (<= ~80 of 102) in GM_SCALAR mode
-template <int W, int LW, bool TERN>
-struct Unroll {
-    static constexpr int words = W * (TERN ? 2 : 1) + LW;
-    static constexpr int value = words <= 5 ? 8 : (words <= 10 ? 4 : 2);
-};
-
-// ---------------------------------------------------------------------------------------------------
-// pass 1: chunk_hist[chunk][d][q] = (#items at distance d) | (#relevant items at distance d) << 16
-// ---------------------------------------------------------------------------------------------------
-template <int W, int LW, bool TERN, int GM>
-__global__ __launch_bounds__(64) void k_scan_hist(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][64]
-    int chunk_id, qtile;
-    if (!map_block(a, chunk_id, qtile)) return;
-    const int lane = threadIdx.x;
-    const int q = qtile * 64 + lane;
-    for (int d = 0; d < a.nb; ++d) lds[d * 64 + lane] = 0u;
-    QueryRegs<W, LW, TERN> qr;
-    qr.load(a, q);
-    using R = Rec<W, LW, TERN>;
-    constexpr int U = Unroll<W, LW, TERN>::value;
-    const int64_t lo = (int64_t)chunk_id * a.chunk;
-    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
-
-    auto count_one = [&](const R& r) {
-        int d;
-        bool rel;
-        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
-        atomicAdd(&lds[d * 64 + lane], rel ? 0x10001u : 1u);
-    };
-    auto count_four = [&](const R (&g)[4]) {                         // records in VGPRs (LDS mode): one-op-per-word relevance
-        int d[4];
-        uint32_t hit[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rec_eval01<W, LW, TERN, 1>(qr, g[u], a.K, d[u], hit[u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            atomicAdd(&lds[d[u] * 64 + lane], (hit[u] << 16) + 1u);
-        }
-    };
-
-    if constexpr (GM == GM_SCALAR) {
-        // Two SGPR-resident groups, ping-pong.  SMEM returns out of order, so the only wait that makes a group usable
-        // is lgkmcnt(0) -- which also drains every LDS op in flight.  The loop therefore puts ONE explicit wait at the
-        // top of each half-iteration and issues, right after it, the next group's s_loads AND the previous group's
-        // atomics (their operands are held in VGPRs for one stage): both then have the whole evaluation of the current
-        // group (~10 VALU/item) to complete, and the next wait finds the counters already at zero.
-        using SG = ScalarGroup<W, LW, TERN, U>;
-        SG ga, gb;
-        int dA[U], dB[U];
-        uint32_t vA[U], vB[U];
-        const int64_t ngroups = (hi - lo) / U;
-        auto load = [&](SG& g, int64_t at) { g.issue(a, at); };
-        auto eval = [&](SG& g, int (&d)[U], uint32_t (&v)[U]) {
-            g.fence();
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                R r;
-                g.get(r, u);
-                uint32_t hit;
-                rec_eval01<W, LW, TERN, 2>(qr, r, a.K, d[u], hit);
-                v[u] = (hit << 16) + 1u;
-            }
-        };
-        auto issue = [&](const int (&d)[U], const uint32_t (&v)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) atomicAdd(&lds[d[u] * 64 + lane], v[u]);
-        };
-        int64_t g = 0;
-        bool eA = false, eB = false;
-        if (ngroups > 0) load(ga, lo);
-        while (g < ngroups) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): ga landed
-            if (g + 1 < ngroups) load(gb, lo + (g + 1) * U);
-            if (eB) issue(dB, vB);
-            eval(ga, dA, vA);
-            eA = true; eB = false;
-            if (++g >= ngroups) break;
-            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // gb landed
-            if (g + 1 < ngroups) load(ga, lo + (g + 1) * U);
-            issue(dA, vA);
-            eval(gb, dB, vB);
-            eB = true; eA = false;
-            ++g;
-        }
-        if (eA) issue(dA, vA);
-        if (eB) issue(dB, vB);
-        for (int64_t i = lo + ngroups * U; i < hi; ++i) {
-            R r;
-            rec_load_uniform<W, LW, TERN>(r, a, i);
-            count_one(r);
-        }
-    } else if constexpr (GM == GM_LDS) {
-        using LB = LdsBatch<W, LW, TERN>;
-        uint32_t* ring = lds + a.nb * 64;                          // [64][RS] after the counters
-        LB cur, nxt;
-        cur.load(a, lo, hi, lane);
-        for (int64_t base = lo; base < hi; base += 64) {
-            cur.publish(ring, lane);
-            nxt.load(a, base + 64, hi, lane);                      // prefetch (vmcnt) while this batch is consumed from LDS
-            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
-            int u0 = 0;
-            if (cnt == 64) {                                         // full batch: unrolled, one-group LDS read-ahead
-                R ga[4], gb[4];
-                LB::get4(ga, ring, 0);
-#pragma unroll
-                for (int g = 0; g < 16; g += 2) {
-                    LB::get4(gb, ring, (g + 1) * 4);
-                    count_four(ga);
-                    if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
-                    count_four(gb);
-                }
-                u0 = 64;
-            }
-            for (; u0 + 4 <= cnt; u0 += 4) {
-                R g[4];
-                LB::get4(g, ring, u0);
-                count_four(g);
-            }
-            for (; u0 < cnt; ++u0) {
-                R r;
-                LB::get(r, ring, u0);
-                count_one(r);
-            }
-            cur = nxt;
-        }
-    }
-    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q;
-    for (int d = 0; d < a.nb; ++d) out[(int64_t)d * a.qpad] = lds[d * 64 + lane];
+    for (int w = 1; w < LW; ++w) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit) : "v"(qr.l[w]), "v"(r.l[w]));
+    asm("v_min_u32 %0, %1, 1" : "=v"(hit01) : "v"(hit));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -483,277 +192,237 @@ __global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pass 2: ranks of relevant items.  cnt[d][lane] is a 64-bit counter {lo: rank of the NEXT item of bucket d,
-// hi: ordinal of the NEXT relevant item of bucket d} (both 1-based); it starts at the bucket's global base
-// and one ds_add_rtn_u64 per pair both advances it and returns (rank, ordinal) of the current item.
-// The loop is software-pipelined by one group: the returns of group g are consumed after group g+1's
-// distances have been computed.
+// the 64-record gallery batch: one record per lane in registers, staged record-major ([item][RS]) in the LDS ring
 // ---------------------------------------------------------------------------------------------------
-template <int W, int LW, bool TERN, bool CAPPED, int GM>
-__global__ __launch_bounds__(64) void k_scan_ap(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
-                                                const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                const uint32_t* __restrict__ nrel_max, int rank_bits) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long cnt[];   // [nb][64]
-    int chunk_id, qtile;
-    if (!map_block(a, chunk_id, qtile)) return;
-    // the 32-bit packed variant (k_scan_ap32) handles this call when rank and ordinal fit one word together
-    if (rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits))) return;
-    const int lane = threadIdx.x;
-    const int q = qtile * 64 + lane;
-    {
-        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q;
-        const uint2* __restrict__ pd = dpre + q;
-        int d = 0;
-        for (; d + 8 <= a.nb; d += 8) {
-            uint2 x[8], y[8];
+template <int W, int LW, bool TERN>
+struct AosBatch {
+    static constexpr int RW = W * (TERN ? 2 : 1) + LW;
+    static constexpr int RS = (RW + 3) / 4 * 4;
+    using R = Rec<W, LW, TERN>;
+    uint32_t w[RS];
+    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
+        const int64_t i = base + lane;
+        const bool ok = i < hi;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                x[j] = pb[(int64_t)(d + j) * a.qpad];
-                y[j] = pd[(int64_t)(d + j) * a.qpad];
-            }
+        for (int x = 0; x < W; ++x) w[x] = ok ? a.rbits[i * W + x] : 0u;
+        if (TERN) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                cnt[(d + j) * 64 + lane] = (unsigned long long)(x[j].x + y[j].x + 1u) | ((unsigned long long)(x[j].y + y[j].y + 1u) << 32);
+            for (int x = 0; x < W; ++x) w[W + x] = ok ? a.rzero[i * W + x] : 0xffffffffu;
         }
-        for (; d < a.nb; ++d) {
-            const uint2 x = pb[(int64_t)d * a.qpad], y = pd[(int64_t)d * a.qpad];
-            cnt[d * 64 + lane] = (unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32);
-        }
+#pragma unroll
+        for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
+#pragma unroll
+        for (int x = RW; x < RS; ++x) w[x] = 0u;
     }
-    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
+    __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
+#pragma unroll
+        for (int x = 0; x < RS; x += 4) *reinterpret_cast<uint4*>(ring + lane * RS + x) = make_uint4(w[x], w[x + 1], w[x + 2], w[x + 3]);
+    }
+    // `mine` = ring + slot * RS (per lane); item = step * S + slot -> constant offset step * S * RS from it
+    static __device__ __forceinline__ void get(R& r, const uint32_t* mine, int off_dwords) {
+        uint32_t t[RS];
+#pragma unroll
+        for (int x = 0; x < RS; x += 4) {
+            if (x + 4 <= RW || RW - x > 2) {
+                const uint4 v = *reinterpret_cast<const uint4*>(mine + off_dwords + x);
+                t[x] = v.x; t[x + 1] = v.y; t[x + 2] = v.z; t[x + 3] = v.w;
+            } else if (RW - x == 2) {
+                const uint2 v = *reinterpret_cast<const uint2*>(mine + off_dwords + x);
+                t[x] = v.x; t[x + 1] = v.y; t[x + 2] = 0u; t[x + 3] = 0u;
+            } else {
+                t[x] = mine[off_dwords + x]; t[x + 1] = 0u; t[x + 2] = 0u; t[x + 3] = 0u;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < W; ++x) r.b[x] = t[x];
+        if (TERN) {
+#pragma unroll
+            for (int x = 0; x < W; ++x) r.z[x] = t[W + x];
+        }
+#pragma unroll
+        for (int x = 0; x < LW; ++x) r.l[x] = t[W * (TERN ? 2 : 1) + x];
+    }
+};
 
+template <int S> struct SlotGeom {
+    static constexpr int QW = 64 / S;
+    static constexpr int LOG_QW = QW == 64 ? 6 : (QW == 32 ? 5 : (QW == 16 ? 4 : (QW == 8 ? 3 : 2)));
+    static constexpr int G = QW < 4 ? QW : 4;          // steps per pipelined group
+    static constexpr int NG = QW / G;                  // groups per 64-item batch (QW steps)
+};
+
+template <int W, int LW, bool TERN, int S>
+__global__ __launch_bounds__(64) void k_scan_hist_s(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] counters, then the ring
+    using SG = SlotGeom<S>;
+    constexpr int QW = SG::QW, G = SG::G, NG = SG::NG;
+    int chunk_id, qtile;
+    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
+    const int lane = threadIdx.x;
+    const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
+    const int q = qtile * QW + ql;
+    const int ncell = a.nb * QW;
+    for (int e = lane; e < ncell; e += 64) lds[e] = 0u;
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
     using R = Rec<W, LW, TERN>;
-    constexpr int U = Unroll<W, LW, TERN>::value;
+    using LB = AosBatch<W, LW, TERN>;
+    uint32_t* ring = lds + ((ncell + 3) & ~3);
+    const uint32_t* mine = ring + slot * LB::RS;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
-    float acc = 0.0f;
 
-    // (rank, ordinal) of a relevant item -> ordinal / rank.  v_rcp_f32 is good to 1 ulp: a term is off by
-    // <= 1.5e-7 relative, far inside the 1e-4 mAP tolerance (measured ~1e-8 on the goldens).
-    // `hit` is the 0/1 relevance that was also the high-word increment: ordinal*hit zeroes non-relevant terms
-    // without keeping a lane mask alive across the pipeline stage.
-    auto credit = [&](unsigned long long old, uint32_t hit) {
-        const uint32_t rank = (uint32_t)old;
-        uint32_t ord = (uint32_t)(old >> 32);
-        if (CAPPED) hit = ord <= cap ? hit : 0u;
-        const float of = (float)__umul24(ord, hit);            // ordinals < 2^24 (R < 16.7 M per shard checked in the plan)
-        acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
+    auto count = [&](const R (&g)[G]) {
+        int d[G];
+        uint32_t hit[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) atomicAdd(&lds[d[u] * QW + ql], (hit[u] << 16) + 1u);
     };
-    constexpr int UG = (GM == GM_LDS) ? 4 : U;                       // items per pipelined group
-    unsigned long long old[UG];
-    uint32_t hitp[UG];
-    auto eval_issue = [&](const R (&g)[UG], bool have_prev) {
-        int d[UG];
-        uint32_t hit[UG];
+    auto fetch = [&](R (&g)[G], int group) {
 #pragma unroll
-        for (int u = 0; u < UG; ++u) rec_eval01<W, LW, TERN, (GM == GM_LDS ? 1 : (GM == GM_SCALAR ? 2 : 0))>(qr, g[u], a.K, d[u], hit[u]);
-        if (have_prev) {
-#pragma unroll
-            for (int u = 0; u < UG; ++u) credit(old[u], hitp[u]);             // previous group's returns
-        }
-#pragma unroll
-        for (int u = 0; u < UG; ++u) {
-            hitp[u] = hit[u];
-            old[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)hit[u] << 32));
-        }
+        for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
     };
-    auto drain = [&]() {
+    LB cur, nxt;
+    cur.load(a, lo, hi, lane);
+    for (int64_t base = lo; base < hi; base += 64) {
+        cur.publish(ring, lane);
+        nxt.load(a, base + 64, hi, lane);
+        const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
+        if (cnt == 64) {
+            R ga[G], gb[G];
+            fetch(ga, 0);
 #pragma unroll
-        for (int u = 0; u < UG; ++u) credit(old[u], hitp[u]);
-    };
-    auto one = [&](const R& r) {
-        int d;
-        bool rel;
-        rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
-        const uint32_t hit = rel ? 1u : 0u;
-        credit(atomicAdd(&cnt[d * 64 + lane], 1ull | ((unsigned long long)hit << 32)), hit);
-    };
-
-    if constexpr (GM == GM_SCALAR) {
-        // Same one-wait-per-group pipeline as k_scan_hist (GM_SCALAR), one stage deeper: after the lgkmcnt(0) at the top
-        // of a half-iteration the wave issues the next group's s_loads and the atomics of the group evaluated in the
-        // PREVIOUS half, credits the group whose returns that wait has just made valid, and evaluates the current one.
-        // Atomics are issued in item order (A0 B0 A1 B1 ...), which is what the running counters need.
-        using SG = ScalarGroup<W, LW, TERN, U>;
-        SG ga, gb;
-        int dA[U], dB[U];
-        uint32_t hA[U], hB[U], cA[U], cB[U];
-        unsigned long long oA[U], oB[U];
-        const int64_t ngroups = (hi - lo) / U;
-        auto load = [&](SG& g, int64_t at) { g.issue(a, at); };
-        auto eval = [&](SG& g, int (&d)[U], uint32_t (&h)[U]) {
-            g.fence();
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int g = 0; g < NG; g += 2) {
+                if (g + 1 < NG) fetch(gb, g + 1);
+                count(ga);
+                if (g + 2 < NG) fetch(ga, g + 2);
+                if (g + 1 < NG) count(gb);
+            }
+        } else {
+            for (int t = 0; t * S < cnt; ++t) {
                 R r;
-                g.get(r, u);
-                rec_eval01<W, LW, TERN, 2>(qr, r, a.K, d[u], h[u]);
+                LB::get(r, mine, t * S * LB::RS);
+                int d;
+                uint32_t hit;
+                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                if (t * S + slot < cnt) atomicAdd(&lds[d * QW + ql], (hit << 16) + 1u);
             }
-        };
-        auto issue = [&](const int (&d)[U], const uint32_t (&h)[U], unsigned long long (&o)[U], uint32_t (&c)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                c[u] = h[u];
-                o[u] = atomicAdd(&cnt[d[u] * 64 + lane], 1ull | ((unsigned long long)h[u] << 32));
-            }
-        };
-        auto settle = [&](const unsigned long long (&o)[U], const uint32_t (&c)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) credit(o[u], c[u]);
-        };
-        int64_t g = 0;
-        bool eA = false, eB = false, iA = false, iB = false;   // e: evaluated, not yet issued; i: issued, not yet credited
-        if (ngroups > 0) load(ga, lo);
-        while (g < ngroups) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): ga landed, oA returned
-            if (g + 1 < ngroups) load(gb, lo + (g + 1) * U);
-            if (eB) { issue(dB, hB, oB, cB); iB = true; eB = false; }
-            if (iA) { settle(oA, cA); iA = false; }
-            eval(ga, dA, hA);
-            eA = true;
-            if (++g >= ngroups) break;
-            __builtin_amdgcn_s_waitcnt(0xc07f);                                  // gb landed, oB returned
-            if (g + 1 < ngroups) load(ga, lo + (g + 1) * U);
-            issue(dA, hA, oA, cA); iA = true; eA = false;
-            if (iB) { settle(oB, cB); iB = false; }
-            eval(gb, dB, hB);
-            eB = true;
-            ++g;
         }
-        // tail: at most one group evaluated-not-issued and one issued-not-credited (the older one)
-        if (eA) { if (iB) { settle(oB, cB); iB = false; } issue(dA, hA, oA, cA); iA = true; }
-        if (eB) { if (iA) { settle(oA, cA); iA = false; } issue(dB, hB, oB, cB); iB = true; }
-        if (iA) settle(oA, cA);
-        if (iB) settle(oB, cB);
-        for (int64_t i = lo + ngroups * U; i < hi; ++i) {
-            R r;
-            rec_load_uniform<W, LW, TERN>(r, a, i);
-            one(r);
-        }
-    } else if constexpr (GM == GM_LDS) {
-        // Batches of 64 records are staged through an LDS ring slot by the wave itself and read back with wave-uniform
-        // ds_read_b128s (broadcast); the next batch's global loads are in flight (vmcnt) during the whole current batch.
-        // LDS is in-order per wave, so every wait in the loop is a counted lgkmcnt.  (A one-group LDS read-ahead with a
-        // two-slot ring was measured and bought nothing: 0.69 vs 0.67 ms.)
-        using LB = LdsBatch<W, LW, TERN>;
-        uint32_t* ring = reinterpret_cast<uint32_t*>(cnt + a.nb * 64);   // [64][RS] after the counters
-        LB cur, nxt;
-        cur.load(a, lo, hi, lane);
-        bool prev = false;
-        for (int64_t base = lo; base < hi; base += 64) {
-            cur.publish(ring, lane);
-            nxt.load(a, base + 64, hi, lane);
-            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-            int u0 = 0;
-            if (cntb == 64) {
-                // full batch, fully unrolled with a one-group LDS read-ahead: the ds_reads of group g+1 are issued
-                // before group g is evaluated (counted lgkmcnt waits: LDS returns in order)
-                R ga[4], gb[4];
-                LB::get4(ga, ring, 0);
-#pragma unroll
-                for (int g = 0; g < 16; g += 2) {
-                    LB::get4(gb, ring, (g + 1) * 4);
-                    eval_issue(ga, prev);
-                    prev = true;
-                    if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
-                    eval_issue(gb, true);
-                }
-                u0 = 64;
-            }
-            for (; u0 + 4 <= cntb; u0 += 4) {
-                R g[4];
-                LB::get4(g, ring, u0);
-                eval_issue(g, prev);
-                prev = true;
-            }
-            if (u0 < cntb) {
-                if (prev) drain();
-                prev = false;
-                for (; u0 < cntb; ++u0) {
-                    R r;
-                    LB::get(r, ring, u0);
-                    one(r);
-                }
-            }
-            cur = nxt;
-        }
-        if (prev) drain();
+        cur = nxt;
     }
-    ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + qtile * QW;
+    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> SG::LOG_QW) * a.qpad + (e & (QW - 1))] = lds[e];
 }
 
-// ---------------------------------------------------------------------------------------------------
-// pass 2, packed variant: when (rank bits) + (ordinal bits) <= 32 -- known on the device after pass 1 -- the two
-// running numbers share ONE 32-bit counter {lo rank_bits: rank, hi: ordinal}.  Half the LDS (two waves per SIMD at
-// K = 64) and a 32-bit returning add per pair.  Gated against k_scan_ap by the same device word, no host sync.
-// ---------------------------------------------------------------------------------------------------
-template <int W, int LW, bool TERN, bool CAPPED>
-__global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+// P32 = packed 32-bit counters {lo rank_bits: rank, hi: ordinal} when both fit one word (known on the device after
+// pass 1: the launch is gated by *nrel_max, no host sync), else 64-bit {lo: rank, hi: ordinal}.  Counters are 1-based
+// and start at the global base of (bucket, chunk).  MASKED: see the header (lane-order fallback).
+template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED>
+__global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ nrel_max, int rank_bits) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cnt32[];            // [nb][64]
+    using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using SG = SlotGeom<S>;
+    constexpr int QW = SG::QW, G = SG::G, NG = SG::NG;
     int chunk_id, qtile;
     if (!map_block(a, chunk_id, qtile)) return;
-    if (!((uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits)))) return;       // k_scan_ap takes this call
-    const int lane = threadIdx.x;
-    const int q = qtile * 64 + lane;
     {
-        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q;
-        const uint2* __restrict__ pd = dpre + q;
-        int d = 0;
-        for (; d + 8 <= a.nb; d += 8) {
+        const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
+        if (P32 != fits32) return;                                   // the other variant takes this call
+    }
+    CT* cnt = reinterpret_cast<CT*>(lds);                            // [nb][QW]
+    const int lane = threadIdx.x;
+    const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
+    const int q = qtile * QW + ql;
+    const int ncell = a.nb * QW;
+    auto pack = [&](uint2 x, uint2 y) -> CT {
+        if (P32) return (CT)((x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits));
+        return (CT)((unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32));
+    };
+    {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + qtile * QW;
+        const uint2* __restrict__ pd = dpre + qtile * QW;
+        int e = lane;
+        for (; e + 7 * 64 < ncell; e += 8 * 64) {
             uint2 x[8], y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                x[j] = pb[(int64_t)(d + j) * a.qpad];
-                y[j] = pd[(int64_t)(d + j) * a.qpad];
+                const int ee = e + j * 64;
+                const int64_t at = (int64_t)(ee >> SG::LOG_QW) * a.qpad + (ee & (QW - 1));
+                x[j] = pb[at];
+                y[j] = pd[at];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cnt32[(d + j) * 64 + lane] = (x[j].x + y[j].x + 1u) | ((x[j].y + y[j].y + 1u) << rank_bits);
+            for (int j = 0; j < 8; ++j) cnt[e + j * 64] = pack(x[j], y[j]);
         }
-        for (; d < a.nb; ++d) {
-            const uint2 x = pb[(int64_t)d * a.qpad], y = pd[(int64_t)d * a.qpad];
-            cnt32[d * 64 + lane] = (x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits);
+        for (; e < ncell; e += 64) {
+            const int64_t at = (int64_t)(e >> SG::LOG_QW) * a.qpad + (e & (QW - 1));
+            cnt[e] = pack(pb[at], pd[at]);
         }
     }
     const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
-    const uint32_t rmask = (1u << rank_bits) - 1u;
-    const uint32_t one_rel = 1u << rank_bits;
+    const uint32_t rmask = P32 ? (1u << rank_bits) - 1u : 0xffffffffu;
 
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
     using R = Rec<W, LW, TERN>;
+    using LB = AosBatch<W, LW, TERN>;
+    uint32_t* ring = lds + ((ncell * (int)(sizeof(CT) / 4) + 3) & ~3);
+    const uint32_t* mine = ring + slot * LB::RS;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     float acc = 0.0f;
-    auto credit = [&](uint32_t old, uint32_t hit) {
-        const uint32_t rank = old & rmask;
-        uint32_t ord = old >> rank_bits;
+
+    auto credit = [&](CT old, uint32_t hit) {
+        uint32_t rank, ord;
+        if (P32) { rank = (uint32_t)old & rmask; ord = (uint32_t)old >> rank_bits; }
+        else { rank = (uint32_t)old; ord = (uint32_t)((unsigned long long)old >> 32); }
         if (CAPPED) hit = ord <= cap ? hit : 0u;
         const float of = (float)__umul24(ord, hit);
         acc = fmaf(of, __builtin_amdgcn_rcpf((float)rank), acc);
     };
-    uint32_t old[4], hitp[4];
-    auto eval_issue = [&](const R (&g)[4], bool have_prev) {
-        int d[4];
-        uint32_t hit[4];
+    auto inc = [&](uint32_t hit) -> CT {
+        if (P32) return (CT)((hit << rank_bits) + 1u);
+        return (CT)(1ull | ((unsigned long long)hit << 32));
+    };
+    CT old[G];
+    uint32_t hitp[G];
+    auto eval_issue = [&](const R (&g)[G], bool have_prev) {
+        int d[G];
+        uint32_t hit[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rec_eval01<W, LW, TERN, 1>(qr, g[u], a.K, d[u], hit[u]);
+        for (int u = 0; u < G; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
         if (have_prev) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
+            for (int u = 0; u < G; ++u) credit(old[u], hitp[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
             hitp[u] = hit[u];
-            old[u] = atomicAdd(&cnt32[d[u] * 64 + lane], (hit[u] << rank_bits) + 1u);      // v_lshl_add_u32
+            CT* cell = &cnt[d[u] * QW + ql];
+            const CT v = inc(hit[u]);
+            if (!MASKED) {
+                old[u] = atomicAdd(cell, v);                          // same-address lanes resolve in lane = item order
+            } else {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (slot == s) old[u] = atomicAdd(cell, v);      // slot order = index order
+                }
+            }
         }
     };
-    // gallery through the LDS ring (see k_scan_ap, GM_LDS)
-    using LB = LdsBatch<W, LW, TERN>;
-    uint32_t* ring = cnt32 + a.nb * 64;                              // [64][RS] after the counters
+    auto drain = [&]() {
+#pragma unroll
+        for (int u = 0; u < G; ++u) credit(old[u], hitp[u]);
+    };
+    auto fetch = [&](R (&g)[G], int group) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
+    };
+
     LB cur, nxt;
     cur.load(a, lo, hi, lane);
     bool prev = false;
@@ -761,49 +430,70 @@ __global__ __launch_bounds__(64) void k_scan_ap32(ScanArgs a, const uint2* __res
         cur.publish(ring, lane);
         nxt.load(a, base + 64, hi, lane);
         const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-        int u0 = 0;
-        if (cntb == 64) {                                            // full batch: unrolled, one-group LDS read-ahead
-            R ga[4], gb[4];
-            LB::get4(ga, ring, 0);
+        if (cntb == 64) {
+            R ga[G], gb[G];
+            fetch(ga, 0);
 #pragma unroll
-            for (int g = 0; g < 16; g += 2) {
-                LB::get4(gb, ring, (g + 1) * 4);
+            for (int g = 0; g < NG; g += 2) {
+                if (g + 1 < NG) fetch(gb, g + 1);
                 eval_issue(ga, prev);
                 prev = true;
-                if (g + 2 < 16) LB::get4(ga, ring, (g + 2) * 4);
-                eval_issue(gb, true);
+                if (g + 2 < NG) fetch(ga, g + 2);
+                if (g + 1 < NG) eval_issue(gb, true);
             }
-            u0 = 64;
-        }
-        for (; u0 + 4 <= cntb; u0 += 4) {
-            R g[4];
-            LB::get4(g, ring, u0);
-            eval_issue(g, prev);
-            prev = true;
-        }
-        if (u0 < cntb) {
-            if (prev) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
-            }
+        } else {
+            if (prev) drain();
             prev = false;
-            for (; u0 < cntb; ++u0) {
+            for (int t = 0; t * S < cntb; ++t) {
                 R r;
-                LB::get(r, ring, u0);
+                LB::get(r, mine, t * S * LB::RS);
                 int d;
-                bool rel;
-                rec_eval<W, LW, TERN>(qr, r, a.K, d, rel);
-                const uint32_t hit = rel ? 1u : 0u;
-                credit(atomicAdd(&cnt32[d * 64 + lane], rel ? one_rel + 1u : 1u), hit);
+                uint32_t hit;
+                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                const bool valid = t * S + slot < cntb;
+                CT o = 0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (slot == s && valid) o = atomicAdd(&cnt[d * QW + ql], inc(hit));
+                }
+                if (valid) credit(o, hit);
             }
         }
         cur = nxt;
     }
-    if (prev) {
+    if (prev) drain();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) credit(old[u], hitp[u]);
+    for (int o = QW; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+}
+
+// Does the LDS hand out same-address returning adds of one instruction in ascending lane order?  (see the header)
+__global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ ok_out) {
+    __shared__ unsigned long long c64[256];
+    __shared__ uint32_t c32[256];
+    const int lane = threadIdx.x;
+    bool ok = true;
+    for (int round = 0; round < 24; ++round) {
+        const int S = 2 << (round % 3 == 2 ? (round % 6 == 5 ? 4 : 2) : round % 3);   // 2, 4, 8, 2, 4, 32, ...
+        const int QW = 64 / S;
+        const int ql = lane & (QW - 1);
+        const int row = (lane * 7 + round * 5 + (lane >> 3)) % 3;                       // a few "buckets" per query
+        const int cell = row * QW + ql;
+        for (int e = lane; e < 256; e += 64) { c64[e] = 1000ull + round; c32[e] = 77u + round; }
+        __syncthreads();
+        int before = 0;
+        for (int l = 0; l < lane; ++l) {
+            const int lrow = (l * 7 + round * 5 + (l >> 3)) % 3;
+            before += (lrow * QW + (l & (QW - 1))) == cell;
+        }
+        const unsigned long long r64 = atomicAdd(&c64[cell], 1ull | (1ull << 32));
+        const uint32_t r32 = atomicAdd(&c32[cell], 0x10001u);
+        ok = ok && r64 == (1000ull + round) + ((unsigned long long)before | ((unsigned long long)before << 32));
+        ok = ok && r32 == 77u + round + (uint32_t)before * 0x10001u;
+        __syncthreads();
     }
-    ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+    const bool all_ok = __all(ok);
+    if (lane == 0) *ok_out = all_ok ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
@@ -832,6 +522,19 @@ __global__ __launch_bounds__(256) void k_map_finalize(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// lanes per query (S): smallest power of two that brings the counters of a wave under the budget.  Budgets from a sweep
+// on MI355X (K = 16..256, dense and sparse relevance): 9 KB for 64-bit counters, 5 KB for 32-bit ones (3-4 waves/SIMD).
+constexpr int kSlotBudget64 = 9 * 1024;
+constexpr int kSlotBudget32 = 5 * 1024;
+constexpr int slots_for(int W, bool tern, int counter_bytes) {
+    const int nbmax = (tern ? 64 : 32) * W + 1;
+    const int budget = counter_bytes == 8 ? kSlotBudget64 : kSlotBudget32;
+    int S = 2;
+    while (S < 8 && nbmax * (64 / S) * counter_bytes > budget) S *= 2;
+    return S;
+}
+inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
+
 struct WsLayout {
     size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, total;
 };
@@ -860,12 +563,14 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (Q <= 0 || R <= 0 || K <= 0) return xmh::fail(XMH_EINVAL, "scan plan: bad shape Q=%lld R=%lld K=%d", (long long)Q, (long long)R, K);
     if (R >= (1ll << 24) || Q >= (1ll << 24)) return xmh::fail(XMH_ENOTSUP, "scan plan: shard too large (R=%lld, Q=%lld)", (long long)R, (long long)Q);
     const int64_t nb = ternary ? 2 * (int64_t)K + 1 : (int64_t)K + 1;
-    const int64_t lds_ap = nb * 64 * 8;
-    if (lds_ap > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave (max 163840); K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
+    const int Wd = (K + 31) / 32;
+    if (Wd > 8) return xmh::fail(XMH_ENOTSUP, "scan plan: K=%d (at most 256 code bits)", K);
+    const int Wc = Wd <= 1 ? 1 : (Wd <= 2 ? 2 : (Wd <= 4 ? 4 : 8));
+    const int64_t lds_ap = nb * (64 / slots_for(Wc, ternary != 0, 8)) * 8;
+    if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const int64_t nqt = xmh::ceil_div(Q, 64);
-    int64_t wpc = (160 * 1024) / (lds_ap / 2);    // waves per CU of the packed pass-2 variant (the 64-bit one fits half)
-    if (wpc > 8) wpc = 8;
-    // pass 2 runs `rounds` resident sets of waves; pass 1 (half the LDS) then gets 2 waves per SIMD
+    const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
+    // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
     const int64_t rounds = rounds_env > 0 ? rounds_env : 1;
@@ -886,11 +591,27 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     return XMH_OK;
 }
 
-int gallery_mode(const char* env, int dflt) {
-    const char* v = getenv(env);
-    if (!v) return dflt;
-    const int m = atoi(v);
-    return m == 0 ? GM_SCALAR : GM_LDS;
+// 1 if same-address returning LDS adds of one instruction come back in ascending lane order on this device (probed once
+// per process with a 1-wave kernel and one blocking copy), 0 otherwise or when XMH_SCAN_MASKED is set
+int lane_order_ok(hipStream_t st) {
+    static int cached[64];
+    static bool have[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (have[dev]) return cached[dev];
+    int ok = 0;
+    if (getenv("XMH_SCAN_MASKED") == nullptr) {
+        uint32_t* flag = nullptr;
+        if (hipMalloc(&flag, 4) == hipSuccess) {
+            uint32_t h = 0;
+            hipLaunchKernelGGL(k_probe_lane_order, dim3(1), dim3(64), 0, st, flag);
+            if (hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) ok = h == 1u;
+            (void)hipFree(flag);
+        }
+    }
+    cached[dev] = ok;
+    have[dev] = true;
+    return ok;
 }
 
 template <typename F>
@@ -961,27 +682,23 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     uint2* tot = reinterpret_cast<uint2*>(base + L.tot);
     hipStream_t st = xmh::as_stream(stream);
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    const int gm = gallery_mode("XMH_SCAN_GM_HIST", GM_LDS);
-    const size_t ring = (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4;     // GM_LDS staging ring
-    const size_t lds = (size_t)p.nbuckets * 64 * 4 + (gm == GM_LDS ? ring : 0);
-    auto launch = [&](auto tern_c, auto gm_c) {
+    auto launch = [&](auto tern_c) {
         constexpr bool T = decltype(tern_c)::value;
-        constexpr int G = decltype(gm_c)::value;
         return dispatch_shape(W, LW, [&](auto w, auto l) {
-            auto kern = k_scan_hist<decltype(w)::value, decltype(l)::value, T, G>;
+            constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
+            constexpr int S = slots_for(WW, T, 4);
+            auto kern = k_scan_hist_s<WW, LL, T, S>;
+            const size_t lds = (((size_t)p.nbuckets * (64 / S) + 3) & ~(size_t)3) * 4 + aos_ring_bytes(WW, LL, T);
             const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
             if (r2) return r2;
+            ScanArgs as = a;
+            as.nqt = a.nqt * S;                                   // tiles of 64/S queries
             xmh::ProfScope prof("scan_hist", st);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, chunk_hist);
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S), dim3(64), lds, st, as, chunk_hist);
             return (int)XMH_OK;
         });
     };
-    using T1 = std::true_type;
-    using T0 = std::false_type;
-    using GS = std::integral_constant<int, GM_SCALAR>;
-    using GD = std::integral_constant<int, GM_LDS>;
-    if (tern) rc = gm == GM_SCALAR ? launch(T1{}, GS{}) : launch(T1{}, GD{});
-    else rc = gm == GM_SCALAR ? launch(T0{}, GS{}) : launch(T0{}, GD{});
+    rc = tern ? launch(std::true_type{}) : launch(std::false_type{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
@@ -1030,55 +747,43 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
                        base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
     XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
-    const int gm = gallery_mode("XMH_SCAN_GM_AP", GM_LDS);
-    const size_t ring = (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4;     // GM_LDS staging ring
-    const size_t lds = (size_t)p.nbuckets * 64 * 8 + (gm == GM_LDS ? ring : 0);
-    auto launch = [&](auto tern_c, auto cap_c, auto gm_c) {
+    const bool capped = k > 0;
+    const bool masked = !lane_order_ok(st);
+    // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run
+    auto launch = [&](auto tern_c, auto cap_c, auto p32_c, auto masked_c) {
         constexpr bool T = decltype(tern_c)::value;
         constexpr bool CP = decltype(cap_c)::value;
-        constexpr int G = decltype(gm_c)::value;
+        constexpr bool P32 = decltype(p32_c)::value;
+        constexpr bool MK = decltype(masked_c)::value;
         return dispatch_shape(W, LW, [&](auto w, auto l) {
-            auto kern = k_scan_ap<decltype(w)::value, decltype(l)::value, T, CP, G>;
+            constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
+            constexpr int S = slots_for(WW, T, P32 ? 4 : 8);
+            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK>;
+            const size_t cells = (size_t)p.nbuckets * (64 / S);
+            const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : cells * 8) + aos_ring_bytes(WW, LL, T);
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
-            xmh::ProfScope prof("scan_ap", st);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+            ScanArgs as = a;
+            as.nqt = a.nqt * S;
+            xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
                                (const uint32_t*)nrel_max, rank_bits);
             return (int)XMH_OK;
         });
     };
     using T1 = std::true_type;
     using T0 = std::false_type;
-    using GS = std::integral_constant<int, GM_SCALAR>;
-    const bool capped = k > 0;
+    auto launch_width = [&](auto p32_c) {
+        auto by_mask = [&](auto tern_c, auto cap_c) { return masked ? launch(tern_c, cap_c, p32_c, T1{}) : launch(tern_c, cap_c, p32_c, T0{}); };
+        if (tern) return capped ? by_mask(T1{}, T1{}) : by_mask(T1{}, T0{});
+        return capped ? by_mask(T0{}, T1{}) : by_mask(T0{}, T0{});
+    };
     if (rank_bits) {
-        const size_t lds32 = (size_t)p.nbuckets * 64 * 4 + ring;
-        auto launch32 = [&](auto tern_c, auto cap_c) {
-            constexpr bool T = decltype(tern_c)::value;
-            constexpr bool CP = decltype(cap_c)::value;
-            return dispatch_shape(W, LW, [&](auto w, auto l) {
-                auto kern = k_scan_ap32<decltype(w)::value, decltype(l)::value, T, CP>;
-                const int r2 = raise_lds(kern, lds32, "xmh_hamming_ap");
-                if (r2) return r2;
-                xmh::ProfScope prof("scan_ap32", st);
-                hipLaunchKernelGGL(kern, dim3(scan_grid(p)), dim3(64), lds32, st, a, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                                   (const uint32_t*)nrel_max, rank_bits);
-                return (int)XMH_OK;
-            });
-        };
-        if (tern) rc = capped ? launch32(T1{}, T1{}) : launch32(T1{}, T0{});
-        else rc = capped ? launch32(T0{}, T1{}) : launch32(T0{}, T0{});
+        rc = launch_width(T1{});
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap packed");
     }
-    if (gm == GM_SCALAR) {
-        if (tern) rc = capped ? launch(T1{}, T1{}, GS{}) : launch(T1{}, T0{}, GS{});
-        else rc = capped ? launch(T0{}, T1{}, GS{}) : launch(T0{}, T0{}, GS{});
-    } else {
-        using GD = std::integral_constant<int, GM_LDS>;
-        if (tern) rc = capped ? launch(T1{}, T1{}, GD{}) : launch(T1{}, T0{}, GD{});
-        else rc = capped ? launch(T0{}, T1{}, GD{}) : launch(T0{}, T0{}, GD{});
-    }
+    rc = launch_width(T0{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
     hipLaunchKernelGGL(k_ap_reduce, dim3((unsigned)xmh::ceil_div(Q, 256)), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);

@@ -378,7 +378,7 @@ def test_long_and_odd_code_lengths_distance(xr, cu, K):
     assert torch.equal(q.unpack().cpu(), qB)
     if K > 256:
         L = torch.ones(9, 3, dtype=torch.int64)
-        with pytest.raises(RuntimeError, match="LDS|unsupported"):
+        with pytest.raises(RuntimeError, match="LDS|unsupported|at most 256"):
             cu.calc_map_k(qB.cuda(), rB.cuda(), L.cuda(), torch.ones(301, 3, dtype=torch.int64).cuda())
 
 
