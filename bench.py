@@ -11,7 +11,7 @@ queries are replicated after the one-off all-gather of packed query codes.
     python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(k_scan_ap), a second roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share) and the
+(k_scan_ap_s), a second roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share) and the
 CPU baseline (oracle port of the reference's calc_map_k) timed on this host.
 """
 import argparse
@@ -67,7 +67,7 @@ def cpu_baseline(qB, qL, rB, rL, budget_s=20.0):
                       % (qsub, qB.shape[0], rB.shape[0], threads, dt), "map": float(m)}
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, kernel_suffix=""):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary under profiles/ (collected by
     tools/profile_round.sh with separate FETCH_SIZE / WRITE_SIZE passes and the gfx950 corrections of
     MI355X_MICROARCH.md); None if no profile has been committed for it."""
@@ -79,7 +79,7 @@ def pmc_traffic(kernel_prefix):
         except Exception:
             continue
         for name, e in d.get("pmc", {}).items():
-            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+            if name.startswith(kernel_prefix) and name.rstrip("> ").endswith(kernel_suffix) and "hbm_bytes_per_launch" in e:
                 best = {"bytes": e["hbm_bytes_per_launch"]["total"], "fetch_raw": e["hbm_bytes_per_launch"]["fetch_raw"],
                         "write_raw": e["hbm_bytes_per_launch"]["write_raw"], "fetch_correction": e["hbm_bytes_per_launch"]["fetch_correction"],
                         "source": os.path.relpath(f, ROOT)}
@@ -173,22 +173,29 @@ def main():
     # pass 2 exists in two device-gated variants (packed 32-bit / 64-bit counters); exactly one of them does the work
     t64, n64 = _lib.prof_read("scan_ap")
     t32, n32 = _lib.prof_read("scan_ap32")
-    ap_kernel = "k_scan_ap32" if t32 > t64 else "k_scan_ap"
+    packed = t32 > t64
+    ap_kernel = "k_scan_ap_s, packed 32-bit counters" if packed else "k_scan_ap_s, 64-bit counters"
+    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED>: the profile summary holds both gated launches
+    ap_traffic = pmc_traffic("k_scan_ap_s<", "true, false" if packed else "false, false")
     t_ap, n_ap = (t32, n32) if t32 > t64 else (t64, n64)
     t_ap *= 1e-3
     _lib.prof_enable(False)
 
     W, Lw = (K + 31) // 32, (C + 31) // 32
     alg_bytes = Rn * 4 * (W + Lw) + Q * 4 * (W + Lw) + Q * 12          # gallery once + queries + ap_sum/cap out
+    pl = scan.plan
+    # the two-pass scheme's own tables that pass 2 reads: below[chunk][bucket][q] (8 B) + dpre[bucket][q] (8 B), written once
+    # by the tiny table kernels -- this, not re-reading of inputs, is what the PMC traffic above the algorithmic bytes is
+    table_bytes = (pl.nchunk + 1) * pl.nbuckets * pl.qpad * 8 + pl.nchunk * pl.qpad * 4
     # VALU instructions per wave-item of pass 2 (ISA count): xor+bcnt per code word, and + and_or per further label word,
     # min, address, (64-bit variant: hi-word mov), credit = 2 cvt + rcp + mul24 + fmac
-    ops_pair_ap = 2 * W + Lw + 1 + 1 + (0 if ap_kernel == "k_scan_ap32" else 1) + 5
+    ops_pair_ap = 2 * W + Lw + 1 + 1 + (0 if packed else 1) + 5
     roofline = {
         "kernel": "%s (pass 2 of the fused mAP scan), HIP events around the launch, %d launches" % (ap_kernel, n_ap),
         "bound": "hbm", "achieved": alg_bytes / t_ap / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_traffic(ap_kernel + "<") or {}).get("bytes"),
-        "traffic_detail": pmc_traffic(ap_kernel + "<"),
-        "algorithmic_bytes": alg_bytes, "avg_launch_ms": t_ap * 1e3,
+        "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": (ap_traffic or {}).get("bytes"),
+        "traffic_detail": ap_traffic,
+        "algorithmic_bytes": alg_bytes, "workspace_table_bytes": table_bytes, "avg_launch_ms": t_ap * 1e3,
         "valu": {"lane_ops_per_pair": ops_pair_ap, "achieved": Q * Rn * ops_pair_ap / t_ap / 1e9,
                  "peak": VALU_PEAK_GLOPS, "unit": "G lane-ops/s", "frac": Q * Rn * ops_pair_ap / t_ap / 1e9 / VALU_PEAK_GLOPS},
         "note": "Q=5000 queries share every gallery byte: this launch is VALU-bound (SURVEY H5), HBM fraction is "
