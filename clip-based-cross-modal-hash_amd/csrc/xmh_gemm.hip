@@ -415,6 +415,144 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_h16(GemmArgsH g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// split path ("f32s"): fp32 activations x fp16-EXACT weights at fp16-MFMA rate with fp32-grade accuracy.
+// CLIP weights are fp16 values held in fp32 (convert_weights + .float(), reference models/CLIP/model.py:415-436), so W
+// is taken as fp16 without loss.  A is split while it is staged: a = hi + lo + r with hi = half(a), lo = half(a - hi),
+// |r| <= 2^-22 |a| (for |a| below 2^-3 the low part is subnormal: absolute error <= 2^-25).  Each fp16 x fp16 product is
+// exact in fp32, so acc += hi*w; acc += lo*w reproduces the fp32 product to 2^-22 relative -- the same order as fp32
+// summation-order noise -- at two fp16 MFMAs per k-slab instead of eight fp32 ones.  Domain |a| < 65504 (fp16 range):
+// true for LayerNorm outputs, attention outputs and QuickGELU activations (the reference's own GPU path computes these in
+// fp16); larger values saturate (finite, inaccurate).  The exact fp32-MFMA kernel stays selectable ("f32x").
+// ---------------------------------------------------------------------------------------------------
+struct GemmArgsS {
+    const float* A;
+    const _Float16* W;
+    const float* bias;
+    const float* residual;
+    float* C;
+    int64_t lda, ldw, ldr, ldc;
+    int M, N, K, act;
+};
+
+template <int MI>
+__global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
+    constexpr int TBM = 64 * MI;
+    __shared__ __attribute__((aligned(16))) _Float16 sAh[2][TBM * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sAl[2][TBM * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LDH];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
+    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 elements per thread
+    float4 fa0, fa1, fa2, fa3;                                 // named staging registers (see k_gemm_nt_h16)
+    uint4 rw0, rw1;
+    fa0 = fa1 = fa2 = fa3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    rw0 = rw1 = make_uint4(0u, 0u, 0u, 0u);
+    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
+    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
+#define XMH_SLOAD(k0)                                                                                               \
+    {                                                                                                               \
+        const float4* pa = reinterpret_cast<const float4*>(g.A + (int64_t)row_a(srow) * g.lda + (k0) + scol);        \
+        fa0 = pa[0]; fa1 = pa[1];                                                                                   \
+        if (MI == 2) {                                                                                              \
+            const float4* pb = reinterpret_cast<const float4*>(g.A + (int64_t)row_a(srow + 64) * g.lda + (k0) + scol); \
+            fa2 = pb[0]; fa3 = pb[1];                                                                               \
+        }                                                                                                           \
+        rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                     \
+        rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);                \
+    }
+#define XMH_SPLIT1(v, h, l)                                                                                         \
+    {                                                                                                               \
+        h = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);      /* saturate instead of inf - inf */      \
+        l = (_Float16)__builtin_amdgcn_fmed3f(v - (float)h, -65504.0f, 65504.0f);                                   \
+    }
+#define XMH_SPLIT8(VA, VB, hi, lo)                                                                                  \
+    {                                                                                                               \
+        XMH_SPLIT1(VA.x, hi[0], lo[0]) XMH_SPLIT1(VA.y, hi[1], lo[1]) XMH_SPLIT1(VA.z, hi[2], lo[2]) XMH_SPLIT1(VA.w, hi[3], lo[3]) \
+        XMH_SPLIT1(VB.x, hi[4], lo[4]) XMH_SPLIT1(VB.y, hi[5], lo[5]) XMH_SPLIT1(VB.z, hi[6], lo[6]) XMH_SPLIT1(VB.w, hi[7], lo[7]) \
+    }
+#define XMH_SWRITE(buf)                                                                                             \
+    {                                                                                                               \
+        f16x8 h8, l8;                                                                                               \
+        XMH_SPLIT8(fa0, fa1, h8, l8)                                                                                \
+        *reinterpret_cast<f16x8*>(&sAh[buf][srow * LDH + scol]) = h8;                                                \
+        *reinterpret_cast<f16x8*>(&sAl[buf][srow * LDH + scol]) = l8;                                                \
+        if (MI == 2) {                                                                                              \
+            XMH_SPLIT8(fa2, fa3, h8, l8)                                                                            \
+            *reinterpret_cast<f16x8*>(&sAh[buf][(srow + 64) * LDH + scol]) = h8;                                     \
+            *reinterpret_cast<f16x8*>(&sAl[buf][(srow + 64) * LDH + scol]) = l8;                                     \
+        }                                                                                                           \
+        *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                \
+        *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;                                         \
+    }
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int nk = g.K / BKH;
+    XMH_SLOAD(0)
+    XMH_SWRITE(0)
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) XMH_SLOAD((kt + 1) * BKH)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {                       // two k-slabs of 16 per BK
+            f16x8 ah[MI], al[MI], b[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(&sAh[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+                al[i] = *reinterpret_cast<const f16x8*>(&sAl[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            // low parts first: the small terms meet the accumulator before the large ones of this slab
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            XMH_SWRITE(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef XMH_SLOAD
+#undef XMH_SPLIT8
+#undef XMH_SPLIT1
+#undef XMH_SWRITE
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][e] + bv, g.act);
+                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cast_f32_h16(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n8) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
         const float4 a = reinterpret_cast<const float4*>(x)[2 * e], b = reinterpret_cast<const float4*>(x)[2 * e + 1];
@@ -511,5 +649,35 @@ extern "C" int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_ha
         hipLaunchKernelGGL(k_gemm_nt_h16<2>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
     }
     XMH_LAUNCH_CHECK("xmh_gemm_nt_h16");
+    return XMH_OK;
+}
+
+extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
+                                   const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                   int act, xmh_stream_t stream) {
+    if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: bad shape");
+    if (M == 0 || N == 0) return XMH_OK;
+    if (!A || !W_half || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: null pointer");
+    if (K % BKH || lda % 4 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(W_half) % 16))
+        return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)K, (long long)lda, (long long)ldw);
+    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: leading dimension too small");
+    if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: unknown activation %d", act);
+    if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: dimension >= 2^31");
+    GemmArgsS g;
+    g.A = A; g.W = static_cast<const _Float16*>(W_half);
+    g.bias = bias; g.residual = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
+    hipStream_t st = xmh::as_stream(stream);
+    int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
+    const bool small = nblk < 3ll * xmh::device_cu_count();
+    xmh::ProfScope prof("gemm_s16", st);
+    if (small) {
+        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
+        hipLaunchKernelGGL(k_gemm_nt_s16<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(k_gemm_nt_s16<2>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    }
+    XMH_LAUNCH_CHECK("xmh_gemm_nt_split16");
     return XMH_OK;
 }

@@ -24,12 +24,12 @@ def _normalize(x: torch.Tensor) -> torch.Tensor:
 
 def cosine(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = a.contiguous(), b.contiguous()
-    return ops.gemm_nt(_normalize(a), _normalize(b), precision=ops.PREC_F32)
+    return ops.gemm_nt(_normalize(a), _normalize(b), precision=ops.PREC_F32X)
 
 
 def pairwise_l2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = a.contiguous(), b.contiguous()
-    g = ops.gemm_nt(a, b, precision=ops.PREC_F32)
+    g = ops.gemm_nt(a, b, precision=ops.PREC_F32X)
     na, nb = _sqnorm(a), _sqnorm(b)          # keep both alive until the launch is enqueued (a freed temporary's block can be re-used)
     check(lib.xmh_pairwise_l2_from_gram(ptr(g), ptr(na), ptr(nb), a.shape[0], b.shape[0], current_stream()), "xmh_pairwise_l2_from_gram")
     return g
@@ -38,7 +38,7 @@ def pairwise_l2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def hamming_dist_float(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
     """0.5 * (K - B1 @ B2^T) for arbitrary float 'codes'."""
     B1, B2 = B1.contiguous(), B2.contiguous()
-    g = ops.gemm_nt(B1, B2, precision=ops.PREC_F32)
+    g = ops.gemm_nt(B1, B2, precision=ops.PREC_F32X)
     check(lib.xmh_affine_inplace(ptr(g), g.numel(), -0.5, 0.5 * B2.shape[1], current_stream()), "xmh_affine_inplace")
     return g
 

@@ -9,19 +9,24 @@ import torch
 from ._lib import check, current_stream, lib, ptr
 
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_TANH, ACT_RELU = range(5)
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_F32X = 0, 1, 2
 
 _precision = PREC_F32
+_NAMES = {"f32": PREC_F32, "f16": PREC_F16, "f32x": PREC_F32X}
 
 
 def set_precision(name: str) -> None:
-    """'f32' = exact fp32 MFMA (parity mode, default); 'f16' = fp16 operands / fp32 accumulate (fast mode)."""
+    """'f32'  parity mode (default): fp32-grade results.  GEMMs whose weights hold fp16-exact values (all CLIP weights)
+              run as two fp16 MFMAs over a hi/lo split of the fp32 activations (xmh_gemm_nt_split16, product error
+              2^-22); any other weight goes through the exact fp32 MFMA kernel.
+       'f32x' exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32).
+       'f16'  fast mode: fp16 operands / fp32 accumulate."""
     global _precision
-    _precision = {"f32": PREC_F32, "f16": PREC_F16}[name]
+    _precision = _NAMES[name]
 
 
 def get_precision() -> str:
-    return "f16" if _precision == PREC_F16 else "f32"
+    return {v: k for k, v in _NAMES.items()}[_precision]
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -39,7 +44,12 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t2 if t2.stride(-1) == 1 else t2.contiguous()
 
 
-_half_weights = {}          # (data_ptr, version, shape) -> fp16 copy of a weight tensor (fast mode converts weights once)
+_half_weights = {}          # (data_ptr, version, shape, stride) -> (fp16 copy, exact, the fp32 tensor itself)
+
+
+def clear_weight_cache() -> None:
+    """drop the cached fp16 copies of weights (they pin their fp32 originals, see _half_weight)."""
+    _half_weights.clear()
 
 
 def cast_f16(x: torch.Tensor) -> torch.Tensor:
@@ -50,15 +60,19 @@ def cast_f16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def _half_weight(W: torch.Tensor) -> torch.Tensor:
-    key = (W.data_ptr(), W._version, tuple(W.shape))
-    h = _half_weights.get(key)
-    if h is None:
+def _half_weight(W: torch.Tensor):
+    """(fp16 copy, exact) of a weight; `exact` = every value survives the fp32 -> fp16 -> fp32 round trip.
+    The entry keeps a reference to W: while it is cached its memory cannot be handed to another tensor, so the
+    address in the key cannot go stale; in-place updates bump `_version`."""
+    key = (W.data_ptr(), W._version, tuple(W.shape), tuple(W.stride()))
+    e = _half_weights.get(key)
+    if e is None:
         if len(_half_weights) > 512:
             _half_weights.clear()
         h = cast_f16(W.detach())
-        _half_weights[key] = h
-    return h
+        e = (h, bool(torch.equal(h.float(), W.detach())), W)       # one-time check per weight (host sync here only)
+        _half_weights[key] = e
+    return e[0], e[1]
 
 
 def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -76,15 +90,22 @@ def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
     res2 = None if residual is None else _rows(residual)
     b = None if bias is None else _f32c(bias)
     prec = _precision if precision is None else precision
+    ldr = 0 if res2 is None else res2.stride(0)
     if prec == PREC_F16 and K % 32 == 0 and W2.is_contiguous() and M * K % 8 == 0:
         # fast mode proper: fp16 operands in memory (weights converted once, activations by one cast pass), fp32 accumulate
         Ah = cast_f16(A2) if A2.is_contiguous() else cast_f16(A2.contiguous())
-        Wh = _half_weight(W2)
-        check(lib.xmh_gemm_nt_h16(ptr(Ah), K, ptr(Wh), K, ptr(b), ptr(res2), 0 if res2 is None else res2.stride(0), ptr(out2),
+        Wh, _ = _half_weight(W2)
+        check(lib.xmh_gemm_nt_h16(ptr(Ah), K, ptr(Wh), K, ptr(b), ptr(res2), ldr, ptr(out2),
                                   out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_h16")
         return out2.reshape(*lead, N)
-    check(lib.xmh_gemm_nt_f32(ptr(A2), A2.stride(0), ptr(W2), W2.stride(0), ptr(b), ptr(res2), 0 if res2 is None else res2.stride(0),
-                              ptr(out2), out2.stride(0), M, N, K, act, _precision if precision is None else precision,
+    if prec == PREC_F32 and K % 32 == 0 and W2.is_contiguous() and A2.stride(0) % 4 == 0 and A2.data_ptr() % 16 == 0:
+        Wh, exact = _half_weight(W2)
+        if exact:                                                # parity mode on fp16-exact weights: hi/lo split, fp16 MFMA rate
+            check(lib.xmh_gemm_nt_split16(ptr(A2), A2.stride(0), ptr(Wh), K, ptr(b), ptr(res2), ldr, ptr(out2),
+                                          out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_split16")
+            return out2.reshape(*lead, N)
+    check(lib.xmh_gemm_nt_f32(ptr(A2), A2.stride(0), ptr(W2), W2.stride(0), ptr(b), ptr(res2), ldr,
+                              ptr(out2), out2.stride(0), M, N, K, act, PREC_F16 if prec == PREC_F16 else PREC_F32,
                               current_stream()), "xmh_gemm_nt_f32")
     return out2.reshape(*lead, N)
 

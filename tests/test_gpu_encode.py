@@ -60,6 +60,45 @@ def test_gemm_f32_transpose_detecting(ops):
     assert torch.equal(got.cpu(), Wt.t())
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (200, 2304, 768), (77, 130, 3072), (1, 64, 32), (129, 512, 96)])
+def test_gemm_split16_parity_mode_on_fp16_exact_weights(ops, M, N, K):
+    """parity mode routes fp16-exact weights (every CLIP weight) through the hi/lo split kernel: fp32-grade error over a wide
+    dynamic range of activations, bias/activation/residual epilogues, strided A."""
+    from xmh import _lib
+    gen = g_(7)
+    A = torch.randn(M, K, generator=gen) * torch.exp(torch.randn(M, K, generator=gen) * 2.0)          # ~1e-4 .. 1e4, inside the fp16 range
+    W = (torch.randn(N, K, generator=g_(8)) * 0.05).half().float()
+    bias, res = torch.randn(N, generator=g_(3)), torch.randn(M, N, generator=g_(4))
+    want = A.double() @ W.double().t()
+    _lib.prof_enable(True)
+    got = ops.gemm_nt(A.cuda(), W.cuda())
+    torch.cuda.synchronize()
+    assert _lib.prof_read("gemm_s16")[1] >= 1                 # the split kernel ran
+    _lib.prof_enable(False)
+    assert rel(got, want) < 2e-6
+    exact = ops.gemm_nt(A.cuda(), W.cuda(), precision=ops.PREC_F32X)
+    assert rel(exact, want) < 5e-6 and rel(got, want) < 2 * rel(exact, want) + 1e-7      # not worse than the fp32 MFMA
+    A1 = torch.randn(M, K, generator=g_(9))                   # O(1) pre-activations: the epilogue check is well conditioned
+    got = ops.gemm_nt(A1.cuda(), W.cuda(), bias.cuda(), residual=res.cuda(), act=ops.ACT_TANH)
+    assert rel(got, torch.tanh(A1.double() @ W.double().t() + bias.double()) + res.double()) < 2e-6
+    Abig = torch.randn(M, K + 8, generator=g_(5)).cuda()
+    assert rel(ops.gemm_nt(Abig[:, :K], W.cuda()), Abig[:, :K].cpu().double() @ W.double().t()) < 2e-6
+    huge = A.clone()
+    huge[0, 0] = 3.0e5                                         # outside the domain: saturates, never inf - inf
+    assert torch.isfinite(ops.gemm_nt(huge.cuda(), W.cuda())).all()
+
+
+def test_gemm_parity_mode_keeps_inexact_weights_on_the_fp32_mfma(ops):
+    A, W = torch.randn(300, 768, generator=g_(1)).cuda(), (torch.randn(256, 768, generator=g_(2)) * 0.1).cuda()     # not fp16-exact
+    assert torch.equal(ops.gemm_nt(A, W), ops.gemm_nt(A, W, precision=ops.PREC_F32X))
+    Wh = W.half().float()
+    Wh2 = Wh.clone()
+    a = ops.gemm_nt(A, Wh)
+    Wh2 += 1e-3                                                # in-place update: the cached fp16 copy must not be reused
+    b = ops.gemm_nt(A, Wh2)
+    assert rel(b, A.cpu().double() @ Wh2.cpu().double().t()) < 5e-6 and not torch.equal(a, b)
+
+
 def test_gemm_f16_fast_mode_error_level(ops):
     A, W = torch.randn(700, 768, generator=g_(1)), (torch.randn(512, 768, generator=g_(2)) * 0.05).half().float()
     want = A.double() @ W.double().t()
