@@ -496,6 +496,43 @@ __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ 
     if (lane == 0) *ok_out = all_ok ? 1u : 0u;
 }
 
+// sharded evaluation: the all-gathered per-shard bucket histograms hist_g[world][2][Q][nb] (plane 0 = all
+// items, plane 1 = relevant) -> the rank offsets pass 2 starts from on shard `rank`:
+//   base[q][d] = (# items in buckets < d on ANY shard) + (# items in bucket d on shards < rank);  nrel[q] = all relevant.
+// One wave per query, lanes over buckets (coalesced), wave prefix scan per 64-bucket segment.
+__global__ __launch_bounds__(64) void k_shard_offsets(const uint32_t* __restrict__ hist_g, int world, int rank, int Q, int nb,
+                                                      uint32_t* __restrict__ base_all, uint32_t* __restrict__ base_rel,
+                                                      uint32_t* __restrict__ nrel_total) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int64_t plane = (int64_t)Q * nb;
+    uint32_t carry_a = 0, carry_r = 0;
+    for (int d0 = 0; d0 < nb; d0 += 64) {
+        const int d = d0 + lane;
+        uint32_t ta = 0, tr = 0, la = 0, lr = 0;
+        if (d < nb) {
+            for (int w = 0; w < world; ++w) {
+                const uint32_t* h = hist_g + (int64_t)w * 2 * plane + (int64_t)q * nb + d;
+                const uint32_t a = h[0], r = h[plane];
+                ta += a; tr += r;
+                if (w < rank) { la += a; lr += r; }
+            }
+        }
+        uint32_t sa = ta, sr = tr;                              // inclusive scan over the segment
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ua = __shfl_up(sa, o, 64), ur = __shfl_up(sr, o, 64);
+            if (lane >= o) { sa += ua; sr += ur; }
+        }
+        if (d < nb) {
+            base_all[(int64_t)q * nb + d] = carry_a + sa - ta + la;
+            base_rel[(int64_t)q * nb + d] = carry_r + sr - tr + lr;
+        }
+        carry_a += __shfl(sa, 63, 64);
+        carry_r += __shfl(sr, 63, 64);
+    }
+    if (lane == 0) nrel_total[q] = carry_r;
+}
+
 __global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
                                                    double* __restrict__ ap_sum) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -795,5 +832,16 @@ extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_
     if (!ap_sum || !cap || !map_out || Q <= 0) return xmh::fail(XMH_EINVAL, "xmh_map_finalize: bad arguments");
     hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, xmh::as_stream(stream), ap_sum, cap, Q, map_out);
     XMH_LAUNCH_CHECK("xmh_map_finalize");
+    return XMH_OK;
+}
+
+extern "C" int xmh_shard_offsets(const uint32_t* hist_gathered, int world, int rank, int64_t Q, int nbuckets, uint32_t* base_all,
+                                 uint32_t* base_rel, uint32_t* nrel_total, xmh_stream_t stream) {
+    if (!hist_gathered || !base_all || !base_rel || !nrel_total) return xmh::fail(XMH_EINVAL, "xmh_shard_offsets: null pointer");
+    if (world <= 0 || rank < 0 || rank >= world || Q <= 0 || nbuckets <= 0 || Q >= (1ll << 24))
+        return xmh::fail(XMH_EINVAL, "xmh_shard_offsets: bad arguments (world=%d rank=%d Q=%lld nb=%d)", world, rank, (long long)Q, nbuckets);
+    hipLaunchKernelGGL(k_shard_offsets, dim3((unsigned)Q), dim3(64), 0, xmh::as_stream(stream), hist_gathered, world, rank, (int)Q, nbuckets,
+                       base_all, base_rel, nrel_total);
+    XMH_LAUNCH_CHECK("xmh_shard_offsets");
     return XMH_OK;
 }

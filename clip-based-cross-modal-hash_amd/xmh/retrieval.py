@@ -193,8 +193,8 @@ class RankingScan:
         """pass 1.  Returns (hist_all, hist_rel) int32 [Q, nbuckets] shard totals (or (None, None))."""
         ha = hr = None
         if want_totals:
-            ha = torch.empty(self.q.n, self.plan.nbuckets, dtype=torch.int32, device=self.ws.device)
-            hr = torch.empty_like(ha)
+            pair = torch.empty(2, self.q.n, self.plan.nbuckets, dtype=torch.int32, device=self.ws.device)
+            ha, hr = pair[0], pair[1]                  # one buffer: the sharded driver all-gathers both planes at once
         check(lib.xmh_hamming_hist(*self._common(), ptr(ha), ptr(hr), current_stream()), "xmh_hamming_hist")
         return ha, hr
 
@@ -215,6 +215,20 @@ def map_finalize(ap_sum: torch.Tensor, cap: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.float64, device=ap_sum.device)
     check(lib.xmh_map_finalize(ptr(ap_sum), ptr(cap), ap_sum.shape[0], ptr(out), current_stream()), "xmh_map_finalize")
     return out
+
+
+def shard_offsets(hist_gathered: torch.Tensor, rank: int):
+    """[world, 2, Q, nb] int32 all-gathered shard histograms -> (base_all, base_rel [Q, nb], nrel_total [Q]) for ``rank``."""
+    world, two, Q, nb = hist_gathered.shape
+    if two != 2 or hist_gathered.dtype != torch.int32 or not hist_gathered.is_contiguous():
+        raise ValueError("shard_offsets: expected a contiguous int32 [world, 2, Q, nb] tensor")
+    dev = hist_gathered.device
+    base_a = torch.empty(Q, nb, dtype=torch.int32, device=dev)
+    base_r = torch.empty_like(base_a)
+    nrel = torch.empty(Q, dtype=torch.int32, device=dev)
+    check(lib.xmh_shard_offsets(ptr(hist_gathered), world, int(rank), Q, nb, ptr(base_a), ptr(base_r), ptr(nrel), current_stream()),
+          "xmh_shard_offsets")
+    return base_a, base_r, nrel
 
 
 def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch.Tensor, Cn: int,

@@ -129,6 +129,12 @@ int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
 /* mean over queries of ap_sum/cap -> map_out[0] (f64, device).  A query with cap == 0 makes the result
  * NaN, as torch.mean of an empty tensor does in the reference (common/calc_utils.py:87-89). */
 int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream);
+/* Sharded evaluation (replaces the dense all_reduce gather of runners/base.py:259-264 on the retrieval side):
+ * hist_gathered = the all-gathered shard totals of xmh_hamming_hist, [world][2][Q][nbuckets] u32 (plane 0 all items,
+ * plane 1 relevant).  Writes the three inputs xmh_hamming_ap takes for shard `rank`: base_all/base_rel [Q][nbuckets] =
+ * items in lower buckets on any shard + items of the same bucket on lower ranks; nrel_total [Q]. */
+int xmh_shard_offsets(const uint32_t* hist_gathered, int world, int rank, int64_t Q, int nbuckets, uint32_t* base_all,
+                      uint32_t* base_rel, uint32_t* nrel_total, xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-query top-k (north_star: "fused bit-packed XOR-popcount + per-query top-k kernel").

@@ -284,9 +284,12 @@ def test_sharded_offsets_reproduce_unsharded(xr):
     lower_r = torch.cumsum(tot_r, 1) - tot_r
     nrel = tot_r.sum(1).to(torch.int32)
     ap = torch.zeros(Q, dtype=torch.float64, device="cuda")
+    gathered = torch.stack([torch.stack([a, b]) for a, b in zip(hall, hrel)]).to(torch.int32).contiguous()    # [S, 2, Q, nb]
     for s in range(S):
         base_a = (lower_a + sum(hall[:s], torch.zeros_like(tot_a))).to(torch.int32).contiguous()
         base_r = (lower_r + sum(hrel[:s], torch.zeros_like(tot_r))).to(torch.int32).contiguous()
+        ka, kr, kn = xr.shard_offsets(gathered, s)               # the one-kernel form the sharded driver uses
+        assert torch.equal(ka, base_a) and torch.equal(kr, base_r) and torch.equal(kn, nrel)
         part, cap = scans[s].ap_sums(50, base_a, base_r, nrel)
         assert torch.equal(cap, cap_ref)
         ap += part
