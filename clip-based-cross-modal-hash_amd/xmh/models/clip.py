@@ -24,6 +24,20 @@ import torch.nn as nn
 from .. import ops
 
 
+
+def _transposed(module, name: str) -> torch.Tensor:
+    """`x @ proj` runs as gemm_nt(x, proj^T): keep ONE contiguous transpose per parameter version (a fresh copy per forward
+    would defeat the fp16 weight cache of ops.gemm_nt and cost a host sync each time)."""
+    p = getattr(module, name)
+    key = (p.data_ptr(), p._version)
+    cache = module.__dict__.setdefault("_xmh_transposed", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, p.detach().t().contiguous())
+        cache[name] = hit
+    return hit[1]
+
+
 class _Block(nn.Module):
     def __init__(self, width: int, heads: int):
         super().__init__()
@@ -78,7 +92,7 @@ class VisionTransformer(nn.Module):
         patches = ops.gemm_nt(cols, self.conv1.weight.reshape(width, -1))
         x = ops.vit_assemble(patches, self.class_embedding, self.positional_embedding, self.ln_pre.weight, self.ln_pre.bias, B, n_patches)
         x = self.transformer.run(x)
-        proj_t = self.proj.t().contiguous()
+        proj_t = _transposed(self, "proj")
         L = n_patches + 1
         if not self.return_patches:
             cls = ops.gather_rows(x, group=L, offset=0)
@@ -116,7 +130,7 @@ class CLIP(nn.Module):
         B, L, _ = x.shape
         kpm = None if key_padding_mask is None else key_padding_mask.to(x.device)
         x = self.transformer.run(x, causal=True, key_padding_mask=kpm)
-        proj_t = self.text_projection.t().contiguous()
+        proj_t = _transposed(self, "text_projection")
         if not self.return_patches:
             e = ops.gather_rows(x, group=L, idx=eos)
             return ops.gemm_nt(ops.layernorm(e, self.ln_final.weight, self.ln_final.bias), proj_t)
