@@ -16,6 +16,8 @@
 // Every one of these is HBM-bound elementwise / row-reduction work; the GEMMs around them dominate the time.
 #include "xmh_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -134,6 +136,125 @@ __global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv
 #pragma unroll
     for (int c = 0; c < DH / 4; ++c)
         *reinterpret_cast<float4*>(orow + c * 4) = make_float4(o[4 * c + 0], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+}
+
+// ---- the same attention on the fp32 MFMA for L <= 64 (ViT-B/32: L = 50, text: L = 32) ----------------------------
+// One wave per (batch, head).  S = (q/sqrt(dh)) K^T and O = P V both run on v_mfma_f32_32x32x2_f32 (exact fp32 products,
+// like the VALU kernel above).  Operand layout of that instruction: A and B give one float per lane, lane&31 = row of A /
+// column of B, lane>>5 = which of the two k; the 32x32 result has column lane&31 and rows (e&3) + 8*(e>>2) + 4*(lane>>5).
+// The sum over k does not care which k sits in which step, so lane (r, kk) simply owns the CONTIGUOUS half
+// k in [32*kk, 32*kk+32) of its row: 8 float4 loads straight from global, no LDS staging of Q, K or V.
+// The score tile goes through LDS once (C layout -> row layout); there lane (r, part) finishes the softmax of row r over
+// columns [32*part, 32*part+32) with one cross-half exchange -- and the probabilities it then holds are exactly the A
+// operand of the PV product (row r, k-half part), so they never go back to memory.
+typedef float attn_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
+                                                         const uint8_t* __restrict__ kpm, float* __restrict__ out) {
+    constexpr int DH = 64, SP = 68;                                  // score row stride: 16-byte aligned, rows on distinct 16-B slots
+    __shared__ __attribute__((aligned(16))) float sS[32 * SP];
+    const int nblk = (L + 31) / 32;                                  // 32-row blocks of queries / keys (1 or 2)
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * DH;
+    const int lane = threadIdx.x, r = lane & 31, kk = lane >> 5;
+    const float* base = qkv + (int64_t)b * L * 3 * D + h * DH;
+    const float scale = rsqrtf((float)DH);
+
+    // B operands that every query block shares: K rows (columns of S) and V columns.  All loads are unconditional on a
+    // clamped row and zeroed by a select afterwards: a branch per load costs more than the load.
+    float kb[2][32], vb[2][32];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const int j = jb * 32 + r;
+        const bool ok = j < L;
+        const float4* p = reinterpret_cast<const float4*>(base + (int64_t)(ok ? j : L - 1) * 3 * D + D + 32 * kk);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = p[c];
+            kb[jb][4 * c] = ok ? v.x : 0.0f; kb[jb][4 * c + 1] = ok ? v.y : 0.0f;
+            kb[jb][4 * c + 2] = ok ? v.z : 0.0f; kb[jb][4 * c + 3] = ok ? v.w : 0.0f;
+        }
+    }
+    uint32_t dead_keys = 0;                                          // bit t: key 32*kk + t is padding or masked for this batch row
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int j = 32 * kk + t;
+        const int jc = j < L ? j : L - 1;
+        const float v0 = base[(int64_t)jc * 3 * D + 2 * D + r], v1 = base[(int64_t)jc * 3 * D + 2 * D + 32 + r];
+        vb[0][t] = j < L ? v0 : 0.0f;                                // key index = k of the PV product
+        vb[1][t] = j < L ? v1 : 0.0f;
+        const uint32_t m = kpm ? (uint32_t)kpm[(int64_t)b * L + jc] : 0u;
+        dead_keys |= ((j >= L || m != 0u) ? 1u : 0u) << t;
+    }
+
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int i = ib * 32 + r;                                   // this lane's query row (A operand / softmax row)
+        float qa[32];
+        {
+            const float4* p = reinterpret_cast<const float4*>(base + (int64_t)(i < L ? i : L - 1) * 3 * D + 32 * kk);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                            // PyTorch scales q before QK^T; rows >= L are never stored
+                const float4 v = p[c];
+                qa[4 * c] = v.x * scale; qa[4 * c + 1] = v.y * scale; qa[4 * c + 2] = v.z * scale; qa[4 * c + 3] = v.w * scale;
+            }
+        }
+        __syncthreads();                                             // previous block's softmax reads are done
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            if (jb >= nblk) break;
+            attn_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[jb][t], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sS[((e & 3) + 8 * (e >> 2) + 4 * kk) * SP + jb * 32 + r] = acc[e];
+        }
+        __syncthreads();
+        // softmax of row r (query i) over columns [32*kk, 32*kk+32); the other half sits in lane r + 32 * (1 - kk)
+        float pa[32];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(&sS[r * SP + 32 * kk + 4 * c]);
+            pa[4 * c] = v.x; pa[4 * c + 1] = v.y; pa[4 * c + 2] = v.z; pa[4 * c + 3] = v.w;
+        }
+        uint32_t dead = dead_keys;
+        if (causal) {                                                // keys j > i: bits t > i - 32*kk
+            const int first = i + 1 - 32 * kk;                       // first dead bit
+            dead |= first <= 0 ? 0xffffffffu : (first >= 32 ? 0u : (0xffffffffu << first));
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            pa[t] = ((dead >> t) & 1u) ? -INFINITY : pa[t];
+            mx = fmaxf(mx, pa[t]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            pa[t] = expf(pa[t] - mx);
+            sum += pa[t];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) pa[t] *= inv;
+        // O[i][c] = sum_j P[i][j] V[j][c]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            attn_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], vb[cb][t], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = ib * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (row < L) out[((int64_t)b * L + row) * D + h * DH + cb * 32 + r] = acc[e];
+            }
+        }
+    }
 }
 
 // ---- patch gather: cols[(b*G*G + gy*G + gx)][c*P*P + dy*P + dx] = image[b][c][gy*P+dy][gx*P+dx] --------
@@ -367,6 +488,12 @@ extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int 
     if (dh != 64) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
     if (L > 128) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
     if (!qkv || !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
+    static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
+    if (L <= 64 && !valu_only) {                                     // fp32-MFMA kernel: one wave per head
+        hipLaunchKernelGGL(k_attention_mfma64, dim3((unsigned)(B * H)), dim3(64), 0, xmh::as_stream(stream), qkv, L, H, causal, key_padding_mask, out);
+        XMH_LAUNCH_CHECK("xmh_attention_f32");
+        return XMH_OK;
+    }
     const size_t lds = ((size_t)2 * L * dh + (size_t)L * (L + 1)) * 4;
     const int threads = L <= 64 ? 64 : 128;
     auto kern = k_attention<64>;
