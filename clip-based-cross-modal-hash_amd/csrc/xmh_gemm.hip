@@ -418,8 +418,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_h16(GemmArgsH g) {
 // ---------------------------------------------------------------------------------------------------
 // split path ("f32s"): fp32 activations x fp16-EXACT weights at fp16-MFMA rate with fp32-grade accuracy.
 // CLIP weights are fp16 values held in fp32 (convert_weights + .float(), reference models/CLIP/model.py:415-436), so W
-// is taken as fp16 without loss.  A is split while it is staged: a = hi + lo + r with hi = half(a), lo = half(a - hi),
-// |r| <= 2^-22 |a| (for |a| below 2^-3 the low part is subnormal: absolute error <= 2^-25).  Each fp16 x fp16 product is
+// is taken as fp16 without loss.  A is split while it is staged: a = hi + lo + r with hi = a truncated to 11 significant
+// bits, lo = half(a - hi) rounded toward zero, |r| <= 2^-21 |a| (for |a| below 2^-3 the low part is subnormal: absolute
+// error <= 2^-24).  Each fp16 x fp16 product is
 // exact in fp32, so acc += hi*w; acc += lo*w reproduces the fp32 product to 2^-22 relative -- the same order as fp32
 // summation-order noise -- at two fp16 MFMAs per k-slab instead of eight fp32 ones.  Domain |a| < 65504 (fp16 range):
 // true for LayerNorm outputs, attention outputs and QuickGELU activations (the reference's own GPU path computes these in
@@ -465,26 +466,31 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
         rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                     \
         rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);                \
     }
-#define XMH_SPLIT1(v, h, l)                                                                                         \
+// two floats -> packed (hi, hi) and (lo, lo) halves in 6 VALU ops: hi = the float truncated to 11 significant bits (a mask:
+// exactly an fp16 value inside the fp16 exponent range), lo = a - hi (exact in fp32), both packed with
+// v_cvt_pkrtz_f16_f32 (round toward zero: exact for hi, <= 2^-21 |a| for lo, and it saturates at 65504 instead of inf).
+#define XMH_SPLIT2(f0, f1, H, L)                                                                                    \
     {                                                                                                               \
-        h = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);      /* saturate instead of inf - inf */      \
-        l = (_Float16)__builtin_amdgcn_fmed3f(v - (float)h, -65504.0f, 65504.0f);                                   \
+        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
+        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
+        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
+        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
     }
 #define XMH_SPLIT8(VA, VB, hi, lo)                                                                                  \
     {                                                                                                               \
-        XMH_SPLIT1(VA.x, hi[0], lo[0]) XMH_SPLIT1(VA.y, hi[1], lo[1]) XMH_SPLIT1(VA.z, hi[2], lo[2]) XMH_SPLIT1(VA.w, hi[3], lo[3]) \
-        XMH_SPLIT1(VB.x, hi[4], lo[4]) XMH_SPLIT1(VB.y, hi[5], lo[5]) XMH_SPLIT1(VB.z, hi[6], lo[6]) XMH_SPLIT1(VB.w, hi[7], lo[7]) \
+        XMH_SPLIT2(VA.x, VA.y, hi.x, lo.x) XMH_SPLIT2(VA.z, VA.w, hi.y, lo.y)                                       \
+        XMH_SPLIT2(VB.x, VB.y, hi.z, lo.z) XMH_SPLIT2(VB.z, VB.w, hi.w, lo.w)                                       \
     }
 #define XMH_SWRITE(buf)                                                                                             \
     {                                                                                                               \
-        f16x8 h8, l8;                                                                                               \
+        uint4 h8, l8;                                                                                               \
         XMH_SPLIT8(fa0, fa1, h8, l8)                                                                                \
-        *reinterpret_cast<f16x8*>(&sAh[buf][srow * LDH + scol]) = h8;                                                \
-        *reinterpret_cast<f16x8*>(&sAl[buf][srow * LDH + scol]) = l8;                                                \
+        *reinterpret_cast<uint4*>(&sAh[buf][srow * LDH + scol]) = h8;                                                \
+        *reinterpret_cast<uint4*>(&sAl[buf][srow * LDH + scol]) = l8;                                                \
         if (MI == 2) {                                                                                              \
             XMH_SPLIT8(fa2, fa3, h8, l8)                                                                            \
-            *reinterpret_cast<f16x8*>(&sAh[buf][(srow + 64) * LDH + scol]) = h8;                                     \
-            *reinterpret_cast<f16x8*>(&sAl[buf][(srow + 64) * LDH + scol]) = l8;                                     \
+            *reinterpret_cast<uint4*>(&sAh[buf][(srow + 64) * LDH + scol]) = h8;                                     \
+            *reinterpret_cast<uint4*>(&sAl[buf][(srow + 64) * LDH + scol]) = l8;                                     \
         }                                                                                                           \
         *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                \
         *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;                                         \
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
     }
 #undef XMH_SLOAD
 #undef XMH_SPLIT8
-#undef XMH_SPLIT1
+#undef XMH_SPLIT2
 #undef XMH_SWRITE
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
