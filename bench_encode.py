@@ -66,6 +66,21 @@ def measure(batch=100, steps=10, warmup=2, K=64):
                 out["%s_gemm_share_%s" % (what, mode)] = gemm_total / dt
         finally:
             ops.set_precision("f32")
+    # the eval transform on raw photo bytes (COCO-like 375 x 500 RGB uint8, device-resident)
+    from xmh.dataset.preprocess import GpuEvalTransform
+    tf = GpuEvalTransform(224)
+    raw = torch.randint(0, 256, (batch, 375, 500, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(warmup):
+        tf(raw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tf(raw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pp_bytes = batch * (375 * 500 * 3 + 2 * 375 * 224 * 3 + 224 * 224 * 12)          # read in, write+read the horizontal pass, write floats
+    out["preprocess"] = {"images_per_s": batch / dt, "ms_per_batch": dt * 1e3, "achieved_GBps": pp_bytes / dt / 1e9,
+                         "workload": "Resize((224,224), BICUBIC) + ToTensor + Normalize of %d RGB uint8 images 375x500, Pillow-exact" % batch}
     ach = out["images_gemm_tflops_f32"]
     out["roofline"] = {"kernel": "k_gemm_nt_s16 (parity mode: all GEMM launches of one image forward, HIP events per launch)", "bound": "mfma",
                        "achieved": ach, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": ach / PEAK["f32"], "traffic": None,

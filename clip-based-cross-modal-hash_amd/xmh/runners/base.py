@@ -192,6 +192,14 @@ class BaseTrainer:
         b = sharded.shard_bounds(length, self.world_size)
         return b[self.rank], b[self.rank + 1]
 
+    def _image_transform(self):
+        t = self.__dict__.get("_gpu_eval_transform")
+        if t is None:
+            from ..dataset.preprocess import GpuEvalTransform
+            t = GpuEvalTransform(int(getattr(self, "image_resolution", 224) or 224))
+            self.__dict__["_gpu_eval_transform"] = t
+        return t
+
     def encode_shard(self, data_loader, length: int):
         """HOT LOOP 1 (runners/base.py:250-257): returns this rank's packed (image, text) code rows + flags."""
         self.change_state(mode="valid")
@@ -203,6 +211,8 @@ class BaseTrainer:
         with torch.no_grad():
             for image, text, key_padding_mask, label, index in data_loader:
                 image = image.to(dev, non_blocking=True)
+                if image.dtype == torch.uint8:               # raw RGB [B, H, W, 3]: the eval transform runs on the GPU
+                    image = self._image_transform()(image)   # (dataset/transformer_dataset.py:38-42, Pillow-exact)
                 text = text.to(dev, non_blocking=True)
                 rows = (index.to(dev, non_blocking=True) - lo).to(torch.int64)
                 image_hash, text_hash = self.generate_hash(image=image, text=text, key_padding_mask=key_padding_mask)

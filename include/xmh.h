@@ -184,6 +184,17 @@ int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const flo
  * key_padding_mask [B, L] bytes (non-zero = ignore key) or NULL. */
 int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
                       float* out, xmh_stream_t stream);
+/* Evaluation image transform (reference dataset/transformer_dataset.py:38-42: torchvision Resize((r, r), BICUBIC) +
+ * ToTensor + Normalize on a PIL image), bit-exact with Pillow's two-pass 8-bit resample.  images [B][H][W][3] u8 RGB.
+ * bounds_x [out][2] = (first input index, count), kk_x [out][ksize_x] = 22-bit fixed-point coefficients (device; built
+ * once per image size by the host).  The horizontal pass (W != out_w) writes tmp [B][H][out_w][3] u8 (caller-owned).
+ * Outputs (either may be NULL): resized_u8 [B][out_h][out_w][3]; out_chw [B][3][out_h][out_w] f32 =
+ * ((u8 / 255) - mean) / std with mean3_host / std3_host three HOST floats each. */
+int xmh_image_preprocess_u8(const uint8_t* images, int64_t B, int H, int W, int out_h, int out_w,
+                            const int32_t* bounds_w, const int32_t* kk_w, int ksize_w,
+                            const int32_t* bounds_h, const int32_t* kk_h, int ksize_h,
+                            const float* mean3_host, const float* std3_host, uint8_t* tmp, uint8_t* resized_u8,
+                            float* out_chw, xmh_stream_t stream);
 /* VisionTransformer.conv1 input gather (models/CLIP/model.py:219,235): image [B,C,res,res] -> cols [B*G*G, C*P*P] */
 int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,
                      xmh_stream_t stream);

@@ -69,6 +69,26 @@ def test_runner_valid_matches_oracle(tmp_path, arch, runner, K):
     assert os.path.exists(os.path.join(str(tmp_path), "mat_files", "test.mat"))
 
 
+def test_runner_takes_raw_uint8_photos(tmp_path):
+    """SURVEY 8f-2: a dataset that yields undecoded-photo-like RGB bytes ([H, W, 3] uint8) instead of transformed floats;
+    the runner resizes/normalises on the GPU (Pillow-exact) and produces the codes the host-side transform would."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from oracle import preprocess as O
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, "DCMHT", "DCMHTTrainer", 16, layers=1)
+    cfg.dataset.raw_image_hw = [96, 130]
+    trainer = registry.get_runner_class("DCMHTTrainer").from_config(cfg=cfg, autorun=False)
+    q_img, _ = trainer.get_code(trainer.query_loader, trainer.query_num)
+    ds = trainer.query_loader.dataset
+    assert ds[0][0].dtype == torch.uint8 and tuple(ds[0][0].shape) == (96, 130, 3)
+    host = torch.from_numpy(np.stack([O.eval_transform(ds[i][0].numpy()) for i in range(8)])).cuda()
+    want = trainer.make_hash_code(trainer.model.encode_image(host))
+    assert torch.equal(q_img[:8].cpu(), want.float().cpu())
+
+
 def test_bench_sharded_path_over_rccl_single_rank():
     """bench.py's multi-GPU exchange path (all_gather of histograms, all_reduce of AP sums over RCCL) on one rank:
     must run and give the same mAP as the single-process path."""
