@@ -199,12 +199,27 @@ struct AosBatch {
     static constexpr int RW = W * (TERN ? 2 : 1) + LW;
     static constexpr int RS = (RW + 3) / 4 * 4;
     using R = Rec<W, LW, TERN>;
+    // Long records (W >= 16 words, 64..256 B): a lane loading "its" record would touch one cache line per lane and
+    // instruction (64 lines per load, 8x traffic once the L1 thrashes -- measured 12x slower).  The 64-record batch is
+    // one contiguous 64*W-dword range instead: piece j of lane l is dwords [j*256 + 4l, +4) of it, which belongs to record
+    // (j*256 + 4l) / W; publish() scatters the pieces to the padded record rows of the ring.
+    static constexpr bool COAL = W >= 16 && !TERN;
     uint32_t w[RS];
     __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
         const int64_t i = base + lane;
         const bool ok = i < hi;
+        if (COAL) {
 #pragma unroll
-        for (int x = 0; x < W; ++x) w[x] = ok ? a.rbits[i * W + x] : 0u;
+            for (int j = 0; j < W / 4; ++j) {
+                const int o = j * 256 + lane * 4;
+                const bool okj = base + o / W < hi;
+                const uint4 v = okj ? *reinterpret_cast<const uint4*>(a.rbits + base * W + o) : make_uint4(0u, 0u, 0u, 0u);
+                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < W; ++x) w[x] = ok ? a.rbits[i * W + x] : 0u;
+        }
         if (TERN) {
 #pragma unroll
             for (int x = 0; x < W; ++x) w[W + x] = ok ? a.rzero[i * W + x] : 0xffffffffu;
@@ -215,6 +230,15 @@ struct AosBatch {
         for (int x = RW; x < RS; ++x) w[x] = 0u;
     }
     __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
+        if (COAL) {
+#pragma unroll
+            for (int j = 0; j < W / 4; ++j) {
+                const int o = j * 256 + lane * 4;
+                *reinterpret_cast<uint4*>(ring + (o / W) * RS + (o % W)) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+            }
+            *reinterpret_cast<uint4*>(ring + lane * RS + W) = make_uint4(w[W], w[W + 1], w[W + 2], w[W + 3]);   // labels + padding (W % 4 == 0)
+            return;
+        }
 #pragma unroll
         for (int x = 0; x < RS; x += 4) *reinterpret_cast<uint4*>(ring + lane * RS + x) = make_uint4(w[x], w[x + 1], w[x + 2], w[x + 3]);
     }
@@ -246,7 +270,7 @@ struct AosBatch {
 
 template <int S> struct SlotGeom {
     static constexpr int QW = 64 / S;
-    static constexpr int LOG_QW = QW == 64 ? 6 : (QW == 32 ? 5 : (QW == 16 ? 4 : (QW == 8 ? 3 : 2)));
+    static constexpr int LOG_QW = QW == 64 ? 6 : (QW == 32 ? 5 : (QW == 16 ? 4 : (QW == 8 ? 3 : (QW == 4 ? 2 : (QW == 2 ? 1 : 0)))));
     static constexpr int G = QW < 4 ? QW : 4;          // steps per pipelined group
     static constexpr int NG = QW / G;                  // groups per 64-item batch (QW steps)
 };
@@ -284,32 +308,32 @@ __global__ __launch_bounds__(64) void k_scan_hist_s(ScanArgs a, uint32_t* __rest
 #pragma unroll
         for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
     };
-    LB cur, nxt;
+    LB cur, nxt;                                                     // the next batch's global loads fly during this one
     cur.load(a, lo, hi, lane);
     for (int64_t base = lo; base < hi; base += 64) {
         cur.publish(ring, lane);
         nxt.load(a, base + 64, hi, lane);
-        const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
-        if (cnt == 64) {
-            R ga[G], gb[G];
-            fetch(ga, 0);
-#pragma unroll
-            for (int g = 0; g < NG; g += 2) {
-                if (g + 1 < NG) fetch(gb, g + 1);
-                count(ga);
-                if (g + 2 < NG) fetch(ga, g + 2);
-                if (g + 1 < NG) count(gb);
+            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
+            if (cnt == 64) {
+                R ga[G], gb[G];
+                fetch(ga, 0);
+    #pragma unroll
+                for (int g = 0; g < NG; g += 2) {
+                    if (g + 1 < NG) fetch(gb, g + 1);
+                    count(ga);
+                    if (g + 2 < NG) fetch(ga, g + 2);
+                    if (g + 1 < NG) count(gb);
+                }
+            } else {
+                for (int t = 0; t * S < cnt; ++t) {
+                    R r;
+                    LB::get(r, mine, t * S * LB::RS);
+                    int d;
+                    uint32_t hit;
+                    rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                    if (t * S + slot < cnt) atomicAdd(&lds[d * QW + ql], (hit << 16) + 1u);
+                }
             }
-        } else {
-            for (int t = 0; t * S < cnt; ++t) {
-                R r;
-                LB::get(r, mine, t * S * LB::RS);
-                int d;
-                uint32_t hit;
-                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                if (t * S + slot < cnt) atomicAdd(&lds[d * QW + ql], (hit << 16) + 1u);
-            }
-        }
         cur = nxt;
     }
     uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + qtile * QW;
@@ -423,42 +447,42 @@ __global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __res
         for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
     };
 
-    LB cur, nxt;
+    LB cur, nxt;                                                     // the next batch's global loads fly during this one
     cur.load(a, lo, hi, lane);
     bool prev = false;
     for (int64_t base = lo; base < hi; base += 64) {
         cur.publish(ring, lane);
         nxt.load(a, base + 64, hi, lane);
-        const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-        if (cntb == 64) {
-            R ga[G], gb[G];
-            fetch(ga, 0);
-#pragma unroll
-            for (int g = 0; g < NG; g += 2) {
-                if (g + 1 < NG) fetch(gb, g + 1);
-                eval_issue(ga, prev);
-                prev = true;
-                if (g + 2 < NG) fetch(ga, g + 2);
-                if (g + 1 < NG) eval_issue(gb, true);
-            }
-        } else {
-            if (prev) drain();
-            prev = false;
-            for (int t = 0; t * S < cntb; ++t) {
-                R r;
-                LB::get(r, mine, t * S * LB::RS);
-                int d;
-                uint32_t hit;
-                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                const bool valid = t * S + slot < cntb;
-                CT o = 0;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (slot == s && valid) o = atomicAdd(&cnt[d * QW + ql], inc(hit));
+            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+            if (cntb == 64) {
+                R ga[G], gb[G];
+                fetch(ga, 0);
+    #pragma unroll
+                for (int g = 0; g < NG; g += 2) {
+                    if (g + 1 < NG) fetch(gb, g + 1);
+                    eval_issue(ga, prev);
+                    prev = true;
+                    if (g + 2 < NG) fetch(ga, g + 2);
+                    if (g + 1 < NG) eval_issue(gb, true);
                 }
-                if (valid) credit(o, hit);
+            } else {
+                if (prev) drain();
+                prev = false;
+                for (int t = 0; t * S < cntb; ++t) {
+                    R r;
+                    LB::get(r, mine, t * S * LB::RS);
+                    int d;
+                    uint32_t hit;
+                    rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                    const bool valid = t * S + slot < cntb;
+                    CT o = 0;
+    #pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (slot == s && valid) o = atomicAdd(&cnt[d * QW + ql], inc(hit));
+                    }
+                    if (valid) credit(o, hit);
+                }
             }
-        }
         cur = nxt;
     }
     if (prev) drain();
@@ -563,11 +587,14 @@ __global__ __launch_bounds__(256) void k_map_finalize(const double* __restrict__
 // on MI355X (K = 16..256, dense and sparse relevance): 9 KB for 64-bit counters, 5 KB for 32-bit ones (3-4 waves/SIMD).
 constexpr int kSlotBudget64 = 9 * 1024;
 constexpr int kSlotBudget32 = 5 * 1024;
+// Long codes (W > 8 words: TwDH-style 512..2048 bits) go up to S = 64, i.e. one query per wave and one
+// gallery item per lane.
 constexpr int slots_for(int W, bool tern, int counter_bytes) {
     const int nbmax = (tern ? 64 : 32) * W + 1;
     const int budget = counter_bytes == 8 ? kSlotBudget64 : kSlotBudget32;
+    const int cap = W > 8 ? 64 : 8;
     int S = 2;
-    while (S < 8 && nbmax * (64 / S) * counter_bytes > budget) S *= 2;
+    while (S < cap && nbmax * (64 / S) * counter_bytes > budget) S *= 2;
     return S;
 }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
@@ -601,9 +628,11 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (R >= (1ll << 24) || Q >= (1ll << 24)) return xmh::fail(XMH_ENOTSUP, "scan plan: shard too large (R=%lld, Q=%lld)", (long long)R, (long long)Q);
     const int64_t nb = ternary ? 2 * (int64_t)K + 1 : (int64_t)K + 1;
     const int Wd = (K + 31) / 32;
-    if (Wd > 8) return xmh::fail(XMH_ENOTSUP, "scan plan: K=%d (at most 256 code bits)", K);
-    const int Wc = Wd <= 1 ? 1 : (Wd <= 2 ? 2 : (Wd <= 4 ? 4 : 8));
-    const int64_t lds_ap = nb * (64 / slots_for(Wc, ternary != 0, 8)) * 8;
+    if (Wd > 64 || (ternary && Wd > 8))
+        return xmh::fail(XMH_ENOTSUP, "scan plan: K=%d%s (at most 2048 code bits, 256 with zero planes)", K, ternary ? " ternary" : "");
+    const int Wc = Wd <= 1 ? 1 : (Wd <= 2 ? 2 : (Wd <= 4 ? 4 : (Wd <= 8 ? 8 : (Wd <= 16 ? 16 : (Wd <= 32 ? 32 : 64)))));
+    const int S64 = slots_for(Wc, ternary != 0, 8);
+    const int64_t lds_ap = nb * (64 / S64) * 8;
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const int64_t nqt = xmh::ceil_div(Q, 64);
     const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
@@ -612,6 +641,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
     const int64_t rounds = rounds_env > 0 ? rounds_env : 1;
     int64_t nchunk = rounds * slots / nqt;
+    if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
     int64_t chunk = xmh::ceil_div(R, nchunk);
@@ -651,7 +681,7 @@ int lane_order_ok(hipStream_t st) {
     return ok;
 }
 
-template <typename F>
+template <bool TERN, typename F>
 int dispatch_shape(int W, int LW, F&& f) {
 #define XMH_CASE(WW, LL) \
     if (W == WW && LW == LL) return f(std::integral_constant<int, WW>{}, std::integral_constant<int, LL>{});
@@ -659,8 +689,14 @@ int dispatch_shape(int W, int LW, F&& f) {
     XMH_CASE(2, 1) XMH_CASE(2, 2) XMH_CASE(2, 3) XMH_CASE(2, 4)
     XMH_CASE(4, 1) XMH_CASE(4, 2) XMH_CASE(4, 3) XMH_CASE(4, 4)
     XMH_CASE(8, 1) XMH_CASE(8, 2) XMH_CASE(8, 3) XMH_CASE(8, 4)
+    if constexpr (!TERN) {                                 // long binary codes
+        XMH_CASE(16, 1) XMH_CASE(16, 2) XMH_CASE(16, 3) XMH_CASE(16, 4)
+        XMH_CASE(32, 1) XMH_CASE(32, 2) XMH_CASE(32, 3) XMH_CASE(32, 4)
+        XMH_CASE(64, 1) XMH_CASE(64, 2) XMH_CASE(64, 3) XMH_CASE(64, 4)
+    }
 #undef XMH_CASE
-    return xmh::fail(XMH_ENOTSUP, "scan: unsupported shape W=%d code words (K in {<=32,64,128,256}), Lw=%d label words (C<=128)", W, LW);
+    return xmh::fail(XMH_ENOTSUP, "scan: unsupported shape W=%d code words (K in {<=32,64,128,256}, binary also 512,1024,2048), Lw=%d label words (C<=128)%s",
+                     W, LW, TERN ? ", ternary" : "");
 }
 
 int check_common(const char* who, const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,
@@ -721,7 +757,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     auto launch = [&](auto tern_c) {
         constexpr bool T = decltype(tern_c)::value;
-        return dispatch_shape(W, LW, [&](auto w, auto l) {
+        return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, 4);
             auto kern = k_scan_hist_s<WW, LL, T, S>;
@@ -792,7 +828,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
         constexpr bool CP = decltype(cap_c)::value;
         constexpr bool P32 = decltype(p32_c)::value;
         constexpr bool MK = decltype(masked_c)::value;
-        return dispatch_shape(W, LW, [&](auto w, auto l) {
+        return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, P32 ? 4 : 8);
             auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK>;

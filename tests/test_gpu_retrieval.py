@@ -433,7 +433,7 @@ def test_float_similarities_and_float_code_fallback(cu):
 @pytest.mark.parametrize("K", [512, 2048, 96])
 def test_long_and_odd_code_lengths_distance(xr, cu, K):
     """TwDH-style long codes (up to 2048 bits) and a non-power-of-two word count go through the generic
-    distance kernel; the ranking scan reports its LDS limit instead of failing silently."""
+    distance kernel; the ranking scan reports what it does not support instead of failing silently."""
     orc = _orc()
     gen = torch.Generator().manual_seed(K)
     qB, rB = torch.randn(9, K, generator=gen).sign(), torch.randn(301, K, generator=gen).sign()
@@ -441,10 +441,35 @@ def test_long_and_odd_code_lengths_distance(xr, cu, K):
     q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
     assert np.array_equal(xr.hamming_dist(q, r, as_u16=True).cpu().numpy().view(np.uint16), orc.hamming_packed(_u32(q.bits), _u32(r.bits)))
     assert torch.equal(q.unpack().cpu(), qB)
-    if K > 256:
-        L = torch.ones(9, 3, dtype=torch.int64)
-        with pytest.raises(RuntimeError, match="LDS|unsupported|at most 256"):
+    L = torch.ones(9, 3, dtype=torch.int64)
+    if K == 96:                                               # word counts that are not a power of two: ranking scan says so
+        with pytest.raises(RuntimeError, match="unsupported shape"):
             cu.calc_map_k(qB.cuda(), rB.cuda(), L.cuda(), torch.ones(301, 3, dtype=torch.int64).cuda())
+    qB4, rB4 = torch.randn(9, 4096, generator=gen).sign(), torch.randn(40, 4096, generator=gen).sign()
+    with pytest.raises(RuntimeError, match="at most 2048"):
+        cu.calc_map_k(qB4.cuda(), rB4.cuda(), L.cuda(), torch.ones(40, 3, dtype=torch.int64).cuda())
+
+
+@pytest.mark.parametrize("Q,R,K,C", [(21, 3000, 512, 24), (9, 2500, 1024, 80), (12, 4100, 2048, 21)])
+def test_scan_long_codes_match_oracle(xr, cu, monkeypatch, Q, R, K, C):
+    """TwDH-style 512..2048-bit codes: one query per wave, one gallery item per lane; histograms bit-exact,
+    mAP (all / @k, packed and 64-bit counters, duplicate gallery codes so that lanes collide) within 1e-6."""
+    orc = _orc()
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R)
+    rB[R // 2:] = rB[torch.randint(0, 7, (R - R // 2,), generator=torch.Generator().manual_seed(K))]     # many equal distances
+    q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+    ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
+    scan = xr.RankingScan(q, ql, r, rl, C)
+    ha, hr = scan.histograms()
+    dist = orc.hamming_packed(_u32(q.bits), _u32(r.bits))
+    rel = orc.relevance_packed(_u32(ql), _u32(rl))
+    wa, wr = orc.bucket_histograms(dist, rel, K + 1)
+    assert np.array_equal(_u32(ha), wa) and np.array_equal(_u32(hr), wr)
+    want, want9 = orc.map_k(qB, rB, qL, rL, stable=True), orc.map_k(qB, rB, qL, rL, 9, stable=True)
+    assert abs(float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())) - float(want)) < MAP_TOL
+    monkeypatch.setenv("XMH_SCAN_NO_PACK32", "1")
+    assert abs(float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())) - float(want)) < MAP_TOL
+    assert abs(float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), 9)) - float(want9)) < MAP_TOL
 
 
 def test_error_paths_report_through_last_error(xr):
