@@ -205,16 +205,18 @@ struct AosBatch {
     // (j*256 + 4l) / W; publish() scatters the pieces to the padded record rows of the ring.
     static constexpr bool COAL = W >= 16 && !TERN;
     uint32_t w[RS];
-    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane) {
+    // NW > 1: the NW waves of a block share the ring; wave `wave` brings pieces wave, wave + NW, ... and wave 0 the labels
+    template <int NW = 1>
+    __device__ __forceinline__ void load(const ScanArgs& a, int64_t base, int64_t hi, int lane, int wave = 0) {
         const int64_t i = base + lane;
         const bool ok = i < hi;
         if (COAL) {
 #pragma unroll
-            for (int j = 0; j < W / 4; ++j) {
-                const int o = j * 256 + lane * 4;
+            for (int jj = 0; jj < W / 4 / NW; ++jj) {
+                const int o = (jj * NW + wave) * 256 + lane * 4;
                 const bool okj = base + o / W < hi;
                 const uint4 v = okj ? *reinterpret_cast<const uint4*>(a.rbits + base * W + o) : make_uint4(0u, 0u, 0u, 0u);
-                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+                w[4 * jj] = v.x; w[4 * jj + 1] = v.y; w[4 * jj + 2] = v.z; w[4 * jj + 3] = v.w;
             }
         } else {
 #pragma unroll
@@ -224,19 +226,23 @@ struct AosBatch {
 #pragma unroll
             for (int x = 0; x < W; ++x) w[W + x] = ok ? a.rzero[i * W + x] : 0xffffffffu;
         }
+        if (NW == 1 || wave == 0) {
 #pragma unroll
-        for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
+            for (int x = 0; x < LW; ++x) w[W * (TERN ? 2 : 1) + x] = ok ? a.rlab[i * LW + x] : 0u;
+        }
 #pragma unroll
         for (int x = RW; x < RS; ++x) w[x] = 0u;
     }
-    __device__ __forceinline__ void publish(uint32_t* ring, int lane) const {
+    template <int NW = 1>
+    __device__ __forceinline__ void publish(uint32_t* ring, int lane, int wave = 0) const {
         if (COAL) {
 #pragma unroll
-            for (int j = 0; j < W / 4; ++j) {
-                const int o = j * 256 + lane * 4;
-                *reinterpret_cast<uint4*>(ring + (o / W) * RS + (o % W)) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+            for (int jj = 0; jj < W / 4 / NW; ++jj) {
+                const int o = (jj * NW + wave) * 256 + lane * 4;
+                *reinterpret_cast<uint4*>(ring + (o / W) * RS + (o % W)) = make_uint4(w[4 * jj], w[4 * jj + 1], w[4 * jj + 2], w[4 * jj + 3]);
             }
-            *reinterpret_cast<uint4*>(ring + lane * RS + W) = make_uint4(w[W], w[W + 1], w[W + 2], w[W + 3]);   // labels + padding (W % 4 == 0)
+            if (NW == 1 || wave == 0)                                // labels + padding (W % 4 == 0)
+                *reinterpret_cast<uint4*>(ring + lane * RS + W) = make_uint4(w[W], w[W + 1], w[W + 2], w[W + 3]);
             return;
         }
 #pragma unroll
@@ -275,23 +281,28 @@ template <int S> struct SlotGeom {
     static constexpr int NG = QW / G;                  // groups per 64-item batch (QW steps)
 };
 
-template <int W, int LW, bool TERN, int S>
-__global__ __launch_bounds__(64) void k_scan_hist_s(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] counters, then the ring
+// NW = waves per block.  1 except for S = 64 (one query per wave): there every wave would stream its whole chunk for a
+// single query -- the gallery re-read Q times from L2 / Infinity Cache (measured 6.5 TB/s, 10x the VALU time) -- so NW = 8
+// waves (8 queries) share ONE staged batch: each wave loads an eighth of it, two barriers per batch.
+template <int W, int LW, bool TERN, int S, int NW>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][QW] counters, then the ring
     using SG = SlotGeom<S>;
     constexpr int QW = SG::QW, G = SG::G, NG = SG::NG;
     int chunk_id, qtile;
-    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
-    const int lane = threadIdx.x;
+    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts tiles of QW * NW queries here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
-    const int q = qtile * QW + ql;
-    const int ncell = a.nb * QW;
-    for (int e = lane; e < ncell; e += 64) lds[e] = 0u;
+    const int q0 = (qtile * NW + wave) * QW;                         // first query of this wave
+    const int q = q0 + ql;
+    const int ncell = a.nb * QW, cstride = (ncell + 3) & ~3;
+    uint32_t* cnt = lds + wave * cstride;
+    for (int e = lane; e < ncell; e += 64) cnt[e] = 0u;
     QueryRegs<W, LW, TERN> qr;
     qr.load(a, q);
     using R = Rec<W, LW, TERN>;
     using LB = AosBatch<W, LW, TERN>;
-    uint32_t* ring = lds + ((ncell + 3) & ~3);
+    uint32_t* ring = lds + NW * cstride;
     const uint32_t* mine = ring + slot * LB::RS;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
@@ -302,49 +313,51 @@ __global__ __launch_bounds__(64) void k_scan_hist_s(ScanArgs a, uint32_t* __rest
 #pragma unroll
         for (int u = 0; u < G; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
 #pragma unroll
-        for (int u = 0; u < G; ++u) atomicAdd(&lds[d[u] * QW + ql], (hit[u] << 16) + 1u);
+        for (int u = 0; u < G; ++u) atomicAdd(&cnt[d[u] * QW + ql], (hit[u] << 16) + 1u);
     };
     auto fetch = [&](R (&g)[G], int group) {
 #pragma unroll
         for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
     };
     LB cur, nxt;                                                     // the next batch's global loads fly during this one
-    cur.load(a, lo, hi, lane);
+    cur.template load<NW>(a, lo, hi, lane, wave);
     for (int64_t base = lo; base < hi; base += 64) {
-        cur.publish(ring, lane);
-        nxt.load(a, base + 64, hi, lane);
-            const int cnt = (hi - base < 64) ? (int)(hi - base) : 64;
-            if (cnt == 64) {
-                R ga[G], gb[G];
-                fetch(ga, 0);
-    #pragma unroll
-                for (int g = 0; g < NG; g += 2) {
-                    if (g + 1 < NG) fetch(gb, g + 1);
-                    count(ga);
-                    if (g + 2 < NG) fetch(ga, g + 2);
-                    if (g + 1 < NG) count(gb);
-                }
-            } else {
-                for (int t = 0; t * S < cnt; ++t) {
-                    R r;
-                    LB::get(r, mine, t * S * LB::RS);
-                    int d;
-                    uint32_t hit;
-                    rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                    if (t * S + slot < cnt) atomicAdd(&lds[d * QW + ql], (hit << 16) + 1u);
-                }
+        if (NW > 1) __syncthreads();                                 // every wave is done reading the previous batch
+        cur.template publish<NW>(ring, lane, wave);
+        nxt.template load<NW>(a, base + 64, hi, lane, wave);
+        if (NW > 1) __syncthreads();                                 // the batch is complete in the ring
+        const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+        if (cntb == 64) {
+            R ga[G], gb[G];
+            fetch(ga, 0);
+#pragma unroll
+            for (int g = 0; g < NG; g += 2) {
+                if (g + 1 < NG) fetch(gb, g + 1);
+                count(ga);
+                if (g + 2 < NG) fetch(ga, g + 2);
+                if (g + 1 < NG) count(gb);
             }
+        } else {
+            for (int t = 0; t * S < cntb; ++t) {
+                R r;
+                LB::get(r, mine, t * S * LB::RS);
+                int d;
+                uint32_t hit;
+                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                if (t * S + slot < cntb) atomicAdd(&cnt[d * QW + ql], (hit << 16) + 1u);
+            }
+        }
         cur = nxt;
     }
-    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + qtile * QW;
-    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> SG::LOG_QW) * a.qpad + (e & (QW - 1))] = lds[e];
+    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> SG::LOG_QW) * a.qpad + (e & (QW - 1))] = cnt[e];
 }
 
 // P32 = packed 32-bit counters {lo rank_bits: rank, hi: ordinal} when both fit one word (known on the device after
 // pass 1: the launch is gated by *nrel_max, no host sync), else 64-bit {lo: rank, hi: ordinal}.  Counters are 1-based
 // and start at the global base of (bucket, chunk).  MASKED: see the header (lane-order fallback).
-template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED>
-__global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW>
+__global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ nrel_max, int rank_bits) {
     using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
@@ -357,18 +370,20 @@ __global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __res
         const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
         if (P32 != fits32) return;                                   // the other variant takes this call
     }
-    CT* cnt = reinterpret_cast<CT*>(lds);                            // [nb][QW]
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;    // NW waves share the ring, see k_scan_hist_s
     const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
-    const int q = qtile * QW + ql;
+    const int q0 = (qtile * NW + wave) * QW;
+    const int q = q0 + ql;
     const int ncell = a.nb * QW;
+    const int cstride = ((ncell * (int)(sizeof(CT) / 4) + 3) & ~3);  // dwords of one wave's counters [nb][QW]
+    CT* cnt = reinterpret_cast<CT*>(lds + wave * cstride);
     auto pack = [&](uint2 x, uint2 y) -> CT {
         if (P32) return (CT)((x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits));
         return (CT)((unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32));
     };
     {
-        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + qtile * QW;
-        const uint2* __restrict__ pd = dpre + qtile * QW;
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+        const uint2* __restrict__ pd = dpre + q0;
         int e = lane;
         for (; e + 7 * 64 < ncell; e += 8 * 64) {
             uint2 x[8], y[8];
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __res
     qr.load(a, q);
     using R = Rec<W, LW, TERN>;
     using LB = AosBatch<W, LW, TERN>;
-    uint32_t* ring = lds + ((ncell * (int)(sizeof(CT) / 4) + 3) & ~3);
+    uint32_t* ring = lds + NW * cstride;
     const uint32_t* mine = ring + slot * LB::RS;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
@@ -448,41 +463,46 @@ __global__ __launch_bounds__(64) void k_scan_ap_s(ScanArgs a, const uint2* __res
     };
 
     LB cur, nxt;                                                     // the next batch's global loads fly during this one
-    cur.load(a, lo, hi, lane);
+    cur.template load<NW>(a, lo, hi, lane, wave);
     bool prev = false;
     for (int64_t base = lo; base < hi; base += 64) {
-        cur.publish(ring, lane);
-        nxt.load(a, base + 64, hi, lane);
-            const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
-            if (cntb == 64) {
-                R ga[G], gb[G];
-                fetch(ga, 0);
-    #pragma unroll
-                for (int g = 0; g < NG; g += 2) {
-                    if (g + 1 < NG) fetch(gb, g + 1);
-                    eval_issue(ga, prev);
-                    prev = true;
-                    if (g + 2 < NG) fetch(ga, g + 2);
-                    if (g + 1 < NG) eval_issue(gb, true);
-                }
-            } else {
-                if (prev) drain();
-                prev = false;
-                for (int t = 0; t * S < cntb; ++t) {
-                    R r;
-                    LB::get(r, mine, t * S * LB::RS);
-                    int d;
-                    uint32_t hit;
-                    rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                    const bool valid = t * S + slot < cntb;
-                    CT o = 0;
-    #pragma unroll
+        if (NW > 1) __syncthreads();                                 // every wave is done reading the previous batch
+        cur.template publish<NW>(ring, lane, wave);
+        nxt.template load<NW>(a, base + 64, hi, lane, wave);
+        if (NW > 1) __syncthreads();                                 // the batch is complete in the ring
+        const int cntb = (hi - base < 64) ? (int)(hi - base) : 64;
+        if (cntb == 64) {
+            R ga[G], gb[G];
+            fetch(ga, 0);
+#pragma unroll
+            for (int g = 0; g < NG; g += 2) {
+                if (g + 1 < NG) fetch(gb, g + 1);
+                eval_issue(ga, prev);
+                prev = true;
+                if (g + 2 < NG) fetch(ga, g + 2);
+                if (g + 1 < NG) eval_issue(gb, true);
+            }
+        } else {
+            if (prev) drain();
+            prev = false;
+            for (int t = 0; t * S < cntb; ++t) {
+                R r;
+                LB::get(r, mine, t * S * LB::RS);
+                int d;
+                uint32_t hit;
+                rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                const bool valid = t * S + slot < cntb;
+                CT o = 0;
+                if (!MASKED) {
+                    if (valid) o = atomicAdd(&cnt[d * QW + ql], inc(hit));       // lanes resolve in item order
+                } else {
                     for (int s = 0; s < S; ++s) {
                         if (slot == s && valid) o = atomicAdd(&cnt[d * QW + ql], inc(hit));
                     }
-                    if (valid) credit(o, hit);
                 }
+                if (valid) credit(o, hit);
             }
+        }
         cur = nxt;
     }
     if (prev) drain();
@@ -597,6 +617,8 @@ constexpr int slots_for(int W, bool tern, int counter_bytes) {
     while (S < cap && nbmax * (64 / S) * counter_bytes > budget) S *= 2;
     return S;
 }
+// waves per block: 8 where a wave owns a single query (S = 64), so that 8 queries share each staged gallery batch
+constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
 
 struct WsLayout {
@@ -760,14 +782,15 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
         return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, 4);
-            auto kern = k_scan_hist_s<WW, LL, T, S>;
-            const size_t lds = (((size_t)p.nbuckets * (64 / S) + 3) & ~(size_t)3) * 4 + aos_ring_bytes(WW, LL, T);
+            constexpr int NW = S == 64 ? waves_for(WW, T) : 1;
+            auto kern = k_scan_hist_s<WW, LL, T, S, NW>;
+            const size_t lds = (((size_t)p.nbuckets * (64 / S) + 3) & ~(size_t)3) * 4 * NW + aos_ring_bytes(WW, LL, T);
             const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
             if (r2) return r2;
             ScanArgs as = a;
-            as.nqt = a.nqt * S;                                   // tiles of 64/S queries
+            as.nqt = a.nqt * S / NW;                              // tiles of (64/S) * NW queries
             xmh::ProfScope prof("scan_hist", st);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S), dim3(64), lds, st, as, chunk_hist);
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, chunk_hist);
             return (int)XMH_OK;
         });
     };
@@ -831,15 +854,16 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
         return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, P32 ? 4 : 8);
-            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK>;
+            constexpr int NW = S == 64 ? waves_for(WW, T) : 1;
+            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW>;
             const size_t cells = (size_t)p.nbuckets * (64 / S);
-            const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : cells * 8) + aos_ring_bytes(WW, LL, T);
+            const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : ((cells * 2 + 3) & ~(size_t)3) * 4) * NW + aos_ring_bytes(WW, LL, T);
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
             ScanArgs as = a;
-            as.nqt = a.nqt * S;
+            as.nqt = a.nqt * S / NW;
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+            hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
                                (const uint32_t*)nrel_max, rank_bits);
             return (int)XMH_OK;
         });
