@@ -429,6 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_h16(GemmArgsH g) {
 struct GemmArgsS {
     const float* A;
     const _Float16* W;
+    const _Float16* Wl;        // low parts of weights that are not fp16-exact (WS kernels), else unused
     const float* bias;
     const float* residual;
     float* C;
@@ -436,12 +437,16 @@ struct GemmArgsS {
     int M, N, K, act;
 };
 
-template <int MI>
+// WS: the weight is split as well (w = wh + wl, both fp16, prepared once by the host) for weights that are NOT fp16-exact
+// -- anything fine-tuned in fp32, e.g. the hash heads or a backbone after training: acc += al*wh + ah*wl + ah*wh, the
+// dropped al*wl term is 2^-22 relative.  Three fp16 MFMAs per product instead of two; 64x128 tiles only (LDS).
+template <int MI, bool WS>
 __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
     constexpr int TBM = 64 * MI;
     __shared__ __attribute__((aligned(16))) _Float16 sAh[2][TBM * LDH];
     __shared__ __attribute__((aligned(16))) _Float16 sAl[2][TBM * LDH];
     __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 sWl[WS ? 2 : 1][WS ? BN * LDH : 8];
     const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
     int tm, tn;
     tile_of_block(nbm, nbn, tm, tn);
@@ -450,9 +455,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
     const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
     const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 elements per thread
     float4 fa0, fa1, fa2, fa3;                                 // named staging registers (see k_gemm_nt_h16)
-    uint4 rw0, rw1;
+    uint4 rw0, rw1, rl0, rl1;
     fa0 = fa1 = fa2 = fa3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    rw0 = rw1 = make_uint4(0u, 0u, 0u, 0u);
+    rw0 = rw1 = rl0 = rl1 = make_uint4(0u, 0u, 0u, 0u);
     auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
     auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
 #define XMH_SLOAD(k0)                                                                                               \
@@ -465,6 +470,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
         }                                                                                                           \
         rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                     \
         rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);                \
+        if (WS) {                                                                                                   \
+            rl0 = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                \
+            rl1 = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);           \
+        }                                                                                                           \
     }
 // two floats -> packed (hi, hi) and (lo, lo) halves in 6 VALU ops: hi = the float truncated to 11 significant bits (a mask:
 // exactly an fp16 value inside the fp16 exponent range), lo = a - hi (exact in fp32), both packed with
@@ -494,6 +503,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
         }                                                                                                           \
         *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                \
         *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;                                         \
+        if (WS) {                                                                                                   \
+            *reinterpret_cast<uint4*>(&sWl[buf][srow * LDH + scol]) = rl0;                                           \
+            *reinterpret_cast<uint4*>(&sWl[buf][(srow + 64) * LDH + scol]) = rl1;                                    \
+        }                                                                                                           \
     }
     f32x16 acc[MI][2];
 #pragma unroll
@@ -525,6 +538,15 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
+            if (WS) {
+                f16x8 bl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&sWl[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -658,19 +680,20 @@ extern "C" int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_ha
     return XMH_OK;
 }
 
-extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
+extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, const void* W_lo_half, int64_t ldw, const float* bias,
                                    const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                    int act, xmh_stream_t stream) {
     if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: bad shape");
     if (M == 0 || N == 0) return XMH_OK;
     if (!A || !W_half || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: null pointer");
-    if (K % BKH || lda % 4 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(W_half) % 16))
+    if (K % BKH || lda % 4 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(W_half) % 16) ||
+        (reinterpret_cast<uintptr_t>(W_lo_half) % 16))
         return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)K, (long long)lda, (long long)ldw);
     if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: leading dimension too small");
     if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: unknown activation %d", act);
     if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: dimension >= 2^31");
     GemmArgsS g;
-    g.A = A; g.W = static_cast<const _Float16*>(W_half);
+    g.A = A; g.W = static_cast<const _Float16*>(W_half); g.Wl = static_cast<const _Float16*>(W_lo_half);
     g.bias = bias; g.residual = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
@@ -678,11 +701,14 @@ extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_ha
     int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
     const bool small = nblk < 3ll * xmh::device_cu_count();
     xmh::ProfScope prof("gemm_s16", st);
-    if (small) {
+    if (W_lo_half) {                                             // three-term product: 64x128 tiles (60 KB of LDS)
         nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
-        hipLaunchKernelGGL(k_gemm_nt_s16<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+        hipLaunchKernelGGL((k_gemm_nt_s16<1, true>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+    } else if (small) {
+        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
+        hipLaunchKernelGGL((k_gemm_nt_s16<1, false>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
     } else {
-        hipLaunchKernelGGL(k_gemm_nt_s16<2>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
+        hipLaunchKernelGGL((k_gemm_nt_s16<2, false>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
     }
     XMH_LAUNCH_CHECK("xmh_gemm_nt_split16");
     return XMH_OK;

@@ -46,7 +46,7 @@ PROTOTYPES = {
     "xmh_shard_offsets": (i32, [vp, i32, i32, i64, i32, vp, vp, vp, vp]),
     "xmh_gemm_nt_f32": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, i32, vp]),
     "xmh_gemm_nt_h16": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
-    "xmh_gemm_nt_split16": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
+    "xmh_gemm_nt_split16": (i32, [vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "xmh_cast_f32_to_f16": (i32, [vp, vp, i64, vp]),
     "xmh_layernorm_f32": (i32, [vp, i64, vp, vp, C.c_float, vp, i64, i64, i32, vp]),
     "xmh_attention_f32": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),

@@ -16,9 +16,9 @@ _NAMES = {"f32": PREC_F32, "f16": PREC_F16, "f32x": PREC_F32X}
 
 
 def set_precision(name: str) -> None:
-    """'f32'  parity mode (default): fp32-grade results.  GEMMs whose weights hold fp16-exact values (all CLIP weights)
-              run as two fp16 MFMAs over a hi/lo split of the fp32 activations (xmh_gemm_nt_split16, product error
-              2^-22); any other weight goes through the exact fp32 MFMA kernel.
+    """'f32'  parity mode (default): fp32-grade results on the fp16 MFMA (xmh_gemm_nt_split16): the fp32 activations are split
+              hi/lo; fp16-exact weights (CLIP weights as released) take two MFMAs per product, any other weight is split
+              too and takes three.  Product error 2^-22.  Unaligned shapes fall through to the exact kernel.
        'f32x' exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32).
        'f16'  fast mode: fp16 operands / fp32 accumulate."""
     global _precision
@@ -61,16 +61,20 @@ def cast_f16(x: torch.Tensor) -> torch.Tensor:
 
 
 def _half_weight(W: torch.Tensor):
-    """(fp16 copy, exact) of a weight; `exact` = every value survives the fp32 -> fp16 -> fp32 round trip.
+    """(hi, lo) fp16 parts of a weight: ``hi = half(W)``; ``lo`` is None when every value survives the fp32 -> fp16 -> fp32
+    round trip (CLIP weights straight from convert_weights), else ``half(W - hi)`` (anything fine-tuned in fp32).
     The entry keeps a reference to W: while it is cached its memory cannot be handed to another tensor, so the
-    address in the key cannot go stale; in-place updates bump `_version`."""
+    address in the key cannot go stale; in-place updates bump ``_version``."""
     key = (W.data_ptr(), W._version, tuple(W.shape), tuple(W.stride()))
     e = _half_weights.get(key)
     if e is None:
         if len(_half_weights) > 512:
             _half_weights.clear()
-        h = cast_f16(W.detach())
-        e = (h, bool(torch.equal(h.float(), W.detach())), W)       # one-time check per weight (host sync here only)
+        Wd = W.detach()
+        h = cast_f16(Wd)
+        rest = Wd - h.float()
+        lo = None if not bool(rest.any()) else cast_f16(rest)     # one-time check per weight (host sync here only)
+        e = (h, lo, W)
         _half_weights[key] = e
     return e[0], e[1]
 
@@ -99,11 +103,11 @@ def gemm_nt(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
                                   out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_h16")
         return out2.reshape(*lead, N)
     if prec == PREC_F32 and K % 32 == 0 and W2.is_contiguous() and A2.stride(0) % 4 == 0 and A2.data_ptr() % 16 == 0:
-        Wh, exact = _half_weight(W2)
-        if exact:                                                # parity mode on fp16-exact weights: hi/lo split, fp16 MFMA rate
-            check(lib.xmh_gemm_nt_split16(ptr(A2), A2.stride(0), ptr(Wh), K, ptr(b), ptr(res2), ldr, ptr(out2),
-                                          out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_split16")
-            return out2.reshape(*lead, N)
+        # parity mode: hi/lo split of the activations on the fp16 MFMA; the weight goes in as one (fp16-exact) or two fp16 parts
+        Wh, Wl = _half_weight(W2)
+        check(lib.xmh_gemm_nt_split16(ptr(A2), A2.stride(0), ptr(Wh), ptr(Wl), K, ptr(b), ptr(res2), ldr, ptr(out2),
+                                      out2.stride(0), M, N, K, act, current_stream()), "xmh_gemm_nt_split16")
+        return out2.reshape(*lead, N)
     check(lib.xmh_gemm_nt_f32(ptr(A2), A2.stride(0), ptr(W2), W2.stride(0), ptr(b), ptr(res2), ldr,
                               ptr(out2), out2.stride(0), M, N, K, act, PREC_F16 if prec == PREC_F16 else PREC_F32,
                               current_stream()), "xmh_gemm_nt_f32")

@@ -170,10 +170,13 @@ int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_half, int64_t
                     int act, xmh_stream_t stream);
 int xmh_cast_f32_to_f16(const float* x, void* y_half, int64_t n, xmh_stream_t stream);
 /* Parity-grade contraction at fp16-MFMA rate: fp32 A is split into two fp16 terms while it is staged (a = hi + lo, 22
- * mantissa bits), W must hold fp16-EXACT values (true for CLIP weights after convert_weights, models/CLIP/model.py:415-436)
- * and is passed as fp16; every product is exact in fp32, accumulation is fp32.  Relative error of a product 2^-22;
- * requires |a| < 65504.  Same shape rules as xmh_gemm_nt_h16 (A rows 16-byte aligned, K % 32 == 0). */
-int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
+ * mantissa bits); every fp16 x fp16 product is exact in fp32, accumulation is fp32.
+ *   W_lo_half == NULL: W_half must hold fp16-EXACT weights (true for CLIP weights after convert_weights,
+ *                      models/CLIP/model.py:415-436): two MFMAs per product, relative error 2^-22;
+ *   W_lo_half != NULL: any fp32 weight, given as w = W_half + W_lo_half (host: hi = half(w), lo = half(w - hi)): three MFMAs
+ *                      per product (the lo*lo term, 2^-22 relative, is dropped).
+ * Requires |a| < 65504 (larger values saturate).  Same shape rules as xmh_gemm_nt_h16 (16-byte aligned rows, K % 32 == 0). */
+int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, const void* W_lo_half, int64_t ldw, const float* bias,
                         const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                         int act, xmh_stream_t stream);
 /* models/CLIP/model.py:153-159 (fp32 LayerNorm) */

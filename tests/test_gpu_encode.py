@@ -35,29 +35,32 @@ def g_(seed=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (128, 128, 16), (37, 70, 50), (1, 1, 1), (200, 2304, 768), (130, 129, 3072), (64, 512, 3)])
-def test_gemm_f32_matches_torch(ops, M, N, K):
+@pytest.mark.parametrize("mode", ["f32", "f32x"])
+def test_gemm_f32_matches_torch(ops, M, N, K, mode):
+    prec = ops._NAMES[mode]            # parity mode (split on the fp16 MFMA where the shape allows) and exact fp32 MFMA
     A, W = torch.randn(M, K, generator=g_(1)), torch.randn(N, K, generator=g_(2)) * 0.1
     bias, res = torch.randn(N, generator=g_(3)), torch.randn(M, N, generator=g_(4))
     want = A.double() @ W.double().t()
-    got = ops.gemm_nt(A.cuda(), W.cuda())
+    got = ops.gemm_nt(A.cuda(), W.cuda(), precision=prec)
     assert rel(got, want) < 5e-6
     for act, fn in ((ops.ACT_QUICKGELU, lambda x: x * torch.sigmoid(1.702 * x)), (ops.ACT_GELU_ERF, F.gelu), (ops.ACT_TANH, torch.tanh),
                     (ops.ACT_RELU, torch.relu)):
-        got = ops.gemm_nt(A.cuda(), W.cuda(), bias.cuda(), residual=res.cuda(), act=act)
+        got = ops.gemm_nt(A.cuda(), W.cuda(), bias.cuda(), residual=res.cuda(), act=act, precision=prec)
         assert rel(got, fn((want + bias.double()).float()).double() + res.double()) < 1e-5
     # strided views (leading dimension > K) and in-place residual
     Abig = torch.randn(M, K + 8, generator=g_(5)).cuda()
     out = res.clone().cuda()
-    ops.gemm_nt(Abig[:, :K], W.cuda(), residual=out, out=out)
+    ops.gemm_nt(Abig[:, :K], W.cuda(), residual=out, out=out, precision=prec)
     assert rel(out, Abig[:, :K].cpu().double() @ W.double().t() + res.double()) < 5e-6   # fp32 chain over K<=3072
 
 
 def test_gemm_f32_transpose_detecting(ops):
     """identity A against an asymmetric W (guide rule 16): C must equal W^T, not W."""
     n = 96
-    Wt = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 100.0
-    got = ops.gemm_nt(torch.eye(n).cuda(), Wt.cuda())
-    assert torch.equal(got.cpu(), Wt.t())
+    Wt = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 128.0      # 14 significant bits: exact in every precision mode but f16
+    for prec in (None, ops.PREC_F32X):
+        got = ops.gemm_nt(torch.eye(n).cuda(), Wt.cuda(), precision=prec)
+        assert torch.equal(got.cpu(), Wt.t())
 
 
 @pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (200, 2304, 768), (77, 130, 3072), (1, 64, 32), (129, 512, 96)])
@@ -88,15 +91,27 @@ def test_gemm_split16_parity_mode_on_fp16_exact_weights(ops, M, N, K):
     assert torch.isfinite(ops.gemm_nt(huge.cuda(), W.cuda())).all()
 
 
-def test_gemm_parity_mode_keeps_inexact_weights_on_the_fp32_mfma(ops):
-    A, W = torch.randn(300, 768, generator=g_(1)).cuda(), (torch.randn(256, 768, generator=g_(2)) * 0.1).cuda()     # not fp16-exact
-    assert torch.equal(ops.gemm_nt(A, W), ops.gemm_nt(A, W, precision=ops.PREC_F32X))
-    Wh = W.half().float()
-    Wh2 = Wh.clone()
-    a = ops.gemm_nt(A, Wh)
-    Wh2 += 1e-3                                                # in-place update: the cached fp16 copy must not be reused
-    b = ops.gemm_nt(A, Wh2)
-    assert rel(b, A.cpu().double() @ Wh2.cpu().double().t()) < 5e-6 and not torch.equal(a, b)
+@pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (300, 256, 768), (77, 130, 3072), (1, 64, 32)])
+def test_gemm_parity_mode_splits_inexact_weights_too(ops, M, N, K):
+    """weights that are NOT fp16-exact (fine-tuned in fp32: hash heads, a trained backbone) are split hi/lo as well: three
+    fp16 MFMAs per product, still fp32-grade."""
+    from xmh import _lib
+    A = (torch.randn(M, K, generator=g_(1)) * torch.exp(torch.randn(M, K, generator=g_(2)))).cuda()
+    W = (torch.randn(N, K, generator=g_(3)) * 0.1).cuda()                                                         # full fp32 mantissas
+    bias = torch.randn(N, generator=g_(4)).cuda()
+    want = A.cpu().double() @ W.cpu().double().t() + bias.cpu().double()
+    _lib.prof_enable(True)
+    got = ops.gemm_nt(A, W, bias)
+    torch.cuda.synchronize()
+    assert _lib.prof_read("gemm_s16")[1] >= 1 and _lib.prof_read("gemm_f32")[1] == 0       # not the exact-MFMA kernel
+    _lib.prof_enable(False)
+    exact = ops.gemm_nt(A, W, bias, precision=ops.PREC_F32X)
+    assert rel(got, want) < 2e-6 and rel(got, want) < 2 * rel(exact, want) + 1e-7
+    Wc = W.clone()
+    a = ops.gemm_nt(A, Wc, bias)
+    Wc += 1e-3                                                 # in-place update: the cached fp16 parts must not be reused
+    b = ops.gemm_nt(A, Wc, bias)
+    assert rel(b, A.cpu().double() @ Wc.cpu().double().t() + bias.cpu().double()) < 2e-6 and not torch.equal(a, b)
 
 
 def test_gemm_f16_fast_mode_error_level(ops):

@@ -10,11 +10,13 @@ from xmh import ops
 
 shapes = [(5000, 2304, 768), (5000, 768, 768), (5000, 3072, 768), (5000, 768, 3072), (3200, 1536, 512), (3200, 512, 512),
           (3200, 2048, 512), (3200, 512, 2048), (100, 512, 768), (4096, 4096, 4096)]
-for name in ("f32x", "f32", "f16"):
-    prec = ops._NAMES[name]
+for name in ("f32x", "f32", "f32w", "f16"):            # f32w = parity mode on weights that are not fp16-exact (3 MFMAs per product)
+    prec = ops._NAMES["f32" if name == "f32w" else name]
     for M, N, K in shapes:
         A = torch.randn(M, K, device="cuda") * 3.0
-        W = (torch.randn(N, K, device="cuda") * 0.05).half().float()            # fp16-exact like CLIP weights
+        W = torch.randn(N, K, device="cuda") * 0.05
+        if name != "f32w":
+            W = W.half().float()                                                # fp16-exact like CLIP weights
         b = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda")
         for _ in range(3):
