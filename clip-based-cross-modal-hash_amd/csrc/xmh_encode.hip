@@ -384,31 +384,37 @@ __global__ __launch_bounds__(256) void k_pair_softmax(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_lta_aggregate(const float* __restrict__ S, const float* __restrict__ X,
                                                        const uint8_t* __restrict__ mask, const float* __restrict__ pe,
                                                        float* __restrict__ M, int L, int K, int D, int topk) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [L][K+1]
+    // grid (B, ceil(D / 64)): every block rebuilds the [L][K] attention of its sample (cheap, all 256 threads) and aggregates
+    // 64 feature columns -- one block per sample left 60 % of the CUs idle and ran 0.46 ms
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [L][K+1] scores -> attention, then thr[L]
     const int b = blockIdx.x;
     const int ld = K + 1;
+    float* thr_s = sm + L * ld;
     for (int e = threadIdx.x; e < L * K; e += 256) {
         const int l = e / K, k = e % K;
         float v = S[((int64_t)b * L + l) * K + k];
         if (mask && mask[(int64_t)b * L + l]) v = -INFINITY;
         sm[l * ld + k] = v > 0.0f ? v : -INFINITY;
     }
+    for (int l = threadIdx.x; l < L; l += 256) thr_s[l] = -INFINITY;
     __syncthreads();
-    // per-token top-k threshold: the value v with #(> v) < topk <= #(>= v)
-    for (int l = threadIdx.x; l < L; l += 256) {
-        float* row = sm + l * ld;
-        float thr = -INFINITY;
-        for (int i = 0; i < K; ++i) {
-            const float v = row[i];
-            int gt = 0, ge = 0;
-            for (int j = 0; j < K; ++j) {
-                gt += row[j] > v;
-                ge += row[j] >= v;
-            }
-            if (gt < topk && topk <= ge) thr = v;
+    // per-token top-k threshold: the value v with #(> v) < topk <= #(>= v); one (token, candidate) pair per thread step.
+    // Several candidates of a row can qualify only if they are equal, so the racing stores write the same value.
+    for (int e = threadIdx.x; e < L * K; e += 256) {
+        const int l = e / K, i = e % K;
+        const float* row = sm + l * ld;
+        const float v = row[i];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < K; ++j) {
+            gt += row[j] > v;
+            ge += row[j] >= v;
         }
-        for (int i = 0; i < K; ++i)
-            if (!(row[i] >= thr)) row[i] = -INFINITY;
+        if (gt < topk && topk <= ge) thr_s[l] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L * K; e += 256) {
+        const int l = e / K, i = e % K;
+        if (!(sm[l * ld + i] >= thr_s[l])) sm[l * ld + i] = -INFINITY;
     }
     __syncthreads();
     // softmax over tokens per concept
@@ -428,22 +434,23 @@ __global__ __launch_bounds__(256) void k_lta_aggregate(const float* __restrict__
         }
     }
     __syncthreads();
-    // aggregate: thread owns feature columns d, walks concepts
-    for (int d = threadIdx.x; d < D; d += 256) {
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float acc[8];
+    // aggregate 64 feature columns: thread = (column, quarter of the concepts), 16 concepts at a time in registers
+    const int d = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int kq = threadIdx.x >> 6;                                 // 0..3
+    if (d >= D) return;
+    for (int k0 = kq * 16; k0 < K; k0 += 64) {
+        float acc[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
-            for (int l = 0; l < L; ++l) {
-                const float x = X[((int64_t)b * L + l) * D + d];
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0f;
+        for (int l = 0; l < L; ++l) {
+            const float x = X[((int64_t)b * L + l) * D + d];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (k0 + u < K) acc[u] = fmaf(sm[l * ld + k0 + u], x, acc[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k0 + u < K) M[((int64_t)b * K + k0 + u) * D + d] = acc[u] + (pe ? pe[(int64_t)(k0 + u) * D + d] : 0.0f);
+            for (int u = 0; u < 16; ++u)
+                if (k0 + u < K) acc[u] = fmaf(sm[l * ld + k0 + u], x, acc[u]);
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (k0 + u < K) M[((int64_t)b * K + k0 + u) * D + d] = acc[u] + (pe ? pe[(int64_t)(k0 + u) * D + d] : 0.0f);
     }
 }
 
@@ -572,13 +579,13 @@ extern "C" int xmh_lta_aggregate(const float* scores, const float* tokens, const
     if (B < 0 || L <= 0 || K <= 0 || D <= 0 || top_k <= 0 || top_k > K) return xmh::fail(XMH_EINVAL, "xmh_lta_aggregate: bad shape L=%d K=%d top_k=%d", L, K, top_k);
     if (B == 0) return XMH_OK;
     if (!scores || !tokens || !out) return xmh::fail(XMH_EINVAL, "xmh_lta_aggregate: null pointer");
-    const size_t lds = (size_t)L * (K + 1) * 4;
+    const size_t lds = ((size_t)L * (K + 1) + L) * 4;
     if (lds > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "xmh_lta_aggregate: L*K too large for LDS");
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lta_aggregate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_lta_aggregate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k_lta_aggregate, dim3((unsigned)B), dim3(256), lds, xmh::as_stream(stream), scores, tokens, token_mask, pos_enc, out, L, K, D, top_k);
+    hipLaunchKernelGGL(k_lta_aggregate, dim3((unsigned)B, (unsigned)xmh::ceil_div(D, 64)), dim3(256), lds, xmh::as_stream(stream), scores, tokens, token_mask, pos_enc, out, L, K, D, top_k);
     XMH_LAUNCH_CHECK("xmh_lta_aggregate");
     return XMH_OK;
 }
