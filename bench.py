@@ -79,7 +79,7 @@ def pmc_traffic(kernel_prefix, kernel_suffix=""):
         except Exception:
             continue
         for name, e in d.get("pmc", {}).items():
-            if name.startswith(kernel_prefix) and name.rstrip("> ").endswith(kernel_suffix) and "hbm_bytes_per_launch" in e:
+            if name.startswith(kernel_prefix) and kernel_suffix in name and "hbm_bytes_per_launch" in e:
                 best = {"bytes": e["hbm_bytes_per_launch"]["total"], "fetch_raw": e["hbm_bytes_per_launch"]["fetch_raw"],
                         "write_raw": e["hbm_bytes_per_launch"]["write_raw"], "fetch_correction": e["hbm_bytes_per_launch"]["fetch_correction"],
                         "source": os.path.relpath(f, ROOT)}
@@ -175,8 +175,8 @@ def main():
     t32, n32 = _lib.prof_read("scan_ap32")
     packed = t32 > t64
     ap_kernel = "k_scan_ap_s, packed 32-bit counters" if packed else "k_scan_ap_s, 64-bit counters"
-    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED>: the profile summary holds both gated launches
-    ap_traffic = pmc_traffic("k_scan_ap_s<", "true, false" if packed else "false, false")
+    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED, NW>: the profile summary holds both gated launches
+    ap_traffic = pmc_traffic("k_scan_ap_s<", ", 4, true, false, 1>" if packed else ", 4, false, false, 1>")
     t_ap, n_ap = (t32, n32) if t32 > t64 else (t64, n64)
     t_ap *= 1e-3
     _lib.prof_enable(False)
