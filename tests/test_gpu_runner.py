@@ -32,6 +32,11 @@ def test_runner_valid_matches_oracle(tmp_path, arch, runner, K):
     trainer = registry.get_runner_class(runner).from_config(cfg=cfg, autorun=False)
     q_img, q_txt = trainer.get_code(trainer.query_loader, trainer.query_num)
     r_img, r_txt = trainer.get_code(trainer.retrieval_loader, trainer.retrieval_num)
+    trainer.encode_fuse = 1                                  # one loader batch per forward, like the reference: same codes
+    q_img1, q_txt1 = trainer.get_code(trainer.query_loader, trainer.query_num)
+    # a different row count picks different GEMM tiles: the only admissible difference is a flipped near-zero logit
+    assert (q_img1 != q_img).float().mean() < 2e-3 and (q_txt1 != q_txt).float().mean() < 2e-3
+    trainer.encode_fuse = 4
     assert q_img.shape == (50, K) and r_txt.shape == (230, K) and q_img.dtype == torch.float32
     assert set(np.unique(q_img.cpu().numpy())) <= {-1.0, 0.0, 1.0}
     maps = trainer.valid(0, k=None)
