@@ -277,7 +277,7 @@ struct AosBatch {
 template <int S> struct SlotGeom {
     static constexpr int QW = 64 / S;
     static constexpr int LOG_QW = QW == 64 ? 6 : (QW == 32 ? 5 : (QW == 16 ? 4 : (QW == 8 ? 3 : (QW == 4 ? 2 : (QW == 2 ? 1 : 0)))));
-    static constexpr int G = QW < 4 ? QW : 4;          // steps per pipelined group
+    static constexpr int G = QW >= 16 ? 8 : (QW < 4 ? QW : 4);   // steps per pipelined group (at K = 64: 8 beats 4 by 4 %, 2 loses 4 %)
     static constexpr int NG = QW / G;                  // groups per 64-item batch (QW steps)
 };
 
