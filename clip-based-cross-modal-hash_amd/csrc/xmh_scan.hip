@@ -146,49 +146,64 @@ __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__
 //   dpre[d][q] = rank offset of bucket d from outside this shard's bucket d: all lower buckets
 //                (locally: exclusive prefix of tot; sharded: the caller's base_all/base_rel)
 //   cap[q]     = min(n_rel, k)
-__global__ __launch_bounds__(64) void k_scan_dpre(const uint2* __restrict__ tot, int Q, int qpad, int nb,
-                                                  const uint32_t* __restrict__ base_all,
-                                                  const uint32_t* __restrict__ base_rel,
-                                                  const uint32_t* __restrict__ nrel_total, int64_t kcap,
-                                                  uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
-                                                  int32_t* __restrict__ cap_out, uint32_t* __restrict__ hist_all,
-                                                  uint32_t* __restrict__ hist_rel, uint32_t* __restrict__ nrel_max) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot, int Q, int qpad, int nb,
+                                                   const uint32_t* __restrict__ base_all,
+                                                   const uint32_t* __restrict__ base_rel,
+                                                   const uint32_t* __restrict__ nrel_total, int64_t kcap,
+                                                   uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
+                                                   int32_t* __restrict__ cap_out, uint32_t* __restrict__ hist_all,
+                                                   uint32_t* __restrict__ hist_rel, uint32_t* __restrict__ nrel_max) {
+    // 64 queries per block, the bucket axis split over the 4 waves: each wave sums its quarter, the quarter sums are
+    // prefixed through LDS, then each wave walks its quarter again (L2 hits) writing the exclusive prefixes.  One wave per
+    // 64 queries walking all buckets was a 13 us latency chain of dependent-free but serialised load groups.
+    __shared__ uint2 part[4][64];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
     const bool qok = q < Q;
-    uint32_t ra = 0, rr = 0;
-    int d = 0;
-    for (; d + 8 <= nb; d += 8) {
+    const int nbq = (nb + 3) / 4;
+    const int d0 = wq * nbq, d1 = (d0 + nbq < nb) ? d0 + nbq : nb;
+    uint32_t sa = 0, sr = 0;
+    for (int d = d0; d < d1; d += 8) {
         uint2 t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = tot[(int64_t)(d + j) * qpad + q];
+        for (int j = 0; j < 8; ++j) t[j] = d + j < d1 ? tot[(int64_t)(d + j) * qpad + q] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa += t[j].x; sr += t[j].y; }
+    }
+    part[wq][lane] = make_uint2(sa, sr);
+    __syncthreads();
+    uint32_t ra = 0, rr = 0, ta = 0, tr = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint2 p = part[w][lane];
+        if (w < wq) { ra += p.x; rr += p.y; }
+        ta += p.x; tr += p.y;
+    }
+    for (int d = d0; d < d1; d += 8) {
+        uint2 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = d + j < d1 ? tot[(int64_t)(d + j) * qpad + q] : make_uint2(0u, 0u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            uint2 o = make_uint2(ra, rr);
-            if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d + j], base_rel[(int64_t)q * nb + d + j]);
-            if (dpre) dpre[(int64_t)(d + j) * qpad + q] = o;
-            if (qok && hist_all) hist_all[(int64_t)q * nb + d + j] = t[j].x;
-            if (qok && hist_rel) hist_rel[(int64_t)q * nb + d + j] = t[j].y;
-            ra += t[j].x;
-            rr += t[j].y;
+            if (d + j < d1) {
+                uint2 o = make_uint2(ra, rr);
+                if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d + j], base_rel[(int64_t)q * nb + d + j]);
+                if (dpre) dpre[(int64_t)(d + j) * qpad + q] = o;
+                if (qok && hist_all) hist_all[(int64_t)q * nb + d + j] = t[j].x;
+                if (qok && hist_rel) hist_rel[(int64_t)q * nb + d + j] = t[j].y;
+                ra += t[j].x;
+                rr += t[j].y;
+            }
         }
     }
-    for (; d < nb; ++d) {
-        const uint2 t = tot[(int64_t)d * qpad + q];
-        uint2 o = make_uint2(ra, rr);
-        if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d], base_rel[(int64_t)q * nb + d]);
-        if (dpre) dpre[(int64_t)d * qpad + q] = o;
-        if (qok && hist_all) hist_all[(int64_t)q * nb + d] = t.x;
-        if (qok && hist_rel) hist_rel[(int64_t)q * nb + d] = t.y;
-        ra += t.x;
-        rr += t.y;
-    }
-    if (cap_ws) {
-        const uint32_t nrel = nrel_total ? (qok ? nrel_total[q] : 0u) : rr;
+    if (cap_ws && wq == 0) {
+        const uint32_t nrel = nrel_total ? (qok ? nrel_total[q] : 0u) : tr;
         const uint32_t cap = (kcap > 0 && (uint64_t)kcap < (uint64_t)nrel) ? (uint32_t)kcap : nrel;
         cap_ws[q] = cap;
         if (qok) cap_out[q] = (int32_t)cap;
         if (qok && nrel_max) atomicMax(nrel_max, nrel);
     }
+    (void)ta;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -661,7 +676,9 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
-    const int64_t rounds = rounds_env > 0 ? rounds_env : 1;
+    // two resident sets of waves balance the tail better, but the [chunk][bucket][query] tables double: pays up to 65 buckets
+    // (K=64: 0.640 -> 0.624 ms, K=16: 0.502 -> 0.476), costs at 257 (K=256: 1.45 -> 1.54)
+    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 65 ? 2 : 1);
     int64_t nchunk = rounds * slots / nqt;
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     if (nchunk < 1) nchunk = 1;
@@ -801,7 +818,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
                        (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, below, tot);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");
     if (hist_all || hist_rel) {
-        hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
+        hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
                            (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int64_t)0,
                            (uint2*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, hist_all, hist_rel, (uint32_t*)nullptr);
         XMH_LAUNCH_CHECK("xmh_hamming_hist totals");
@@ -839,7 +856,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
         if (rank_bits > 24) rank_bits = 0;
     }
     if (rank_bits) XMH_HIP(hipMemsetAsync(nrel_max, 0, 4, st));
-    hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(64), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
+    hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
                        base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
     XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
