@@ -16,16 +16,18 @@
 // Ordering: the S lanes of a query may hit the same counter in one instruction.  Pass 1 only needs totals.  Pass 2 needs
 // the returns in item order; the LDS serialises same-address lanes in ascending lane order (= item order, slot being the
 // high lane bits).  That is observed behaviour, not an ISA promise, so xmh_hamming_ap probes it once per process
-// (k_probe_lane_order) and otherwise issues the add once per slot under an exec mask (MASKED, ~1.6x slower).
+// (k_probe_lane_order) and otherwise issues the add once per slot under an exec mask (MASKED, ~2x slower).
 //
 // The gallery batch: lane i loads record base+i (coalesced, vmcnt; the next batch is in flight during the current one),
 // the wave stages it record-major in a small LDS ring, and a lane reads the record of its own item with ds_read_b128s
 // (S distinct addresses per instruction, each broadcast to QW lanes).  LDS ops of a wave complete in order, so every
-// wait in the loop is a counted lgkmcnt; reads run one 4-step group ahead of their use.
+// wait in the loop is a counted lgkmcnt; reads run one group of steps (SlotGeom::G) ahead of their use.  Records of 64 B
+// and more (K >= 512) are loaded as one contiguous range and scattered to padded rows, and at one query per wave
+// (S = 64) eight waves share each staged batch (see AosBatch, k_scan_hist_s).
 //
 // Bound: VALU issue.  tools/ubench_valu.hip measures ~4.0-4.4 cycles per wave64 instruction per SIMD for
 // the instruction mix of these loops (v_xor/v_and/v_add alone reach 2.4, VOP3 ops such as v_bcnt_u32_b32 /
-// v_and_or_b32 / v_lshl_add_u32 4.2, v_rcp_f32 8.2): 10 (pass 1) / 14 (pass 2) VALU instructions per pair-step of a
+// v_and_or_b32 / v_lshl_add_u32 4.2, v_rcp_f32 8.2): 10 (pass 1) / 14-15 (pass 2) VALU instructions per pair-step of a
 // wave at K=64, C=80.  The relevance test is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does
 // not form them).  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
