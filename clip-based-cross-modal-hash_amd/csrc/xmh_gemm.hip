@@ -18,6 +18,8 @@
 // DESIGN.md section 3.4), with the MFMA peak above it.  Algorithmic flops per launch = 2*M*N*K.
 #include "xmh_common.h"
 
+#include <stdlib.h>
+
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -583,6 +585,128 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// split path, 128 x 256 block tile (waves 2x2, each 64 x 128 = 2x4 MFMA tiles) for large grids.  The GEMMs are bound by
+// L2 -> CU bandwidth: per k a tile moves 4*TBM + 2*TBN bytes for 2*TBM*TBN flops, so 128x256 carries 64 flop/B
+// against 42.7 at 128x128 and 32 at 64x128.  Needs >= 2 blocks per CU to pay, i.e. M of 16 k rows and more (fused
+// evaluation batches, BaseTrainer.encode_shard).  fp16-exact weights only; 80 KB of dynamic LDS (double-buffered).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt_s16_wide(GemmArgsS g) {
+    constexpr int TBM = 128, TBN = 256;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
+    _Float16* sAh = smem_w;                                    // [2][TBM * LDH]
+    _Float16* sAl = sAh + 2 * TBM * LDH;                       // [2][TBM * LDH]
+    _Float16* sW = sAl + 2 * TBM * LDH;                        // [2][TBN * LDH]
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 elements per thread
+    float4 fa0, fa1, fa2, fa3;
+    uint4 rw0, rw1, rw2, rw3;
+    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
+    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
+    const float* pa0 = g.A + (int64_t)row_a(srow) * g.lda + scol;
+    const float* pa1 = g.A + (int64_t)row_a(srow + 64) * g.lda + scol;
+    const _Float16* pw0 = g.W + (int64_t)row_w(srow) * g.ldw + scol;
+    const _Float16* pw1 = g.W + (int64_t)row_w(srow + 64) * g.ldw + scol;
+    const _Float16* pw2 = g.W + (int64_t)row_w(srow + 128) * g.ldw + scol;
+    const _Float16* pw3 = g.W + (int64_t)row_w(srow + 192) * g.ldw + scol;
+#define XMH_WL(k0)                                                                                                  \
+    {                                                                                                               \
+        fa0 = reinterpret_cast<const float4*>(pa0 + (k0))[0]; fa1 = reinterpret_cast<const float4*>(pa0 + (k0))[1]; \
+        fa2 = reinterpret_cast<const float4*>(pa1 + (k0))[0]; fa3 = reinterpret_cast<const float4*>(pa1 + (k0))[1]; \
+        rw0 = *reinterpret_cast<const uint4*>(pw0 + (k0)); rw1 = *reinterpret_cast<const uint4*>(pw1 + (k0));       \
+        rw2 = *reinterpret_cast<const uint4*>(pw2 + (k0)); rw3 = *reinterpret_cast<const uint4*>(pw3 + (k0));       \
+    }
+#define XMH_WS2(f0, f1, H, L)                                                                                       \
+    {                                                                                                               \
+        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
+        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
+        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
+        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
+    }
+#define XMH_WW(buf)                                                                                                 \
+    {                                                                                                               \
+        uint4 h, l;                                                                                                 \
+        XMH_WS2(fa0.x, fa0.y, h.x, l.x) XMH_WS2(fa0.z, fa0.w, h.y, l.y) XMH_WS2(fa1.x, fa1.y, h.z, l.z) XMH_WS2(fa1.z, fa1.w, h.w, l.w) \
+        *reinterpret_cast<uint4*>(&sAh[(buf) * TBM * LDH + srow * LDH + scol]) = h;                                  \
+        *reinterpret_cast<uint4*>(&sAl[(buf) * TBM * LDH + srow * LDH + scol]) = l;                                  \
+        XMH_WS2(fa2.x, fa2.y, h.x, l.x) XMH_WS2(fa2.z, fa2.w, h.y, l.y) XMH_WS2(fa3.x, fa3.y, h.z, l.z) XMH_WS2(fa3.z, fa3.w, h.w, l.w) \
+        *reinterpret_cast<uint4*>(&sAh[(buf) * TBM * LDH + (srow + 64) * LDH + scol]) = h;                           \
+        *reinterpret_cast<uint4*>(&sAl[(buf) * TBM * LDH + (srow + 64) * LDH + scol]) = l;                           \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + srow * LDH + scol]) = rw0;                                 \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rw1;                          \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 128) * LDH + scol]) = rw2;                         \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 192) * LDH + scol]) = rw3;                         \
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int nk = g.K / BKH;
+    XMH_WL(0)
+    XMH_WW(0)
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) XMH_WL((kt + 1) * BKH)
+        const _Float16* cAh = sAh + buf * TBM * LDH;
+        const _Float16* cAl = sAl + buf * TBM * LDH;
+        const _Float16* cW = sW + buf * TBN * LDH;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            f16x8 ah[2], al[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(&cAh[(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+                al[i] = *reinterpret_cast<const f16x8*>(&cAl[(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            XMH_WW(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef XMH_WL
+#undef XMH_WS2
+#undef XMH_WW
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) {
+                    float v = apply_act(acc[i][j][e] + bv, g.act);
+                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                    g.C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cast_f32_h16(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n8) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
         const float4 a = reinterpret_cast<const float4*>(x)[2 * e], b = reinterpret_cast<const float4*>(x)[2 * e + 1];
@@ -703,7 +827,18 @@ extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_ha
     int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
     const bool small = nblk < 3ll * xmh::device_cu_count();
     xmh::ProfScope prof("gemm_s16", st);
-    if (W_lo_half) {                                             // three-term product: 64x128 tiles (60 KB of LDS)
+    const int64_t nwide = xmh::ceil_div(M, 128) * xmh::ceil_div(N, 256);
+    static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
+    if (!W_lo_half && !no_wide && K >= 768 && nwide * 2 >= 3ll * xmh::device_cu_count()) {     // 128x256 tiles: more flops per L2 byte (short K: the epilogue dominates, measured slower)
+        const size_t lds = (size_t)2 * (128 + 128 + 256) * LDH * sizeof(_Float16);
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_s16_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return xmh::fail(XMH_EHIP, "xmh_gemm_nt_split16: cannot raise dynamic LDS to %zu", lds);
+            raised = true;
+        }
+        hipLaunchKernelGGL(k_gemm_nt_s16_wide, dim3((unsigned)nwide), dim3(kThreads), lds, st, g);
+    } else if (W_lo_half) {                                      // three-term product: 64x128 tiles (60 KB of LDS)
         nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
         hipLaunchKernelGGL((k_gemm_nt_s16<1, true>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
     } else if (small) {

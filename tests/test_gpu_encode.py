@@ -63,7 +63,7 @@ def test_gemm_f32_transpose_detecting(ops):
         assert torch.equal(got.cpu(), Wt.t())
 
 
-@pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (200, 2304, 768), (77, 130, 3072), (1, 64, 32), (129, 512, 96)])
+@pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (200, 2304, 768), (77, 130, 3072), (1, 64, 32), (129, 512, 96), (20001, 2304, 768)])   # last: 128x256 tiles
 def test_gemm_split16_parity_mode_on_fp16_exact_weights(ops, M, N, K):
     """parity mode routes fp16-exact weights (every CLIP weight) through the hi/lo split kernel: fp32-grade error over a wide
     dynamic range of activations, bias/activation/residual epilogues, strided A."""

@@ -9,7 +9,8 @@ import torch
 from xmh import ops
 
 shapes = [(5000, 2304, 768), (5000, 768, 768), (5000, 3072, 768), (5000, 768, 3072), (3200, 1536, 512), (3200, 512, 512),
-          (3200, 2048, 512), (3200, 512, 2048), (100, 512, 768), (4096, 4096, 4096)]
+          (3200, 2048, 512), (3200, 512, 2048), (100, 512, 768), (4096, 4096, 4096),
+          (20000, 2304, 768), (20000, 768, 768), (20000, 3072, 768), (20000, 768, 3072)]      # fused evaluation batches (4 x 100 images)
 for name in ("f32x", "f32", "f32w", "f16"):            # f32w = parity mode on weights that are not fp16-exact (3 MFMAs per product)
     prec = ops._NAMES["f32" if name == "f32w" else name]
     for M, N, K in shapes:
