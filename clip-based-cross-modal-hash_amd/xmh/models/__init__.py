@@ -3,3 +3,4 @@ from .base import BaseModel  # noqa: F401
 from .dcmht import DCMHT  # noqa: F401
 from .dsph import DSPH  # noqa: F401
 from .mith import MITH  # noqa: F401
+from .twdh import TwDH  # noqa: F401

@@ -202,17 +202,26 @@ class BaseTrainer:
             self.__dict__["_gpu_eval_transform"] = t
         return t
 
-    def encode_shard(self, data_loader, length: int):
-        """HOT LOOP 1 (runners/base.py:250-257): returns this rank's packed (image, text) code rows + flags."""
+    def generate_hashes(self, image, text, key_padding_mask=None) -> dict:
+        """name -> (image_hash, text_hash) for every code stream of one forward; the base methods have one stream, ""
+        (TwDH emits a long code and several short ones from the same forward, runners/TwDH/runner.py:138-143)."""
+        return {"": self.generate_hash(image=image, text=text, key_padding_mask=key_padding_mask)}
+
+    def code_streams(self) -> dict:
+        """name -> code length K of every stream generate_hashes returns."""
+        return {"": self.output_dim}
+
+    def encode_streams(self, data_loader, length: int) -> dict:
+        """HOT LOOP 1 (runners/base.py:250-257): name -> this rank's packed (image, text) code rows."""
         self.change_state(mode="valid")
         lo, hi = self._shard(length)
         dev = torch.device("cuda", self.device) if isinstance(self.device, int) else torch.device(self.device)
-        img = R.empty_packed(hi - lo, self.output_dim, dev, with_zero=True)
-        txt = R.empty_packed(hi - lo, self.output_dim, dev, with_zero=True)
+        dims = self.code_streams()
+        bufs = {n: (R.empty_packed(hi - lo, K, dev, with_zero=True), R.empty_packed(hi - lo, K, dev, with_zero=True)) for n, K in dims.items()}
         flags = torch.zeros(1, dtype=torch.int32, device=dev)
         # Evaluation is per-sample independent, so several loader batches are fused into one forward: the encoder's GEMMs
         # sit on an L2-bandwidth roofline that rises with the number of rows (DESIGN 3.4: B=100 -> 22.5k images/s,
-        # B=400 -> 26.9k).  `run.encode_fuse` loader batches per forward (default 4; 1 = the reference's granularity).
+        # B=400 -> 28k).  `run.encode_fuse` loader batches per forward (default 4; 1 = the reference's granularity).
         fuse = max(1, int(getattr(self, "encode_fuse", 4) or 1))
         pending = []
 
@@ -228,9 +237,9 @@ class BaseTrainer:
             pending.clear()
             if image.dtype == torch.uint8:                   # raw RGB [B, H, W, 3]: the eval transform runs on the GPU
                 image = self._image_transform()(image)       # (dataset/transformer_dataset.py:38-42, Pillow-exact)
-            image_hash, text_hash = self.generate_hash(image=image, text=text, key_padding_mask=kpm)
-            self.pack_hash_code(image_hash, img, rows, flags)
-            self.pack_hash_code(text_hash, txt, rows, flags)
+            for name, (image_hash, text_hash) in self.generate_hashes(image, text, kpm).items():
+                self.pack_hash_code(image_hash, bufs[name][0], rows, flags)
+                self.pack_hash_code(text_hash, bufs[name][1], rows, flags)
 
         with torch.no_grad():
             for image, text, key_padding_mask, label, index in data_loader:
@@ -243,8 +252,13 @@ class BaseTrainer:
                     flush()
             flush()
         if not (int(flags.item()) & 1):                      # no exact zero anywhere: drop the zero planes
-            img.zero = txt.zero = None
-        return img, txt
+            for img, txt in bufs.values():
+                img.zero = txt.zero = None
+        return bufs
+
+    def encode_shard(self, data_loader, length: int):
+        """this rank's packed (image, text) code rows of the single-stream methods."""
+        return self.encode_streams(data_loader, length)[""]
 
     def _gather_packed(self, p: R.PackedCodes, length: int) -> R.PackedCodes:
         if not self.distributed:

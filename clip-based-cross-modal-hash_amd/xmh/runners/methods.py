@@ -5,6 +5,8 @@
 model and then calls ``run()``."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import retrieval as R
@@ -72,3 +74,99 @@ class MITHTrainer(_MethodTrainer):
     def generate_hash(self, image, text, key_padding_mask=None):
         _, img_cls_hash, tokens_hash_i, _, _, txt_cls_hash, tokens_hash_t, _ = self.model(image, text, key_padding_mask=key_padding_mask)
         return img_cls_hash + tokens_hash_i, txt_cls_hash + tokens_hash_t
+
+
+@registry.register_runner("TwDHTrainer")
+class TwDHTrainer(DCMHTTrainer):
+    """runners/TwDH/runner.py: one forward yields the long code and every short code (:138-143); evaluation reports the four
+    mAPs per code length (:181-228).  Code streams: "long" (long_dim bits) and one per short length, all quantised by the
+    DCMHT pair-argmax (:82-95 of the DCMHT runner, inherited)."""
+
+    def __init__(self, cfg, *a, **k):
+        self.long_dim = cfg.model.get("long_dim", 512)
+        self.max_short, self.best_epoch_short = {}, {}
+        super().__init__(cfg, *a, **k)
+
+    def build_model(self, cfg_model, output_dim=16):
+        super().build_model(cfg_model, output_dim=output_dim)
+        for item in self.model.get_short_dims():
+            self.max_short[str(item)] = {"i2t": 0, "t2i": 0}
+            self.best_epoch_short[str(item)] = {"i2t": 0, "t2i": 0}
+
+    def generate_hash(self, image, text, key_padding_mask=None):
+        long_image_hash, short_image_hash = self.model.encode_image(image)
+        long_text_hash, short_text_hash = self.model.encode_text(text)
+        return long_image_hash, short_image_hash, long_text_hash, short_text_hash
+
+    def generate_hashes(self, image, text, key_padding_mask=None):
+        li, si, lt, st = self.generate_hash(image, text, key_padding_mask)
+        out = {"long": (li, lt)}
+        for key in si:
+            out[key] = (si[key], st[key])
+        return out
+
+    def code_streams(self):
+        dims = {"long": self.long_dim}
+        for d in self.model.get_short_dims():
+            dims[str(d)] = int(d)
+        return dims
+
+    def encode_shard(self, data_loader, length):
+        return self.encode_streams(data_loader, length)["long"]
+
+    def get_code(self, data_loader, length):
+        """reference :145-179 -- (long_img, long_txt, {short: img}, {short: txt}) fp32 +-1 buffers, complete on every rank."""
+        streams = self.encode_streams(data_loader, length)
+        full = {n: (self._gather_packed(i, length).unpack(), self._gather_packed(t, length).unpack()) for n, (i, t) in streams.items()}
+        return (full["long"][0], full["long"][1], {n: v[0] for n, v in full.items() if n != "long"},
+                {n: v[1] for n, v in full.items() if n != "long"})
+
+    def _evaluate_streams(self, k):
+        self._qlab = self._rlab = None
+        qs = self.encode_streams(self.query_loader, self.query_num)
+        rs = self.encode_streams(self.retrieval_loader, self.retrieval_num)
+        out = {}
+        for name in qs:
+            q_img, q_txt = self._gather_packed(qs[name][0], self.query_num), self._gather_packed(qs[name][1], self.query_num)
+            r_img, r_txt = rs[name]
+            maps = (self._map(q_img, r_txt, k), self._map(q_txt, r_img, k), self._map(q_img, r_img, k), self._map(q_txt, r_txt, k))
+            out[name] = (maps, (q_img, q_txt, r_img, r_txt))
+        return out
+
+    def valid(self, epoch, k=None):
+        assert self.query_loader is not None and self.retrieval_loader is not None
+        save_dir = os.path.join(self.save_dir, "mat_files")
+        os.makedirs(save_dir, exist_ok=True)
+        self.logger.info("Valid.")
+        results = self._evaluate_streams(k)
+        for name, ((mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes) in results.items():
+            bits = codes[0].K
+            if name == "long":                                   # reference valid_each, short is None (:194-208)
+                if self.max_mapi2t < mAPi2t:
+                    self.best_epoch_i = epoch
+                    self._save_codes(codes, os.path.join(save_dir, "i2t-long.mat"))
+                    if self._is_writer():
+                        self.save_model(save_dir=self.save_dir, epoch=epoch)
+                self.max_mapi2t = max(self.max_mapi2t, mAPi2t)
+                if self.max_mapt2i < mAPt2i:
+                    self.best_epoch_t = epoch
+                    self._save_codes(codes, os.path.join(save_dir, "t2i-long.mat"))
+                    if self._is_writer():
+                        self.save_model(save_dir=self.save_dir, epoch=epoch)
+                self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
+                self.logger.info(f">>>>>> [{epoch}/{self.epochs}], Long, {bits} Bit, MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, "
+                                 f"MAP(i->i): {mAPi2i}, MAX MAP(i->t): {self.max_mapi2t}, epoch: {self.best_epoch_i}, MAX MAP(t->i): {self.max_mapt2i}, "
+                                 f"epoch: {self.best_epoch_t}")
+            else:                                                # short codes (:209-228)
+                if self.max_short[name]["i2t"] < mAPi2t:
+                    self.best_epoch_short[name]["i2t"] = epoch
+                    self._save_codes(codes, os.path.join(save_dir, f"i2t-short-{name}.mat"))
+                self.max_short[name]["i2t"] = max(self.max_short[name]["i2t"], mAPi2t)
+                if self.max_short[name]["t2i"] < mAPt2i:
+                    self.best_epoch_short[name]["t2i"] = epoch
+                    self._save_codes(codes, os.path.join(save_dir, f"t2i-short-{name}.mat"))
+                self.max_short[name]["t2i"] = max(self.max_short[name]["t2i"], mAPt2i)
+                self.logger.info(f">>>>>> [{epoch}/{self.epochs}], Short, {bits} Bit, MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, "
+                                 f"MAP(i->i): {mAPi2i}, MAX MAP(i->t): {self.max_short[name]['i2t']}, epoch: {self.best_epoch_short[name]['i2t']}, "
+                                 f"MAX MAP(t->i): {self.max_short[name]['t2i']}, epoch: {self.best_epoch_short[name]['t2i']}")
+        return {name: maps for name, (maps, _) in results.items()}

@@ -155,3 +155,11 @@ def mith_head(hp, cls, tokens_lnd, mask, modality: str, top_k: int = 8):
     x = _blocks(x, sd, "", _count_layers(sd, ""), x.shape[-1] // 64, None)
     bits = torch.stack([F.linear(x[k], hp[pre + "hashing.fc_list.%d.weight" % k], hp[pre + "hashing.fc_list.%d.bias" % k]) for k in range(K)])
     return cls_hash, torch.tanh(bits.permute(1, 0, 2).squeeze(-1))
+
+
+def twdh_short(long_hash: torch.Tensor, trans: torch.Tensor) -> torch.Tensor:
+    """TwDH short code of one transform (reference models/TwDH/TwDH.py:70-74 / :80-84):
+    ``hash.quantization(long_hash.matmul(trans))`` with the softmax hash of models/common/hash.py:21-31 --
+    [B, 2*long] x [2*long, 2*short] -> pair softmax -> [B, 2*short]."""
+    z = long_hash.matmul(trans)
+    return torch.softmax(z.view(z.shape[0], -1, 2), dim=-1).view(z.shape[0], -1)

@@ -260,6 +260,28 @@ def test_heads_match_reference_goldens(ops):
         assert (code != g["dsph128_%s_code" % mod]).mean() < 0.002
 
 
+def test_twdh_heads_match_reference_golden(ops):
+    """the long (512-bit) DCMHT hash layer and the [2*long, 2*short] transforms of models/TwDH/TwDH.py:66-85."""
+    from test_oracle_encode import dcmht_params
+    from xmh import retrieval as xr
+    from xmh.models import heads, weights as W
+    g = np.load(os.path.join(GOLDEN, "encode_twdh.npz"))
+    seed = int(g["seed"])
+    emb = torch.from_numpy(g["emb"]).cuda()
+    layer = heads.DCMHTHashLayer(512, 512)
+    _load_head(layer.img_hash, dcmht_params(W, seed, 512, "img", family="twdh"))
+    _load_head(layer.txt_hash, dcmht_params(W, seed, 512, "txt", family="twdh"))
+    for mod, fn in (("img", layer.encode_img), ("txt", layer.encode_txt)):
+        long_hash = fn(emb)
+        assert (long_hash.cpu() - torch.from_numpy(g["long_%s" % mod])).abs().max() < 3e-6
+        assert (xr.pack_pair_argmax(long_hash).unpack().cpu().numpy() != g["long_%s_code" % mod]).mean() < 0.002
+        for S in (16, 64):
+            w = torch.from_numpy(g["trans%d" % S]).cuda().t().contiguous()
+            short = ops.pair_softmax(ops.gemm_nt(torch.from_numpy(g["long_%s" % mod]).cuda(), w))
+            assert (short.cpu() - torch.from_numpy(g["short%d_%s" % (S, mod)])).abs().max() < 3e-6
+            assert (xr.pack_pair_argmax(short).unpack().cpu().numpy() != g["short%d_%s_code" % (S, mod)]).mean() < 0.01
+
+
 def test_fast_mode_fp16_error_and_bit_agreement(ops, clip_models):
     """fp16 activations -> ~1e-3 embedding error, well under 1 % code-bit flips."""
     g, W, m, _ = clip_models

@@ -94,6 +94,35 @@ def test_runner_takes_raw_uint8_photos(tmp_path):
     assert torch.equal(q_img[:8].cpu(), want.float().cpu())
 
 
+def test_twdh_runner_long_and_short_codes(tmp_path):
+    """TwDHTrainer encodes once and evaluates the 512-bit long code and two short codes; every mAP equals the
+    oracle's calc_map_k port on the codes it produced (the long one through the long-code scan kernels)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from oracle import retrieval as orc
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, "TwDH", "TwDHTrainer", 16, layers=1)
+    cfg.model.long_dim = 512
+    cfg.model.trans_matrix = "synthetic"
+    cfg.model.short_dims = [16, 64]
+    trainer = registry.get_runner_class("TwDHTrainer").from_config(cfg=cfg, autorun=False)
+    assert sorted(trainer.model.get_short_dims()) == [16, 64]
+    ql_img, ql_txt, qs_img, qs_txt = trainer.get_code(trainer.query_loader, trainer.query_num)
+    rl_img, rl_txt, rs_img, rs_txt = trainer.get_code(trainer.retrieval_loader, trainer.retrieval_num)
+    assert ql_img.shape == (50, 512) and rs_txt["64"].shape == (230, 64) and set(qs_img) == {"16", "64"}
+    maps = trainer.valid(0, k=None)
+    qL, rL = trainer.query_labels, trainer.retrieval_labels
+    for name, (qi, qt, ri, rt) in (("long", (ql_img, ql_txt, rl_img, rl_txt)), ("16", (qs_img["16"], qs_txt["16"], rs_img["16"], rs_txt["16"])),
+                                   ("64", (qs_img["64"], qs_txt["64"], rs_img["64"], rs_txt["64"]))):
+        want = [orc.map_k(a.cpu(), b.cpu(), qL, rL, None, stable=True) for a, b in ((qi, rt), (qt, ri), (qi, ri), (qt, rt))]
+        for got, w in zip(maps[name], want):
+            assert abs(got - float(w)) < 1e-6, name
+    files = set(os.listdir(os.path.join(str(tmp_path), "mat_files")))
+    assert {"i2t-long.mat", "t2i-long.mat", "i2t-short-16.mat", "t2i-short-64.mat"} <= files
+
+
 def test_bench_sharded_path_over_rccl_single_rank():
     """bench.py's multi-GPU exchange path (all_gather of histograms, all_reduce of AP sums over RCCL) on one rank:
     must run and give the same mAP as the single-process path."""

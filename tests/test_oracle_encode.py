@@ -45,9 +45,9 @@ def head_params(W, seed, prefix, shapes):
     return {k: v for k, v in shapes.items()}
 
 
-def dcmht_params(W, seed, K, modality):
-    """the same named tensors oracle/make_golden_encode.py loaded into the reference head."""
-    pre = "dcmht%d.%s_hash." % (K, modality)
+def dcmht_params(W, seed, K, modality, family="dcmht"):
+    """the same named tensors oracle/make_golden_encode.py (make_golden_twdh.py: family "twdh") loaded into the reference head."""
+    pre = "%s%d.%s_hash." % (family, K, modality)
     p = {
         "atten.in_proj_weight": W.synth_tensor(seed, pre + "atten.in_proj_weight", (1536, 512), 0.05),
         "atten.in_proj_bias": W.synth_tensor(seed, pre + "atten.in_proj_bias", (1536,), 0.02),
@@ -157,3 +157,18 @@ def test_mith_head_matches_reference_goldens():
             assert np.abs(got.numpy() - g["k%d_%s" % (K, key)]).max() < 5e-6, (K, key)
         assert np.array_equal((ch_i + th_i).sign().numpy(), g["k%d_code_i" % K])
         assert np.array_equal((ch_t + th_t).sign().numpy(), g["k%d_code_t" % K])
+
+
+def test_twdh_long_and_short_heads_match_reference_golden():
+    """DCMHT hash layer at long_dim = 512 and the TwDH short transforms (models/TwDH/TwDH.py:66-85)."""
+    import importlib
+    from oracle import encode as E
+    W = importlib.import_module("xmh.models.weights")
+    g = np.load(os.path.join(GOLDEN, "encode_twdh.npz"))
+    emb = torch.from_numpy(g["emb"])
+    for name in ("img", "txt"):
+        long_hash = E.dcmht_head(dcmht_params(W, int(g["seed"]), 512, name, family="twdh"), emb, image=name == "img")
+        assert np.allclose(long_hash.numpy(), g["long_%s" % name], rtol=0, atol=2e-6)
+        for S in (16, 64):
+            short = E.twdh_short(torch.from_numpy(g["long_%s" % name]), torch.from_numpy(g["trans%d" % S]))
+            assert np.allclose(short.numpy(), g["short%d_%s" % (S, name)], rtol=0, atol=2e-6)
