@@ -93,7 +93,20 @@ class GpuEvalTransform:
                                           ptr(tmp), ptr(out_u8), ptr(out_f), current_stream()), "xmh_image_preprocess_u8")
         return out_u8, out_f
 
-    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+    def __call__(self, images) -> torch.Tensor:
+        """a stacked uint8 batch, or a list of [H, W, 3] uint8 photos of any sizes (one launch pair per size group)."""
+        if isinstance(images, (list, tuple)):
+            if not images:
+                raise ValueError("empty image list")
+            out = torch.empty(len(images), 3, self.resolution, self.resolution, dtype=torch.float32, device="cuda")
+            groups: Dict[tuple, list] = {}
+            for i, im in enumerate(images):
+                groups.setdefault(tuple(im.shape), []).append(i)
+            for shape, idx in groups.items():
+                batch = torch.stack([images[i] if images[i].is_cuda else images[i].cuda(non_blocking=True) for i in idx])
+                res = self._run(batch, False, True)[1]
+                out[torch.tensor(idx, device=out.device)] = res
+            return out
         return self._run(images, False, True)[1]
 
     def resize_u8(self, images: torch.Tensor) -> torch.Tensor:

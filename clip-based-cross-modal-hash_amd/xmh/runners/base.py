@@ -122,28 +122,38 @@ class BaseTrainer:
         else:
             builder = registry.get_dataset_class(arch)
             if builder is None:
-                raise NotImplementedError(
-                    "dataset arch '%s': the reference's .mat/PIL/BPE pipeline is host I/O outside this path (SURVEY 8f-2); "
-                    "register a dataset class yielding (image, caption, key_padding_mask, label, index) under that name, "
-                    "or call build_loader() with your own datasets" % arch)
-            train_data, query_data, retrieval_data = builder.build(cfg, train_num=train_num, query_num=query_num)
+                raise NotImplementedError("dataset arch '%s' is not registered (known: %s)" % (arch, registry.list_datasets()))
+            if hasattr(builder, "build"):
+                train_data, query_data, retrieval_data = builder.build(cfg, train_num=train_num, query_num=query_num)
+            else:                                            # the reference's file layout (runners/base.py:145-159)
+                from ..dataset import build_dataloader
+                dataname, path = cfg.get("name", "mirflickr25k"), cfg.get("path", "./data")
+                tok = registry.get_tokenizer_class(cfg.get("tokenizer_arch", "clip_tokenizer"))
+                assert tok is not None, "tokenizer '%s' is not registered" % cfg.get("tokenizer_arch", "clip_tokenizer")
+                train_data, query_data, retrieval_data = build_dataloader(
+                    captionFile=os.path.join(path, dataname, cfg.get("txt_file", "caption.mat")),
+                    indexFile=os.path.join(path, dataname, cfg.get("img_file", "index.mat")),
+                    labelFile=os.path.join(path, dataname, cfg.get("label_file", "caption.mat")),
+                    imageResolution=cfg.get("image_resolution", 224), maxWords=cfg.get("max_word", 32), query_num=query_num,
+                    train_num=train_num, dataset_cls=arch, tokenizer=tok())
         self.build_loader(train_data, query_data, retrieval_data, batch_size, num_workers, pin_memory, shuffle)
 
     def build_loader(self, train_data, query_data, retrieval_data, batch_size, num_workers, pin_memory, shuffle, drop_last=False):
-        self.train_labels = train_data.get_all_label()
+        self.train_labels = train_data.get_all_label() if train_data is not None else None     # no training split on this path
         self.query_labels = query_data.get_all_label()
         self.retrieval_labels = retrieval_data.get_all_label()
         self.retrieval_num = len(self.retrieval_labels)
         for nm, t in (("train", self.train_labels), ("query", self.query_labels), ("retrieval", self.retrieval_labels)):
-            self.logger.info(f"{nm} shape: {tuple(t.shape)}")
+            if t is not None:
+                self.logger.info(f"{nm} shape: {tuple(t.shape)}")
         qs = rs = None
         if self.distributed:
             qs = ContiguousShardSampler(len(query_data), self.rank, self.world_size)
             rs = ContiguousShardSampler(len(retrieval_data), self.rank, self.world_size)
             batch_size = max(1, batch_size // self.world_size)
         mk = lambda d, s, sh: DataLoader(d, batch_size=batch_size, num_workers=num_workers, pin_memory=pin_memory, sampler=s,   # noqa: E731
-                                         shuffle=sh, drop_last=False)
-        self.train_loader = mk(train_data, None, shuffle and not self.distributed)
+                                         shuffle=sh, drop_last=False, collate_fn=getattr(d, "collate", None))
+        self.train_loader = mk(train_data, None, shuffle and not self.distributed) if train_data is not None else None
         self.query_loader = mk(query_data, qs, False)
         self.retrieval_loader = mk(retrieval_data, rs, False)
 
@@ -228,14 +238,17 @@ class BaseTrainer:
         def flush():
             if not pending:
                 return
-            image = torch.cat([p[0] for p in pending]) if len(pending) > 1 else pending[0][0]
+            if isinstance(pending[0][0], list):              # undecoded photos of different sizes: one list for the group
+                image = [im for p in pending for im in p[0]]
+            else:
+                image = torch.cat([p[0] for p in pending]) if len(pending) > 1 else pending[0][0]
             text = torch.cat([p[1] for p in pending]) if len(pending) > 1 else pending[0][1]
             kpm = None
             if pending[0][2] is not None:
                 kpm = torch.cat([p[2] for p in pending]) if len(pending) > 1 else pending[0][2]
             rows = torch.cat([p[3] for p in pending]) if len(pending) > 1 else pending[0][3]
             pending.clear()
-            if image.dtype == torch.uint8:                   # raw RGB [B, H, W, 3]: the eval transform runs on the GPU
+            if isinstance(image, list) or image.dtype == torch.uint8:     # raw RGB bytes: the eval transform runs on the GPU
                 image = self._image_transform()(image)       # (dataset/transformer_dataset.py:38-42, Pillow-exact)
             for name, (image_hash, text_hash) in self.generate_hashes(image, text, kpm).items():
                 self.pack_hash_code(image_hash, bufs[name][0], rows, flags)
@@ -243,9 +256,12 @@ class BaseTrainer:
 
         with torch.no_grad():
             for image, text, key_padding_mask, label, index in data_loader:
-                if pending and tuple(image.shape[1:]) != tuple(pending[0][0].shape[1:]):
-                    flush()                                  # raw photos of another size start a new group
-                pending.append((image.to(dev, non_blocking=True), text.to(dev, non_blocking=True),
+                as_list = isinstance(image, (list, tuple))
+                if pending and (as_list != isinstance(pending[0][0], list) or
+                                (not as_list and tuple(image.shape[1:]) != tuple(pending[0][0].shape[1:]))):
+                    flush()                                  # stacked batches of another size / kind start a new group
+                image = [im.to(dev, non_blocking=True) for im in image] if as_list else image.to(dev, non_blocking=True)
+                pending.append((image, text.to(dev, non_blocking=True),
                                 None if key_padding_mask is None else key_padding_mask.to(dev, non_blocking=True),
                                 (index.to(dev, non_blocking=True) - lo).to(torch.int64)))
                 if len(pending) == fuse:

@@ -123,6 +123,63 @@ def test_twdh_runner_long_and_short_codes(tmp_path):
     assert {"i2t-long.mat", "t2i-long.mat", "i2t-short-16.mat", "t2i-short-64.mat"} <= files
 
 
+def test_runner_on_mat_files_and_photos_of_mixed_sizes(tmp_path):
+    """SURVEY 8f-2 end to end: the reference's file layout (index/caption/label .mat + image files) through the
+    ``transformer_dataset`` mirror -- PIL only decodes, photos of different sizes reach the runner as a list and are resized /
+    normalised on the GPU.  The BPE merge table does not travel to the GPU box, so a toy tokenizer is registered instead."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import scipy.io as scio
+    from PIL import Image
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    import xmh.dataset  # noqa: F401
+    from oracle import preprocess as O
+    from xmh.common.register import registry
+
+    if registry.get_tokenizer_class("toy_words") is None:
+        @registry.register_tokenizer("toy_words")
+        class ToyWords:                                           # same two methods the dataset calls
+            def tokenize(self, text):
+                return str(text).strip().lower().split()
+
+            def convert_tokens_to_ids(self, tokens):
+                return [49406 if t == "<|startoftext|>" else 49407 if t == "<|endoftext|>" else 1 + sum(map(ord, t)) % 4000 for t in tokens]
+
+    rng = np.random.default_rng(11)
+    root = tmp_path / "data" / "tiny"
+    root.mkdir(parents=True)
+    n, C = 23, 6
+    paths = []
+    for i in range(n):
+        h, w = [(40, 64), (64, 48), (50, 50)][i % 3]
+        p = root / ("img%02d.png" % i)
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), mode="RGB").save(p)
+        paths.append(str(p))
+    labels = (rng.random((n, C)) < 0.4).astype(np.int64)
+    labels[:, 0] = 1
+    scio.savemat(root / "index.mat", {"index": np.asarray(paths)})
+    scio.savemat(root / "caption.mat", {"caption": np.asarray([["photo number %d of a dog" % i] for i in range(n)])})
+    scio.savemat(root / "label.mat", {"category": labels})
+    cfg = make_cfg(tmp_path, "DCMHT", "DCMHTTrainer", 16, layers=1)
+    cfg.dataset.update({"arch": "transformer_dataset", "name": "tiny", "path": str(tmp_path / "data"), "label_file": "label.mat",
+                        "tokenizer_arch": "toy_words"})
+    cfg.run.query_num, cfg.run.batch_size = 7, 5
+    np.random.seed(3)
+    trainer = registry.get_runner_class("DCMHTTrainer").from_config(cfg=cfg, autorun=False)
+    assert trainer.query_num == 7 and trainer.retrieval_num == n - 7 and trainer.train_loader is None
+    r_img, r_txt = trainer.get_code(trainer.retrieval_loader, trainer.retrieval_num)
+    ds = trainer.retrieval_loader.dataset
+    host = torch.from_numpy(np.stack([O.eval_transform(ds[i][0].numpy()) for i in range(len(ds))])).cuda()
+    want = trainer.make_hash_code(trainer.model.encode_image(host)).float().cpu()
+    assert r_img.shape == (n - 7, 16) and (r_img.cpu() != want).float().mean() < 0.01       # batch-size dependent GEMM tiling only
+    ids = torch.stack([ds[i][1] for i in range(len(ds))]).cuda()
+    want_t = trainer.make_hash_code(trainer.model.encode_text(ids)).float().cpu()
+    assert (r_txt.cpu() != want_t).float().mean() < 0.01
+    maps = trainer.valid(0, k=None)
+    assert all(0.0 <= m <= 1.0 for m in maps)
+
+
 def test_bench_sharded_path_over_rccl_single_rank():
     """bench.py's multi-GPU exchange path (all_gather of histograms, all_reduce of AP sums over RCCL) on one rank:
     must run and give the same mAP as the single-process path."""
