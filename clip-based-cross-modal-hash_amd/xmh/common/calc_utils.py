@@ -39,6 +39,23 @@ def _pack_codes(B: torch.Tensor) -> R.PackedCodes:
     return p
 
 
+_label_cache = {}            # (data_ptr, version, shape, dtype, device) -> (packed masks, the label tensor itself)
+
+
+def _packed_labels(L: torch.Tensor) -> torch.Tensor:
+    """bit-packed label masks on the GPU.  valid() calls calc_map_k four times with the same two label matrices
+    (runners/base.py:312-315), usually int64 on the CPU: they are moved and packed once.  The entry keeps a reference to the
+    label tensor, so its address cannot be reused while it is cached; in-place edits bump ``_version``."""
+    key = (L.data_ptr(), L._version, tuple(L.shape), L.dtype, str(L.device))
+    hit = _label_cache.get(key)
+    if hit is None:
+        if len(_label_cache) >= 8:
+            _label_cache.clear()
+        hit = (R.pack_labels(_to_gpu(L)), L)
+        _label_cache[key] = hit
+    return hit[0]
+
+
 def _is_quantised(*packed: R.PackedCodes) -> bool:
     return not any(p.flags & 2 for p in packed)
 
@@ -68,12 +85,12 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
     if num_query == 1:
         raise IndexError("calc_map_k needs more than one query (reference squeezes the query axis, calc_utils.py:72)")
     q, r = _pack_codes(qB), _pack_codes(rB)
-    qL, rL = _to_gpu(query_L), _to_gpu(retrieval_L)
+    ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]
     if _is_quantised(q, r):
-        res = R.map_k_packed(q, r, R.pack_labels(qL), R.pack_labels(rL), qL.shape[1], k)
+        res = R.map_k_packed(q, r, ql, rl, C, k)
     else:
         from .. import dense
-        res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), R.pack_labels(qL), R.pack_labels(rL), qL.shape[1], k)
+        res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), ql, rl, C, k)
     return res.to(torch.float32).cpu().reshape(())
 
 

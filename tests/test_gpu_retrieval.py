@@ -264,6 +264,18 @@ def test_scan_masked_fallback_in_a_fresh_process():
     assert abs(outs[0] - outs[1]) < 1e-9 and abs(outs[0] - outs[2]) < 1e-9, outs
 
 
+def test_calc_map_k_label_cache_sees_in_place_edits(cu):
+    orc = _orc()
+    qB, rB, qL, rL = _synth(12, 900, 64, 10, seed=4)
+    a = float(cu.calc_map_k(qB, rB, qL, rL))
+    assert abs(a - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL
+    assert abs(float(cu.calc_map_k(qB, rB, qL, rL)) - a) < 1e-12             # second call: packed labels come from the cache
+    rL[: 450] = 0
+    rL[: 450, 3] = 1                                                          # in-place edit bumps the tensor version
+    b = float(cu.calc_map_k(qB, rB, qL, rL))
+    assert abs(b - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL and abs(a - b) > 1e-4
+
+
 def test_sharded_offsets_reproduce_unsharded(xr):
     """contiguous gallery shards + bucket offsets from the exchanged histograms == one gallery."""
     Q, R, K, C, S = 96, 7000, 64, 80, 3
