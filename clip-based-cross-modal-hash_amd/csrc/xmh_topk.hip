@@ -633,14 +633,15 @@ struct TopkPlan {
     size_t ws_bytes;
 };
 
-int ipt_for(int W) { return W >= 8 ? 4 : 8; }
+int ipt_for(int W) { return W >= 16 ? 1 : (W >= 8 ? 4 : 8); }      // long codes: one 64..256-byte record per thread and tile
 
 int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     if (Q <= 0 || R <= 0 || K <= 0) return xmh::fail(XMH_EINVAL, "topk: bad shape Q=%lld R=%lld K=%d", (long long)Q, (long long)R, K);
     if (k <= 0 || k > 1024) return xmh::fail(XMH_EINVAL, "topk: k=%d out of range (1..1024)", k);
     if (R >= (1ll << 31) - 65536) return xmh::fail(XMH_ENOTSUP, "topk: shard of %lld rows (max 2^31-1)", (long long)R);
     const int W = (K + 31) / 32;
-    if (W != 1 && W != 2 && W != 4 && W != 8) return xmh::fail(XMH_ENOTSUP, "topk: K=%d unsupported (code words must be 1,2,4 or 8)", K);
+    if (W != 1 && W != 2 && W != 4 && W != 8 && W != 16 && W != 32 && W != 64)
+        return xmh::fail(XMH_ENOTSUP, "topk: K=%d unsupported (code words must be a power of two up to 64, i.e. K <= 2048)", K);
     p->W = W;
     p->ipt = ipt_for(W);
     p->tile = kThreads * p->ipt;
@@ -735,22 +736,32 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
             hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)xmh::ceil_div(Q, 64)), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
                                target, f.t_est);                                                                           \
             const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
-            const int qn = Q >= 8 ? 8 : (Q >= 4 ? 4 : (Q >= 2 ? 2 : 1));                                                   \
+            const int qmax = WW >= 64 ? 1 : (WW >= 32 ? 2 : (WW >= 16 ? 4 : 8));      /* query words live in VGPRs */     \
+            const int qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));       \
             const unsigned gy = (unsigned)xmh::ceil_div(Q, qn);                                                            \
             int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;                                                         \
             if (fb < xmh::device_cu_count()) fb = xmh::device_cu_count();                                                  \
             if (fb > ft) fb = ft;                                                                                          \
             xmh::ProfScope prof("topk_filter", st);                                                                        \
-            if (qn == 8) hipLaunchKernelGGL((k_topk_filter<WW, II, 8>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
-            else if (qn == 4) hipLaunchKernelGGL((k_topk_filter<WW, II, 4>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
-            else if (qn == 2) hipLaunchKernelGGL((k_topk_filter<WW, II, 2>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
-            else hipLaunchKernelGGL((k_topk_filter<WW, II, 1>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            if constexpr (WW < 16) {                                                                                       \
+                if (qn == 8) hipLaunchKernelGGL((k_topk_filter<WW, II, 8>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            }                                                                                                              \
+            if constexpr (WW < 32) {                                                                                       \
+                if (qn == 4) hipLaunchKernelGGL((k_topk_filter<WW, II, 4>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            }                                                                                                              \
+            if constexpr (WW < 64) {                                                                                       \
+                if (qn == 2) hipLaunchKernelGGL((k_topk_filter<WW, II, 2>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            }                                                                                                              \
+            if (qn == 1) hipLaunchKernelGGL((k_topk_filter<WW, II, 1>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
         }
         switch (p.W) {
             case 1: XMH_FAST(1, 8) break;
             case 2: XMH_FAST(2, 8) break;
             case 4: XMH_FAST(4, 4) break;
-            default: XMH_FAST(8, 4) break;
+            case 8: XMH_FAST(8, 4) break;
+            case 16: XMH_FAST(16, 1) break;
+            case 32: XMH_FAST(32, 1) break;
+            default: XMH_FAST(64, 1) break;
         }
 #undef XMH_FAST
         XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
@@ -779,7 +790,10 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
         case 1: XMH_TOPK_LAUNCH(1, 8) break;
         case 2: XMH_TOPK_LAUNCH(2, 8) break;
         case 4: XMH_TOPK_LAUNCH(4, 8) break;
-        default: XMH_TOPK_LAUNCH(8, 4) break;
+        case 8: XMH_TOPK_LAUNCH(8, 4) break;
+        case 16: XMH_TOPK_LAUNCH(16, 1) break;
+        case 32: XMH_TOPK_LAUNCH(32, 1) break;
+        default: XMH_TOPK_LAUNCH(64, 1) break;
     }
 #undef XMH_TOPK_LAUNCH
     XMH_LAUNCH_CHECK("xmh_hamming_topk stream");

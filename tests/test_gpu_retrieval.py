@@ -361,7 +361,7 @@ def _topk_check(xr, Q, R, K, k, seed, base_index=0, dup=False):
     assert np.array_equal(d.cpu().numpy().view(np.uint16), wd)
 
 
-@pytest.mark.parametrize("Q,R,K,k", [(3, 5000, 64, 10), (8, 70000, 256, 100), (9, 33333, 128, 1), (17, 20000, 16, 50),
+@pytest.mark.parametrize("Q,R,K,k", [(3, 5000, 64, 10), (8, 70000, 256, 100), (9, 33333, 128, 1), (17, 20000, 16, 50), (5, 30000, 512, 20), (3, 9000, 2048, 7), (6, 12000, 1024, 100),
                                      (2, 100, 64, 200), (1, 1, 32, 1), (5, 2049, 64, 1024), (4, 300000, 32, 100)])
 def test_topk_matches_oracle(xr, Q, R, K, k):
     _topk_check(xr, Q, R, K, k, seed=Q + R + K + k, base_index=12345)
@@ -370,6 +370,7 @@ def test_topk_matches_oracle(xr, Q, R, K, k):
 def test_topk_heavy_ties_index_order(xr):
     _topk_check(xr, 6, 40000, 64, 100, seed=1, dup=True)
     _topk_check(xr, 3, 9000, 16, 1000, seed=2, dup=True)
+    _topk_check(xr, 3, 15000, 1024, 64, seed=3, dup=True)
 
 
 def test_topk_adversarial_descending_distance(xr):
@@ -414,6 +415,8 @@ def test_topk_robust_path_alone(xr, monkeypatch):
     _topk_check(xr, 8, 70000, 256, 100, seed=11)
     _topk_check(xr, 5, 30000, 64, 17, seed=12, dup=True)
     _topk_check(xr, 3, 3000, 16, 1000, seed=13)
+    _topk_check(xr, 4, 20000, 512, 50, seed=14, dup=True)      # long codes (TwDH lengths)
+    _topk_check(xr, 2, 7000, 2048, 9, seed=15)
 
 
 def test_topk_full_size_sample_path(xr):
