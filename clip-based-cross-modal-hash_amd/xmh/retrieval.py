@@ -59,6 +59,26 @@ class PackedCodes:
         return out
 
 
+_KERNEL_WORDS = (1, 2, 4, 8, 16, 32, 64)
+
+
+def widened(p: PackedCodes) -> PackedCodes:
+    """The ranking kernels are instantiated for power-of-two word counts.  A code of, say, 96 bits (3 words) is handed to
+    them as a 128-bit code whose extra word is zero on both sides (and flagged "exact zero" in the zero plane): binary
+    distances are unchanged, ternary half-unit distances all shift by the same constant, the ranking is the same."""
+    W = p.bits.shape[1]
+    if W in _KERNEL_WORDS or W > _KERNEL_WORDS[-1]:             # beyond 2048 bits the C side reports the limit
+        return p
+    Wp = next(w for w in _KERNEL_WORDS if w >= W)
+    bits = torch.zeros(p.n, Wp, dtype=torch.int32, device=p.bits.device)
+    bits[:, :W] = p.bits
+    zero = None
+    if p.zero is not None:
+        zero = torch.full((p.n, Wp), -1, dtype=torch.int32, device=p.bits.device)
+        zero[:, :W] = p.zero
+    return PackedCodes(bits, zero, 32 * Wp, p.flags)
+
+
 def empty_packed(n: int, K: int, device, with_zero: bool = False) -> PackedCodes:
     bits = torch.zeros(n, words(K), dtype=torch.int32, device=device)
     zero = None
@@ -180,6 +200,7 @@ class RankingScan:
         _require_cuda(q.bits, r.bits, qlab, rlab)
         if q.K != r.K:
             raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
+        q, r = widened(q), widened(r)
         self.q, self.r, self.qlab, self.rlab, self.C = q, r, qlab.contiguous(), rlab.contiguous(), Cn
         self.qz, self.rz = _both_planes(q, r)
         self.plan = scan_plan(q.n, r.n, q.K, self.qz is not None)
@@ -249,6 +270,7 @@ def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0):
         raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
     if q.zero is not None or r.zero is not None:
         raise NotImplementedError("top-k over ternary codes is not supported; quantise without zeros")
+    q, r = widened(q), widened(r)
     Q, R = q.n, r.n
     dev = q.bits.device
     need = lib.xmh_topk_ws_bytes(Q, R, q.K, k)

@@ -457,9 +457,21 @@ def test_long_and_odd_code_lengths_distance(xr, cu, K):
     assert np.array_equal(xr.hamming_dist(q, r, as_u16=True).cpu().numpy().view(np.uint16), orc.hamming_packed(_u32(q.bits), _u32(r.bits)))
     assert torch.equal(q.unpack().cpu(), qB)
     L = torch.ones(9, 3, dtype=torch.int64)
-    if K == 96:                                               # word counts that are not a power of two: ranking scan says so
-        with pytest.raises(RuntimeError, match="unsupported shape"):
-            cu.calc_map_k(qB.cuda(), rB.cuda(), L.cuda(), torch.ones(301, 3, dtype=torch.int64).cuda())
+    if K == 96:                                               # 3 words: the ranking kernels see a zero-padded 4-word code
+        gL = torch.Generator().manual_seed(7)
+        qL, rL = (torch.rand(9, 5, generator=gL) < 0.4).long(), (torch.rand(301, 5, generator=gL) < 0.4).long()
+        qL[:, 0] = 1
+        rL[::2, 0] = 1
+        for kk in (None, 11):
+            assert abs(float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), kk)) - float(orc.map_k(qB, rB, qL, rL, kk, stable=True))) < MAP_TOL
+        qT = qB.clone()
+        qT[:, ::7] = 0.0                                      # ternary on one side
+        assert abs(float(cu.calc_map_k(qT.cuda(), rB.cuda(), qL.cuda(), rL.cuda())) - float(orc.map_k(qT, rB, qL, rL, stable=True))) < MAP_TOL
+        d, i = xr.hamming_topk(q, r, 10)
+        want_d, want_i = orc.topk_packed(_u32(q.bits), _u32(r.bits), 10) if hasattr(orc, "topk_packed") else (None, None)
+        full = orc.hamming_packed(_u32(q.bits), _u32(r.bits)).astype(np.int64)
+        order = np.argsort(full * 1000 + np.arange(301)[None, :], axis=1, kind="stable")[:, :10]
+        assert np.array_equal(i.cpu().numpy(), order) and np.array_equal(d.cpu().numpy().view(np.uint16), np.take_along_axis(full, order, 1).astype(np.uint16))
     qB4, rB4 = torch.randn(9, 4096, generator=gen).sign(), torch.randn(40, 4096, generator=gen).sign()
     with pytest.raises(RuntimeError, match="at most 2048"):
         cu.calc_map_k(qB4.cuda(), rB4.cuda(), L.cuda(), torch.ones(40, 3, dtype=torch.int64).cuda())
