@@ -204,15 +204,16 @@ __device__ void feed_tile(const Sel& s, const Shared& sh, const int (&d)[IPT], c
 }
 
 struct Layout {
-    int nb, cap;
+    int nb, cap, nq;        // buckets, candidate slots per query, query slots (kQG in the stream kernel; the merge kernel keeps one
+                            // query and sorts in the slots behind it: 3 slots give the 8 KB the 1024-key sort needs)
     __host__ __device__ size_t hist_off(int q) const { return (size_t)q * nb * 4; }
-    __host__ __device__ size_t bi_off(int q) const { return (size_t)kQG * nb * 4 + (size_t)q * cap * 4; }
-    __host__ __device__ size_t bd_off(int q) const { return (size_t)kQG * nb * 4 + (size_t)kQG * cap * 4 + (size_t)q * cap * 2; }
+    __host__ __device__ size_t bi_off(int q) const { return (size_t)nq * nb * 4 + (size_t)q * cap * 4; }
+    __host__ __device__ size_t bd_off(int q) const { return (size_t)nq * nb * 4 + (size_t)nq * cap * 4 + (size_t)q * cap * 2; }
     __host__ __device__ size_t meta_off() const {
-        size_t o = (size_t)kQG * nb * 4 + (size_t)kQG * cap * 6;
+        size_t o = (size_t)nq * nb * 4 + (size_t)nq * cap * 6;
         return (o + 15) & ~(size_t)15;
     }
-    __host__ __device__ size_t bytes() const { return meta_off() + (kQG * 4 + kWaves + 2 + 2) * 4; }
+    __host__ __device__ size_t bytes() const { return meta_off() + (nq * 4 + kWaves + 2 + 2) * 4; }
 };
 
 __device__ __forceinline__ Sel sel_of(char* smem, const Layout& L, int q) {
@@ -225,14 +226,14 @@ __device__ __forceinline__ Sel sel_of(char* smem, const Layout& L, int q) {
 }
 __device__ __forceinline__ Shared shared_of(char* smem, const Layout& L) {
     Shared sh;
-    int* base = reinterpret_cast<int*>(smem + L.meta_off()) + kQG * 4;
+    int* base = reinterpret_cast<int*>(smem + L.meta_off()) + L.nq * 4;
     sh.wave_tot = base;
     sh.mask = base + kWaves;
     return sh;
 }
 
 __device__ void init_state(char* smem, const Layout& L) {
-    for (int q = 0; q < kQG; ++q) {
+    for (int q = 0; q < L.nq; ++q) {
         Sel s = sel_of(smem, L, q);
         for (int d = threadIdx.x; d < L.nb; d += kThreads) s.hist[d] = 0u;
         if (threadIdx.x == 0) {
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
     const int n = s.meta[0];
     int P = 1;
     while (P < k) P <<= 1;
-    // keys live in the (unused) buffer slots of queries 1.. of the layout: (kQG-1)*cap*4 B >= 8 KB = 1024 keys
+    // keys live in the (unused) buffer slots of queries 1.. of the layout: (nq-1)*cap*4 B >= 8 KB = 1024 keys
     unsigned long long* key = reinterpret_cast<unsigned long long*>(smem + L.bi_off(1));
     for (int p = threadIdx.x; p < P; p += kThreads)
         key[p] = p < n ? (((unsigned long long)s.bd[p] << 32) | (unsigned int)s.bi[p]) : ~0ull;
@@ -646,6 +647,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->ipt = ipt_for(W);
     p->tile = kThreads * p->ipt;
     p->L.nb = K + 1;
+    p->L.nq = kQG;
     p->L.cap = k + p->tile + 64;
     if (p->L.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d needs %zu B of LDS (max 163840)", k, K, p->L.bytes());
     if ((p->L.cap + kThreads - 1) / kThreads > 24) return xmh::fail(XMH_ENOTSUP, "topk: candidate buffer too large for the compaction segment");
@@ -659,7 +661,9 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->nblocks = (int)xmh::ceil_div(ntiles, p->tiles_per_block);
     p->nqg = (int)xmh::ceil_div(Q, kQG);
     p->Lm.nb = K + 1;
+    p->Lm.nq = 3;
     p->Lm.cap = k + kThreads * 4 + 64;
+    if (p->Lm.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d needs %zu B of LDS in the merge (max 163840)", k, K, p->Lm.bytes());
     p->robust_bytes = ((size_t)Q * p->nblocks * k * 6 + 255) & ~(size_t)255;
     size_t o = p->robust_bytes;
     auto take = [&](size_t bytes) {

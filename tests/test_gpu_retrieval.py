@@ -276,6 +276,38 @@ def test_calc_map_k_label_cache_sees_in_place_edits(cu):
     assert abs(b - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL and abs(a - b) > 1e-4
 
 
+def test_scan_fuzz_shapes_lengths_and_caps(cu, monkeypatch):
+    """40 seeded random configurations: every code length the kernels or the widening cover, ragged Q / R around the tile and
+    batch sizes, binary and ternary codes, duplicated gallery codes, mAP@all and mAP@k, both counter widths."""
+    orc = _orc()
+    rng = np.random.default_rng(2024)
+    lengths = [8, 16, 24, 32, 48, 64, 96, 128, 160, 256, 512, 1024]
+    for case in range(40):
+        K = int(rng.choice(lengths))
+        Q = int(rng.choice([2, 3, 15, 16, 17, 63, 64, 65, 100, 129]))
+        R = int(rng.choice([2, 63, 64, 65, 127, 255, 256, 257, 1000, 2049, 4100]))
+        C = int(rng.choice([1, 7, 24, 33, 80, 100]))
+        gen = torch.Generator().manual_seed(1000 + case)
+        qB, rB = torch.randn(Q, K, generator=gen).sign(), torch.randn(R, K, generator=gen).sign()
+        if case % 3 == 0 and R > 8:
+            rB = rB[torch.randint(0, 6, (R,), generator=gen)]                 # heavy ties
+        ternary = case % 4 == 1 and K <= 256
+        if ternary:
+            qB[torch.rand(Q, K, generator=gen) < 0.1] = 0.0
+            rB[torch.rand(R, K, generator=gen) < 0.1] = 0.0
+        qL, rL = (torch.rand(Q, C, generator=gen) < 0.3).long(), (torch.rand(R, C, generator=gen) < 0.3).long()
+        qL[:, 0] = 1
+        rL[0, 0] = 1
+        k = None if case % 2 else int(rng.integers(1, 40))
+        if case % 5 == 4:
+            monkeypatch.setenv("XMH_SCAN_NO_PACK32", "1")
+        else:
+            monkeypatch.delenv("XMH_SCAN_NO_PACK32", raising=False)
+        want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))
+        got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), k))
+        assert abs(got - want) < MAP_TOL, (case, Q, R, K, C, k, ternary)
+
+
 def test_sharded_offsets_reproduce_unsharded(xr):
     """contiguous gallery shards + bucket offsets from the exchanged histograms == one gallery."""
     Q, R, K, C, S = 96, 7000, 64, 80, 3
@@ -365,6 +397,17 @@ def _topk_check(xr, Q, R, K, k, seed, base_index=0, dup=False):
                                      (2, 100, 64, 200), (1, 1, 32, 1), (5, 2049, 64, 1024), (4, 300000, 32, 100)])
 def test_topk_matches_oracle(xr, Q, R, K, k):
     _topk_check(xr, Q, R, K, k, seed=Q + R + K + k, base_index=12345)
+
+
+def test_topk_fuzz(xr):
+    """30 seeded random (Q, R, K, k) incl. k > R, single rows, every kernel word count, duplicate-heavy galleries."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        K = int(rng.choice([8, 32, 64, 128, 256, 512, 1024, 2048]))
+        Q = int(rng.choice([1, 2, 7, 8, 9, 33]))
+        R = int(rng.choice([1, 5, 255, 256, 1025, 5000, 40001]))
+        k = int(rng.choice([1, 2, 10, 100, 1000]))
+        _topk_check(xr, Q, R, K, k, seed=500 + case, base_index=int(rng.integers(0, 1 << 20)), dup=case % 3 == 0 and R > 16)
 
 
 def test_topk_heavy_ties_index_order(xr):
