@@ -114,6 +114,32 @@ def test_gemm_parity_mode_splits_inexact_weights_too(ops, M, N, K):
     assert rel(b, A.cpu().double() @ Wc.cpu().double().t() + bias.cpu().double()) < 2e-6 and not torch.equal(a, b)
 
 
+def test_gemm_fuzz_shapes_modes_epilogues(ops):
+    """30 seeded random (M, N, K, mode, weight kind, epilogue): ragged tiles, K with and without the 32-alignment the MFMA fp16
+    paths need (the wrapper must fall back), fp16-exact and full-mantissa weights, strided A, in-place residual."""
+    rng = np.random.default_rng(5)
+    acts = {ops.ACT_NONE: lambda x: x, ops.ACT_QUICKGELU: lambda x: x * torch.sigmoid(1.702 * x), ops.ACT_GELU_ERF: F.gelu,
+            ops.ACT_TANH: torch.tanh, ops.ACT_RELU: torch.relu}
+    for case in range(30):
+        M, N = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        K = int(rng.choice([32, 64, 96, 160, 768, 1024])) if case % 3 else int(rng.integers(1, 300))
+        mode = ["f32", "f32x", "f16"][case % 3 if case % 7 else 0]
+        gen = g_(100 + case)
+        A = torch.randn(M, K + 8, generator=gen)[:, :K] if case % 4 == 0 else torch.randn(M, K, generator=gen)
+        W = torch.randn(N, K, generator=gen) * 0.1
+        if case % 2:
+            W = W.half().float()
+        bias = torch.randn(N, generator=gen) if case % 5 else None
+        res = torch.randn(M, N, generator=gen) if case % 3 == 1 else None
+        act = list(acts)[case % 5]
+        pre = A.double() @ W.double().t() + (0 if bias is None else bias.double())
+        want = acts[act](pre.float()).double() + (0 if res is None else res.double())
+        out = None if res is None else res.clone().cuda()
+        got = ops.gemm_nt(A.cuda(), W.cuda(), None if bias is None else bias.cuda(), residual=out, act=act, out=out, precision=ops._NAMES[mode])
+        tol = 3e-3 if mode == "f16" else 1e-5
+        assert rel(got, want) < tol, (case, M, N, K, mode)
+
+
 def test_gemm_f16_fast_mode_error_level(ops):
     A, W = torch.randn(700, 768, generator=g_(1)), (torch.randn(512, 768, generator=g_(2)) * 0.05).half().float()
     want = A.double() @ W.double().t()
@@ -157,6 +183,31 @@ def test_attention_matches_torch(ops, B, L, H, causal, masked):
     want = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, D)
     got = ops.attention(qkv.cuda(), H, causal=causal, key_padding_mask=None if kpm is None else kpm.cuda())
     assert rel(got, want) < 3e-6
+
+
+def test_attention_fuzz_lengths_and_masks(ops):
+    """25 seeded random (B, L, H, causal, padding mask): both kernels (MFMA for L <= 64, VALU above), L off the 32-row blocks."""
+    rng = np.random.default_rng(9)
+    for case in range(25):
+        B, H = int(rng.integers(1, 5)), int(rng.choice([1, 8, 12]))
+        L = int(rng.choice([1, 2, 31, 32, 33, 50, 63, 64, 65, 77, 128]))
+        causal = bool(case % 2)
+        D = 64 * H
+        qkv = torch.randn(B, L, 3 * D, generator=g_(300 + case)) * float(rng.choice([0.3, 1.0, 3.0]))
+        kpm = None
+        if case % 3 == 0 and L > 2:
+            kpm = torch.zeros(B, L, dtype=torch.bool)
+            for b in range(B):
+                kpm[b, int(rng.integers(1, L)):] = True               # key 0 always stays: no fully masked row
+        q, k, v = [t.view(B, L, H, 64).transpose(1, 2) for t in qkv.chunk(3, -1)]
+        sc = (q / 8.0) @ k.transpose(-1, -2)
+        if causal:
+            sc = sc + torch.full((L, L), float("-inf")).triu_(1)
+        if kpm is not None:
+            sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+        want = (torch.softmax(sc.double(), -1) @ v.double()).transpose(1, 2).reshape(B, L, D)
+        got = ops.attention(qkv.cuda(), H, causal=causal, key_padding_mask=None if kpm is None else kpm.cuda())
+        assert rel(got, want) < 5e-6, (case, B, L, H, causal)
 
 
 def test_patch_and_embedding_kernels(ops):
