@@ -340,6 +340,35 @@ def test_sharded_offsets_reproduce_unsharded(xr):
     assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)
 
 
+def test_sharded_fuzz_random_splits(xr):
+    """12 seeded random (Q, R, K, world, shard bounds, k): gallery split into contiguous shards of very different sizes, offsets
+    from the one-kernel form, partial AP sums added up == the unsharded scan (bit-exact caps, 1e-6 sums)."""
+    rng = np.random.default_rng(31)
+    for case in range(12):
+        K = int(rng.choice([16, 64, 128, 512]))
+        Q, R, C = int(rng.choice([5, 64, 97])), int(rng.choice([300, 2000, 5003])), int(rng.choice([3, 24, 80]))
+        world = int(rng.integers(2, 6))
+        cuts = np.sort(rng.choice(np.arange(1, R), size=world - 1, replace=False))
+        bounds = [0] + cuts.tolist() + [R]
+        k = None if case % 2 else int(rng.integers(1, 60))
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=700 + case)
+        if case % 3 == 0:
+            rB = rB[torch.randint(0, 9, (R,), generator=torch.Generator().manual_seed(case))]
+        q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+        r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+        whole = xr.RankingScan(q, ql, r, rl, C)
+        whole.histograms(False)
+        ap_ref, cap_ref = whole.ap_sums(k)
+        scans = [xr.RankingScan(q, ql, r.rows(bounds[s], bounds[s + 1]), rl[bounds[s]:bounds[s + 1]].contiguous(), C) for s in range(world)]
+        gathered = torch.stack([torch.stack(sc.histograms()) for sc in scans]).contiguous()
+        ap = torch.zeros(Q, dtype=torch.float64, device="cuda")
+        for s in range(world):
+            part, cap = scans[s].ap_sums(k, *xr.shard_offsets(gathered, s))
+            assert torch.equal(cap, cap_ref), case
+            ap += part
+        assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9), (case, Q, R, K, world, bounds)
+
+
 def test_full_size_properties_coco_shape(xr):
     """BASELINE configs[1] shape (Q 5000 x R 117218, 64 bit, 80 classes): properties that do not need the
     [Q,R] matrix, plus exact agreement with the oracle on a query subsample."""
