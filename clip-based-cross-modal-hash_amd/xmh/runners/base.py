@@ -254,16 +254,33 @@ class BaseTrainer:
                 self.pack_hash_code(image_hash, bufs[name][0], rows, flags)
                 self.pack_hash_code(text_hash, bufs[name][1], rows, flags)
 
+        # Host-to-device copies go on their own HIP stream: with pinned loader batches (pin_memory=True) the copy of the next
+        # group overlaps the forward of the current one (60 MB of fp32 pixels per 100 images is 2-3 ms of PCIe time against a
+        # 4.3 ms forward).  The compute stream waits on one event per loader batch; record_stream keeps the caching allocator
+        # from recycling a buffer the other stream still reads.
+        compute = torch.cuda.current_stream(dev)
+        copy_stream = compute if os.environ.get("XMH_NO_COPY_STREAM") else self.__dict__.setdefault("_h2d_stream", torch.cuda.Stream(device=dev))
+
+        def upload(t):
+            if t is None or t.device == dev:
+                return t
+            t = t.to(dev, non_blocking=True)
+            t.record_stream(compute)
+            return t
+
         with torch.no_grad():
             for image, text, key_padding_mask, label, index in data_loader:
                 as_list = isinstance(image, (list, tuple))
                 if pending and (as_list != isinstance(pending[0][0], list) or
                                 (not as_list and tuple(image.shape[1:]) != tuple(pending[0][0].shape[1:]))):
                     flush()                                  # stacked batches of another size / kind start a new group
-                image = [im.to(dev, non_blocking=True) for im in image] if as_list else image.to(dev, non_blocking=True)
-                pending.append((image, text.to(dev, non_blocking=True),
-                                None if key_padding_mask is None else key_padding_mask.to(dev, non_blocking=True),
-                                (index.to(dev, non_blocking=True) - lo).to(torch.int64)))
+                with torch.cuda.stream(copy_stream):
+                    image = [upload(im) for im in image] if as_list else upload(image)
+                    text, key_padding_mask, index = upload(text), upload(key_padding_mask), upload(index)
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
+                compute.wait_event(ready)                    # stream-side wait: the host does not block
+                pending.append((image, text, key_padding_mask, (index - lo).to(torch.int64)))
                 if len(pending) == fuse:
                     flush()
             flush()
