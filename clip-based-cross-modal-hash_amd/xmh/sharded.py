@@ -32,20 +32,31 @@ def shard_bounds(n: int, world: int) -> list:
 
 
 class HipShardOps:
-    """Per-shard compute through libxmh.so (the product path)."""
+    """Per-shard compute through libxmh.so (the product path).  A rank may own no gallery rows at all (fewer rows than
+    ranks): it then contributes zero histograms and zero partial sums, and derives the caps like every other rank."""
 
     def __init__(self, q, qlab, r, rlab, C):
         from . import retrieval as R
         self._R = R
-        self.scan = R.RankingScan(q, qlab, r, rlab, C)
+        self.q = R.widened(q)
+        self.empty = r.n == 0
+        self.scan = None if self.empty else R.RankingScan(q, qlab, r, rlab, C)
+        self._ternary = (q.zero is not None) or (r.zero is not None)
 
     def histograms(self):
+        if self.empty:
+            nb = self._R.scan_plan(self.q.n, 1, self.q.K, self._ternary).nbuckets
+            pair = torch.zeros(2, self.q.n, nb, dtype=torch.int32, device=self.q.bits.device)
+            return pair[0], pair[1]
         return self.scan.histograms(True)
 
     def offsets(self, hist_gathered, rank):
         return self._R.shard_offsets(hist_gathered, rank)        # one kernel instead of a dozen tensor ops
 
     def ap_sums(self, k, base_all, base_rel, nrel_total):
+        if self.empty:
+            cap = nrel_total if k is None else torch.clamp(nrel_total, max=int(k))
+            return torch.zeros(self.q.n, dtype=torch.float64, device=nrel_total.device), cap.to(torch.int32)
         return self.scan.ap_sums(k, base_all, base_rel, nrel_total)
 
     def finalize(self, ap, cap):

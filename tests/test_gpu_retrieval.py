@@ -369,6 +369,30 @@ def test_sharded_fuzz_random_splits(xr):
         assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9), (case, Q, R, K, world, bounds)
 
 
+def test_sharded_ops_with_an_empty_shard(xr):
+    """a rank without gallery rows (fewer rows than ranks) takes part in the exchange with zeros; ternary codes included so the
+    bucket count of the empty rank has to match the others'."""
+    from xmh import sharded
+    Q, R, K, C = 20, 50, 64, 7
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=5)
+    qB[:, ::9] = 0.0
+    q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+    r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+    whole = xr.RankingScan(q, ql, r, rl, C)
+    whole.histograms(False)
+    ap_ref, cap_ref = whole.ap_sums(9)
+    shards = [sharded.HipShardOps(q, ql, r.rows(0, 30), rl[:30].contiguous(), C), sharded.HipShardOps(q, ql, r.rows(30, 30), rl[30:30].contiguous(), C),
+              sharded.HipShardOps(q, ql, r.rows(30, R), rl[30:].contiguous(), C)]
+    assert shards[1].empty
+    gathered = torch.stack([torch.stack(o.histograms()) for o in shards]).contiguous()
+    ap = torch.zeros(Q, dtype=torch.float64, device="cuda")
+    for s, o in enumerate(shards):
+        part, cap = o.ap_sums(9, *o.offsets(gathered, s))
+        assert torch.equal(cap, cap_ref)
+        ap += part
+    assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)
+
+
 def test_full_size_properties_coco_shape(xr):
     """BASELINE configs[1] shape (Q 5000 x R 117218, 64 bit, 80 classes): properties that do not need the
     [Q,R] matrix, plus exact agreement with the oracle on a query subsample."""
