@@ -492,21 +492,32 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
     }
 }
 
-// t_est[q] = smallest distance whose sampled cumulative count reaches `target` (nb-1 if it never does)
+// t_est[q] = smallest distance whose sampled cumulative count reaches `target` (nb-1 if it never does).
+// One wave per query: lanes take 64 consecutive buckets, wave prefix sum, first lane over the target wins (a thread per
+// query walking the buckets one dependent load at a time took 13 us -- a quarter of the Q=1 filter pass).
 __global__ __launch_bounds__(64) void k_topk_pick(const uint32_t* __restrict__ hist, int Q, int nb, uint32_t target,
                                                   uint32_t* __restrict__ t_est) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
+    const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= Q) return;
-    uint32_t run = 0;
+    uint32_t carry = 0;
     int t = nb - 1;
-    for (int d = 0; d < nb; ++d) {
-        run += hist[(int64_t)q * nb + d];
-        if (run >= target) {
-            t = d;
+    for (int d0 = 0; d0 < nb; d0 += 64) {
+        const int d = d0 + lane;
+        const uint32_t v = d < nb ? hist[(int64_t)q * nb + d] : 0u;
+        uint32_t s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(s, o, 64);
+            if (lane >= o) s += u;
+        }
+        const unsigned long long over = __ballot(d < nb && carry + s >= target);
+        if (over) {
+            t = d0 + __ffsll((long long)over) - 1;
             break;
         }
+        carry += __shfl(s, 63, 64);
     }
-    t_est[q] = (uint32_t)t;
+    if (lane == 0) t_est[q] = (uint32_t)t;
 }
 
 // rare path of the filter, kept out of line so the streaming loop stays small: wave-aggregated append
@@ -590,9 +601,14 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
 
 // one block per query: verify, bitonic-sort the candidate keys, write the first k
 __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ cnt,
-                                                          int64_t R, int k, int64_t base_index, uint16_t* __restrict__ out_d,
+                                                          int64_t R, int k, int nb, int64_t base_index, uint16_t* __restrict__ out_d,
                                                           int32_t* __restrict__ out_i, int* __restrict__ fail) {
+    // LDS: key[kCandCap] (64-bit (distance, index) keys), surv[1024], hist[max(nb, 1024)], a few scalars
     extern __shared__ __attribute__((aligned(16))) unsigned long long key[];
+    unsigned long long* surv = key + kCandCap;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(surv + 1024);
+    const int nh = nb > 2048 ? nb : 2048;                       // >= 8 KB: reused as a list of 1024 keys
+    int* sc = reinterpret_cast<int*>(hist + nh);               // [0] d*, [1] count below d*, [2] bin*, [3] count below bin*, [4] survivors, [5] keys in the last bin
     const int q = blockIdx.x;
     const uint32_t n = cnt[q];
     const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
@@ -600,30 +616,108 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
         if (threadIdx.x == 0) atomicOr(fail, 1);
         return;
     }
-    int P = 1;
-    while (P < (int)n || P < k) P <<= 1;
-    for (int p = threadIdx.x; p < P; p += kThreads) key[p] = p < (int)n ? cand[(int64_t)q * kCandCap + p] : ~0ull;
+    const int kk = (int)want;                                   // number of real results (<= k)
+    // Radix selection instead of sorting all candidates: a distance histogram finds the bucket d* where the k-th result lies;
+    // everything below it survives, inside it a histogram over the top 10 index bits finds the bin, and only the (few)
+    // candidates of that last bin are ranked against each other.  The <= k survivors are then placed by counting.
+    for (int p = threadIdx.x; p < (int)n; p += kThreads) key[p] = cand[(int64_t)q * kCandCap + p];
+    for (int e = threadIdx.x; e < nh; e += kThreads) hist[e] = 0u;
+    if (threadIdx.x == 0) sc[4] = 0;
     __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int p = threadIdx.x; p < P / 2; p += kThreads) {
-                const int i = 2 * p - (p & (stride - 1));
-                const int j2 = i + stride;
-                const bool up = ((i & size) == 0);
-                const unsigned long long x = key[i], y = key[j2];
-                if ((x > y) == up) {
-                    key[i] = y;
-                    key[j2] = x;
-                }
+    for (int p = threadIdx.x; p < (int)n; p += kThreads) atomicAdd(&hist[(uint32_t)(key[p] >> 32)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                     // first bucket where the cumulative count reaches kk
+        const int lane = threadIdx.x;
+        uint32_t carry = 0;
+        for (int d0 = 0; d0 < nb; d0 += 64) {
+            const int d = d0 + lane;
+            uint32_t sfx = d < nb ? hist[d] : 0u;
+            const uint32_t own = sfx;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(sfx, o, 64);
+                if (lane >= o) sfx += u;
             }
-            __syncthreads();
+            const unsigned long long over = __ballot(d < nb && carry + sfx >= (uint32_t)kk);
+            if (over) {
+                const int win = __ffsll((long long)over) - 1;
+                const uint32_t below = carry + __shfl(sfx - own, win, 64);
+                if (lane == 0) { sc[0] = d0 + win; sc[1] = (int)below; }
+                break;
+            }
+            carry += __shfl(sfx, 63, 64);
         }
     }
-    for (int p = threadIdx.x; p < k; p += kThreads) {
-        const unsigned long long v = key[p];
-        const bool ok = v != ~0ull;
-        out_d[(int64_t)q * k + p] = ok ? (uint16_t)(v >> 32) : (uint16_t)kInf;
-        out_i[(int64_t)q * k + p] = ok ? (int32_t)(base_index + (int64_t)(uint32_t)v) : -1;
+    __syncthreads();
+    const uint32_t dstar = (uint32_t)sc[0];
+    const int need = kk - sc[1];                               // results still to come from bucket d*
+    int shift = 0;
+    while ((R >> shift) > 1024) ++shift;                        // 1024 index bins
+    for (int e = threadIdx.x; e < 1024; e += kThreads) hist[e] = 0u;
+    __syncthreads();
+    for (int p = threadIdx.x; p < (int)n; p += kThreads)
+        if ((uint32_t)(key[p] >> 32) == dstar) atomicAdd(&hist[(uint32_t)key[p] >> shift], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t carry = 0;
+        for (int d0 = 0; d0 < 1024; d0 += 64) {
+            uint32_t sfx = hist[d0 + lane];
+            const uint32_t own = sfx;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(sfx, o, 64);
+                if (lane >= o) sfx += u;
+            }
+            const unsigned long long over = __ballot(carry + sfx >= (uint32_t)need);
+            if (over) {
+                const int win = __ffsll((long long)over) - 1;
+                const uint32_t below = carry + __shfl(sfx - own, win, 64);
+                if (lane == 0) { sc[2] = d0 + win; sc[3] = (int)below; }
+                break;
+            }
+            carry += __shfl(sfx, 63, 64);
+        }
+    }
+    __syncthreads();
+    const uint32_t bstar = (uint32_t)sc[2];
+    const int need2 = need - sc[3];                            // results still to come from (d*, bin*)
+    unsigned long long* grp = reinterpret_cast<unsigned long long*>(hist);      // the histogram is done: its space lists the last bin
+    if (threadIdx.x == 0) sc[5] = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < (int)n; p += kThreads) {
+        const unsigned long long mine = key[p];
+        const uint32_t d = (uint32_t)(mine >> 32), bin = (uint32_t)mine >> shift;
+        if (d < dstar || (d == dstar && bin < bstar)) surv[atomicAdd(&sc[4], 1)] = mine;
+        else if (d == dstar && bin == bstar) {
+            const int g = atomicAdd(&sc[5], 1);
+            if (g < 1024) grp[g] = mine;
+        }
+    }
+    __syncthreads();
+    const int ng = sc[5];
+    if (ng > 1024) {                                           // thousands of equal distances inside one index bin: leave it to
+        if (threadIdx.x == 0) atomicOr(fail, 1);               // the robust path
+        return;
+    }
+    for (int p = threadIdx.x; p < ng; p += kThreads) {         // rank inside the last bin (usually a handful of keys)
+        const unsigned long long mine = grp[p];
+        int pos = 0;
+        for (int j = 0; j < ng; ++j) pos += grp[j] < mine;
+        if (pos < need2) surv[atomicAdd(&sc[4], 1)] = mine;
+    }
+    __syncthreads();
+    const int ns = sc[4];                                       // == kk
+    for (int p = threadIdx.x; p < ns; p += kThreads) {
+        const unsigned long long mine = surv[p];
+        int pos = 0;
+        for (int j = 0; j < ns; ++j) pos += surv[j] < mine;
+        out_d[(int64_t)q * k + pos] = (uint16_t)(mine >> 32);
+        out_i[(int64_t)q * k + pos] = (int32_t)(base_index + (int64_t)(uint32_t)mine);
+    }
+    for (int p = kk + threadIdx.x; p < k; p += kThreads) {      // shard smaller than k: unused slots
+        out_d[(int64_t)q * k + p] = (uint16_t)kInf;
+        out_i[(int64_t)q * k + p] = -1;
     }
 }
 
@@ -737,7 +831,7 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
         {                                                                                                                  \
             hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
                                per_block, f.hist);                                                                         \
-            hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)xmh::ceil_div(Q, 64)), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
+            hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
                                target, f.t_est);                                                                           \
             const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
             const int qmax = WW >= 64 ? 1 : (WW >= 32 ? 2 : (WW >= 16 ? 4 : 8));      /* query words live in VGPRs */     \
@@ -771,11 +865,11 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
         XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
         {
             auto kern = k_topk_select;
-            const size_t sel_lds = (size_t)kCandCap * 8;
+            const size_t sel_lds = (size_t)kCandCap * 8 + 1024 * 8 + (size_t)(K + 1 > 2048 ? K + 1 : 2048) * 4 + 64;
             rc = raise_lds(kern, sel_lds, "xmh_hamming_topk select");
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), sel_lds, st, (const unsigned long long*)f.cand,
-                               (const uint32_t*)f.cnt, R, k, base_index, dist, idx, f.fail);
+                               (const uint32_t*)f.cnt, R, k, K + 1, base_index, dist, idx, f.fail);
         }
         XMH_LAUNCH_CHECK("xmh_hamming_topk select");
         gate = f.fail;                                   // the robust kernels below run only if a query failed
