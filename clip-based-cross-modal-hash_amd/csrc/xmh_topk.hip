@@ -575,22 +575,28 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
                 load_rec<W>(nxt[j], rbits, it, it < R);
             }
         }
+        // all QN x IPT distances first, ONE wave vote over every comparison, and the (rare) append code behind it: per-query
+        // votes put the argument set-up of the out-of-line append on the common path (22 v_mov per query in the ISA)
+        int dd[QN][IPT];
+        bool hit_any = false;
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            int dd[IPT];                                   // word-major: IPT independent popcount chains interleave
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) dd[j] = 0;
+            for (int j = 0; j < IPT; ++j) dd[q][j] = 0;
 #pragma unroll
-            for (int x = 0; x < W; ++x)
+            for (int x = 0; x < W; ++x)                     // word-major: IPT independent popcount chains interleave
 #pragma unroll
-                for (int j = 0; j < IPT; ++j) dd[j] += __popc(cur[j].w[x] ^ qw[q][x]);
-            unsigned long long any = 0;
+                for (int j = 0; j < IPT; ++j) dd[q][j] += __popc(cur[j].w[x] ^ qw[q][x]);
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) any |= __ballot(item_of(tile, j) < R && dd[j] <= thr[q]);
-            if (!any) continue;                            // common case: no candidate in this tile for this query
+            for (int j = 0; j < IPT; ++j) hit_any |= item_of(tile, j) < R && dd[q][j] <= thr[q];
+        }
+        if (__ballot(hit_any)) {                            // uncommon: some lane holds a candidate for some query of the group
 #pragma unroll
-            for (int j = 0; j < IPT; ++j)
-                append_candidates(item_of(tile, j), dd[j], item_of(tile, j) < R && dd[j] <= thr[q], cnt + q0 + q, cand + (int64_t)(q0 + q) * kCandCap);
+            for (int q = 0; q < QN; ++q) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j)
+                    append_candidates(item_of(tile, j), dd[q][j], item_of(tile, j) < R && dd[q][j] <= thr[q], cnt + q0 + q, cand + (int64_t)(q0 + q) * kCandCap);
+            }
         }
         if (tn < ntiles) {
 #pragma unroll
