@@ -51,6 +51,13 @@ def measure(batch=100, steps=10, warmup=2, K=64):
                     fn()
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / steps
+                host = 0.0                                         # host time to enqueue one forward (GPU idle when it starts)
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    fn()
+                    host += (time.perf_counter() - t1) / 3
+                out["%s_host_enqueue_ms_%s" % (what, mode)] = host * 1e3
                 _lib.prof_enable(True)                             # separate pass: HIP events around every GEMM launch
                 for _ in range(steps):
                     fn()

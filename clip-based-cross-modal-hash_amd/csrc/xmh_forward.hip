@@ -1,0 +1,204 @@
+// Whole-tower entry points (include/xmh.h, "Whole-tower entry points"): the CLIP ViT-B/32 image forward and the text forward
+// of the reference (models/CLIP/model.py:167-268, :373-396) as one C call each.  Nothing is computed here: this file is the
+// native executor that enqueues the kernel chain of xmh_encode.hip / xmh_gemm.hip on one stream, with every intermediate in a
+// caller-owned workspace -- no allocation, no host synchronisation, so a caller may capture a call in a hipGraph.
+//
+//   image: im2col -> GEMM(conv1) -> cls/pos/ln_pre -> blocks -> ln_post -> GEMM proj   (cls row only, or every token)
+//   text : embed + pos -> blocks (causal [+ key padding]) -> ln_final -> GEMM text_projection -> EOS row
+//   block: LN, GEMM qkv, attention, GEMM out + residual, LN, GEMM c_fc + QuickGELU, GEMM c_proj + residual
+#include "xmh_common.h"
+
+namespace {
+
+constexpr int kActNone = 0, kActQuickGelu = 1;
+constexpr int kPrecParity = 0, kPrecFast = 1, kPrecExact = 2;
+constexpr float kLnEps = 1e-5f;                      // nn.LayerNorm default, as in the reference
+
+inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+// carve-out of the workspace; the same arithmetic sizes it (xmh_clip_workspace_bytes) and hands out the pieces
+struct Arena {
+    char* base;
+    size_t used = 0;
+    explicit Arena(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += align_up(count * sizeof(T));
+        return p;
+    }
+};
+
+struct BlockScratch {
+    float *h, *qkv, *a, *f;
+    void* half;                                      // fast mode: fp16 image of the current GEMM's activations
+};
+
+BlockScratch carve_blocks(Arena& ar, int64_t M, int width, int precision) {
+    BlockScratch s;
+    s.h = ar.take<float>((size_t)M * width);
+    s.qkv = ar.take<float>((size_t)M * width * 3);
+    s.a = ar.take<float>((size_t)M * width);
+    s.f = ar.take<float>((size_t)M * width * 4);
+    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)M * width * 4) : nullptr;
+    return s;
+}
+
+// act(A @ W^T + bias) (+ residual), dispatch as xmh/ops.py:gemm_nt does it
+int linear(const xmh_linear& l, const float* A, int64_t lda, const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M,
+           int act, int precision, void* half, xmh_stream_t st) {
+    const int64_t N = l.n, K = l.k;
+    if (precision == kPrecFast && l.w_hi && K % 32 == 0 && lda == K && (M * K) % 8 == 0 && half) {
+        int rc = xmh_cast_f32_to_f16(A, half, M * K, st);
+        if (rc) return rc;
+        return xmh_gemm_nt_h16(half, K, l.w_hi, K, l.bias, residual, ldr, C, ldc, M, N, K, act, st);
+    }
+    if (precision == kPrecParity && l.w_hi && K % 32 == 0 && lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0)
+        return xmh_gemm_nt_split16(A, lda, l.w_hi, l.w_lo, K, l.bias, residual, ldr, C, ldc, M, N, K, act, st);
+    if (!l.w_f32) return xmh::fail(-22, "xmh forward: a %lld x %lld layer needs its fp32 weight for this shape / precision", (long long)N, (long long)K);
+    return xmh_gemm_nt_f32(A, lda, l.w_f32, K, l.bias, residual, ldr, C, ldc, M, N, K, act, precision == kPrecFast ? 1 : 0, st);
+}
+
+int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L, int causal,
+               const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st) {
+    const int64_t M = B * L;
+    const int D = width;
+    for (int i = 0; i < layers; ++i) {
+        const xmh_clip_block& b = blocks[i];
+        if (b.qkv.n != 3 * D || b.qkv.k != D || b.out.n != D || b.out.k != D || b.fc.k != D || b.fc.n != 4 * D || b.proj.n != D || b.proj.k != b.fc.n)
+            return xmh::fail(-22, "xmh forward: block %d has layer shapes that do not fit width %d", i, D);
+        int rc = xmh_layernorm_f32(x, D, b.ln1_w, b.ln1_b, kLnEps, s.h, D, M, D, st);
+        if (rc) return rc;
+        rc = linear(b.qkv, s.h, D, nullptr, 0, s.qkv, 3 * D, M, kActNone, precision, s.half, st);
+        if (rc) return rc;
+        rc = xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
+        if (rc) return rc;
+        rc = linear(b.out, s.a, D, x, D, x, D, M, kActNone, precision, s.half, st);
+        if (rc) return rc;
+        rc = xmh_layernorm_f32(x, D, b.ln2_w, b.ln2_b, kLnEps, s.h, D, M, D, st);
+        if (rc) return rc;
+        rc = linear(b.fc, s.h, D, nullptr, 0, s.f, b.fc.n, M, kActQuickGelu, precision, s.half, st);
+        if (rc) return rc;
+        rc = linear(b.proj, s.f, b.fc.n, x, D, x, D, M, kActNone, precision, s.half, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+struct TowerScratch {
+    BlockScratch blk;
+    float *x, *cols, *patches, *row_a, *row_b, *y;
+    int32_t* eos;
+};
+
+// conv_k > 0: image tower (im2col columns + patch embeddings); out_dim > 0: all tokens go through the final LN + projection
+TowerScratch carve_tower(Arena& ar, int64_t B, int L, int width, int conv_k, int out_dim, int precision) {
+    TowerScratch t;
+    const int64_t M = B * L;
+    t.blk = carve_blocks(ar, M, width, precision);
+    t.x = ar.take<float>((size_t)M * width);
+    t.cols = conv_k > 0 ? ar.take<float>((size_t)B * (L - 1) * conv_k) : nullptr;
+    t.patches = conv_k > 0 ? ar.take<float>((size_t)B * (L - 1) * width) : nullptr;
+    t.row_a = ar.take<float>((size_t)B * width);
+    t.row_b = ar.take<float>((size_t)B * width);
+    t.y = out_dim > 0 ? ar.take<float>((size_t)M * width) : nullptr;
+    t.eos = ar.take<int32_t>((size_t)B);
+    return t;
+}
+
+int check_precision(int precision) {
+    if (precision != kPrecParity && precision != kPrecFast && precision != kPrecExact) return xmh::fail(-22, "xmh forward: precision must be 0 (parity), 1 (fast) or 2 (exact), got %d", precision);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t xmh_clip_workspace_bytes(int64_t B, int L, int width, int conv_k, int out_dim, int precision) {
+    if (B <= 0 || L <= 0 || width <= 0) return 0;
+    Arena ar(nullptr);
+    carve_tower(ar, B, L, width, conv_k, out_dim, precision);
+    return ar.used;
+}
+
+extern "C" int xmh_clip_blocks_forward(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
+                                       int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
+                                       size_t workspace_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!blocks || !x || !workspace || layers < 0 || heads <= 0 || width % heads) return xmh::fail(-22, "xmh_clip_blocks_forward: bad arguments");
+    Arena ar(workspace);
+    const BlockScratch s = carve_blocks(ar, B * L, width, precision);
+    if (ar.used > workspace_bytes)
+        return xmh::fail(-12, "xmh_clip_blocks_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    return run_blocks(blocks, layers, width, heads, x, B, L, causal, key_padding_mask, precision, s, stream);
+}
+
+extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image, int64_t B, int precision, float* out_cls,
+                                   float* out_tokens, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!w || !image || !workspace || (!out_cls && !out_tokens)) return xmh::fail(-22, "xmh_vit_b32_forward: bad arguments");
+    if (w->patch <= 0 || w->resolution % w->patch || w->heads <= 0 || w->width % w->heads)
+        return xmh::fail(-22, "xmh_vit_b32_forward: resolution %d / patch %d / width %d / heads %d do not fit", w->resolution, w->patch, w->width, w->heads);
+    const int G = w->resolution / w->patch, P = G * G, L = P + 1, D = w->width, conv_k = 3 * w->patch * w->patch;
+    if (w->conv1.n != D || w->conv1.k != conv_k || w->proj.n != w->out_dim || w->proj.k != D)
+        return xmh::fail(-22, "xmh_vit_b32_forward: conv1 / proj shapes do not fit the tower");
+    Arena ar(workspace);
+    const TowerScratch t = carve_tower(ar, B, L, D, conv_k, out_tokens ? w->out_dim : 0, precision);
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_vit_b32_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    const int64_t M = B * L;
+    int rc = xmh_im2col_patch(image, B, 3, w->resolution, w->patch, t.cols, stream);
+    if (rc) return rc;
+    rc = linear(w->conv1, t.cols, conv_k, nullptr, 0, t.patches, D, B * P, kActNone, precision, t.blk.half, stream);
+    if (rc) return rc;
+    rc = xmh_vit_assemble(t.patches, w->cls, w->pos, w->ln_pre_w, w->ln_pre_b, kLnEps, t.x, B, P, D, stream);
+    if (rc) return rc;
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 0, nullptr, precision, t.blk, stream);
+    if (rc) return rc;
+    if (out_tokens) {                                 // return_patches: ln_post + proj on every token (model.py:257-265)
+        rc = xmh_layernorm_f32(t.x, D, w->ln_post_w, w->ln_post_b, kLnEps, t.y, D, M, D, stream);
+        if (rc) return rc;
+        rc = linear(w->proj, t.y, D, nullptr, 0, out_tokens, w->out_dim, M, kActNone, precision, t.blk.half, stream);
+        if (rc) return rc;
+        if (out_cls) rc = xmh_gather_rows(out_tokens, w->out_dim, nullptr, 0, L, out_cls, B, w->out_dim, stream);
+        return rc;
+    }
+    rc = xmh_gather_rows(t.x, D, nullptr, 0, L, t.row_a, B, D, stream);       // the cls row is all the caller keeps
+    if (rc) return rc;
+    rc = xmh_layernorm_f32(t.row_a, D, w->ln_post_w, w->ln_post_b, kLnEps, t.row_b, D, B, D, stream);
+    if (rc) return rc;
+    return linear(w->proj, t.row_b, D, nullptr, 0, out_cls, w->out_dim, B, kActNone, precision, t.blk.half, stream);
+}
+
+extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
+                                int precision, float* out_eos, float* out_tokens, int32_t* eos_index, void* workspace,
+                                size_t workspace_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!w || !ids || !workspace || (!out_eos && !out_tokens)) return xmh::fail(-22, "xmh_text_forward: bad arguments");
+    if (L <= 0 || L > w->context) return xmh::fail(-22, "xmh_text_forward: %d tokens, the positional embedding holds %d", L, w->context);
+    const int D = w->width;
+    if (w->heads <= 0 || D % w->heads || w->proj.n != w->out_dim || w->proj.k != D) return xmh::fail(-22, "xmh_text_forward: shapes do not fit the tower");
+    Arena ar(workspace);
+    const TowerScratch t = carve_tower(ar, B, L, D, 0, out_tokens ? w->out_dim : 0, precision);
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_text_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    const int64_t M = B * L;
+    int32_t* eos = eos_index ? eos_index : t.eos;
+    int rc = xmh_text_embed(ids, w->tok_emb, w->pos, t.x, eos, B, L, D, w->vocab, stream);
+    if (rc) return rc;
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream);
+    if (rc) return rc;
+    if (out_tokens) {
+        rc = xmh_layernorm_f32(t.x, D, w->ln_final_w, w->ln_final_b, kLnEps, t.y, D, M, D, stream);
+        if (rc) return rc;
+        rc = linear(w->proj, t.y, D, nullptr, 0, out_tokens, w->out_dim, M, kActNone, precision, t.blk.half, stream);
+        if (rc) return rc;
+        if (out_eos) rc = xmh_gather_rows(out_tokens, w->out_dim, eos, 0, L, out_eos, B, w->out_dim, stream);
+        return rc;
+    }
+    rc = xmh_gather_rows(t.x, D, eos, 0, L, t.row_a, B, D, stream);
+    if (rc) return rc;
+    rc = xmh_layernorm_f32(t.row_a, D, w->ln_final_w, w->ln_final_b, kLnEps, t.row_b, D, B, D, stream);
+    if (rc) return rc;
+    return linear(w->proj, t.row_b, D, nullptr, 0, out_eos, w->out_dim, B, kActNone, precision, t.blk.half, stream);
+}

@@ -27,6 +27,27 @@ class ScanPlan(C.Structure):
     _fields_ = [("chunk", i64), ("nchunk", i64), ("nqtile", i64), ("qpad", i64), ("nbuckets", i64), ("ws_bytes", sz)]
 
 
+class Linear(C.Structure):                     # xmh_linear
+    _fields_ = [("w_f32", vp), ("w_hi", vp), ("w_lo", vp), ("bias", vp), ("n", i64), ("k", i64)]
+
+
+class ClipBlock(C.Structure):                  # xmh_clip_block
+    _fields_ = [("ln1_w", vp), ("ln1_b", vp), ("ln2_w", vp), ("ln2_b", vp),
+                ("qkv", Linear), ("out", Linear), ("fc", Linear), ("proj", Linear)]
+
+
+class VitWeights(C.Structure):                 # xmh_vit_weights
+    _fields_ = [("resolution", i32), ("patch", i32), ("width", i32), ("heads", i32), ("layers", i32), ("out_dim", i32),
+                ("conv1", Linear), ("cls", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp), ("ln_post_w", vp),
+                ("ln_post_b", vp), ("proj", Linear), ("blocks", C.POINTER(ClipBlock))]
+
+
+class TextWeights(C.Structure):                # xmh_text_weights
+    _fields_ = [("vocab", i32), ("context", i32), ("width", i32), ("heads", i32), ("layers", i32), ("out_dim", i32),
+                ("tok_emb", vp), ("pos", vp), ("ln_final_w", vp), ("ln_final_b", vp), ("proj", Linear),
+                ("blocks", C.POINTER(ClipBlock))]
+
+
 # name -> (restype, argtypes); mirrors include/xmh.h one to one
 PROTOTYPES = {
     "xmh_version": (i32, []),
@@ -59,6 +80,10 @@ PROTOTYPES = {
     "xmh_pair_softmax": (i32, [vp, vp, i64, i32, vp]),
     "xmh_lta_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "xmh_bitwise_hash": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "xmh_clip_workspace_bytes": (sz, [i64, i32, i32, i32, i32, i32]),
+    "xmh_clip_blocks_forward": (i32, [C.POINTER(ClipBlock), i32, i32, i32, vp, i64, i32, i32, vp, i32, vp, sz, vp]),
+    "xmh_vit_b32_forward": (i32, [C.POINTER(VitWeights), vp, i64, i32, vp, vp, vp, sz, vp]),
+    "xmh_text_forward": (i32, [C.POINTER(TextWeights), vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "xmh_row_l2normalize": (i32, [vp, i64, i32, vp, vp, vp]),
     "xmh_pairwise_l2_from_gram": (i32, [vp, vp, vp, i64, i64, vp]),
     "xmh_affine_inplace": (i32, [vp, i64, C.c_float, C.c_float, vp]),

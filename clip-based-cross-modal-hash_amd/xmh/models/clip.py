@@ -16,12 +16,21 @@ are not materialised (no in-scope caller consumes them); with ``return_patches=F
 on the cls / EOS row only (the reference projects every token and then discards all but one, :257-265)."""
 from __future__ import annotations
 
+import ctypes
+import os
+import weakref
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
+from .._lib import check, current_stream, lib, ptr
+
+# The towers run through the whole-tower entry points of libxmh.so (xmh_vit_b32_forward / xmh_text_forward /
+# xmh_clip_blocks_forward: one C call enqueues the ~150 launches).  XMH_FORWARD=ops keeps the per-primitive chain below
+# (the same kernels in the same order, enqueued from Python) -- the tests run both and compare them bit for bit.
+NATIVE_FORWARD = os.environ.get("XMH_FORWARD", "native") != "ops"
 
 
 
@@ -36,6 +45,58 @@ def _transposed(module, name: str) -> torch.Tensor:
         hit = (key, p.detach().t().contiguous())
         cache[name] = hit
     return hit[1]
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _linear_desc(W: torch.Tensor, bias, precision: int, keep: list) -> "_lib.Linear":
+    """xmh_linear of a [N, K] weight; `keep` collects every tensor whose address goes into the descriptor."""
+    W2 = ops._f32c(W.detach())
+    W2 = W2 if W2.is_contiguous() else W2.contiguous()
+    hi = lo = None
+    if precision != ops.PREC_F32X and W2.shape[1] % 32 == 0:
+        hi, lo = ops._half_weight(W2)
+    b = None if bias is None else ops._f32c(bias.detach())
+    keep.extend((W2, hi, lo, b))
+    return _lib.Linear(_addr(W2), _addr(hi), _addr(lo), _addr(b), W2.shape[0], W2.shape[1])
+
+
+def _blocks_desc(blocks, precision: int, keep: list):
+    arr = (_lib.ClipBlock * len(blocks))()
+    for i, blk in enumerate(blocks):
+        ln = [ops._f32c(t.detach()) for t in (blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias)]
+        keep.extend(ln)
+        arr[i] = _lib.ClipBlock(_addr(ln[0]), _addr(ln[1]), _addr(ln[2]), _addr(ln[3]),
+                                _linear_desc(blk.attn.in_proj_weight, blk.attn.in_proj_bias, precision, keep),
+                                _linear_desc(blk.attn.out_proj.weight, blk.attn.out_proj.bias, precision, keep),
+                                _linear_desc(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, precision, keep),
+                                _linear_desc(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, precision, keep))
+    return arr
+
+
+_descriptors = weakref.WeakKeyDictionary()     # module -> {slot: (key, descriptor, tensors it points into)}; not in the module's
+                                                # __dict__: ctypes structs holding pointers cannot be deep-copied / pickled
+
+
+def _cached_desc(module, build, params=None, slot="tower"):
+    """descriptor of `module`'s weights for the current precision, rebuilt when any parameter moved or changed in place."""
+    precision = ops._precision
+    key = (precision,) + tuple((p.data_ptr(), p._version) for p in (module.parameters() if params is None else params))
+    slots = _descriptors.setdefault(module, {})
+    hit = slots.get(slot)
+    if hit is None or hit[0] != key:
+        keep = []
+        hit = (key, build(precision, keep), keep)
+        slots[slot] = hit
+    return hit[1], precision
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    # per call, from torch's stream-aware caching allocator: the runner drives several forwards of ONE model on different
+    # streams at a time, a workspace owned by the module would be shared between them
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
 class _Block(nn.Module):
@@ -66,8 +127,18 @@ class Transformer(nn.Module):
 
     def run(self, x: torch.Tensor, causal: bool = False, key_padding_mask=None) -> torch.Tensor:
         """x [B, L, D] fp32 on the GPU; updated in place and returned."""
-        for blk in self.resblocks:
-            x = blk.run(x, causal, key_padding_mask)
+        if not NATIVE_FORWARD or not x.is_contiguous() or x.dtype != torch.float32:
+            for blk in self.resblocks:
+                x = blk.run(x, causal, key_padding_mask)
+            return x
+        B, L, D = x.shape
+        blocks, precision = _cached_desc(self, lambda prec, keep: _blocks_desc(list(self.resblocks), prec, keep))
+        kpm = None if key_padding_mask is None else key_padding_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+        nbytes = lib.xmh_clip_workspace_bytes(B, L, D, 0, 0, precision)
+        ws = _workspace(nbytes, x.device)
+        check(lib.xmh_clip_blocks_forward(blocks, len(self.resblocks), D, self.resblocks[0].heads if len(self.resblocks) else 1,
+                                          ptr(x), B, L, int(causal), ptr(kpm), precision, ptr(ws), nbytes, current_stream()),
+              "xmh_clip_blocks_forward")
         return x
 
 
@@ -84,7 +155,38 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(torch.zeros(width, output_dim))
         self.return_patches = return_patches
 
+    def _desc(self, precision: int, keep: list):
+        width = self.conv1.weight.shape[0]
+        blocks = _blocks_desc(list(self.transformer.resblocks), precision, keep)
+        small = [ops._f32c(t.detach()).contiguous() for t in (self.class_embedding, self.positional_embedding, self.ln_pre.weight,
+                                                              self.ln_pre.bias, self.ln_post.weight, self.ln_post.bias)]
+        keep.extend(small)
+        keep.append(blocks)
+        heads = self.transformer.resblocks[0].heads if len(self.transformer.resblocks) else 1
+        return _lib.VitWeights(self.input_resolution, self.patch_size, width, heads, len(self.transformer.resblocks), self.proj.shape[1],
+                               _linear_desc(self.conv1.weight.reshape(width, -1), None, precision, keep),
+                               *[_addr(t) for t in small],
+                               _linear_desc(_transposed(self, "proj"), None, precision, keep), blocks)
+
     def run(self, image: torch.Tensor):
+        if NATIVE_FORWARD:
+            image = ops._f32c(image).contiguous()
+            B, out_dim = image.shape[0], self.proj.shape[1]
+            if image.shape[1:] != (3, self.input_resolution, self.input_resolution):
+                raise ValueError("image batch is %s, the tower takes [B, 3, %d, %d]" % (tuple(image.shape), self.input_resolution, self.input_resolution))
+            L = self.positional_embedding.shape[0]
+            desc, precision = _cached_desc(self, self._desc)
+            nbytes = lib.xmh_clip_workspace_bytes(B, L, desc.width, 3 * self.patch_size ** 2, out_dim if self.return_patches else 0, precision)
+            ws = _workspace(nbytes, image.device)
+            if not self.return_patches:
+                out = torch.empty(B, out_dim, dtype=torch.float32, device=image.device)
+                check(lib.xmh_vit_b32_forward(ctypes.byref(desc), ptr(image), B, precision, ptr(out), None, ptr(ws), nbytes, current_stream()),
+                      "xmh_vit_b32_forward")
+                return out
+            y = torch.empty(B, L, out_dim, dtype=torch.float32, device=image.device)
+            check(lib.xmh_vit_b32_forward(ctypes.byref(desc), ptr(image), B, precision, None, ptr(y), ptr(ws), nbytes, current_stream()),
+                  "xmh_vit_b32_forward")
+            return y[:, 0, :], y[:, 1:, :].permute(1, 0, 2), None                                # cls, tokens (LND), attn
         B = image.shape[0]
         width = self.conv1.weight.shape[0]
         n_patches = self.positional_embedding.shape[0] - 1
@@ -124,8 +226,47 @@ class CLIP(nn.Module):
     def encode_image(self, image):
         return self.visual.run(image)
 
+    def _text_desc(self, precision: int, keep: list):
+        blocks = _blocks_desc(list(self.transformer.resblocks), precision, keep)
+        small = [ops._f32c(t.detach()).contiguous() for t in (self.token_embedding.weight, self.positional_embedding,
+                                                              self.ln_final.weight, self.ln_final.bias)]
+        keep.extend(small)
+        keep.append(blocks)
+        width = self.token_embedding.weight.shape[1]
+        heads = self.transformer.resblocks[0].heads if len(self.transformer.resblocks) else 1
+        return _lib.TextWeights(self.token_embedding.weight.shape[0], self.positional_embedding.shape[0], width, heads,
+                                len(self.transformer.resblocks), self.text_projection.shape[1], *[_addr(t) for t in small],
+                                _linear_desc(_transposed(self, "text_projection"), None, precision, keep), blocks)
+
+    def _text_params(self):
+        yield from self.transformer.parameters()
+        yield from (self.token_embedding.weight, self.positional_embedding, self.ln_final.weight, self.ln_final.bias, self.text_projection)
+
+    def _encode_text_native(self, text, key_padding_mask):
+        if not text.is_cuda:
+            raise RuntimeError("xmh ops need CUDA/HIP tensors; there is no CPU fallback")
+        ids = text.to(torch.int64).contiguous()
+        B, L = ids.shape
+        desc, precision = _cached_desc(self, self._text_desc, params=self._text_params(), slot="text")
+        out_dim = self.text_projection.shape[1]
+        kpm = None if key_padding_mask is None else key_padding_mask.to(device=ids.device, dtype=torch.uint8).contiguous()
+        nbytes = lib.xmh_clip_workspace_bytes(B, L, desc.width, 0, out_dim if self.return_patches else 0, precision)
+        ws = _workspace(nbytes, ids.device)
+        eos_tok = torch.empty(B, out_dim, dtype=torch.float32, device=ids.device)
+        if not self.return_patches:
+            check(lib.xmh_text_forward(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), None, None, ptr(ws), nbytes,
+                                       current_stream()), "xmh_text_forward")
+            return eos_tok
+        y = torch.empty(B, L, out_dim, dtype=torch.float32, device=ids.device)
+        check(lib.xmh_text_forward(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), ptr(y), None, ptr(ws), nbytes,
+                                   current_stream()), "xmh_text_forward")
+        new_mask = None if kpm is None else (kpm.bool() | (ids == self.vocab_size - 1))
+        return eos_tok, y.permute(1, 0, 2), None, new_mask
+
     @torch.no_grad()
     def encode_text(self, text, key_padding_mask=None):
+        if NATIVE_FORWARD:
+            return self._encode_text_native(text, key_padding_mask)
         x, eos = ops.text_embed(text, self.token_embedding.weight, self.positional_embedding)
         B, L, _ = x.shape
         kpm = None if key_padding_mask is None else key_padding_mask.to(x.device)

@@ -227,6 +227,59 @@ int xmh_bitwise_hash(const float* z, const float* w, const float* bias, const fl
                      int K, int D, xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole-tower entry points: the CLIP ViT / text forward of models/CLIP/model.py as ONE call each (the kernel chain of
+ * the primitives above, enqueued from C++: ~150 launches per tower without a host round trip per primitive).
+ * All pointers are device pointers except the descriptor structs themselves and `blocks`, which live on the host.
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Linear / MHA projection / `x @ proj` (W [N, K], row-major).  The three precisions of xmh_gemm_nt_* read different
+ * members: exact (2) w_f32; parity (0) w_hi (+ w_lo for weights that are not fp16-exact), else w_f32 when w_hi is NULL or the
+ * shape is unaligned; fast (1) w_hi. */
+typedef struct xmh_linear {
+    const float* w_f32;
+    const void* w_hi;      /* IEEE fp16 [N, K] = half(W), or NULL */
+    const void* w_lo;      /* IEEE fp16 [N, K] = half(W - w_hi) when W is not fp16-exact, else NULL */
+    const float* bias;     /* [N] or NULL */
+    int64_t n, k;
+} xmh_linear;
+/* ResidualAttentionBlock (models/CLIP/model.py:167-197) */
+typedef struct xmh_clip_block {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    xmh_linear qkv, out, fc, proj;
+} xmh_clip_block;
+/* VisionTransformer (models/CLIP/model.py:206-268) */
+typedef struct xmh_vit_weights {
+    int resolution, patch, width, heads, layers, out_dim;
+    xmh_linear conv1;                                  /* [width, 3*patch*patch], no bias */
+    const float *cls, *pos, *ln_pre_w, *ln_pre_b, *ln_post_w, *ln_post_b;
+    xmh_linear proj;                                   /* visual.proj TRANSPOSED: [out_dim, width] */
+    const xmh_clip_block* blocks;                      /* host array [layers] */
+} xmh_vit_weights;
+/* text tower of CLIP (models/CLIP/model.py:373-396) */
+typedef struct xmh_text_weights {
+    int vocab, context, width, heads, layers, out_dim;
+    const float *tok_emb, *pos, *ln_final_w, *ln_final_b;
+    xmh_linear proj;                                   /* text_projection TRANSPOSED: [out_dim, width] */
+    const xmh_clip_block* blocks;
+} xmh_text_weights;
+/* bytes of caller-owned scratch the calls below need for B items of L tokens at `width` (conv_k = 3*patch*patch for the image
+ * tower, 0 for text; out_dim > 0 only when all tokens are projected) */
+size_t xmh_clip_workspace_bytes(int64_t B, int L, int width, int conv_k, int out_dim, int precision);
+/* Transformer.forward (models/CLIP/model.py:200-211) on token-major x [B, L, width], in place. */
+int xmh_clip_blocks_forward(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
+                            int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
+                            size_t workspace_bytes, xmh_stream_t stream);
+/* VisionTransformer.forward: image [B, 3, r, r] f32 -> out_cls [B, out_dim]; out_tokens [B, L, out_dim] (L = patches + 1,
+ * every token through ln_post and proj: the return_patches mode, row 0 of each item = the cls feature) or NULL.
+ * Exactly one of out_cls / out_tokens may be NULL. */
+int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image, int64_t B, int precision, float* out_cls,
+                        float* out_tokens, void* workspace, size_t workspace_bytes, xmh_stream_t stream);
+/* CLIP.encode_text: ids [B, L] i64 (+ key_padding_mask [B, L] bytes or NULL) -> out_eos [B, out_dim] (feature of the EOS
+ * token, argmax(ids)); out_tokens [B, L, out_dim] or NULL; eos_index [B] i32 or NULL (the EOS positions). */
+int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
+                     int precision, float* out_eos, float* out_tokens, int32_t* eos_index, void* workspace,
+                     size_t workspace_bytes, xmh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Float similarities of common/calc_utils.py on un-quantised inputs (a-3, a-4).
  * ------------------------------------------------------------------------------------------- */
 /* y = x / ||x|| row-wise (cosine_similarity :38-49, no eps) and/or sqnorm[r] = ||x_r||^2; y or sqnorm may be NULL */

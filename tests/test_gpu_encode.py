@@ -254,6 +254,67 @@ def test_clip_towers_match_reference_goldens(ops, clip_models):
     assert rel(ttok.cpu()[keep], torch.from_numpy(g["txt_tokens_rp"])[keep]) < 1e-4
 
 
+def test_whole_tower_entry_points_equal_the_primitive_chain(ops, clip_models):
+    """xmh_vit_b32_forward / xmh_text_forward / xmh_clip_blocks_forward enqueue the same kernels in the same order as the
+    per-primitive chain driven from Python: results must be identical bit for bit, in every precision and both token modes."""
+    import xmh.models.clip as C
+    g, W, m, m_rp = clip_models
+    image, (ids, pad) = W.synth_images(3, 5).cuda(), W.synth_text(3, 5)
+    ids, pad = ids.cuda(), pad.cuda()
+
+    def run_all():
+        outs = [m.encode_image(image), m.encode_text(ids), m.encode_text(ids, key_padding_mask=pad)]
+        cls, tok, _ = m_rp.encode_image(image)
+        eos, ttok, _, nm = m_rp.encode_text(ids, key_padding_mask=pad)
+        eos2, ttok2, _, nm2 = m_rp.encode_text(ids)
+        assert nm2 is None
+        return outs + [cls, tok, eos, ttok, nm, eos2, ttok2]
+
+    before = ops.get_precision()
+    try:
+        for prec in ("f32", "f32x", "f16"):
+            ops.set_precision(prec)
+            assert C.NATIVE_FORWARD
+            native = [t.clone() for t in run_all()]
+            C.NATIVE_FORWARD = False
+            try:
+                chain = run_all()
+            finally:
+                C.NATIVE_FORWARD = True
+            for a, b in zip(native, chain):
+                assert a.shape == b.shape and torch.equal(a, b), prec
+    finally:
+        ops.set_precision(before)
+
+
+def test_whole_tower_entry_points_follow_weight_updates_and_reject_bad_input(ops, clip_models):
+    import copy
+    import xmh.models.clip as C
+    from xmh._lib import XmhError, lib
+    g, W, m, _ = clip_models
+    image = W.synth_images(4, 2).cuda()
+    m2 = copy.deepcopy(m)                                          # descriptors live outside the module: deep copies work
+    a = m2.encode_image(image)
+    with torch.no_grad():
+        m2.visual.ln_post.weight.mul_(2.0)                         # in-place update -> descriptor is rebuilt
+    b = m2.encode_image(image)
+    C.NATIVE_FORWARD = False
+    try:
+        want = m2.encode_image(image)
+    finally:
+        C.NATIVE_FORWARD = True
+    assert torch.equal(b, want) and not torch.equal(a, b)
+    with pytest.raises(ValueError):
+        m.encode_image(image[:, :, :100, :100])
+    assert lib.xmh_clip_workspace_bytes(0, 50, 768, 3072, 0, 0) == 0
+    x = torch.zeros(1, 4, 64, device="cuda")
+    blk = (C._lib.ClipBlock * 1)()
+    with pytest.raises(XmhError):                                  # precision out of range
+        C.check(lib.xmh_clip_blocks_forward(blk, 1, 64, 1, C.ptr(x), 1, 4, 0, None, 7, C.ptr(x), 16, C.current_stream()), "blocks")
+    with pytest.raises(XmhError):                                  # workspace too small
+        C.check(lib.xmh_clip_blocks_forward(blk, 1, 64, 1, C.ptr(x), 1, 4, 0, None, 0, C.ptr(x), 16, C.current_stream()), "blocks")
+
+
 def test_clip_state_dict_keys_are_the_reference_contract(clip_models):
     _, W, m, _ = clip_models
     want = set(W.synth_clip_state_dict(1).keys())
