@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int kActNone = 0, kActQuickGelu = 1;
+constexpr int kActNone = 0, kActQuickGelu = 1, kActTanh = 3, kActRelu = 4;
 constexpr int kPrecParity = 0, kPrecFast = 1, kPrecExact = 2;
 constexpr float kLnEps = 1e-5f;                      // nn.LayerNorm default, as in the reference
 
@@ -201,4 +201,82 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
     rc = xmh_layernorm_f32(t.row_a, D, w->ln_final_w, w->ln_final_b, kLnEps, t.row_b, D, B, D, stream);
     if (rc) return rc;
     return linear(w->proj, t.row_b, D, nullptr, 0, out_eos, w->out_dim, B, kActNone, precision, t.blk.half, stream);
+}
+
+// ---- hash heads ---------------------------------------------------------------------------------------
+
+extern "C" size_t xmh_head_workspace_bytes(int64_t B, int E, int precision) {
+    if (B <= 0 || E <= 0) return 0;
+    Arena ar(nullptr);
+    ar.take<float>((size_t)B * E);
+    ar.take<float>((size_t)B * E);
+    ar.take<float>((size_t)B * E * 2);                   // fc2 / fc output (2K <= 2E is checked) ...
+    ar.take<float>((size_t)B * E * 2);                   // ... and the probabilities when the caller only wants bits
+    if (precision == kPrecFast) ar.take<uint16_t>((size_t)B * E);
+    return ar.used;
+}
+
+namespace {
+struct HeadScratch {
+    float *a, *b, *wide, *wide2;
+    void* half;
+};
+int carve_head(void* workspace, size_t workspace_bytes, int64_t B, int E, int precision, HeadScratch& s, const char* who) {
+    Arena ar(workspace);
+    s.a = ar.take<float>((size_t)B * E);
+    s.b = ar.take<float>((size_t)B * E);
+    s.wide = ar.take<float>((size_t)B * E * 2);
+    s.wide2 = ar.take<float>((size_t)B * E * 2);
+    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)B * E) : nullptr;
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, ar.used);
+    return 0;
+}
+}  // namespace
+
+extern "C" int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t B, int precision, float* probs, uint32_t* bits,
+                              const int64_t* row_index, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!h || !emb || !workspace || (!probs && !bits)) return xmh::fail(-22, "xmh_head_dcmht: bad arguments");
+    const int E = (int)h->v_proj.k;
+    const int64_t K2 = h->fc2.n;
+    if (h->v_proj.n != E || h->out_proj.n != E || h->out_proj.k != E || h->fc2.k != E || K2 % 2 || K2 > 2 * E)
+        return xmh::fail(-22, "xmh_head_dcmht: layer shapes do not fit (E = %d, fc2 %lld x %lld)", E, (long long)K2, (long long)h->fc2.k);
+    HeadScratch s;
+    if (int rc = carve_head(workspace, workspace_bytes, B, E, precision, s, "xmh_head_dcmht")) return rc;
+    int rc = linear(h->v_proj, emb, E, nullptr, 0, s.a, E, B, kActNone, precision, s.half, stream);
+    if (rc) return rc;
+    rc = linear(h->out_proj, s.a, E, nullptr, 0, s.b, E, B, kActNone, precision, s.half, stream);
+    if (rc) return rc;
+    rc = h->norm_is_batchnorm ? xmh_affine_cols(s.b, h->bn_mean, h->bn_var, h->norm_w, h->norm_b, h->norm_eps, s.a, B, E, stream)
+                              : xmh_layernorm_f32(s.b, E, h->norm_w, h->norm_b, h->norm_eps, s.a, E, B, E, stream);
+    if (rc) return rc;
+    rc = linear(h->fc2, s.a, E, nullptr, 0, s.wide, K2, B, kActRelu, precision, s.half, stream);
+    if (rc) return rc;
+    float* p = probs ? probs : s.wide2;
+    rc = xmh_pair_softmax(s.wide, p, B, (int)(K2 / 2), stream);
+    if (rc) return rc;
+    if (bits) rc = xmh_pack_pair_argmax(p, B, (int)(K2 / 2), row_index, bits, stream);
+    return rc;
+}
+
+extern "C" int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, int precision, float* out, uint32_t* bits,
+                             uint32_t* zero, int32_t* flags, const int64_t* row_index, void* workspace, size_t workspace_bytes,
+                             xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!fc || !emb || (!out && !bits)) return xmh::fail(-22, "xmh_head_dsph: bad arguments");
+    const int E = (int)fc->k;
+    const int64_t K = fc->n;
+    if (K > 2 * E) return xmh::fail(-22, "xmh_head_dsph: %lld bits from %d features exceed the workspace layout", (long long)K, E);
+    HeadScratch s{};
+    if (!out || precision == kPrecFast) {
+        if (!workspace) return xmh::fail(-22, "xmh_head_dsph: workspace needed");
+        if (int rc = carve_head(workspace, workspace_bytes, B, E, precision, s, "xmh_head_dsph")) return rc;
+    }
+    float* o = out ? out : s.wide;
+    int rc = linear(*fc, emb, E, nullptr, 0, o, K, B, kActTanh, precision, s.half, stream);
+    if (rc) return rc;
+    if (bits) rc = xmh_pack_sign(o, B, (int)K, row_index, bits, zero, flags, stream);
+    return rc;
 }

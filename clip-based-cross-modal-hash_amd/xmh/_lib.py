@@ -48,6 +48,11 @@ class TextWeights(C.Structure):                # xmh_text_weights
                 ("blocks", C.POINTER(ClipBlock))]
 
 
+class DcmhtHead(C.Structure):                  # xmh_dcmht_head
+    _fields_ = [("v_proj", Linear), ("out_proj", Linear), ("norm_is_batchnorm", i32), ("norm_eps", C.c_float),
+                ("norm_w", vp), ("norm_b", vp), ("bn_mean", vp), ("bn_var", vp), ("fc2", Linear)]
+
+
 # name -> (restype, argtypes); mirrors include/xmh.h one to one
 PROTOTYPES = {
     "xmh_version": (i32, []),
@@ -84,6 +89,9 @@ PROTOTYPES = {
     "xmh_clip_blocks_forward": (i32, [C.POINTER(ClipBlock), i32, i32, i32, vp, i64, i32, i32, vp, i32, vp, sz, vp]),
     "xmh_vit_b32_forward": (i32, [C.POINTER(VitWeights), vp, i64, i32, vp, vp, vp, sz, vp]),
     "xmh_text_forward": (i32, [C.POINTER(TextWeights), vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "xmh_head_workspace_bytes": (sz, [i64, i32, i32]),
+    "xmh_head_dcmht": (i32, [C.POINTER(DcmhtHead), vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "xmh_head_dsph": (i32, [C.POINTER(Linear), vp, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "xmh_row_l2normalize": (i32, [vp, i64, i32, vp, vp, vp]),
     "xmh_pairwise_l2_from_gram": (i32, [vp, vp, vp, i64, i64, vp]),
     "xmh_affine_inplace": (i32, [vp, i64, C.c_float, C.c_float, vp]),

@@ -6,10 +6,14 @@
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
+from .._lib import check, current_stream, lib, ptr
+from . import clip as _clip
 
 
 class DCMHTModalityHash(nn.Module):
@@ -20,8 +24,36 @@ class DCMHTModalityHash(nn.Module):
         self.norm = nn.LayerNorm(inputDim) if layernorm else nn.BatchNorm1d(inputDim)
         self.fc2 = nn.Linear(inputDim, outputDim * 2)
 
+    def _desc(self, precision: int, keep: list):
+        E = self.atten.in_proj_weight.shape[1]
+        bn = isinstance(self.norm, nn.BatchNorm1d)
+        small = [ops._f32c(t.detach()).contiguous() for t in ((self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var)
+                                                              if bn else (self.norm.weight, self.norm.bias))]
+        keep.extend(small)
+        return _lib.DcmhtHead(_clip._linear_desc(self.atten.in_proj_weight[2 * E:3 * E], self.atten.in_proj_bias[2 * E:3 * E], precision, keep),
+                              _clip._linear_desc(self.atten.out_proj.weight, self.atten.out_proj.bias, precision, keep),
+                              int(bn), float(self.norm.eps), small[0].data_ptr(), small[1].data_ptr(),
+                              small[2].data_ptr() if bn else None, small[3].data_ptr() if bn else None,
+                              _clip._linear_desc(self.fc2.weight, self.fc2.bias, precision, keep))
+
+    def _native(self, data: torch.Tensor) -> torch.Tensor:
+        """xmh_head_dcmht: the five launches below from one C call."""
+        data = ops._f32c(data).contiguous()
+        B, E = data.shape
+        desc, precision = _clip._cached_desc(self, self._desc, params=list(self.parameters()) + list(self.buffers()), slot="dcmht")
+        nbytes = lib.xmh_head_workspace_bytes(B, E, precision)
+        ws = _clip._workspace(nbytes, data.device)
+        probs = torch.empty(B, self.fc2.weight.shape[0], dtype=torch.float32, device=data.device)
+        check(lib.xmh_head_dcmht(ctypes.byref(desc), ptr(data), B, precision, ptr(probs), None, None, ptr(ws), nbytes, current_stream()),
+              "xmh_head_dcmht")
+        return probs
+
     @torch.no_grad()
     def forward(self, data: torch.Tensor) -> torch.Tensor:
+        if isinstance(self.norm, nn.BatchNorm1d) and self.training:
+            raise RuntimeError("the HIP path implements eval-mode BatchNorm only (running statistics)")
+        if _clip.NATIVE_FORWARD and data.dim() == 2:
+            return self._native(data)
         E = data.shape[1]
         wv, bv = self.atten.in_proj_weight[2 * E:3 * E], self.atten.in_proj_bias[2 * E:3 * E]
         v = ops.gemm_nt(data, wv, bv)
@@ -64,6 +96,16 @@ class DSPHLinearHash(nn.Module):
     def forward(self, data):
         if self.training:
             raise RuntimeError("the HIP path is inference-only (dropout inactive)")
+        if _clip.NATIVE_FORWARD and data.dim() == 2:
+            data = ops._f32c(data).contiguous()
+            B, E = data.shape
+            desc, precision = _clip._cached_desc(self, lambda prec, keep: _clip._linear_desc(self.fc.weight, self.fc.bias, prec, keep), slot="dsph")
+            nbytes = lib.xmh_head_workspace_bytes(B, E, precision)
+            ws = _clip._workspace(nbytes, data.device)
+            out = torch.empty(B, self.fc.weight.shape[0], dtype=torch.float32, device=data.device)
+            check(lib.xmh_head_dsph(ctypes.byref(desc), ptr(data), B, precision, ptr(out), None, None, None, None, ptr(ws), nbytes,
+                                    current_stream()), "xmh_head_dsph")
+            return out
         return ops.gemm_nt(data, self.fc.weight, self.fc.bias, act=ops.ACT_TANH)
 
 

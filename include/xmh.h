@@ -279,6 +279,29 @@ int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_
                      int precision, float* out_eos, float* out_tokens, int32_t* eos_index, void* workspace,
                      size_t workspace_bytes, xmh_stream_t stream);
 
+/* One modality of the DCMHT head in eval mode (models/DCMHT/hash/hash.py:15-82): MultiheadAttention over a length-1
+ * sequence == out_proj(v_proj(x)) (softmax over one key is 1), BatchNorm1d with running statistics (image) or LayerNorm
+ * (text), fc2 + relu, softmax over each (off, on) pair. */
+typedef struct xmh_dcmht_head {
+    xmh_linear v_proj;                                 /* rows [2E, 3E) of atten.in_proj_weight / in_proj_bias */
+    xmh_linear out_proj;                               /* atten.out_proj */
+    int norm_is_batchnorm;                             /* 1: bn_mean / bn_var are used; 0: LayerNorm */
+    float norm_eps;
+    const float *norm_w, *norm_b, *bn_mean, *bn_var;
+    xmh_linear fc2;                                    /* [2K, E] */
+} xmh_dcmht_head;
+size_t xmh_head_workspace_bytes(int64_t B, int E, int precision);
+/* emb [B, E] -> probs [B, 2K] (what DCMHT.encode_image / encode_text return) and/or the packed K-bit code of
+ * DCMHTTrainer.make_hash_code (runners/DCMHT/runner.py:82-95: bit = p_on > p_off) scattered to rows row_index[i] (NULL:
+ * row i).  probs or bits may be NULL, not both. */
+int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t B, int precision, float* probs, uint32_t* bits,
+                   const int64_t* row_index, void* workspace, size_t workspace_bytes, xmh_stream_t stream);
+/* DSPH head in eval mode (models/DSPH/hash/hash.py:6-45): out = tanh(fc(emb)) [B, K]; and/or the sign-quantised packed
+ * code of BaseTrainer.make_hash_code (runners/base.py:407-410) with its zero plane and value flags (see xmh_pack_sign). */
+int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, int precision, float* out, uint32_t* bits,
+                  uint32_t* zero, int32_t* flags, const int64_t* row_index, void* workspace, size_t workspace_bytes,
+                  xmh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Float similarities of common/calc_utils.py on un-quantised inputs (a-3, a-4).
  * ------------------------------------------------------------------------------------------- */

@@ -315,6 +315,58 @@ def test_whole_tower_entry_points_follow_weight_updates_and_reject_bad_input(ops
         C.check(lib.xmh_clip_blocks_forward(blk, 1, 64, 1, C.ptr(x), 1, 4, 0, None, 0, C.ptr(x), 16, C.current_stream()), "blocks")
 
 
+def test_head_entry_points_equal_the_primitive_chain_and_pack(ops):
+    """xmh_head_dcmht / xmh_head_dsph against the per-primitive chain (bit for bit), and their packed outputs against
+    xmh_pack_pair_argmax / xmh_pack_sign on the float outputs, including the row scatter."""
+    import ctypes
+    import xmh.models.clip as C
+    from xmh import retrieval as xr
+    from xmh._lib import check, current_stream, lib, ptr
+    from xmh.models import heads
+    g = torch.Generator().manual_seed(11)
+    emb = torch.randn(37, 512, generator=g).cuda()
+    before = ops.get_precision()
+    try:
+        for prec in ("f32", "f32x", "f16"):
+            ops.set_precision(prec)
+            for K in (16, 64, 512):
+                torch.manual_seed(K)
+                layer = heads.DCMHTHashLayer(512, K).cuda().eval()
+                with torch.no_grad():
+                    layer.img_hash.norm.running_mean.normal_()
+                    layer.img_hash.norm.running_var.uniform_(0.5, 2.0)
+                dsph = heads.DSPHHashLayer(512, K).cuda().eval()
+                for mod in (layer.img_hash, layer.txt_hash, dsph.img_hash):
+                    native = mod(emb)
+                    C.NATIVE_FORWARD = False
+                    try:
+                        chain = mod(emb)
+                    finally:
+                        C.NATIVE_FORWARD = True
+                    assert torch.equal(native, chain), (prec, K, type(mod).__name__)
+                # packed outputs, scattered to permuted rows
+                perm = torch.randperm(37, generator=g).cuda()
+                nbytes = lib.xmh_head_workspace_bytes(37, 512, ops._precision)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                desc, precision = C._cached_desc(layer.txt_hash, layer.txt_hash._desc,
+                                                 params=list(layer.txt_hash.parameters()) + list(layer.txt_hash.buffers()), slot="dcmht")
+                got = xr.empty_packed(37, K, emb.device)
+                check(lib.xmh_head_dcmht(ctypes.byref(desc), ptr(emb), 37, precision, None, ptr(got.bits), ptr(perm), ptr(ws), nbytes,
+                                         current_stream()), "xmh_head_dcmht")
+                want = xr.pack_pair_argmax(layer.txt_hash(emb), row_index=perm, out=xr.empty_packed(37, K, emb.device))
+                assert torch.equal(got.bits, want.bits)
+                fdesc, precision = C._cached_desc(dsph.txt_hash, lambda p, keep: C._linear_desc(dsph.txt_hash.fc.weight, dsph.txt_hash.fc.bias, p, keep), slot="dsph")
+                got = xr.empty_packed(37, K, emb.device, with_zero=True)
+                flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+                check(lib.xmh_head_dsph(ctypes.byref(fdesc), ptr(emb), 37, precision, None, ptr(got.bits), ptr(got.zero), ptr(flags), ptr(perm),
+                                        ptr(ws), nbytes, current_stream()), "xmh_head_dsph")
+                want = xr.empty_packed(37, K, emb.device, with_zero=True)
+                xr.pack_sign(dsph.txt_hash(emb), out=want, row_index=perm, flags=torch.zeros(1, dtype=torch.int32, device="cuda"))
+                assert torch.equal(got.bits, want.bits) and torch.equal(got.zero, want.zero)
+    finally:
+        ops.set_precision(before)
+
+
 def test_clip_state_dict_keys_are_the_reference_contract(clip_models):
     _, W, m, _ = clip_models
     want = set(W.synth_clip_state_dict(1).keys())
