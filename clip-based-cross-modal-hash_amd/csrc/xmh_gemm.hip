@@ -17,6 +17,7 @@
 // Bound in practice: L2 -> CU bandwidth (each tile re-reads its operands from L2; 8.5 TB/s measured at both tile sizes,
 // DESIGN.md section 3.4), with the MFMA peak above it.  Algorithmic flops per launch = 2*M*N*K.
 #include "xmh_common.h"
+#include <string.h>
 
 #include <stdlib.h>
 
@@ -532,11 +533,11 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
             f16x8 ah[MI], al[MI], b[2];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(&sAh[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
-                al[i] = *reinterpret_cast<const f16x8*>(&sAl[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+                ah[i] = *reinterpret_cast<const f16x8*>(&sAh[buf][(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
+                al[i] = *reinterpret_cast<const f16x8*>(&sAl[buf][(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
             // low parts first: the small terms meet the accumulator before the large ones of this slab
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
             if (WS) {
                 f16x8 bl[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&sWl[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+                for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&sWl[buf][(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -665,11 +666,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             f16x8 ah[2], al[2], b[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(&cAh[(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
-                al[i] = *reinterpret_cast<const f16x8*>(&cAl[(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+                ah[i] = *reinterpret_cast<const f16x8*>(&cAh[(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
+                al[i] = *reinterpret_cast<const f16x8*>(&cAl[(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -702,6 +703,137 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
                     g.C[(int64_t)row * g.ldc + col] = v;
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// split path, A straight from global ("direct A").  Phase probes of k_gemm_nt_s16 (its k-loop with parts removed, 4096^3):
+// MFMAs alone 0.151 ms, + ds_reads and barrier 0.162 ms, everything BUT the MFMAs 0.232 ms, all of it 0.300 ms -- the
+// staging side (global -> registers -> split -> ds_write, then every wave re-reading hi and lo planes) costs more than the
+// matrix work, and a deeper prefetch does not change it: the LDS pipe carries 72 KB per 128x128 k-step against 512 clk
+// of MFMA.  Here the A operand never touches LDS: a wave owns 32 ROWS of the block tile and all of its 32*NJ columns, lane
+// (row, half) loads its row's 16-float half of the k-step (64 contiguous bytes = half a cache line, no duplication
+// between waves) directly in MFMA operand layout and splits it in registers.  The k-sum does not care which k sits in
+// which MFMA slot, so slab s takes elements [8s, 8s+8) of each lane's 16 -- the W fragments are read from LDS with the
+// same permutation (offset half*16 + s*8; the LDS-staged kernels use the same one, so all of them produce identical bits).
+// Only W goes through LDS: 8 / 16 KB written and 4 x 8 / 16 KB read per k-step (NJ = 4 / 8).
+// Outcome: +10-16 % for the three-term product (W split too: the LDS-staged kernel holds four planes), within +-4 % of the
+// LDS-staged kernels otherwise (462 vs 444 TF at 4096^3) -- taking A out of LDS moved the load to the vector memory
+// path: each of the four loads per k-step touches 32 cache lines for 1 KB.  The dispatcher uses it for the former only.
+// ---------------------------------------------------------------------------------------------------
+template <int NJ, bool WS>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_nt_s16_da(GemmArgsS g) {
+    constexpr int TBM = 128, TBN = 32 * NJ, NP = TBN / 64;     // NP staging passes of 64 W rows (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_d[];
+    _Float16* sW = smem_d;                                     // [2][TBN * LDH]
+    _Float16* sWl = sW + 2 * TBN * LDH;                        // [2][TBN * LDH], WS only
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int wm = wave * 32;
+    const int arow = m0 + wm + fr < g.M ? m0 + wm + fr : g.M - 1;                 // clamped rows are never stored
+    const float* pA = g.A + (int64_t)arow * g.lda + fh * 16;
+    const int srow = tid >> 2, scol = (tid & 3) * 8;           // W staging: 64 rows per pass, 8 halves per thread
+    // named registers, no arrays: hipcc keeps small arrays of pointers / uint4 in scratch here
+#define XMH_DROW(p) ((int64_t)(n0 + srow + 64 * (p) < g.N ? n0 + srow + 64 * (p) : g.N - 1) * g.ldw + scol)
+    const int64_t ow0 = XMH_DROW(0), ow1 = XMH_DROW(1), ow2 = NP > 2 ? XMH_DROW(2) : 0, ow3 = NP > 2 ? XMH_DROW(3) : 0;
+#undef XMH_DROW
+    float4 an0, an1, an2, an3;                                 // the next k-step's 16 floats of this lane's row
+    uint4 rw0, rw1, rw2, rw3, rl0, rl1;
+    rw2 = rw3 = rl0 = rl1 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 h0, h1, l0, l1;                                      // current k-step: packed hi / lo halves, slab 0 and slab 1
+#define XMH_DS2(f0, f1, H, L)                                                                                       \
+    {                                                                                                               \
+        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
+        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
+        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
+        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
+    }
+#define XMH_DLOAD(k0)                                                                                               \
+    {                                                                                                               \
+        an0 = reinterpret_cast<const float4*>(pA + (k0))[0]; an1 = reinterpret_cast<const float4*>(pA + (k0))[1];   \
+        an2 = reinterpret_cast<const float4*>(pA + (k0))[2]; an3 = reinterpret_cast<const float4*>(pA + (k0))[3];   \
+        rw0 = *reinterpret_cast<const uint4*>(g.W + ow0 + (k0)); rw1 = *reinterpret_cast<const uint4*>(g.W + ow1 + (k0)); \
+        if (NP > 2) { rw2 = *reinterpret_cast<const uint4*>(g.W + ow2 + (k0)); rw3 = *reinterpret_cast<const uint4*>(g.W + ow3 + (k0)); } \
+        if (WS) { rl0 = *reinterpret_cast<const uint4*>(g.Wl + ow0 + (k0)); rl1 = *reinterpret_cast<const uint4*>(g.Wl + ow1 + (k0)); }  \
+    }
+#define XMH_DWRITE(buf)                                                                                             \
+    {                                                                                                               \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + srow * LDH + scol]) = rw0;                                 \
+        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rw1;                          \
+        if (NP > 2) {                                                                                               \
+            *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 128) * LDH + scol]) = rw2;                     \
+            *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 192) * LDH + scol]) = rw3;                     \
+        }                                                                                                           \
+        if (WS) {                                                                                                   \
+            *reinterpret_cast<uint4*>(&sWl[(buf) * TBN * LDH + srow * LDH + scol]) = rl0;                            \
+            *reinterpret_cast<uint4*>(&sWl[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rl1;                     \
+        }                                                                                                           \
+    }
+    static_assert(!WS || NP == 2, "the three-term variant stages two passes of W and W_lo");
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const int nk = g.K / BKH;
+    XMH_DLOAD(0)
+    XMH_DWRITE(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        XMH_DS2(an0.x, an0.y, h0.x, l0.x) XMH_DS2(an0.z, an0.w, h0.y, l0.y) XMH_DS2(an1.x, an1.y, h0.z, l0.z) XMH_DS2(an1.z, an1.w, h0.w, l0.w)
+        XMH_DS2(an2.x, an2.y, h1.x, l1.x) XMH_DS2(an2.z, an2.w, h1.y, l1.y) XMH_DS2(an3.x, an3.y, h1.z, l1.z) XMH_DS2(an3.z, an3.w, h1.w, l1.w)
+        if (kt + 1 < nk) XMH_DLOAD((kt + 1) * BKH)
+        const _Float16* cW = sW + buf * TBN * LDH;
+        const _Float16* cL = sWl + buf * TBN * LDH;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, sl == 0 ? h0 : h1), al = __builtin_bit_cast(f16x8, sl == 0 ? l0 : l1);
+#pragma unroll
+            for (int jq = 0; jq < NJ; jq += 4) {                // four column fragments at a time (16 VGPRs of W in flight)
+                f16x8 b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[((jq + j) * 32 + fr) * LDH + fh * 16 + sl * 8]);
+                // low parts first: the small terms meet the accumulator before the large ones of this slab
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[j], acc[jq + j], 0, 0, 0);
+                if (WS) {
+                    f16x8 bl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&cL[((jq + j) * 32 + fr) * LDH + fh * 16 + sl * 8]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[jq + j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[j], acc[jq + j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            XMH_DWRITE(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef XMH_DS2
+#undef XMH_DLOAD
+#undef XMH_DWRITE
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + j * 32 + fr;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (row < g.M) {
+                float v = apply_act(acc[j][e] + bv, g.act);
+                if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
+                g.C[(int64_t)row * g.ldc + col] = v;
             }
         }
     }
@@ -829,7 +961,19 @@ extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_ha
     xmh::ProfScope prof("gemm_s16", st);
     const int64_t nwide = xmh::ceil_div(M, 128) * xmh::ceil_div(N, 256);
     static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-    if (!W_lo_half && !no_wide && K >= 768 && nwide * 2 >= 3ll * xmh::device_cu_count()) {     // 128x256 tiles: more flops per L2 byte (short K: the epilogue dominates, measured slower)
+    // direct-A kernels (k_gemm_nt_s16_da): measured +10-16 % for the three-term product (229 vs 198 TF at 20000x2304x768), within
+    // +-4 % of the LDS-staged kernels for fp16-exact weights -- used for the former; XMH_GEMM_DIRECT_A=all routes every large
+    // enough shape through them (experiments, tests), =off none
+    static const char* da_env = getenv("XMH_GEMM_DIRECT_A");
+    static const int da_mode = !da_env ? 1 : (!strcmp(da_env, "all") ? 2 : (!strcmp(da_env, "off") ? 0 : 1));
+    const int64_t n128 = xmh::ceil_div(M, 128) * xmh::ceil_div(N, 128);
+    if (da_mode == 2 && !W_lo_half && nwide * 2 >= 3ll * xmh::device_cu_count()) {
+        hipLaunchKernelGGL((k_gemm_nt_s16_da<8, false>), dim3((unsigned)nwide), dim3(kThreads), (size_t)2 * 256 * LDH * sizeof(_Float16), st, g);
+    } else if (da_mode == 2 && !W_lo_half && n128 >= xmh::device_cu_count()) {
+        hipLaunchKernelGGL((k_gemm_nt_s16_da<4, false>), dim3((unsigned)n128), dim3(kThreads), (size_t)2 * 128 * LDH * sizeof(_Float16), st, g);
+    } else if (da_mode >= 1 && W_lo_half && n128 >= xmh::device_cu_count()) {
+        hipLaunchKernelGGL((k_gemm_nt_s16_da<4, true>), dim3((unsigned)n128), dim3(kThreads), (size_t)4 * 128 * LDH * sizeof(_Float16), st, g);
+    } else if (!W_lo_half && !no_wide && K >= 768 && nwide * 2 >= 3ll * xmh::device_cu_count()) {     // 128x256 tiles: more flops per L2 byte (short K: the epilogue dominates, measured slower)
         const size_t lds = (size_t)2 * (128 + 128 + 256) * LDH * sizeof(_Float16);
         static bool raised = false;
         if (!raised) {

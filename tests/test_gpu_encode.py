@@ -367,6 +367,37 @@ def test_head_entry_points_equal_the_primitive_chain_and_pack(ops):
         ops.set_precision(before)
 
 
+_DIRECT_A_CHILD = r"""
+import os, sys, torch
+sys.path[:0] = [os.environ["XMH_ROOT"], os.path.join(os.environ["XMH_ROOT"], "clip-based-cross-modal-hash_amd")]
+from xmh import ops
+g = torch.Generator().manual_seed(5)
+for (M, N, K) in ((33000, 256, 64), (4100, 1024, 96), (40000, 768, 64), (3000, 2304, 160)):
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    for exact in (True, False):
+        W = (torch.randn(N, K, generator=g) * 0.1)
+        W = (W.half().float() if exact else W).cuda()
+        b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+        out = ops.gemm_nt(A, W, b, residual=res, act=ops.ACT_QUICKGELU)
+        rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).cuda()
+        z = A[rows].double() @ W.double().t() + b.double()
+        ref = z * torch.sigmoid(1.702 * z) + res[rows].double()
+        err = float((out[rows].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (M, N, K, exact, err)
+        ops.set_precision("f32")
+print("direct-a ok")
+"""
+
+
+def test_direct_a_split_gemm_variants_in_a_child_process(ops):
+    """XMH_GEMM_DIRECT_A=all routes fp16-exact weights through the direct-A kernels too (128x128 and 128x256 tiles; by default
+    only the three-term product uses them): ragged M / N edges, bias + residual + activation epilogue, against float64."""
+    import subprocess, sys
+    env = dict(os.environ, XMH_GEMM_DIRECT_A="all", XMH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _DIRECT_A_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "direct-a ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_clip_state_dict_keys_are_the_reference_contract(clip_models):
     _, W, m, _ = clip_models
     want = set(W.synth_clip_state_dict(1).keys())
