@@ -232,12 +232,30 @@ def main():
         t_host = (time.perf_counter() - t0) / 3
         out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
                                      "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
-    if rank == 0 and world == 1 and not args.no_encode:
+    if rank == 0 and world == 1 and not use_dist and not args.no_encode:
         try:
             import bench_encode
             out["encode"] = bench_encode.measure()
         except Exception as exc:
             out["encode"] = {"error": repr(exc)}
+    if use_dist and not args.no_encode:
+        # encode is data-parallel (every rank encodes its own shard of images / captions, no collective on the path): each rank
+        # measures its own rate at the same time as the others, the job rate is the sum
+        try:
+            import bench_encode
+            e = bench_encode.measure(warmup=5, modes=("f32",), extras=False)
+            mine = [e["images_per_s_f32"], e["captions_per_s_f32"]]
+        except Exception as exc:                                            # every rank still joins the collective below
+            mine = [float("nan"), float("nan")]
+            print("encode leg failed on rank %d: %r" % (rank, exc), file=sys.stderr)
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        lo = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        out["encode"] = {"images_per_s_f32": float(t[0]), "captions_per_s_f32": float(t[1]), "slowest_rank_images_per_s": float(lo[0]),
+                         "slowest_rank_captions_per_s": float(lo[1]), "n_gpus": world,
+                         "config": {"workload": "CLIP ViT-B/32 + DCMHT 64-bit head, batch 100 per GPU, parity mode; one replica per GPU, "
+                                                "rates summed over ranks (measured concurrently)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _, _, rB0, rL0 = rB, rL, rB, rL
         out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, args.cpu_seconds)

@@ -27,7 +27,7 @@ PEAK = {"f32": 2500.0 / 2, "f32x": 157.3, "f16": 2500.0}
 SLOTS = {"f32": ("gemm_s16", "gemm_f32"), "f32x": ("gemm_f32",), "f16": ("gemm_f16", "gemm_f32")}
 
 
-def measure(batch=100, steps=10, warmup=2, K=64):
+def measure(batch=100, steps=10, warmup=2, K=64, modes=("f32", "f32x", "f16"), extras=True):
     from xmh import _lib, ops
     from xmh import retrieval as R
     from xmh.models.dcmht import DCMHT
@@ -38,7 +38,7 @@ def measure(batch=100, steps=10, warmup=2, K=64):
     ids, _ = W.synth_text(5, batch)
     ids = ids.cuda()
     out = {}
-    for mode in ("f32", "f32x", "f16"):
+    for mode in modes:
         ops.set_precision(mode)
         try:
             for what, fn, flop in (("images", lambda: R.pack_pair_argmax(model.encode_image(image)), FLOP_IMAGE),
@@ -73,6 +73,8 @@ def measure(batch=100, steps=10, warmup=2, K=64):
                 out["%s_gemm_share_%s" % (what, mode)] = gemm_total / dt
         finally:
             ops.set_precision("f32")
+    if not extras:                                             # multi-GPU leg of bench.py: throughput of the chosen modes only
+        return out
     # the eval transform on raw photo bytes (COCO-like 375 x 500 RGB uint8, device-resident)
     from xmh.dataset.preprocess import GpuEvalTransform
     tf = GpuEvalTransform(224)

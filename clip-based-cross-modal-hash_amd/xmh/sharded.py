@@ -107,7 +107,7 @@ def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None) -> torch.T
 def map_k_sharded(ops, k: Optional[int] = None, group=None):
     """mAP over a gallery sharded across ``group``.  ``ops`` wraps this rank's shard (HipShardOps or a test
     double) and already holds the FULL (all-gathered) query set.  Returns (map float64 tensor [1], ap_sum,
-    cap) -- identical on every rank.  Per call: pass 1, ONE all-gather of the [2, Q, nb] histograms (5.2 MB/rank at
+    cap) -- identical on every rank.  Per call: pass 1, ONE all-gather of the [2, Q, nb] histograms (2.6 MB/rank at
     Q=5000, K=64), one offsets kernel, pass 2, one all-reduce of [Q] f64, one finalize kernel."""
     rank = dist.get_rank(group)
     ha, hr = ops.histograms()                                    # pass 1 on the local shard
