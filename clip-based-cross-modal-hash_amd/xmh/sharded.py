@@ -88,8 +88,8 @@ def rank_offsets(hist_all: torch.Tensor, hist_rel: torch.Tensor, rank: int):
     return base_a.to(i32).contiguous(), base_r.to(i32).contiguous(), nrel.to(i32).contiguous()
 
 
-def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None) -> torch.Tensor:
-    """both histogram planes of every shard in ONE collective -> [world, 2, Q, nb]."""
+def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None, async_op: bool = False):
+    """both histogram planes of every shard in ONE collective -> [world, 2, Q, nb] (async_op: (tensor, work handle))."""
     world = dist.get_world_size(group)
     base = getattr(ha, "_base", None)
     if base is not None and base.dim() == 3 and base.shape[0] == 2 and base.is_contiguous() and hr._base is base:
@@ -98,10 +98,28 @@ def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None) -> torch.T
         pair = torch.stack([ha, hr]).contiguous()
     out = torch.empty((world,) + tuple(pair.shape), dtype=pair.dtype, device=pair.device)
     if hasattr(dist, "all_gather_into_tensor") and pair.is_cuda:
-        dist.all_gather_into_tensor(out, pair, group=group)
+        work = dist.all_gather_into_tensor(out, pair, group=group, async_op=async_op)
     else:                                                        # gloo (CPU tests) has no all_gather_into_tensor
-        dist.all_gather(list(out.unbind(0)), pair, group=group)
-    return out
+        work = dist.all_gather(list(out.unbind(0)), pair, group=group, async_op=async_op)
+    return (out, work) if async_op else out
+
+
+class QueryBlocks:
+    """The query set cut into contiguous blocks, one shard-ops object per block (same gallery shard).  map_k_sharded then
+    pipelines them: the histogram gather of block b travels while pass 1 of block b+1 (and pass 2 of block b-1) runs, so
+    only the first gather's head and the last one's tail stay on the critical path."""
+
+    def __init__(self, blocks: Sequence):
+        if not blocks:
+            raise ValueError("QueryBlocks needs at least one block")
+        self.blocks = list(blocks)
+
+    @staticmethod
+    def split(q, qlab, r, rlab, C, nblocks: int) -> "QueryBlocks":
+        """HipShardOps per query block; q / qlab are PackedCodes / packed labels of ALL queries."""
+        n = q.n
+        bounds = shard_bounds(n, max(1, min(int(nblocks), n)))
+        return QueryBlocks([HipShardOps(q.rows(lo, hi), qlab[lo:hi], r, rlab, C) for lo, hi in zip(bounds[:-1], bounds[1:])])
 
 
 def map_k_sharded(ops, k: Optional[int] = None, group=None):
@@ -110,6 +128,8 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None):
     cap) -- identical on every rank.  Per call: pass 1, ONE all-gather of the [2, Q, nb] histograms (2.6 MB/rank at
     Q=5000, K=64), one offsets kernel, pass 2, one all-reduce of [Q] f64, one finalize kernel."""
     rank = dist.get_rank(group)
+    if isinstance(ops, QueryBlocks):
+        return _map_k_blocks(ops.blocks, k, rank, group)
     ha, hr = ops.histograms()                                    # pass 1 on the local shard
     g = _gather_hist_pair(ha, hr, group)                         # [world, 2, Q, nb]
     if hasattr(ops, "offsets"):
@@ -122,6 +142,38 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None):
         m = ops.finalize(ap, cap)
     else:
         m = (ap / cap.to(torch.float64)).mean().reshape(1)       # cap == 0 -> NaN like the reference
+    return m, ap, cap
+
+
+def _offsets(ops, g, rank):
+    if hasattr(ops, "offsets"):
+        return ops.offsets(g, rank)
+    return rank_offsets(g[:, 0], g[:, 1], rank)
+
+
+def _map_k_blocks(blocks, k, rank, group):
+    """map_k_sharded over query blocks.  Every rank issues the same collectives in the same order (one gather per block, in
+    block order, then one all-reduce).  The gathers are asynchronous: torch runs them on the process group's own stream,
+    ordered after the kernels enqueued so far, and ``wait()`` orders the current stream after them -- no host blocking on
+    RCCL."""
+    inflight = []
+    for b in blocks:
+        ha, hr = b.histograms()                                  # pass 1 of block b; its gather overlaps pass 1 of b+1
+        inflight.append(_gather_hist_pair(ha, hr, group, async_op=True))
+    aps, caps = [], []
+    for b, (g, work) in zip(blocks, inflight):
+        work.wait()
+        base_a, base_r, nrel = _offsets(b, g, rank)
+        ap, cap = b.ap_sums(k, base_a, base_r, nrel)             # pass 2 of block b; overlaps the gather of b+1
+        aps.append(ap)
+        caps.append(cap)
+    ap, cap = torch.cat(aps), torch.cat(caps)
+    dist.all_reduce(ap, op=dist.ReduceOp.SUM, group=group)       # [Q] f64
+    fin = blocks[0]
+    if hasattr(fin, "finalize"):
+        m = fin.finalize(ap, cap)
+    else:
+        m = (ap / cap.to(torch.float64)).mean().reshape(1)
     return m, ap, cap
 
 

@@ -72,6 +72,15 @@ def _worker(rank, world, port, tmp):
             assert np.array_equal(cap.numpy(), want_cap)
             assert np.allclose(ap.numpy(), want_s, rtol=1e-12)
             assert abs(float(m) - float(np.mean(want_s / want_cap))) < 1e-12
+        # the same over query blocks (asynchronous gathers, one per block): identical results
+        for nblk in (2, 3):
+            qbl = sharded.shard_bounds(Q, nblk)
+            for k in (None, 5):
+                blocks = sharded.QueryBlocks([OracleShardOps(qb[a:c], ql[a:c], rb[lo:hi], rl[lo:hi], K + 1) for a, c in zip(qbl[:-1], qbl[1:])])
+                m, ap, cap = sharded.map_k_sharded(blocks, k)
+                want_s, want_cap = co.ap(qb, ql, rb, rl, K + 1, k)
+                assert np.array_equal(cap.numpy(), want_cap) and np.allclose(ap.numpy(), want_s, rtol=1e-12)
+                assert abs(float(m) - float(np.mean(want_s / want_cap))) < 1e-12
         # top-k: per-shard exact lists gathered and merged on the host
         kk = 20
         d, i = co.topk(qb, rb[lo:hi], K + 1, kk, base_index=lo)
