@@ -49,6 +49,7 @@ struct ScanArgs {
     const uint32_t* rlab;
     int Q, R, K;
     int chunk, nchunk, nqt, qpad, nb;
+    uint4* pair_cache;      // pass 1 -> pass 2: (distance | relevant << 7) of every pair, see k_scan_hist_s; null = recompute
 };
 
 // blockIdx -> (chunk, query tile).  Block b runs on XCD b%8 (observed, speed only): pin chunk c to XCD c%8
@@ -301,7 +302,11 @@ template <int S> struct SlotGeom {
 // NW = waves per block.  1 except for S = 64 (one query per wave): there every wave would stream its whole chunk for a
 // single query -- the gallery re-read Q times from L2 / Infinity Cache (measured 6.5 TB/s, 10x the VALU time) -- so NW = 8
 // waves (8 queries) share ONE staged batch: each wave loads an eighth of it, two barriers per batch.
-template <int W, int LW, bool TERN, int S, int NW>
+// CACHE (S = 4, one wave per block, codes of at most 127 bits): pass 1 also writes one byte per pair, distance | relevant << 7,
+// so that pass 2 does not evaluate the pair again (XOR / popcount / label AND: 8 of its 15 VALU instructions) nor stage the
+// gallery: lane l of the wave of (chunk, query tile) owns 16 consecutive bytes = its 16 steps of a 64-item batch, a wave
+// stores 1 KB per batch.  Q x R bytes in all (593 MB at the COCO shape), streamed once each way while both passes are VALU-bound.
+template <int W, int LW, bool TERN, int S, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* __restrict__ chunk_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][QW] counters, then the ring
     using SG = SlotGeom<S>;
@@ -324,14 +329,25 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
 
-    auto count = [&](const R (&g)[G]) {
+    static_assert(!CACHE || (S == 4 && NW == 1 && G == 8 && NG == 2), "the pair cache is laid out for 16 steps per batch in two groups");
+    uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;                 // CACHE: this lane's 16 bytes of the current batch
+    auto count = [&](const R (&g)[G], uint32_t& wa, uint32_t& wb) {
         int d[G];
         uint32_t hit[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
 #pragma unroll
         for (int u = 0; u < G; ++u) atomicAdd(&cnt[d[u] * QW + ql], (hit[u] << 16) + 1u);
+        if (CACHE) {                                                 // append a byte per step: w = byte << 24 | w >> 8
+            // (counters indexed by that byte, so that the add is a constant 1, were tried: 3x the LDS per wave, pass 1 0.27 -> 0.31 ms)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wa = __builtin_amdgcn_alignbyte((hit[u] << 7) | (uint32_t)d[u], wa, 1);
+#pragma unroll
+            for (int u = 4; u < 8; ++u) wb = __builtin_amdgcn_alignbyte((hit[u] << 7) | (uint32_t)d[u], wb, 1);
+        }
     };
+    const int nbatch = (a.chunk + 63) >> 6;
+    uint4* crow = CACHE ? a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane : nullptr;
     auto fetch = [&](R (&g)[G], int group) {
 #pragma unroll
         for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
@@ -350,11 +366,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
 #pragma unroll
             for (int g = 0; g < NG; g += 2) {
                 if (g + 1 < NG) fetch(gb, g + 1);
-                count(ga);
+                count(ga, cw0, cw1);
                 if (g + 2 < NG) fetch(ga, g + 2);
-                if (g + 1 < NG) count(gb);
+                if (g + 1 < NG) count(gb, cw2, cw3);
             }
-        } else {
+        } else if (!CACHE) {
             for (int t = 0; t * S < cntb; ++t) {
                 R r;
                 LB::get(r, mine, t * S * LB::RS);
@@ -363,6 +379,29 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
                 rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
                 if (t * S + slot < cntb) atomicAdd(&cnt[d * QW + ql], (hit << 16) + 1u);
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QW; ++t) {                           // unrolled: the bytes land in fixed registers
+                uint32_t b = 0u;
+                if (t * S < cntb) {
+                    R r;
+                    LB::get(r, mine, t * S * LB::RS);
+                    int d;
+                    uint32_t hit;
+                    rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
+                    b = (hit << 7) | (uint32_t)d;
+                    if (t * S + slot < cntb) atomicAdd(&cnt[d * QW + ql], (hit << 16) + 1u);
+                }
+                uint32_t& w = t < 4 ? cw0 : (t < 8 ? cw1 : (t < 12 ? cw2 : cw3));
+                w = __builtin_amdgcn_alignbyte(b, w, 1);
+            }
+        }
+        if (CACHE) {                                                 // streamed once: non-temporal, so that the 593 MB do not sit dirty in
+            uint4* dst = crow + ((base - lo) >> 6) * 64;                 // L2 / Infinity Cache while the small table kernels run
+            __builtin_nontemporal_store(cw0, &dst->x);
+            __builtin_nontemporal_store(cw1, &dst->y);
+            __builtin_nontemporal_store(cw2, &dst->z);
+            __builtin_nontemporal_store(cw3, &dst->w);
         }
         cur = nxt;
     }
@@ -373,7 +412,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
 // P32 = packed 32-bit counters {lo rank_bits: rank, hi: ordinal} when both fit one word (known on the device after
 // pass 1: the launch is gated by *nrel_max, no host sync), else 64-bit {lo: rank, hi: ordinal}.  Counters are 1-based
 // and start at the global base of (bucket, chunk).  MASKED: see the header (lane-order fallback).
-template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW>
+// CACHE: the pairs come from the byte cache of pass 1 (see k_scan_hist_s) instead of the gallery.
+template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ nrel_max, int rank_bits) {
@@ -479,6 +519,50 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         for (int u = 0; u < G; ++u) LB::get(g[u], mine, (group * G + u) * S * LB::RS);
     };
 
+    if constexpr (CACHE) {
+        static_assert(S == 4 && NW == 1 && G == 8 && NG == 2 && !MASKED, "pair cache geometry");
+        // one group of 8 steps from two cache words; the returned counters are credited while the next group's adds fly
+        auto issue = [&](uint32_t wa, uint32_t wb, bool have_prev) {
+            if (have_prev) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) credit(old[u], hitp[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const uint32_t w = u < 4 ? wa : wb;
+                const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * (u & 3), 7), hit = __builtin_amdgcn_ubfe(w, 8 * (u & 3) + 7, 1);
+                hitp[u] = hit;
+                old[u] = atomicAdd(&cnt[d * QW + ql], inc(hit));      // same-address lanes resolve in lane = item order
+            }
+        };
+        const int nbatch = (a.chunk + 63) >> 6;
+        const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
+        const int nfull = (int)((hi - lo) >> 6);                     // whole batches of this chunk
+        uint4 cw = crow[0];
+        bool prev = false;
+        for (int bi = 0; bi < nfull; ++bi) {
+            const uint4 nw = crow[(int64_t)(bi + 1 < nbatch ? bi + 1 : bi) * 64];      // unconditional: counted vmcnt, no predication
+            issue(cw.x, cw.y, prev);
+            prev = true;
+            issue(cw.z, cw.w, true);
+            cw = nw;
+        }
+        if (prev) drain();
+        const int cntb = (int)(hi - lo) - nfull * 64;                // ragged last batch (cw holds its words)
+#pragma unroll
+        for (int t = 0; t < QW; ++t) {
+            if (t * S + slot < cntb) {
+                const uint32_t w = t < 4 ? cw.x : (t < 8 ? cw.y : (t < 12 ? cw.z : cw.w));
+                const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * (t & 3), 7), hit = __builtin_amdgcn_ubfe(w, 8 * (t & 3) + 7, 1);
+                const CT o = atomicAdd(&cnt[d * QW + ql], inc(hit));
+                credit(o, hit);
+            }
+        }
+#pragma unroll
+        for (int o = QW; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+        return;
+    }
     LB cur, nxt;                                                     // the next batch's global loads fly during this one
     cur.template load<NW>(a, lo, hi, lane, wave);
     bool prev = false;
@@ -634,15 +718,27 @@ constexpr int slots_for(int W, bool tern, int counter_bytes) {
     while (S < cap && nbmax * (64 / S) * counter_bytes > budget) S *= 2;
     return S;
 }
+// the pair cache of k_scan_hist_s: two code words, binary, four slots in both passes and both counter widths
+template <int W, bool TERN>
+constexpr bool kPairCacheShape = !TERN && W == 2 && slots_for(W, TERN, 4) == 4 && slots_for(W, TERN, 8) == 4;
 // waves per block: 8 where a wave owns a single query (S = 64), so that 8 queries share each staged gallery batch
 constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
 
 struct WsLayout {
-    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, total;
+    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, pair_cache, total;
 };
 
-WsLayout ws_layout(const xmh_scan_plan& p) {
+// Pair cache (k_scan_hist_s): only for the geometry it is laid out for -- binary codes of 33..64 bits (S = 4 in both passes,
+// distances below 128) -- and while Q x R bytes stay under XMH_SCAN_CACHE_MB (default 4096; 0 switches it off).
+size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
+    static const long long cap_mb = getenv("XMH_SCAN_CACHE_MB") ? atoll(getenv("XMH_SCAN_CACHE_MB")) : 4096;
+    if (ternary || K <= 32 || K > 64 || cap_mb <= 0) return 0;
+    const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * 4) * (size_t)((p.chunk + 63) / 64) * 1024;
+    return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
+}
+
+WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes) {
     WsLayout L;
     const size_t cells = (size_t)p.nchunk * p.nbuckets * p.qpad;
     size_t o = 0;
@@ -658,6 +754,7 @@ WsLayout ws_layout(const xmh_scan_plan& p) {
     L.cap = take((size_t)p.qpad * 4);
     L.gate = take(256);
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
+    L.pair_cache = take(cache_bytes);
     L.total = o;
     return L;
 }
@@ -695,7 +792,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     p->nqtile = nqt;
     p->qpad = nqt * 64;
     p->nbuckets = nb;
-    p->ws_bytes = ws_layout(*p).total;
+    p->ws_bytes = ws_layout(*p, pair_cache_bytes(*p, K, ternary != 0)).total;
     return XMH_OK;
 }
 
@@ -757,6 +854,7 @@ ScanArgs make_args(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
     a.rbits = rbits; a.rzero = rzero; a.rlab = rlab;
     a.Q = (int)Q; a.R = (int)R; a.K = K;
     a.chunk = (int)p.chunk; a.nchunk = (int)p.nchunk; a.nqt = (int)p.nqtile; a.qpad = (int)p.qpad; a.nb = (int)p.nbuckets;
+    a.pair_cache = nullptr;
     return a;
 }
 
@@ -789,7 +887,8 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     rc = check_common("xmh_hamming_hist", qbits, qzero, qlab, rbits, rzero, rlab, C, ws, ws_bytes, p);
     if (rc) return rc;
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    const WsLayout L = ws_layout(p);
+    const size_t cache_bytes = pair_cache_bytes(p, K, tern);
+    const WsLayout L = ws_layout(p, cache_bytes);
     char* base = static_cast<char*>(ws);
     uint32_t* chunk_hist = reinterpret_cast<uint32_t*>(base + L.chunk_hist);
     uint2* below = reinterpret_cast<uint2*>(base + L.below);
@@ -802,13 +901,24 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, 4);
             constexpr int NW = S == 64 ? waves_for(WW, T) : 1;
-            auto kern = k_scan_hist_s<WW, LL, T, S, NW>;
+            constexpr bool CAN = kPairCacheShape<WW, T>;           // the shape the pair cache is laid out for
             const size_t lds = (((size_t)p.nbuckets * (64 / S) + 3) & ~(size_t)3) * 4 * NW + aos_ring_bytes(WW, LL, T);
-            const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-            if (r2) return r2;
             ScanArgs as = a;
             as.nqt = a.nqt * S / NW;                              // tiles of (64/S) * NW queries
             xmh::ProfScope prof("scan_hist", st);
+            if constexpr (CAN) {
+                if (cache_bytes) {
+                    auto kc = k_scan_hist_s<WW, LL, T, S, NW, true>;
+                    const int r3 = raise_lds(kc, lds, "xmh_hamming_hist");
+                    if (r3) return r3;
+                    as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
+                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, chunk_hist);
+                    return (int)XMH_OK;
+                }
+            }
+            auto kern = k_scan_hist_s<WW, LL, T, S, NW, false>;
+            const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+            if (r2) return r2;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, chunk_hist);
             return (int)XMH_OK;
         });
@@ -842,7 +952,8 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     const int ext = (base_all != nullptr) + (base_rel != nullptr) + (nrel_total != nullptr);
     if (ext != 0 && ext != 3) return xmh::fail(XMH_EINVAL, "xmh_hamming_ap: base_all, base_rel and nrel_total go together");
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    const WsLayout L = ws_layout(p);
+    const size_t cache_bytes = pair_cache_bytes(p, K, tern);
+    const WsLayout L = ws_layout(p, cache_bytes);
     char* base = static_cast<char*>(ws);
     const uint2* below = reinterpret_cast<const uint2*>(base + L.below);
     const uint2* tot = reinterpret_cast<const uint2*>(base + L.tot);
@@ -874,14 +985,26 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             constexpr int S = slots_for(WW, T, P32 ? 4 : 8);
             constexpr int NW = S == 64 ? waves_for(WW, T) : 1;
-            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW>;
             const size_t cells = (size_t)p.nbuckets * (64 / S);
             const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : ((cells * 2 + 3) & ~(size_t)3) * 4) * NW + aos_ring_bytes(WW, LL, T);
-            const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
-            if (r2) return r2;
             ScanArgs as = a;
             as.nqt = a.nqt * S / NW;
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
+            if constexpr (kPairCacheShape<WW, T> && !MK && S == 4) {
+                if (cache_bytes) {                                    // pass 1 of this call pair left the pairs in the workspace
+                    auto kc = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, true>;
+                    const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : ((cells * 2 + 3) & ~(size_t)3) * 4) * NW;   // counters only: no gallery ring
+                    const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
+                    if (r3) return r3;
+                    as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
+                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws,
+                                       ap_part, (const uint32_t*)nrel_max, rank_bits);
+                    return (int)XMH_OK;
+                }
+            }
+            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, false>;
+            const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
+            if (r2) return r2;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
                                (const uint32_t*)nrel_max, rank_bits);
             return (int)XMH_OK;
