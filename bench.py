@@ -174,14 +174,15 @@ def main():
         scan.histograms(False)
         scan.ap_sums(None)
     torch.cuda.synchronize()
-    t_hist = _lib.prof_read("scan_hist")[0] * 1e-3
+    t_hist, n_hist = _lib.prof_read("scan_hist")
+    t_hist *= 1e-3
     # pass 2 exists in two device-gated variants (packed 32-bit / 64-bit counters); exactly one of them does the work
     t64, n64 = _lib.prof_read("scan_ap")
     t32, n32 = _lib.prof_read("scan_ap32")
     packed = t32 > t64
     ap_kernel = "k_scan_ap_s, packed 32-bit counters" if packed else "k_scan_ap_s, 64-bit counters"
-    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED, NW>: the profile summary holds both gated launches
-    ap_traffic = pmc_traffic("k_scan_ap_s<", ", 4, true, false, 1>" if packed else ", 4, false, false, 1>")
+    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED, NW, CACHE>: the profile summary holds both gated launches
+    ap_traffic = pmc_traffic("k_scan_ap_s<", ", 4, true, false, 1," if packed else ", 4, false, false, 1,")
     t_ap, n_ap = (t32, n32) if t32 > t64 else (t64, n64)
     t_ap *= 1e-3
     _lib.prof_enable(False)
@@ -192,21 +193,42 @@ def main():
     # the two-pass scheme's own tables that pass 2 reads: below[chunk][bucket][q] (8 B) + dpre[bucket][q] (8 B), written once
     # by the tiny table kernels -- this, not re-reading of inputs, is what the PMC traffic above the algorithmic bytes is
     table_bytes = (pl.nchunk + 1) * pl.nbuckets * pl.qpad * 8 + pl.nchunk * pl.qpad * 4
-    # VALU instructions per wave-item of pass 2 (ISA count): xor+bcnt per code word, and + and_or per further label word,
-    # min, address, (64-bit variant: hi-word mov), credit = 2 cvt + rcp + mul24 + fmac
-    ops_pair_ap = 2 * W + Lw + 1 + 1 + (0 if packed else 1) + 5
+    # pair cache (xmh_scan_pair_cache_bytes): pass 1 writes a byte per pair, pass 2 reads it instead of evaluating the pair again
+    cache_bytes = int(_lib.lib.xmh_scan_pair_cache_bytes(Q, Rn, K, 0))
+    cached = cache_bytes > 0
+    # VALU instructions per wave-item (ISA count).  Pair evaluation: xor+bcnt per code word, and + and_or per further label word, min.
+    ops_eval = 2 * W + Lw + 1
+    ops_pair_hist = ops_eval + 2 + (2 if cached else 0)                 # + counter address, add operand (+ cache byte, append)
+    # pass 2: (cached: two field extracts instead of the evaluation) + address (+ hi-word mov of the 64-bit variant),
+    # credit = 2 cvt + rcp + mul24 + fmac
+    ops_pair_ap = (2 if cached else ops_eval) + 1 + (0 if packed else 1) + 5
+    hist_kernel = "k_scan_hist_s (pass 1 of the fused mAP scan: pair evaluation + bucket histogram%s)" % (" + pair cache" if cached else "")
+    # the roofline object describes the DOMINANT kernel of the step: whichever pass takes longer
+    dom_is_hist = t_hist > t_ap
+    t_dom, n_dom = (t_hist, n_hist) if dom_is_hist else (t_ap, n_ap)
+    ops_dom = ops_pair_hist if dom_is_hist else ops_pair_ap
+    dom_traffic = pmc_traffic("k_scan_hist_s<", "") if dom_is_hist else ap_traffic
     roofline = {
-        "kernel": "%s (pass 2 of the fused mAP scan), HIP events around the launch, %d launches" % (ap_kernel, n_ap),
-        "bound": "hbm", "achieved": alg_bytes / t_ap / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg_bytes / t_ap / 1e9 / HBM_PEAK_GBS, "traffic": (ap_traffic or {}).get("bytes"),
-        "traffic_detail": ap_traffic,
-        "algorithmic_bytes": alg_bytes, "workspace_table_bytes": table_bytes, "avg_launch_ms": t_ap * 1e3,
-        "valu": {"lane_ops_per_pair": ops_pair_ap, "achieved": Q * Rn * ops_pair_ap / t_ap / 1e9,
-                 "peak": VALU_PEAK_GLOPS, "unit": "G lane-ops/s", "frac": Q * Rn * ops_pair_ap / t_ap / 1e9 / VALU_PEAK_GLOPS},
+        "kernel": "%s, HIP events around the launch, %d launches" % (hist_kernel if dom_is_hist else ap_kernel + " (pass 2 of the fused mAP scan)", n_dom),
+        "bound": "hbm", "achieved": alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": (dom_traffic or {}).get("bytes"),
+        "traffic_detail": dom_traffic,
+        "algorithmic_bytes": alg_bytes, "workspace_table_bytes": table_bytes, "pair_cache_bytes": cache_bytes, "avg_launch_ms": t_dom * 1e3,
+        "valu": {"lane_ops_per_pair": ops_dom, "achieved": Q * Rn * ops_dom / t_dom / 1e9,
+                 "peak": VALU_PEAK_GLOPS, "unit": "G lane-ops/s", "frac": Q * Rn * ops_dom / t_dom / 1e9 / VALU_PEAK_GLOPS},
         "note": "Q=5000 queries share every gallery byte: this launch is VALU-bound (SURVEY H5), HBM fraction is "
-                "reported as the contract asks; the HBM-bound regime is in roofline_hbm_regime",
-        "pass1_avg_launch_ms": t_hist * 1e3,
+                "reported as the contract asks; the HBM-bound regime is in roofline_hbm_regime.  PMC traffic includes the "
+                "scheme's own tables and the pair cache (one byte per pair, written by pass 1, read by pass 2)",
+        "pass1_avg_launch_ms": t_hist * 1e3, "pass2_avg_launch_ms": t_ap * 1e3,
+        "pass1_valu": {"lane_ops_per_pair": ops_pair_hist, "frac": Q * Rn * ops_pair_hist / t_hist / 1e9 / VALU_PEAK_GLOPS},
+        "pass2_valu": {"lane_ops_per_pair": ops_pair_ap, "frac": Q * Rn * ops_pair_ap / t_ap / 1e9 / VALU_PEAK_GLOPS},
     }
+    if ap_traffic is not None:
+        # the cached pass 2 streams the pair cache with 16-byte loads per lane, which FETCH_SIZE counts at half on gfx950
+        # (MI355X_MICROARCH.md, HBM section); its 8-byte table reads are counted in full
+        corr = cache_bytes / 2 if cached else 0
+        roofline["pass2_traffic"] = {"bytes": ap_traffic["bytes"] + corr, "fetch_raw": ap_traffic["fetch_raw"], "write_raw": ap_traffic["write_raw"],
+                                     "wide_read_correction_bytes": corr, "source": ap_traffic["source"]}
 
     out = {
         "metric": "Hamming query x gallery pairs/sec (fused mAP@all pass, DCMHT COCO-shaped 64-bit)",

@@ -876,6 +876,12 @@ extern "C" int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_
     return make_plan(Q, R, K, ternary, plan_host);
 }
 
+extern "C" size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary) {
+    xmh_scan_plan p;
+    if (make_plan(Q, R, K, ternary, &p)) return 0;
+    return pair_cache_bytes(p, K, ternary != 0);
+}
+
 extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,
                                 const uint32_t* rbits, const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R,
                                 int K, int C, void* ws, size_t ws_bytes, uint32_t* hist_all, uint32_t* hist_rel,
