@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
 
-    static_assert(!CACHE || (S == 4 && NW == 1 && G == 8 && NG == 2), "the pair cache is laid out for 16 steps per batch in two groups");
+    // cache entry: EB bits = distance | relevant << (EB-1); a lane's QW steps of a batch fill exactly 16 bytes (8-bit entries at
+    // 16 steps: codes up to 64 bits; 16-bit entries at 8 steps: 65..256 bits), each group of G steps two dwords
+    constexpr int EB = 128 / QW, EPW = 32 / EB;
+    static_assert(!CACHE || (NW == 1 && (S == 4 || S == 8) && NG == 2 && G == 2 * EPW), "pair cache geometry: 16 bytes per lane and batch, two groups");
     uint32_t cw0 = 0u, cw1 = 0u, cw2 = 0u, cw3 = 0u;                 // CACHE: this lane's 16 bytes of the current batch
     auto count = [&](const R (&g)[G], uint32_t& wa, uint32_t& wb) {
         int d[G];
@@ -338,12 +341,12 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
         for (int u = 0; u < G; ++u) rec_eval01<W, LW, TERN>(qr, g[u], a.K, d[u], hit[u]);
 #pragma unroll
         for (int u = 0; u < G; ++u) atomicAdd(&cnt[d[u] * QW + ql], (hit[u] << 16) + 1u);
-        if (CACHE) {                                                 // append a byte per step: w = byte << 24 | w >> 8
+        if (CACHE) {                                                 // append an entry per step: w = entry << (32 - EB) | w >> EB
             // (counters indexed by that byte, so that the add is a constant 1, were tried: 3x the LDS per wave, pass 1 0.27 -> 0.31 ms)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wa = __builtin_amdgcn_alignbyte((hit[u] << 7) | (uint32_t)d[u], wa, 1);
+            for (int u = 0; u < G / 2; ++u) wa = __builtin_amdgcn_alignbyte((hit[u] << (EB - 1)) | (uint32_t)d[u], wa, EB / 8);
 #pragma unroll
-            for (int u = 4; u < 8; ++u) wb = __builtin_amdgcn_alignbyte((hit[u] << 7) | (uint32_t)d[u], wb, 1);
+            for (int u = G / 2; u < G; ++u) wb = __builtin_amdgcn_alignbyte((hit[u] << (EB - 1)) | (uint32_t)d[u], wb, EB / 8);
         }
     };
     const int nbatch = (a.chunk + 63) >> 6;
@@ -389,11 +392,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
                     int d;
                     uint32_t hit;
                     rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                    b = (hit << 7) | (uint32_t)d;
+                    b = (hit << (EB - 1)) | (uint32_t)d;
                     if (t * S + slot < cntb) atomicAdd(&cnt[d * QW + ql], (hit << 16) + 1u);
                 }
-                uint32_t& w = t < 4 ? cw0 : (t < 8 ? cw1 : (t < 12 ? cw2 : cw3));
-                w = __builtin_amdgcn_alignbyte(b, w, 1);
+                uint32_t& w = t < EPW ? cw0 : (t < 2 * EPW ? cw1 : (t < 3 * EPW ? cw2 : cw3));
+                w = __builtin_amdgcn_alignbyte(b, w, EB / 8);
             }
         }
         if (CACHE) {                                                 // streamed once: non-temporal, so that the 593 MB do not sit dirty in
@@ -520,7 +523,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
     };
 
     if constexpr (CACHE) {
-        static_assert(S == 4 && NW == 1 && G == 8 && NG == 2 && !MASKED, "pair cache geometry");
+        constexpr int EB = 128 / QW, EPW = 32 / EB;                   // entry bits, entries per word (see k_scan_hist_s)
+        static_assert(NW == 1 && (S == 4 || S == 8) && NG == 2 && G == 2 * EPW && !MASKED, "pair cache geometry");
         // one group of 8 steps from two cache words; the returned counters are credited while the next group's adds fly
         auto issue = [&](uint32_t wa, uint32_t wb, bool have_prev) {
             if (have_prev) {
@@ -529,8 +533,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                const uint32_t w = u < 4 ? wa : wb;
-                const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * (u & 3), 7), hit = __builtin_amdgcn_ubfe(w, 8 * (u & 3) + 7, 1);
+                const uint32_t w = u < EPW ? wa : wb;
+                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (u % EPW), EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (u % EPW) + EB - 1, 1);
                 hitp[u] = hit;
                 old[u] = atomicAdd(&cnt[d * QW + ql], inc(hit));      // same-address lanes resolve in lane = item order
             }
@@ -552,8 +556,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
 #pragma unroll
         for (int t = 0; t < QW; ++t) {
             if (t * S + slot < cntb) {
-                const uint32_t w = t < 4 ? cw.x : (t < 8 ? cw.y : (t < 12 ? cw.z : cw.w));
-                const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * (t & 3), 7), hit = __builtin_amdgcn_ubfe(w, 8 * (t & 3) + 7, 1);
+                const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
+                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (t % EPW), EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + EB - 1, 1);
                 const CT o = atomicAdd(&cnt[d * QW + ql], inc(hit));
                 credit(o, hit);
             }
@@ -720,7 +724,8 @@ constexpr int slots_for(int W, bool tern, int counter_bytes) {
 }
 // the pair cache of k_scan_hist_s: two code words, binary, four slots in both passes and both counter widths
 template <int W, bool TERN>
-constexpr bool kPairCacheShape = !TERN && W == 2 && slots_for(W, TERN, 4) == 4 && slots_for(W, TERN, 8) == 4;
+constexpr bool kPairCacheShape = !TERN && (W == 2 || W == 4 || W == 8) && slots_for(W, TERN, 4) == (W == 2 ? 4 : 8) &&
+                                 slots_for(W, TERN, 8) == (W == 2 ? 4 : 8);
 // waves per block: 8 where a wave owns a single query (S = 64), so that 8 queries share each staged gallery batch
 constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
@@ -729,12 +734,13 @@ struct WsLayout {
     size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, pair_cache, total;
 };
 
-// Pair cache (k_scan_hist_s): only for the geometry it is laid out for -- binary codes of 33..64 bits (S = 4 in both passes,
-// distances below 128) -- and while Q x R bytes stay under XMH_SCAN_CACHE_MB (default 4096; 0 switches it off).
+// Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
+// pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 4096; 0 = off).
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     static const long long cap_mb = getenv("XMH_SCAN_CACHE_MB") ? atoll(getenv("XMH_SCAN_CACHE_MB")) : 4096;
-    if (ternary || K <= 32 || K > 64 || cap_mb <= 0) return 0;
-    const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * 4) * (size_t)((p.chunk + 63) / 64) * 1024;
+    if (ternary || K <= 32 || K > 256 || cap_mb <= 0) return 0;
+    const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
+    const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
 }
 
@@ -996,7 +1002,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
             ScanArgs as = a;
             as.nqt = a.nqt * S / NW;
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
-            if constexpr (kPairCacheShape<WW, T> && !MK && S == 4) {
+            if constexpr (kPairCacheShape<WW, T> && !MK) {
                 if (cache_bytes) {                                    // pass 1 of this call pair left the pairs in the workspace
                     auto kc = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, true>;
                     const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : ((cells * 2 + 3) & ~(size_t)3) * 4) * NW;   // counters only: no gallery ring

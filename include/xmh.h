@@ -106,8 +106,9 @@ typedef struct xmh_scan_plan {
 
 int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host);
 /* Bytes of the workspace (included in plan.ws_bytes) that hold the PAIR CACHE: xmh_hamming_hist leaves one byte per (query,
- * gallery item) pair -- distance | relevant << 7 -- and xmh_hamming_ap reads it instead of evaluating the pair again.  Used
- * for binary codes of 33..64 bits while Q x R bytes stay under XMH_SCAN_CACHE_MB (default 4096 MB; 0 = off); 0 = not used. */
+ * gallery item) pair -- distance | relevant << 7; two bytes for codes of 65..256 bits -- and xmh_hamming_ap reads it instead of
+ * evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 4096 MB;
+ * 0 = off); returns 0 when it is not used. */
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 
 /* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).

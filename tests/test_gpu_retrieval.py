@@ -264,6 +264,37 @@ def test_scan_masked_fallback_in_a_fresh_process():
     assert abs(outs[0] - outs[1]) < 1e-9 and abs(outs[0] - outs[2]) < 1e-9, outs
 
 
+def test_scan_pair_cache_on_and_off_give_identical_bits():
+    """The pair cache (pass 1 leaves distance | relevant per pair for pass 2; XMH_SCAN_CACHE_MB, read once per process)
+    must not change a single bit: same counter adds in the same order.  Code lengths of both entry widths, ragged
+    gallery sizes around the 64-item batch, mAP@all and mAP@k, sparse labels (packed counters) and dense ones."""
+    import subprocess, sys
+    code = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "from xmh import retrieval as R\n"
+        "from xmh._lib import lib\n"
+        "g = torch.Generator().manual_seed(77)\n"
+        "for (Q, Rn, K, C, p, k) in ((70, 5000, 64, 12, .3, None), (33, 4097, 48, 40, .02, 7), (129, 6463, 128, 80, .05, None),\n"
+        "                            (17, 3000, 256, 9, .3, 50), (64, 64, 96, 5, .5, None), (5, 63, 64, 3, .5, 2), (200, 20001, 160, 20, .01, None)):\n"
+        "    qB, rB = torch.randn(Q, K, generator=g).sign(), torch.randn(37, K, generator=g).sign()[torch.randint(0, 37, (Rn,), generator=g)]\n"
+        "    qL, rL = (torch.rand(Q, C, generator=g) < p).long(), (torch.rand(Rn, C, generator=g) < p).long()\n"
+        "    qL[:, 0] = 1; rL[::3, 0] = 1\n"
+        "    scan = R.RankingScan(R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda()), C)\n"
+        "    scan.histograms(False)\n"
+        "    a, c = scan.ap_sums(k)\n"
+        "    print('ROW', int(lib.xmh_scan_pair_cache_bytes(Q, Rn, K, 0)) > 0, a.cpu().numpy().tobytes().hex(), c.cpu().numpy().tobytes().hex())\n"
+    ) % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"))
+    rows = []
+    for extra in ({}, {"XMH_SCAN_CACHE_MB": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows.append([l.split()[1:] for l in r.stdout.splitlines() if l.startswith("ROW ")])
+    on, off = rows
+    assert len(on) == 7 and len(off) == 7
+    assert all(x[0] == "True" for x in on) and all(x[0] == "False" for x in off)
+    assert [x[1:] for x in on] == [x[1:] for x in off]
+
+
 def test_calc_map_k_label_cache_sees_in_place_edits(cu):
     orc = _orc()
     qB, rB, qL, rL = _synth(12, 900, 64, 10, seed=4)
