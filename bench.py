@@ -144,8 +144,7 @@ def main():
     def step():
         if not use_dist:
             scan.histograms(False)
-            a, c = scan.ap_sums(None)
-            return R.map_finalize(a, c)
+            return scan.map_all(None)[0]
         return sharded.map_k_sharded(piped if piped is not None else ops, None)[0]
 
     def barrier():

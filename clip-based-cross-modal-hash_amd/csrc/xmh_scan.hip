@@ -783,7 +783,9 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
     // two resident sets of waves balance the tail better, but the [chunk][bucket][query] tables double: pays up to 65 buckets
     // (K=64: 0.640 -> 0.624 ms, K=16: 0.502 -> 0.476), costs at 257 (K=256: 1.45 -> 1.54)
-    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 65 ? 2 : 1);
+    // with the pair cache (binary codes of 33..64 bits) the passes are shorter and the tables weigh more: one set (0.543 -> 0.536 ms)
+    const bool cache_shape = !ternary && K > 32 && K <= 64 && !(getenv("XMH_SCAN_CACHE_MB") && atoll(getenv("XMH_SCAN_CACHE_MB")) <= 0);
+    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 65 && !cache_shape ? 2 : 1);
     int64_t nchunk = rounds * slots / nqt;
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     if (nchunk < 1) nchunk = 1;
@@ -950,10 +952,11 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     return XMH_OK;
 }
 
-extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
-                              const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
-                              size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
-                              const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream) {
+namespace {
+int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                    const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                    size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
+                    const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream) {
     const bool tern = qzero != nullptr;
     xmh_scan_plan p;
     int rc = make_plan(Q, R, K, tern, &p);
@@ -1039,7 +1042,28 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
     hipLaunchKernelGGL(k_ap_reduce, dim3((unsigned)xmh::ceil_div(Q, 256)), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);
     XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
+    if (map_out) {                                                   // (both in ONE block was tried: 40 us instead of 20, a block cannot pull 1 MB fast)
+        hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);
+        XMH_LAUNCH_CHECK("xmh_hamming_map finalize");
+    }
     return XMH_OK;
+}
+}  // namespace
+
+extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                              const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                              size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
+                              const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream) {
+    return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, base_all, base_rel, nrel_total, k, ap_sum, cap,
+                           nullptr, stream);
+}
+
+extern "C" int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                               const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                               size_t ws_bytes, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream) {
+    if (!map_out) return xmh::fail(XMH_EINVAL, "xmh_hamming_map: null output");
+    return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_out,
+                           stream);
 }
 
 extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream) {

@@ -232,6 +232,19 @@ class RankingScan:
         return ap, cap
 
 
+    def map_all(self, k: Optional[int] = None):
+        """pass 2 of an unsharded gallery with the finalisation folded in -> (map float64 [1], ap_sum [Q], cap [Q])."""
+        dev = self.ws.device
+        ap = torch.empty(self.q.n, dtype=torch.float64, device=dev)
+        cap = torch.empty(self.q.n, dtype=torch.int32, device=dev)
+        out = torch.empty(1, dtype=torch.float64, device=dev)
+        kk = 0 if k is None else int(k)
+        if k is not None and kk <= 0:
+            raise ValueError("k must be positive or None")
+        check(lib.xmh_hamming_map(*self._common(), kk, ptr(ap), ptr(cap), ptr(out), current_stream()), "xmh_hamming_map")
+        return out, ap, cap
+
+
 def map_finalize(ap_sum: torch.Tensor, cap: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.float64, device=ap_sum.device)
     check(lib.xmh_map_finalize(ptr(ap_sum), ptr(cap), ap_sum.shape[0], ptr(out), current_stream()), "xmh_map_finalize")
@@ -257,8 +270,7 @@ def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch
     """mAP of one query set against one (unsharded) gallery; float64 [1] on the device."""
     scan = RankingScan(q, qlab, r, rlab, Cn)
     scan.histograms(want_totals=False)
-    ap, cap = scan.ap_sums(k)
-    return map_finalize(ap, cap)
+    return scan.map_all(k)[0]
 
 
 def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0):

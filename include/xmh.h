@@ -131,6 +131,11 @@ int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
                    const uint32_t* base_all, const uint32_t* base_rel, const uint32_t* nrel_total,
                    int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
 
+/* xmh_hamming_ap of an UNSHARDED gallery followed by xmh_map_finalize in one call: ap_sum / cap as xmh_hamming_ap writes
+ * them, map_out[0] = mean_q ap_sum[q] / cap[q]. */
+int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                    const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                    size_t ws_bytes, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream);
 /* mean over queries of ap_sum/cap -> map_out[0] (f64, device).  A query with cap == 0 makes the result
  * NaN, as torch.mean of an empty tensor does in the reference (common/calc_utils.py:87-89). */
 int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream);
