@@ -400,6 +400,35 @@ def test_sharded_fuzz_random_splits(xr):
         assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9), (case, Q, R, K, world, bounds)
 
 
+def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():
+    """xmh.sharded.map_k_sharded through a real RCCL process group (world size 1, fresh process): the one-shot form and the
+    query-block pipeline (asynchronous gathers) against the unsharded scan."""
+    import subprocess, sys
+    code = (
+        "import os, sys, torch; sys.path[:0] = [%r, %r]\n"
+        "import torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from xmh import retrieval as R, sharded\n"
+        "g = torch.Generator().manual_seed(9)\n"
+        "for (Q, Rn, K, C, k) in ((150, 9000, 64, 30, None), (37, 2500, 128, 80, 11), (64, 1000, 16, 5, None)):\n"
+        "    qB, rB = torch.randn(Q, K, generator=g).sign(), torch.randn(50, K, generator=g).sign()[torch.randint(0, 50, (Rn,), generator=g)]\n"
+        "    qL, rL = (torch.rand(Q, C, generator=g) < .2).long(), (torch.rand(Rn, C, generator=g) < .2).long()\n"
+        "    qL[:, 0] = 1; rL[::4, 0] = 1\n"
+        "    q, ql, r, rl = R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda())\n"
+        "    whole = R.RankingScan(q, ql, r, rl, C); whole.histograms(False)\n"
+        "    m0, a0, c0 = whole.map_all(k)\n"
+        "    m1, a1, c1 = sharded.map_k_sharded(sharded.HipShardOps(q, ql, r, rl, C), k)\n"
+        "    assert torch.equal(c0, c1) and torch.allclose(a0, a1, rtol=1e-12) and abs(float(m0) - float(m1)) < 1e-12\n"
+        "    for nb in (2, 3, 200):\n"
+        "        m2, a2, c2 = sharded.map_k_sharded(sharded.QueryBlocks.split(q, ql, r, rl, C, nb), k)\n"
+        "        assert torch.equal(c0, c2) and torch.allclose(a0, a2, rtol=1e-9) and abs(float(m0) - float(m2)) < 1e-9, (Q, K, nb)\n"
+        "torch.cuda.synchronize(); dist.destroy_process_group(); print('rccl ok')\n"
+    ) % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 def test_sharded_ops_with_an_empty_shard(xr):
     """a rank without gallery rows (fewer rows than ranks) takes part in the exchange with zeros; ternary codes included so the
     bucket count of the empty rank has to match the others'."""
