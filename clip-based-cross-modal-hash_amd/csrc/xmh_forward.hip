@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int kActNone = 0, kActQuickGelu = 1, kActTanh = 3, kActRelu = 4;
+constexpr int kActNone = 0, kActQuickGelu = 1, kActGeluErf = 2, kActTanh = 3, kActRelu = 4;
 constexpr int kPrecParity = 0, kPrecFast = 1, kPrecExact = 2;
 constexpr float kLnEps = 1e-5f;                      // nn.LayerNorm default, as in the reference
 
@@ -279,4 +279,77 @@ extern "C" int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, 
     if (rc) return rc;
     if (bits) rc = xmh_pack_sign(o, B, (int)K, row_index, bits, zero, flags, stream);
     return rc;
+}
+
+// ---- MITH head ---------------------------------------------------------------------------------------------------------
+
+namespace {
+struct MithScratch {
+    float *y, *hbuf, *f, *scores, *m, *ycls, *hcls, *fcls;
+    BlockScratch blk;
+    void* half;
+};
+void carve_mith(Arena& ar, int64_t B, int L, int D, int K, int precision, MithScratch& s) {
+    const int64_t M = B * L, M2 = B * K;
+    s.y = ar.take<float>((size_t)M * D);
+    s.hbuf = ar.take<float>((size_t)M * D);
+    s.f = ar.take<float>((size_t)M * D * 4);
+    s.scores = ar.take<float>((size_t)M * K);
+    s.m = ar.take<float>((size_t)M2 * D);
+    s.ycls = ar.take<float>((size_t)B * D);
+    s.hcls = ar.take<float>((size_t)B * D);
+    s.fcls = ar.take<float>((size_t)B * D * 4);
+    s.blk = carve_blocks(ar, M2, D, precision);
+    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)(M > M2 ? M : M2) * D * 4) : nullptr;
+}
+// GlobalConceptLearning on `rows` rows: y = ResidualMLPs(x) (x is not modified), scores = tanh(concept(y))
+int mith_gcl(const xmh_mith_head* h, const float* x, int64_t rows, float* y, float* hb, float* f, float* scores, int precision, void* half,
+             xmh_stream_t st) {
+    const int D = h->width;
+    const float* cur = x;
+    for (int i = 0; i < h->res_layers; ++i) {
+        const xmh_mith_mlp& m = h->mlps[i];
+        if (m.fc1.k != D || m.fc2.n != D || m.fc2.k != m.fc1.n || m.fc1.n > 4 * D) return xmh::fail(-22, "xmh_head_mith: MLP %d shapes do not fit width %d", i, D);
+        int rc = xmh_layernorm_f32(cur, D, m.ln_w, m.ln_b, m.ln_eps, hb, D, rows, D, st);
+        if (rc) return rc;
+        rc = linear(m.fc1, hb, D, nullptr, 0, f, m.fc1.n, rows, kActGeluErf, precision, half, st);
+        if (rc) return rc;
+        rc = linear(m.fc2, f, m.fc1.n, cur, D, y, D, rows, kActNone, precision, half, st);       // y = cur + fc2(..): no clone of x needed
+        if (rc) return rc;
+        cur = y;
+    }
+    return linear(h->concept, cur, D, nullptr, 0, scores, h->k_bits, rows, kActTanh, precision, half, st);
+}
+}  // namespace
+
+extern "C" size_t xmh_head_mith_workspace_bytes(int64_t B, int L, int width, int k_bits, int precision) {
+    if (B <= 0 || L <= 0 || width <= 0 || k_bits <= 0) return 0;
+    Arena ar(nullptr);
+    MithScratch s;
+    carve_mith(ar, B, L, width, k_bits, precision, s);
+    return ar.used;
+}
+
+extern "C" int xmh_head_mith(const xmh_mith_head* h, const float* cls, const float* tokens, const uint8_t* token_mask, int64_t B, int L,
+                             int precision, float* cls_hash, float* tokens_hash, void* workspace, size_t workspace_bytes,
+                             xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!h || !cls || !tokens || !cls_hash || !tokens_hash || !workspace || L <= 0) return xmh::fail(-22, "xmh_head_mith: bad arguments");
+    const int D = h->width, K = h->k_bits;
+    if (D <= 0 || K <= 0 || h->heads <= 0 || D % h->heads || h->concept.n != K || h->concept.k != D || h->res_layers < 0 || h->layers < 0)
+        return xmh::fail(-22, "xmh_head_mith: head shapes do not fit (width %d, %d bits, %d heads)", D, K, h->heads);
+    Arena ar(workspace);
+    MithScratch s;
+    carve_mith(ar, B, L, D, K, precision, s);
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_head_mith: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    int rc = mith_gcl(h, cls, B, s.ycls, s.hcls, s.fcls, cls_hash, precision, s.half, stream);
+    if (rc) return rc;
+    rc = mith_gcl(h, tokens, B * L, s.y, s.hbuf, s.f, s.scores, precision, s.half, stream);
+    if (rc) return rc;
+    rc = xmh_lta_aggregate(s.scores, tokens, token_mask, h->pos_enc, s.m, B, L, K, D, h->top_k, stream);
+    if (rc) return rc;
+    rc = run_blocks(h->blocks, h->layers, D, h->heads, s.m, B, K, 0, nullptr, precision, s.blk, stream);
+    if (rc) return rc;
+    return xmh_bitwise_hash(s.m, h->hash_w, h->hash_b, nullptr, tokens_hash, B, K, D, stream);
 }

@@ -53,6 +53,16 @@ class DcmhtHead(C.Structure):                  # xmh_dcmht_head
                 ("norm_w", vp), ("norm_b", vp), ("bn_mean", vp), ("bn_var", vp), ("fc2", Linear)]
 
 
+class MithMlp(C.Structure):                    # xmh_mith_mlp
+    _fields_ = [("ln_w", vp), ("ln_b", vp), ("ln_eps", C.c_float), ("fc1", Linear), ("fc2", Linear)]
+
+
+class MithHead(C.Structure):                   # xmh_mith_head
+    _fields_ = [("width", i32), ("k_bits", i32), ("top_k", i32), ("res_layers", i32), ("layers", i32), ("heads", i32),
+                ("mlps", C.POINTER(MithMlp)), ("concept", Linear), ("pos_enc", vp), ("blocks", C.POINTER(ClipBlock)),
+                ("hash_w", vp), ("hash_b", vp)]
+
+
 # name -> (restype, argtypes); mirrors include/xmh.h one to one
 PROTOTYPES = {
     "xmh_version": (i32, []),
@@ -94,6 +104,8 @@ PROTOTYPES = {
     "xmh_head_workspace_bytes": (sz, [i64, i32, i32]),
     "xmh_head_dcmht": (i32, [C.POINTER(DcmhtHead), vp, i64, i32, vp, vp, vp, vp, sz, vp]),
     "xmh_head_dsph": (i32, [C.POINTER(Linear), vp, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "xmh_head_mith_workspace_bytes": (sz, [i64, i32, i32, i32, i32]),
+    "xmh_head_mith": (i32, [C.POINTER(MithHead), vp, vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]),
     "xmh_row_l2normalize": (i32, [vp, i64, i32, vp, vp, vp]),
     "xmh_pairwise_l2_from_gram": (i32, [vp, vp, vp, i64, i64, vp]),
     "xmh_affine_inplace": (i32, [vp, i64, C.c_float, C.c_float, vp]),

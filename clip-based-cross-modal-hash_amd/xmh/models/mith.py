@@ -5,13 +5,16 @@ dataflow is SURVEY 2.4.  ``res_*_cls`` / ``trans_tokens_*`` only feed the traini
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
+from .._lib import check, current_stream, lib, ptr
 from ..common.register import registry
+from . import clip as _clip
 from .base import BaseModel
 from .clip import Transformer
 
@@ -100,9 +103,45 @@ class MITHHashLayer(nn.Module):
         self.img_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
         self.txt_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
 
+    def _desc(self, gcl, lct, precision: int, keep: list):
+        """xmh_mith_head of one modality (its GlobalConceptLearning + LocalConceptTransforming)."""
+        D = lct.hashing.fc_list[0].weight.shape[1]
+        layers = list(gcl.mlp.mlps) if isinstance(gcl.mlp, ResidualMLPs) else []
+        mlps = (_lib.MithMlp * max(len(layers), 1))()
+        for i, (mlp, ln) in enumerate(zip(layers, gcl.mlp.lns if layers else [])):
+            lw, lb = ops._f32c(ln.weight.detach()), ops._f32c(ln.bias.detach())
+            keep.extend((lw, lb))
+            mlps[i] = _lib.MithMlp(lw.data_ptr(), lb.data_ptr(), float(ln.eps), _clip._linear_desc(mlp[0].weight, mlp[0].bias, precision, keep),
+                                   _clip._linear_desc(mlp[3].weight, mlp[3].bias, precision, keep))
+        blocks = _clip._blocks_desc(list(lct.transformer.resblocks), precision, keep)
+        w, b = lct.hashing.stacked()
+        w, b, pe = ops._f32c(w.detach()).contiguous(), ops._f32c(b.detach()).contiguous(), ops._f32c(lct.position.pe.detach()).contiguous()
+        keep.extend((mlps, blocks, w, b, pe))
+        heads = lct.transformer.resblocks[0].heads if len(lct.transformer.resblocks) else 1
+        return _lib.MithHead(D, self.k_bits, lct.lta.top_k, len(layers), len(lct.transformer.resblocks), heads, mlps,
+                             _clip._linear_desc(gcl.common_concept_embedding.weight, None, precision, keep), pe.data_ptr(), blocks,
+                             w.data_ptr(), b.data_ptr())
+
+    def _encode_native(self, gcl, lct, cls, tokens, mask):
+        """xmh_head_mith: the whole eval dataflow of one modality from one C call."""
+        cls, tokens = ops._f32c(cls).contiguous(), ops._f32c(tokens).contiguous()
+        B, L, D = tokens.shape
+        params = list(gcl.parameters()) + list(lct.parameters()) + list(lct.buffers())
+        desc, precision = _clip._cached_desc(lct, lambda prec, keep: self._desc(gcl, lct, prec, keep), params=params, slot="mith")
+        m = None if mask is None else mask.to(device=tokens.device, dtype=torch.uint8).contiguous()
+        nbytes = lib.xmh_head_mith_workspace_bytes(B, L, D, self.k_bits, precision)
+        ws = _clip._workspace(nbytes, tokens.device)
+        cls_hash = torch.empty(B, self.k_bits, dtype=torch.float32, device=tokens.device)
+        tokens_hash = torch.empty_like(cls_hash)
+        check(lib.xmh_head_mith(ctypes.byref(desc), ptr(cls), ptr(tokens), ptr(m), B, L, precision, ptr(cls_hash), ptr(tokens_hash), ptr(ws),
+                                nbytes, current_stream()), "xmh_head_mith")
+        return None, cls_hash, tokens_hash, None
+
     @torch.no_grad()
     def _encode(self, gcl, lct, cls, tokens_lnd, mask):
         tokens = tokens_lnd.permute(1, 0, 2)                       # LND view of a [B,L,D] buffer -> back to [B,L,D]
+        if _clip.NATIVE_FORWARD and cls.dim() == 2 and tokens.dim() == 3:
+            return self._encode_native(gcl, lct, cls, tokens, mask)
         _, cls_hash = gcl.run(cls)
         _, scores = gcl.run(tokens)                                # concept scores of every token, [B,L,K]
         tokens_hash = lct.run(tokens, scores, mask)

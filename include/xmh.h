@@ -312,6 +312,31 @@ int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, int precisi
                   uint32_t* zero, int32_t* flags, const int64_t* row_index, void* workspace, size_t workspace_bytes,
                   xmh_stream_t stream);
 
+/* One modality of the MITH head in eval mode (models/MITH/hash/hash.py:172-254; dataflow SURVEY 2.4):
+ *   GlobalConceptLearning: y = ResidualMLPs(x) (per layer x += fc2(gelu(fc1(LN(x))))), concept scores tanh(E y), on the cls /
+ *   EOS feature -> cls_hash [B, K] and on every token -> scores [B, L, K];
+ *   LocalConceptTransforming: localized token aggregation of the RAW tokens by those scores (+ positional encoding)
+ *   -> [B, K, D], transformer blocks over the K concept tokens, bitwise hashing -> tokens_hash [B, K]. */
+typedef struct xmh_mith_mlp {
+    const float *ln_w, *ln_b;
+    float ln_eps;
+    xmh_linear fc1, fc2;                               /* [4D, D], [D, 4D] */
+} xmh_mith_mlp;
+typedef struct xmh_mith_head {
+    int width, k_bits, top_k, res_layers, layers, heads;
+    const xmh_mith_mlp* mlps;                          /* host array [res_layers] */
+    xmh_linear concept;                                /* common_concept_embedding [K, D], no bias */
+    const float* pos_enc;                              /* [K, D] (already divided by sqrt(D)) */
+    const xmh_clip_block* blocks;                      /* host array [layers] */
+    const float *hash_w, *hash_b;                      /* the K one-row linears stacked: [K, D], [K] */
+} xmh_mith_head;
+size_t xmh_head_mith_workspace_bytes(int64_t B, int L, int width, int k_bits, int precision);
+/* cls [B, D], tokens [B, L, D] (contiguous), token_mask [B, L] bytes (non-zero = ignore) or NULL
+ * -> cls_hash [B, K], tokens_hash [B, K] (what MITH.encode_image / encode_text return as elements 1 and 2). */
+int xmh_head_mith(const xmh_mith_head* h, const float* cls, const float* tokens, const uint8_t* token_mask, int64_t B, int L,
+                  int precision, float* cls_hash, float* tokens_hash, void* workspace, size_t workspace_bytes,
+                  xmh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Float similarities of common/calc_utils.py on un-quantised inputs (a-3, a-4).
  * ------------------------------------------------------------------------------------------- */

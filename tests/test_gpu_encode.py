@@ -518,6 +518,44 @@ def test_mith_head_matches_reference_goldens(ops):
         assert ((ch_t + th_t).sign().cpu().numpy() != g["k%d_code_t" % K]).mean() < 0.01
 
 
+def test_mith_head_entry_point_equals_the_primitive_chain(ops):
+    """xmh_head_mith against the per-primitive chain, bit for bit, both modalities (text with a token mask), all precisions;
+    an in-place weight update must reach the cached descriptor."""
+    import xmh.models.clip as C
+    from test_oracle_encode import mith_inputs
+    from xmh.models import weights as W
+    from xmh.models.mith import MITHHashLayer
+    cls_i, tok_i, cls_t, tok_t, mask = (t.cuda() for t in mith_inputs(W, 3))
+    torch.manual_seed(4)
+    head = MITHHashLayer(512, 32).cuda().eval()
+
+    def both():
+        _, a, b, _ = head.encode_img(cls_i, tok_i)
+        _, c, d, _ = head.encode_txt(cls_t, tok_t, mask)
+        return [a, b, c, d]
+
+    before = ops.get_precision()
+    try:
+        for prec in ("f32", "f32x", "f16"):
+            ops.set_precision(prec)
+            native = both()
+            C.NATIVE_FORWARD = False
+            try:
+                chain = both()
+            finally:
+                C.NATIVE_FORWARD = True
+            for x, y in zip(native, chain):
+                assert x.shape == y.shape and torch.equal(x, y), prec
+        ops.set_precision("f32")
+        first = both()
+        with torch.no_grad():
+            head.lct_i.hashing.fc_list[3].weight.mul_(-1.0)
+        second = both()
+        assert not torch.equal(first[1], second[1]) and torch.equal(first[3], second[3])      # image tokens_hash changed, text untouched
+    finally:
+        ops.set_precision(before)
+
+
 def test_lta_edge_cases_against_oracle(ops):
     """tokens with fewer than top-k positive concepts, fully masked concepts (NaN -> 0), exact ties."""
     from oracle import encode as enc
