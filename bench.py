@@ -11,7 +11,7 @@ queries are replicated after the one-off all-gather of packed query codes.
     python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(k_scan_ap_s), a second roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share) and the
+(the longer of the two passes: k_scan_hist_s with the pair cache, else k_scan_ap_s), a second roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share) and the
 CPU baseline (oracle port of the reference's calc_map_k) timed on this host.
 """
 import argparse
@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+# the host driver of this pool only supports dmabuf IPC: RCCL / CUDA-tensor sharing across processes needs this before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
