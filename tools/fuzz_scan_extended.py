@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One-off extended fuzz of the fused mAP scan against the oracle (run on the GPU box): many more seeds than the test
+suite, sizes that cross the chunk / batch / tile boundaries, focus on the pair-cache code lengths (33..256 bits binary).
+    python tools/fuzz_scan_extended.py [cases]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")]
+import numpy as np
+import torch
+from oracle import retrieval as orc
+from xmh.common import calc_utils as cu
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(99)
+bad = 0
+for case in range(n):
+    K = int(rng.choice([33, 40, 48, 64, 64, 64, 65, 96, 128, 128, 160, 200, 256, 16, 32]))
+    Q = int(rng.choice([2, 3, 15, 16, 17, 31, 33, 64, 65, 127, 200, 513]))            # Q = 1 / R = 1: the reference itself fails (squeeze)
+    R = int(rng.integers(2, 9000)) if case % 3 else int(rng.choice([2, 63, 64, 65, 128, 4096, 8191, 8192, 8193, 20000]))
+    C = int(rng.choice([1, 5, 24, 32, 33, 64, 80, 96, 128]))
+    p = float(rng.choice([0.01, 0.1, 0.5]))
+    gen = torch.Generator().manual_seed(5000 + case)
+    qB, rB = torch.randn(Q, K, generator=gen).sign(), torch.randn(R, K, generator=gen).sign()
+    if case % 4 == 0 and R > 8:
+        rB = rB[torch.randint(0, int(rng.integers(1, 12)), (R,), generator=gen)]          # heavy ties
+    qL, rL = (torch.rand(Q, C, generator=gen) < p).long(), (torch.rand(R, C, generator=gen) < p).long()
+    qL[:, 0] = 1
+    rL[0, 0] = 1
+    k = None if case % 2 else int(rng.integers(1, 200))
+    want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))       # float32 like the reference: ~1e-6 of accumulation noise at Q in the hundreds
+    got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), k))
+    if not abs(got - want) < 1e-6:
+        # float64 evaluation of the same definition decides (case 160 of the default run: oracle 2.2e-6 off, HIP 1.4e-8)
+        d = (0.5 * (K - qB.double() @ rB.double().t())).numpy()
+        rel = ((qL.double() @ rL.double().t()) > 0).numpy()
+        tot = 0.0
+        for i in range(Q):
+            hits = rel[i][np.argsort(d[i], kind="stable")]
+            m = min(int(rel[i].sum()), k if k else R)
+            tot += float(np.mean(np.arange(1, m + 1, dtype=np.float64) / (np.nonzero(hits)[0][:m].astype(np.float64) + 1.0)))
+        exact = tot / Q
+        if not abs(got - exact) < 1e-6:
+            bad += 1
+            print("MISMATCH", case, Q, R, K, C, p, k, got, want, exact, flush=True)
+        else:
+            print("oracle float32 noise at case %d: oracle %.3e off, HIP %.3e off the float64 value" % (case, abs(want - exact), abs(got - exact)), flush=True)
+print("cases %d, mismatches %d" % (n, bad))
+sys.exit(1 if bad else 0)
