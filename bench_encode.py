@@ -27,7 +27,7 @@ PEAK = {"f32": 2500.0 / 2, "f32x": 157.3, "f16": 2500.0}
 SLOTS = {"f32": ("gemm_s16", "gemm_f32"), "f32x": ("gemm_f32",), "f16": ("gemm_f16", "gemm_f32")}
 
 
-def measure(batch=100, steps=10, warmup=2, K=64, modes=("f32", "f32x", "f16"), extras=True):
+def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), extras=True):
     from xmh import _lib, ops
     from xmh import retrieval as R
     from xmh.models.dcmht import DCMHT
