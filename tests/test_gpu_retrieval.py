@@ -407,7 +407,10 @@ def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():
     code = (
         "import os, sys, torch; sys.path[:0] = [%r, %r]\n"
         "import torch.distributed as dist\n"
-        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')\n"
+        "import socket\n"
+        "with socket.socket() as _s:\n"
+        "    _s.bind(('127.0.0.1', 0)); _port = _s.getsockname()[1]\n"
+        "os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(_port)\n"
         "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "from xmh import retrieval as R, sharded\n"
         "g = torch.Generator().manual_seed(9)\n"
