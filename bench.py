@@ -3,20 +3,29 @@
 (BASELINE.json metric, configs[1] = DCMHT COCO-shaped 64-bit: Q 5000 x R 117218, 80 classes).
 
 One "step" = one calc_map_k-equivalent pass over packed codes already resident in HBM:
-  pass 1 (bucket histograms) -> [N>1: RCCL all-gather of histograms] -> pass 2 (ranks + AP sums)
-  -> [N>1: all-reduce of the per-query sums] -> mean.
-N GPUs: every rank holds its own R-row gallery shard (weak scaling, contiguous global index ranges);
-queries are replicated after the one-off all-gather of packed query codes.
+  [N>1: RCCL all-gather of the packed query codes / labels each rank "encoded"] -> pass 1 (bucket histograms)
+  -> [N>1: RCCL all-gather of histograms] -> pass 2 (ranks + AP sums) -> [N>1: all-reduce of the per-query sums] -> mean.
+N GPUs (default, "weak"): every rank holds its own R-row gallery shard (contiguous global index ranges), the query set is
+split over the ranks and all-gathered inside the timed step, like runners/base.py does after encoding.
+After the headline the N>1 run also measures the fixed-gallery ("strong") shapes of BASELINE configs[2] (NUS-WIDE-shaped
+mAP scan, Q 5000 x R 188 000 in total) and configs[4] (10 M x 256-bit top-k, shard top-k -> gather -> host merge) and
+reports them under "strong_scaling".
 
-    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(the longer of the two passes: k_scan_hist_s with the pair cache, else k_scan_ap_s), a second roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share) and the
-CPU baseline (oracle port of the reference's calc_map_k) timed on this host.
+N>1 may be launched either way: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE
+in the environment), or plain `python bench.py --gpus N`, which re-executes itself under torch.distributed.run
+(rendezvous on 127.0.0.1, a free port) -- the reference's own entry script spawns its ranks the same way (main.py:38-51).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel of the step, a second
+roofline for the HBM-bound top-k regime (configs[4] shape, one GPU's share), the encoder leg and the CPU baselines (oracle
+ports of the reference's calc_map_k and CLIP forward) timed on this host.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,11 +40,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_GLOPS = 39321.6         # VALU issue: 256 CU x 4 SIMD x 64 lanes / 4 cycles x 2.4 GHz (tools/ubench_valu.hip: 4.0-4.4 cycles per wave64 op for this mix)
+import bench_roofline as RL  # noqa: E402
 
 
-def synth(Q, R, K, C, seed, p=0.04, device="cuda"):
+def synth(Q, R, K, C, seed, p=0.04):
     """SURVEY 8d synthetic inputs: label-correlated +-1 codes, multi-hot labels with >= 1 label per row."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     Wm = torch.randn(C, K, generator=g)
@@ -51,10 +59,35 @@ def synth(Q, R, K, C, seed, p=0.04, device="cuda"):
     return qB, qL, rB, rL
 
 
-def cpu_baseline(qB, qL, rB, rL, budget_s=20.0):
-    """The oracle's step-by-step port of the reference calc_map_k (float GEMM + int64 label matmul + full
-    sort + per-query loop) on a bounded query subsample, on this host's cores.  A 32-query probe sizes the
-    sample so the whole leg takes about `budget_s` seconds."""
+def host_description():
+    """CPU model string, logical CPUs and physical cores of this host ('core count and CPU model printed')."""
+    model, phys, sockets = "unknown", None, set()
+    try:
+        cores = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+                sockets.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": phys, "sockets": len(sockets) or None}
+
+
+def cpu_baseline(qB, qL, rB, rL, budget_s=20.0, gpu_map_fn=None):
+    """The oracle's step-by-step port of the reference calc_map_k (float GEMM + int64 label matmul + full sort + per-query
+    loop) on a bounded query subsample, on this host's cores.  A 32-query probe sizes the sample so the timed leg takes
+    about `budget_s` seconds.  The same sample is then ranked once more with the reference's DEFAULT (unstable) sort, and by
+    the GPU path, so the line carries the real tie-order delta at this scale ('5e-4' was a guess)."""
     from oracle import retrieval as orc
     threads = min(32, os.cpu_count() or 1)       # the int64 label matmul stops scaling (and thrashes) beyond that
     torch.set_num_threads(threads)
@@ -65,31 +98,62 @@ def cpu_baseline(qB, qL, rB, rL, budget_s=20.0):
     t0 = time.perf_counter()
     m = orc.map_k(qB[:qsub].clone(), rB, qL[:qsub].clone(), rL, None, stable=True)
     dt = time.perf_counter() - t0
-    return {"value": qsub * rB.shape[0] / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "first %d of %d queries x full %d-item gallery, oracle.retrieval.map_k (torch CPU, %d threads), %.1f s"
-                      % (qsub, qB.shape[0], rB.shape[0], threads, dt), "map": float(m)}
+    m_default = orc.map_k(qB[:qsub].clone(), rB, qL[:qsub].clone(), rL, None, stable=False)
+    host = host_description()
+    out = {"value": qsub * rB.shape[0] / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+           "sample": "first %d of %d queries x full %d-item gallery, oracle.retrieval.map_k (torch CPU, %d threads), %.1f s"
+                     % (qsub, qB.shape[0], rB.shape[0], threads, dt),
+           "cpu_model": host["cpu_model"], "physical_cores": host["physical_cores"], "logical_cpus": host["logical_cpus"],
+           "map_stable": float(m), "map_default": float(m_default), "abs_delta_default_vs_stable": abs(float(m) - float(m_default))}
+    if gpu_map_fn is not None:
+        g = float(gpu_map_fn(qsub))
+        out["map_gpu_same_sample"] = g
+        out["abs_delta_gpu_vs_stable"] = abs(g - float(m))
+        out["abs_delta_gpu_vs_default"] = abs(g - float(m_default))
+    return out
 
 
-def pmc_traffic(kernel_prefix, kernel_suffix=""):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary under profiles/ (collected by
-    tools/profile_round.sh with separate FETCH_SIZE / WRITE_SIZE passes and the gfx950 corrections of
-    MI355X_MICROARCH.md); None if no profile has been committed for it."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for name, e in d.get("pmc", {}).items():
-            if name.startswith(kernel_prefix) and kernel_suffix in name and "hbm_bytes_per_launch" in e:
-                best = {"bytes": e["hbm_bytes_per_launch"]["total"], "fetch_raw": e["hbm_bytes_per_launch"]["fetch_raw"],
-                        "write_raw": e["hbm_bytes_per_launch"]["write_raw"], "fetch_correction": e["hbm_bytes_per_launch"]["fetch_correction"],
-                        "source": os.path.relpath(f, ROOT)}
-    return best
+def cpu_encode_baseline(batch=100):
+    """the fp32 PyTorch encode on this host's cores -- the oracle's restatement of the reference CLIP
+    ViT-B/32 forward (oracle/encode.py) on one batch of 100 images and one of 100 captions, synthetic weights."""
+    from oracle import encode as enc
+    from xmh.models import weights as W
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = W.synth_clip_state_dict(1814) if hasattr(W, "synth_clip_state_dict") else None
+    if sd is None:
+        return {"error": "no synthetic state-dict generator"}
+    image = W.synth_images(5, batch)
+    ids, _ = W.synth_text(5, batch)
+    res = {}
+    with torch.no_grad():
+        for what, fn in (("images", lambda: enc.clip_image(sd, image)), ("captions", lambda: enc.clip_text(sd, ids))):
+            fn()                                                        # first call pays allocator / thread-pool start-up
+            t0 = time.perf_counter()
+            fn()
+            res[what + "_per_s"] = batch / (time.perf_counter() - t0)
+    res.update({"cores": threads, "kind": "port", "cpu_model": host_description()["cpu_model"],
+                "sample": "one batch of %d images and one of %d captions through oracle.encode.clip_image / clip_text (torch CPU fp32, %d threads)"
+                          % (batch, batch, threads)})
+    return res
 
 
-def main():
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args_list, n):
+    """plain `python bench.py --gpus N`: re-execute under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + args_list
+    env = dict(os.environ)
+    env["XMH_BENCH_CHILD"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -98,44 +162,184 @@ def main():
                          "steady state (measured 0.62 ms/step over the first 5 steps against 0.52 in steady state)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--Q", type=int, default=5000)
-    ap.add_argument("--R", type=int, default=117218, help="gallery rows PER GPU")
+    ap.add_argument("--R", type=int, default=117218, help="gallery rows PER GPU (weak scaling)")
     ap.add_argument("--K", type=int, default=64)
     ap.add_argument("--C", type=int, default=80)
     ap.add_argument("--p-label", type=float, default=0.04, help="per-class label probability of the synthetic multi-hot labels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-regime", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N>1: skip the fixed-gallery legs (configs[2], configs[4])")
+    ap.add_argument("--no-extra-configs", action="store_true", help="N=1: skip the configs[3] (K=128) and MITH encode legs")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU exchange path even with one rank (RCCL smoke test)")
     ap.add_argument("--query-blocks", type=int, default=1,
                     help="sharded path: query blocks whose histogram gathers are pipelined (default 1: on one GPU every extra "
                          "block costs 0.18 ms per step, more than the gather it would hide)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher + rendezvous + the step's collectives on zero tensors over gloo, no GPU work (CPU test of the N>1 path)")
+    return ap.parse_args(argv)
+
+
+def dry_run(args, world, rank):
+    """the N>1 choreography of one step on CPU tensors over gloo: query all-gather, histogram all-gather, all-reduce"""
+    from xmh import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranks = dist.get_world_size() if world > 1 else 1
+    assert ranks == args.gpus, (ranks, args.gpus)
+    Q, nb, W = 64, 65, 2
+    qb = sharded.shard_bounds(Q, world)
+    mine = torch.full((qb[rank + 1] - qb[rank], W), rank + 1, dtype=torch.int32)
+    t0 = time.perf_counter()
+    if world > 1:
+        full = sharded.all_gather_rows(mine, [qb[r + 1] - qb[r] for r in range(world)])
+        g = sharded._gather_hist_pair(torch.zeros(Q, nb, dtype=torch.int32), torch.ones(Q, nb, dtype=torch.int32))
+        ap = torch.ones(Q, dtype=torch.float64)
+        dist.all_reduce(ap)
+        assert full.shape == (Q, W) and g.shape == (world, 2, Q, nb) and float(ap[0]) == world
+        assert all(int(full[qb[r]][0]) == r + 1 for r in range(world))
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return {"dry_run": True, "n_gpus": args.gpus, "ranks_in_group": ranks, "backend": "gloo" if world > 1 else None, "exchange_ms": dt * 1e3}
+
+
+class ShardedQueries:
+    """This rank's slice of the packed query set plus persistent full-size buffers the scan objects point at: gather() is
+    the all-gather runners/base.py performs after encoding (packed codes <= 40 KB, packed labels <= 60 KB in all)."""
+
+    def __init__(self, q, ql, world, rank):
+        from xmh import sharded
+        self.sharded = sharded
+        b = sharded.shard_bounds(q.n, world)
+        self.counts = [b[r + 1] - b[r] for r in range(world)]
+        self.q_loc, self.ql_loc = q.bits[b[rank]:b[rank + 1]].clone(), ql[b[rank]:b[rank + 1]].clone()
+        self.q_full, self.ql_full = q, ql                     # the gathered rows are written into these (same values)
+
+    def gather(self):
+        self.q_full.bits.copy_(self.sharded.all_gather_rows(self.q_loc, self.counts))
+        self.ql_full.copy_(self.sharded.all_gather_rows(self.ql_loc, self.counts))
+
+
+def timed(step, barrier, steps, use_dist):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, m
+
+
+def strong_legs(args, world, rank, barrier):
+    """Fixed-gallery shapes sharded with shard_bounds.  configs[2]: NUS-WIDE-shaped mAP scan, Q 5000 x
+    R 188 000 IN TOTAL, C 21, K 64; configs[4]: exact top-100 over 10 M x 256 bit IN TOTAL for Q in {1, 8, 64}: shard
+    top-k -> all-gather of the lists -> host merge (north_star)."""
+    from xmh import retrieval as R
+    from xmh import sharded
+    out = {}
+    # ---- configs[2] ----
+    Q, Rt, K, C = 5000, 188000, 64, 21
+    b = sharded.shard_bounds(Rt, world)
+    qB, qL, _, _ = synth(Q, 8, K, C, seed=2814, p=0.1)
+    n_loc = b[rank + 1] - b[rank]
+    _, _, rB, rL = synth(8, n_loc, K, C, seed=2815 + rank, p=0.1)
+    q, ql = R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda())
+    r, rl = R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda())
+    sq = ShardedQueries(q, ql, world, rank)
+    ops = sharded.HipShardOps(q, ql, r, rl, C)
+
+    def step():
+        sq.gather()
+        return sharded.map_k_sharded(ops, None)[0]
+    for _ in range(10):
+        step()
+    steps = max(20, args.steps // 4)
+    dt, m = timed(step, barrier, steps, True)
+    out["configs2_nuswide_map"] = {"workload": "MITH NUS-WIDE-shaped 64-bit mAP scan: Q=%d x R=%d IN TOTAL over %d contiguous shards, C=%d" % (Q, Rt, world, C),
+                                   "scaling": "strong", "pairs_per_s": Q * Rt * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+                                   "mAP": float(m.item()), "rows_this_rank": n_loc}
+    del ops, sq, q, ql, r, rl
+    # ---- configs[4] ----
+    Rt, K, k = 10_000_000, 256, 100
+    W = K // 32
+    b = sharded.shard_bounds(Rt, world)
+    n_loc = b[rank + 1] - b[rank]
+    g = torch.Generator(device="cuda").manual_seed(4814 + rank)
+    rb = torch.randint(-2**31, 2**31 - 1, (n_loc, W), dtype=torch.int32, device="cuda", generator=g)
+    g.manual_seed(4813)
+    qall = torch.randint(-2**31, 2**31 - 1, (64, W), dtype=torch.int32, device="cuda", generator=g)
+    r = R.PackedCodes(rb, None, K)
+    legs = {}
+    for Qn in (1, 8, 64):
+        qq = R.PackedCodes(qall[:Qn].contiguous(), None, K)
+
+        def tstep():
+            return sharded.topk_sharded(qq, r, k, b[rank])
+        for _ in range(3):
+            tstep()
+        steps = 20
+        dt, res = timed(tstep, barrier, steps, True)
+        legs["Q%d" % Qn] = {"pairs_per_s": Qn * Rt * steps / dt, "ms_per_call": dt / steps * 1e3,
+                            "gallery_GBps": Rt * W * 4 * steps / dt / 1e9, "first_hit": [int(res[0][0, 0]), int(res[1][0, 0])]}
+    out["configs4_topk_10M_256bit"] = {"workload": "exact top-%d over R=%d x %d-bit IN TOTAL (%d shards of ~%d rows): shard top-k, "
+                                                   "all-gather of [Q,k] lists, host merge" % (k, Rt, K, world, n_loc),
+                                       "scaling": "strong", "legs": legs}
+    return out
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        if os.environ.get("XMH_BENCH_CHILD"):
+            raise SystemExit("bench.py: launched as a child without RANK/WORLD_SIZE")
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     # stdout must carry exactly ONE JSON line: route everything else (RCCL banners printed from C, warnings) to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    def emit(obj):
+        sys.stdout.flush()
+        if rank == 0:
+            os.write(json_fd, (json.dumps(obj) + "\n").encode())
+        os.close(json_fd)
+
+    if args.dry_run:
+        emit(dry_run(args, world, rank))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_sharded
+    ranks_in_group = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        ranks_in_group = dist.get_world_size()
+        if ranks_in_group != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (ranks_in_group, args.gpus))
 
     from xmh import retrieval as R
     from xmh import sharded
 
     Q, Rn, K, C = args.Q, args.R, args.K, args.C
-    # every rank synthesises the same queries and its own shard (global rows [rank*R, (rank+1)*R))
+    # every rank synthesises the same queries (it keeps its own slice) and its own shard (global rows [rank*R, (rank+1)*R))
     qB, qL, _, _ = synth(Q, 8, K, C, seed=1814, p=args.p_label)
     _, _, rB, rL = synth(8, Rn, K, C, seed=1814 + 1 + rank, p=args.p_label)
     q = R.pack_sign(qB.cuda())
@@ -146,11 +350,13 @@ def main():
     scan = ops.scan
     nqb = max(1, args.query_blocks)
     piped = sharded.QueryBlocks.split(q, ql, r, rl, C, nqb) if use_dist and nqb > 1 else None
+    sq = ShardedQueries(q, ql, world, rank) if use_dist else None
 
     def step():
         if not use_dist:
             scan.histograms(False)
             return scan.map_all(None)[0]
+        sq.gather()                                            # packed query codes + labels over RCCL, inside the timed step
         return sharded.map_k_sharded(piped if piped is not None else ops, None)[0]
 
     def barrier():
@@ -160,80 +366,10 @@ def main():
 
     for _ in range(max(0, args.settle) + args.warmup):
         m = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        m = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, m = timed(step, barrier, args.steps, use_dist)
     map_value = float(m.item())
 
-    # per-kernel timing: the library brackets each scan kernel with HIP events on the launch stream
-    from xmh import _lib
-    _lib.prof_enable(True)
-    for _ in range(max(args.steps, 10)):
-        scan.histograms(False)
-        scan.ap_sums(None)
-    torch.cuda.synchronize()
-    t_hist, n_hist = _lib.prof_read("scan_hist")
-    t_hist *= 1e-3
-    # pass 2 exists in two device-gated variants (packed 32-bit / 64-bit counters); exactly one of them does the work
-    t64, n64 = _lib.prof_read("scan_ap")
-    t32, n32 = _lib.prof_read("scan_ap32")
-    packed = t32 > t64
-    ap_kernel = "k_scan_ap_s, packed 32-bit counters" if packed else "k_scan_ap_s, 64-bit counters"
-    # template arguments <W, Lw, TERN, CAPPED, S, P32, MASKED, NW, CACHE>: the profile summary holds both gated launches
-    ap_traffic = pmc_traffic("k_scan_ap_s<", ", 4, true, false, 1," if packed else ", 4, false, false, 1,")
-    t_ap, n_ap = (t32, n32) if t32 > t64 else (t64, n64)
-    t_ap *= 1e-3
-    _lib.prof_enable(False)
-
-    W, Lw = (K + 31) // 32, (C + 31) // 32
-    alg_bytes = Rn * 4 * (W + Lw) + Q * 4 * (W + Lw) + Q * 12          # gallery once + queries + ap_sum/cap out
-    pl = scan.plan
-    # the two-pass scheme's own tables that pass 2 reads: below[chunk][bucket][q] (8 B) + dpre[bucket][q] (8 B), written once
-    # by the tiny table kernels -- this, not re-reading of inputs, is what the PMC traffic above the algorithmic bytes is
-    table_bytes = (pl.nchunk + 1) * pl.nbuckets * pl.qpad * 8 + pl.nchunk * pl.qpad * 4
-    # pair cache (xmh_scan_pair_cache_bytes): pass 1 writes a byte per pair, pass 2 reads it instead of evaluating the pair again
-    cache_bytes = int(_lib.lib.xmh_scan_pair_cache_bytes(Q, Rn, K, 0))
-    cached = cache_bytes > 0
-    # VALU instructions per wave-item (ISA count).  Pair evaluation: xor+bcnt per code word, and + and_or per further label word, min.
-    ops_eval = 2 * W + Lw + 1
-    ops_pair_hist = ops_eval + 2 + (2 if cached else 0)                 # + counter address, add operand (+ cache byte, append)
-    # pass 2: (cached: two field extracts instead of the evaluation) + address (+ hi-word mov of the 64-bit variant),
-    # credit = 2 cvt + rcp + mul24 + fmac
-    ops_pair_ap = (2 if cached else ops_eval) + 1 + (0 if packed else 1) + 5
-    hist_kernel = "k_scan_hist_s (pass 1 of the fused mAP scan: pair evaluation + bucket histogram%s)" % (" + pair cache" if cached else "")
-    # the roofline object describes the DOMINANT kernel of the step: whichever pass takes longer
-    dom_is_hist = t_hist > t_ap
-    t_dom, n_dom = (t_hist, n_hist) if dom_is_hist else (t_ap, n_ap)
-    ops_dom = ops_pair_hist if dom_is_hist else ops_pair_ap
-    dom_traffic = pmc_traffic("k_scan_hist_s<", "") if dom_is_hist else ap_traffic
-    roofline = {
-        "kernel": "%s, HIP events around the launch, %d launches" % (hist_kernel if dom_is_hist else ap_kernel + " (pass 2 of the fused mAP scan)", n_dom),
-        "bound": "hbm", "achieved": alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, "traffic": (dom_traffic or {}).get("bytes"),
-        "traffic_detail": dom_traffic,
-        "algorithmic_bytes": alg_bytes, "workspace_table_bytes": table_bytes, "pair_cache_bytes": cache_bytes, "avg_launch_ms": t_dom * 1e3,
-        "valu": {"lane_ops_per_pair": ops_dom, "achieved": Q * Rn * ops_dom / t_dom / 1e9,
-                 "peak": VALU_PEAK_GLOPS, "unit": "G lane-ops/s", "frac": Q * Rn * ops_dom / t_dom / 1e9 / VALU_PEAK_GLOPS},
-        "note": "Q=5000 queries share every gallery byte: this launch is VALU-bound (SURVEY H5), HBM fraction is "
-                "reported as the contract asks; the HBM-bound regime is in roofline_hbm_regime.  PMC traffic includes the "
-                "scheme's own tables and the pair cache (one byte per pair, written by pass 1, read by pass 2)",
-        "pass1_avg_launch_ms": t_hist * 1e3, "pass2_avg_launch_ms": t_ap * 1e3,
-        "pass1_valu": {"lane_ops_per_pair": ops_pair_hist, "frac": Q * Rn * ops_pair_hist / t_hist / 1e9 / VALU_PEAK_GLOPS},
-        "pass2_valu": {"lane_ops_per_pair": ops_pair_ap, "frac": Q * Rn * ops_pair_ap / t_ap / 1e9 / VALU_PEAK_GLOPS},
-    }
-    if ap_traffic is not None:
-        # the cached pass 2 streams the pair cache with 16-byte loads per lane, which FETCH_SIZE counts at half on gfx950
-        # (MI355X_MICROARCH.md, HBM section); its 8-byte table reads are counted in full
-        corr = cache_bytes / 2 if cached else 0
-        roofline["pass2_traffic"] = {"bytes": ap_traffic["bytes"] + corr, "fetch_raw": ap_traffic["fetch_raw"], "write_raw": ap_traffic["write_raw"],
-                                     "wide_read_correction_bytes": corr, "source": ap_traffic["source"]}
+    roofline = RL.scan_roofline(scan, Q, Rn, K, C, steps=max(args.steps, 10))
 
     out = {
         "metric": "Hamming query x gallery pairs/sec (fused mAP@all pass, DCMHT COCO-shaped 64-bit)",
@@ -243,7 +379,9 @@ def main():
         "config": {"workload": "configs[1] DCMHT COCO 64-bit retrieval: Q=%d queries x R=%d gallery items per GPU "
                                "(x%d GPUs, contiguous shards), K=%d bits, C=%d classes, mAP@all" % (Q, Rn, world, K, C),
                    "Q": Q, "R_per_gpu": Rn, "K": K, "C": C, "parallelism": "gallery-shard x%d" % world,
-                   "query_blocks": nqb if use_dist else 1},
+                   "query_blocks": nqb if use_dist else 1,
+                   "collectives_in_step": ["all_gather packed queries", "all_gather [2,Q,K+1] histograms", "all_reduce [Q] f64"] if use_dist else []},
+        "rccl_ranks": ranks_in_group, "launcher": "torch.distributed.run" if world > 1 else "single process",
         "mAP": map_value, "roofline": roofline,
     }
 
@@ -252,6 +390,7 @@ def main():
             import bench_topk
             out["roofline_hbm_regime"] = bench_topk.measure(Q=1)
             out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
+            out["topk_structured_codes"] = bench_topk.measure_structured()
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}
     if rank == 0 and world == 1:
@@ -265,10 +404,17 @@ def main():
         t_host = (time.perf_counter() - t0) / 3
         out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
                                      "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
+    if rank == 0 and world == 1 and not use_dist and not args.no_extra_configs:
+        try:
+            out["configs3_dsph_128bit"] = RL.extra_scan_leg(synth, Q, Rn, 128, C, args.p_label)
+        except Exception as exc:
+            out["configs3_dsph_128bit"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not use_dist and not args.no_encode:
         try:
             import bench_encode
             out["encode"] = bench_encode.measure()
+            if not args.no_extra_configs:
+                out["encode_mith"] = bench_encode.measure_mith()
         except Exception as exc:
             out["encode"] = {"error": repr(exc)}
     if use_dist and not args.no_encode:
@@ -289,16 +435,27 @@ def main():
                          "slowest_rank_captions_per_s": float(lo[1]), "n_gpus": world,
                          "config": {"workload": "CLIP ViT-B/32 + DCMHT 64-bit head, batch 100 per GPU, parity mode; one replica per GPU, "
                                                 "rates summed over ranks (measured concurrently)"}}
+    if world > 1 and not args.no_strong:
+        del ops, scan, piped, sq
+        torch.cuda.empty_cache()
+        try:
+            out["strong_scaling"] = strong_legs(args, world, rank, barrier)
+        except Exception as exc:
+            out["strong_scaling"] = {"error": repr(exc)}
+            print("strong-scaling legs failed on rank %d: %r" % (rank, exc), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        _, _, rB0, rL0 = rB, rL, rB, rL
-        out["cpu_baseline"] = cpu_baseline(qB, qL, rB0, rL0, args.cpu_seconds)
+        def gpu_map(qsub):
+            return R.map_k_packed(R.pack_sign(qB[:qsub].cuda()), r, R.pack_labels(qL[:qsub].cuda()), rl, C, None).item()
+        out["cpu_baseline"] = cpu_baseline(qB, qL, rB, rL, args.cpu_seconds, gpu_map)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if not args.no_encode:
+            try:
+                out["cpu_baseline_encode"] = cpu_encode_baseline()
+            except Exception as exc:
+                out["cpu_baseline_encode"] = {"error": repr(exc)}
     if use_dist:
         dist.destroy_process_group()
-    sys.stdout.flush()
-    if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    os.close(json_fd)
+    emit(out)
 
 
 if __name__ == "__main__":

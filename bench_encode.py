@@ -102,6 +102,33 @@ def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), e
     return out
 
 
+def measure_mith(batch=100, steps=10, warmup=5, K=64):
+    """BASELINE configs[2]'s method: MITH (CLIP in return_patches mode + the concept/token hash head), parity mode, batch 100."""
+    import xmh.models  # noqa: F401
+    from xmh.common.register import registry
+    from xmh.models import weights as W
+    from xmh.utils.config import Config
+    model = registry.get_model_class("MITH").from_config(Config({"clip_path": "synthetic:1814"}), output_dim=K, train_num=1000).cuda().eval()
+    image = W.synth_images(5, batch).cuda()
+    ids, _ = W.synth_text(5, batch)
+    ids = ids.cuda()
+    kpm = ids == 0
+    out = {"config": {"workload": "CLIP ViT-B/32 (return_patches) + MITH %d-bit head, batch %d, parity mode, random-init weights" % (K, batch)}}
+    with torch.no_grad():
+        for what, fn in (("images", lambda: model.encode_image(image)), ("captions", lambda: model.encode_text(ids, kpm))):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[what + "_per_s"] = batch / dt
+            out[what + "_ms_per_batch"] = dt * 1e3
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=100)

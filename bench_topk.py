@@ -23,21 +23,49 @@ HBM_PEAK_GBS = 8000.0
 
 def _traffic():
     try:
-        import bench
-        t = bench.pmc_traffic("k_topk_filter")
+        import bench_roofline
+        t = bench_roofline.pmc_traffic("k_topk_filter")
         return None if t is None else t["bytes"]
     except Exception:
         return None
 
 
-def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3):
+def _codes(kind, R, K, Q, seed=1814):
+    """packed gallery / query codes on the GPU.  "iid": uniform random bits (the sampled threshold's ideal case);
+    "structured": SURVEY 8d's sign(L W + 0.8 randn) with 80 COCO-like classes -- items sharing labels cluster, so the distance
+    distribution of a query is multi-modal and heavy near 0; "duplicates": the structured gallery with every item repeated 64
+    times in a row (ties far beyond k at every distance: the exact (distance, index) tie-break does the work)."""
+    from xmh import retrieval as X
+    W = (K + 31) // 32
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if kind == "iid":
+        rb = torch.randint(-2**31, 2**31 - 1, (R, W), dtype=torch.int32, device="cuda", generator=g)
+        qb = torch.randint(-2**31, 2**31 - 1, (Q, W), dtype=torch.int32, device="cuda", generator=g)
+        return X.PackedCodes(qb, None, K), X.PackedCodes(rb, None, K)
+    C, p = 80, 0.04
+    Wm = torch.randn(C, K, device="cuda", generator=g)
+
+    def side(n):
+        out = X.empty_packed(n, K, "cuda")
+        for lo in range(0, n, 1 << 20):                      # 1 M rows at a time: the fp32 codes never exist in full
+            m = min(1 << 20, n - lo)
+            L = (torch.rand(m, C, device="cuda", generator=g) < p).float()
+            L[torch.arange(m, device="cuda"), torch.randint(0, C, (m,), device="cuda", generator=g)] = 1.0
+            B = L @ Wm + 0.8 * torch.randn(m, K, device="cuda", generator=g)
+            out.bits[lo:lo + m] = X.pack_sign(torch.where(B == 0, torch.ones_like(B), B).sign()).bits
+        return out
+    if kind == "structured":
+        return side(Q), side(R)
+    base = side((R + 63) // 64)
+    rep = X.PackedCodes(base.bits.repeat_interleave(64, dim=0)[:R].contiguous(), None, K)
+    return side(Q), rep
+
+
+def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
     from xmh import retrieval as X
     from xmh._lib import lib
     W = (K + 31) // 32
-    g = torch.Generator(device="cuda").manual_seed(1814)
-    rb = torch.randint(-2**31, 2**31 - 1, (R, W), dtype=torch.int32, device="cuda", generator=g)
-    qb = torch.randint(-2**31, 2**31 - 1, (Q, W), dtype=torch.int32, device="cuda", generator=g)
-    q, r = X.PackedCodes(qb, None, K), X.PackedCodes(rb, None, K)
+    q, r = _codes(kind, R, K, Q)
     from xmh import _lib
     for _ in range(warmup):
         d, i = X.hamming_topk(q, r, k)
@@ -58,8 +86,29 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3):
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
             "traffic": _traffic(), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
             "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9,
-            "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU" % (k, Q, R, K),
-            "pairs_per_s_whole_call": Q * R / t_call}
+            "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU, %s codes" % (k, Q, R, K, kind),
+            "pairs_per_s_whole_call": Q * R / t_call, "robust_path_launches": _robust_launches(launches)}
+
+
+def _robust_launches(filter_launches):
+    """how often the gated robust path did the work (its kernels return at once when the fast path's lists held)"""
+    try:
+        from xmh import _lib
+        t, n = _lib.prof_read("topk_robust")
+        return {"launches": n, "avg_ms": t}
+    except Exception:
+        return None
+
+
+def measure_structured(R=10_000_000, K=256, k=100):
+    """the sampled threshold is ideal on i.i.d. codes -- the same call on label-correlated codes and on a
+    duplicate-heavy gallery (lists overflow -> the robust path recomputes), Q = 1 and 8."""
+    out = {}
+    for kind in ("structured", "duplicates"):
+        for Q in (1, 8):
+            m = measure(R=R, K=K, Q=Q, k=k, iters=10, kind=kind)
+            out["%s_Q%d" % (kind, Q)] = {x: m[x] for x in ("whole_call_ms", "whole_call_GBps", "avg_launch_ms", "achieved", "workload", "robust_path_launches")}
+    return out
 
 
 if __name__ == "__main__":

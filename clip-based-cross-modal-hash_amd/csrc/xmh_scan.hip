@@ -691,6 +691,47 @@ __global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_
     ap_sum[q] = s;
 }
 
+// k_ap_reduce + k_map_finalize in one launch (unsharded evaluation): every block also leaves the sum of ap/cap over its 256
+// queries in part[], takes a ticket, and the block that draws the last ticket adds the partials IN BLOCK ORDER (deterministic)
+// into the mean.  Hand-off per the gfx950 rule: plain stores, vmcnt(0), one agent-scope release before the ticket, one
+// agent-scope acquire in the last block before it reads the other blocks' partials; the ticket word is zeroed by the
+// hipMemsetAsync ahead of the launch.  (One block doing all of it was tried: 40 us -- a single block cannot pull 1 MB fast.)
+__global__ __launch_bounds__(256) void k_ap_reduce_map(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
+                                                       const int32_t* __restrict__ cap, double* __restrict__ ap_sum,
+                                                       double* __restrict__ part, uint32_t* __restrict__ ticket,
+                                                       double* __restrict__ map_out) {
+    __shared__ double red[256];
+    __shared__ int last;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    double term = 0.0;
+    if (q < Q) {
+        double s = 0.0;
+        for (int c = 0; c < nchunk; ++c) s += (double)ap_part[(int64_t)c * qpad + q];
+        ap_sum[q] = s;
+        term = s / (double)cap[q];                                   // cap == 0 -> NaN (0/0), like the reference
+    }
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = red[0];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double m = 0.0;
+            for (unsigned b = 0; b < gridDim.x; ++b) m += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            map_out[0] = m / (double)Q;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_map_finalize(const double* __restrict__ ap_sum, const int32_t* __restrict__ cap,
                                                       int64_t Q, double* __restrict__ map_out) {
     __shared__ double part[256];
@@ -758,7 +799,7 @@ WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes) {
     L.tot = take((size_t)p.nbuckets * p.qpad * 8);
     L.dpre = take((size_t)p.nbuckets * p.qpad * 8);
     L.cap = take((size_t)p.qpad * 4);
-    L.gate = take(256);
+    L.gate = take(256 + 8 * 4096);           // [0]: nrel_max gate word, [1]: finalize ticket, +256: per-block partial sums (<= 4096 blocks)
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
     L.pair_cache = take(cache_bytes);
     L.total = o;
@@ -983,7 +1024,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         while ((1ll << rank_bits) < R + 2) ++rank_bits;
         if (rank_bits > 24) rank_bits = 0;
     }
-    if (rank_bits) XMH_HIP(hipMemsetAsync(nrel_max, 0, 4, st));
+    XMH_HIP(hipMemsetAsync(nrel_max, 0, 8, st));                     // gate word + the finalize ticket next to it
     hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
                        base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
     XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
@@ -1040,9 +1081,16 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     rc = launch_width(T0{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
-    hipLaunchKernelGGL(k_ap_reduce, dim3((unsigned)xmh::ceil_div(Q, 256)), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);
+    const unsigned nred = (unsigned)xmh::ceil_div(Q, 256);
+    if (map_out && nred <= 4096) {                                   // reduce + mean in one launch (last-ticket block finalises)
+        hipLaunchKernelGGL(k_ap_reduce_map, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, (const int32_t*)cap, ap_sum,
+                           reinterpret_cast<double*>(base + L.gate + 256), nrel_max + 1, map_out);
+        XMH_LAUNCH_CHECK("xmh_hamming_map reduce+finalize");
+        return XMH_OK;
+    }
+    hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);
     XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
-    if (map_out) {                                                   // (both in ONE block was tried: 40 us instead of 20, a block cannot pull 1 MB fast)
+    if (map_out) {
         hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);
         XMH_LAUNCH_CHECK("xmh_hamming_map finalize");
     }

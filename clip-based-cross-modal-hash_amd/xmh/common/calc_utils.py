@@ -11,7 +11,8 @@ Differences that are deliberate and documented (DESIGN.md "Parity"):
   * ranking ties are broken by gallery index (torch.sort(stable=True)); the reference's unstable sort
     leaves them unspecified.
   * inputs may live on the CPU like in the reference (calc_map_k moves them there, :62-64); here they
-    are moved TO the GPU instead, and calc_map_k still returns a CPU 0-dim float32 tensor.
+    are moved TO the GPU instead; calc_map_k still returns a CPU 0-dim float32 tensor and the other
+    functions return on the device their inputs came from (host in -> host out).
   * there is no CPU fallback: without a GPU these functions raise.
 """
 from __future__ import annotations
@@ -32,6 +33,27 @@ def _device() -> torch.device:
 
 def _to_gpu(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_cuda else t.to(_device(), non_blocking=True)
+
+
+class _on_device_of:
+    """run the body with the device of the first CUDA operand current (libxmh launches on the current device's stream), and
+    remember whether every operand came from the host: the reference returns its result on the inputs' device
+    (common/calc_utils.py:8-56), so ``back()`` moves a result there."""
+
+    def __init__(self, *tensors):
+        cuda = [t for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda]
+        self.all_host = not cuda
+        self.ctx = torch.cuda.device(cuda[0].device if cuda else _device())
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+    def back(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if self.all_host else t
 
 
 def _pack_codes(B: torch.Tensor) -> R.PackedCodes:
@@ -61,20 +83,22 @@ def _is_quantised(*packed: R.PackedCodes) -> bool:
 
 
 def calc_label_sim(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """(a @ b^T > 0).float() for multi-hot label matrices; result on the GPU (inputs' device if CUDA)."""
-    a, b = _to_gpu(a), _to_gpu(b)
-    return R.label_sim(R.pack_labels(a), R.pack_labels(b), a.shape[1])
+    """(a @ b^T > 0).float() for multi-hot label matrices; computed on the GPU, returned on the inputs' device."""
+    with _on_device_of(a, b) as dv:
+        a, b = _to_gpu(a), _to_gpu(b)
+        return dv.back(R.label_sim(R.pack_labels(a), R.pack_labels(b), a.shape[1]))
 
 
 def calc_hammingDist(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
     """0.5 * (K - B1 @ B2^T), float32 [Q,R]; a 1-D B1 is one query (reference :53-54)."""
     if B1.dim() < 2:
         B1 = B1.unsqueeze(0)
-    q, r = _pack_codes(B1), _pack_codes(B2)
-    if _is_quantised(q, r):
-        return R.hamming_dist(q, r)
-    from .. import dense                           # un-quantised float "codes" (UMoED-style, SURVEY H3)
-    return dense.hamming_dist_float(_to_gpu(B1).float(), _to_gpu(B2).float())
+    with _on_device_of(B1, B2) as dv:
+        q, r = _pack_codes(B1), _pack_codes(B2)
+        if _is_quantised(q, r):
+            return dv.back(R.hamming_dist(q, r))
+        from .. import dense                           # un-quantised float "codes" (UMoED-style, SURVEY H3)
+        return dv.back(dense.hamming_dist_float(_to_gpu(B1).float(), _to_gpu(B2).float()))
 
 
 def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
@@ -84,20 +108,22 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
     num_query = query_L.shape[0]
     if num_query == 1:
         raise IndexError("calc_map_k needs more than one query (reference squeezes the query axis, calc_utils.py:72)")
-    q, r = _pack_codes(qB), _pack_codes(rB)
-    ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]
-    if _is_quantised(q, r):
-        res = R.map_k_packed(q, r, ql, rl, C, k)
-    else:
-        from .. import dense
-        res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), ql, rl, C, k)
-    return res.to(torch.float32).cpu().reshape(())
+    with _on_device_of(qB, rB, query_L, retrieval_L):
+        q, r = _pack_codes(qB), _pack_codes(rB)
+        ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]
+        if _is_quantised(q, r):
+            res = R.map_k_packed(q, r, ql, rl, C, k)
+        else:
+            from .. import dense
+            res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), ql, rl, C, k)
+        return res.to(torch.float32).cpu().reshape(())
 
 
 def cosine_similarity(a: Union[torch.Tensor, np.ndarray], b: Union[torch.Tensor, np.ndarray]):
     if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
         from .. import dense
-        return dense.cosine(_to_gpu(a).float(), _to_gpu(b).float())
+        with _on_device_of(a, b) as dv:
+            return dv.back(dense.cosine(_to_gpu(a).float(), _to_gpu(b).float()))
     if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
         from .. import dense
         return dense.cosine(_to_gpu(torch.from_numpy(a)).float(), _to_gpu(torch.from_numpy(b)).float()).cpu().numpy()
@@ -107,7 +133,8 @@ def cosine_similarity(a: Union[torch.Tensor, np.ndarray], b: Union[torch.Tensor,
 def euclidean_similarity(a: Union[torch.Tensor, np.ndarray], b: Union[torch.Tensor, np.ndarray]):
     if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
         from .. import dense
-        return dense.pairwise_l2(_to_gpu(a).float(), _to_gpu(b).float())
+        with _on_device_of(a, b) as dv:
+            return dv.back(dense.pairwise_l2(_to_gpu(a).float(), _to_gpu(b).float()))
     if isinstance(a, np.ndarray) and isinstance(b, np.ndarray):
         from .. import dense
         return dense.pairwise_l2(_to_gpu(torch.from_numpy(a)).float(), _to_gpu(torch.from_numpy(b)).float()).cpu().numpy()

@@ -98,12 +98,13 @@ class GpuEvalTransform:
         if isinstance(images, (list, tuple)):
             if not images:
                 raise ValueError("empty image list")
-            out = torch.empty(len(images), 3, self.resolution, self.resolution, dtype=torch.float32, device="cuda")
+            dev = images[0].device if images[0].is_cuda else torch.device("cuda", torch.cuda.current_device())
+            out = torch.empty(len(images), 3, self.resolution, self.resolution, dtype=torch.float32, device=dev)
             groups: Dict[tuple, list] = {}
             for i, im in enumerate(images):
                 groups.setdefault(tuple(im.shape), []).append(i)
             for shape, idx in groups.items():
-                batch = torch.stack([images[i] if images[i].is_cuda else images[i].cuda(non_blocking=True) for i in idx])
+                batch = torch.stack([images[i] if images[i].is_cuda else images[i].to(dev, non_blocking=True) for i in idx])
                 res = self._run(batch, False, True)[1]
                 out[torch.tensor(idx, device=out.device)] = res
             return out

@@ -43,11 +43,30 @@ def hamming_dist_float(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
     return g
 
 
+_FLOAT_TILE_BYTES = 1 << 30        # the [q-tile, R] fp32 distance block of the float path stays under 1 GiB
+
+
 def map_k_float(qB, rB, qlab, rlab, C: int, k: Optional[int]) -> torch.Tensor:
-    d = hamming_dist_float(qB, rB)
-    Q, Rn = d.shape
-    ap = torch.empty(Q, dtype=torch.float64, device=d.device)
-    cap = torch.empty(Q, dtype=torch.int32, device=d.device)
-    check(lib.xmh_float_rank_ap(ptr(d), ptr(qlab), ptr(rlab), Q, Rn, C, 0 if k is None else int(k), ptr(ap), ptr(cap), current_stream()),
-          "xmh_float_rank_ap")
+    """calc_map_k on un-quantised float "codes": distances by exact-fp32 GEMM, ranks by comparison counting.  The queries are
+    tiled so that at most 1 GiB of distances exists at a time (Q=5000 x R=117k would be 2.3 GB at once); the ranking itself
+    is O(nrel * R) per query -- this is the slow path, and the caller is told so once."""
+    global _warned_float
+    if not _warned_float:
+        import warnings
+        warnings.warn("xmh: codes contain values outside {-1,0,+1}: using the float ranking path (GEMM + comparison counting), "
+                      "orders of magnitude slower than the bit-packed scan; quantise the codes (make_hash_code) to avoid it")
+        _warned_float = True
+    qB, rB = qB.contiguous(), rB.contiguous()
+    Q, Rn = qB.shape[0], rB.shape[0]
+    ap = torch.empty(Q, dtype=torch.float64, device=qB.device)
+    cap = torch.empty(Q, dtype=torch.int32, device=qB.device)
+    tile = max(1, min(Q, _FLOAT_TILE_BYTES // (4 * max(Rn, 1))))
+    for lo in range(0, Q, tile):
+        hi = min(Q, lo + tile)
+        d = hamming_dist_float(qB[lo:hi], rB)
+        check(lib.xmh_float_rank_ap(ptr(d), ptr(qlab[lo:hi]), ptr(rlab), hi - lo, Rn, C, 0 if k is None else int(k), ptr(ap[lo:hi]),
+                                    ptr(cap[lo:hi]), current_stream()), "xmh_float_rank_ap")
     return R.map_finalize(ap, cap)
+
+
+_warned_float = False

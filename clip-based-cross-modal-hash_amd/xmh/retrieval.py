@@ -23,9 +23,15 @@ _DT = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.b
 
 
 def _require_cuda(*tensors):
+    """libxmh launches on the current device's current stream: every operand must live there."""
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("xmh ops need CUDA/HIP tensors (got a %s tensor); there is no CPU fallback" % t.device)
+        if t.device.index != torch.cuda.current_device():
+            raise RuntimeError("xmh op on a %s tensor while cuda:%d is current: wrap the call in torch.cuda.device(%d) "
+                               "or torch.cuda.set_device first" % (t.device, torch.cuda.current_device(), t.device.index))
 
 
 def words(K: int) -> int:
@@ -50,7 +56,7 @@ class PackedCodes:
         return self.zero is not None
 
     def rows(self, lo: int, hi: int) -> "PackedCodes":
-        return PackedCodes(self.bits[lo:hi], None if self.zero is None else self.zero[lo:hi], self.K)
+        return PackedCodes(self.bits[lo:hi], None if self.zero is None else self.zero[lo:hi], self.K, self.flags)
 
     def unpack(self) -> torch.Tensor:
         """-> float32 [n, K] of -1/0/+1 (what BaseTrainer.get_code hands to calc_map_k / save_mat)."""

@@ -69,6 +69,10 @@ class BaseTrainer:
             self._init_distribution(rank=device, world_size=world_size)
         self.logger.info(f"parameters: {dict(cfg)}")
         self.device = device
+        if not distributed and torch.cuda.is_available() and device is not None:
+            # libxmh launches on the CURRENT device's stream: make run.device current (the reference reaches any device
+            # through .to(self.device), runners/base.py:105-107)
+            torch.cuda.set_device(torch.device("cuda", device) if isinstance(device, int) else torch.device(device))
         self.output_dim, self.train_num, self.query_num = output_dim, train_num, query_num
         self.epochs, self.display_step, self.top_k = epochs, display_step, top_k
         self.model_state, self.batch_size, self.save_dir = model_state, batch_size, save_dir
@@ -284,6 +288,8 @@ class BaseTrainer:
                 if len(pending) == fuse:
                     flush()
             flush()
+        if self.distributed:                                 # ternary-ness is a property of the whole code set: every rank must
+            sharded.reduce_flags(flags)                      # rank its shard in the same bucket units (2K+1 vs K+1 buckets)
         if not (int(flags.item()) & 1):                      # no exact zero anywhere: drop the zero planes
             for img, txt in bufs.values():
                 img.zero = txt.zero = None
@@ -304,7 +310,7 @@ class BaseTrainer:
         zero = None
         if int(has_zero.item()):
             zero = sharded.all_gather_rows(R.zero_plane_or_default(p), counts)
-        return R.PackedCodes(bits, zero, p.K)
+        return R.PackedCodes(bits, zero, p.K, p.flags)
 
     def get_code(self, data_loader, length: int):
         """reference :242-266 -- two [length, K] fp32 buffers of -1/0/+1, complete on every rank."""
@@ -324,6 +330,12 @@ class BaseTrainer:
             if self.calc_map_k is calc_map_k:
                 return float(R.map_k_packed(q, r_shard, self._qlab, self._rlab, C, k).item())
             return float(self.calc_map_k(q.unpack(), r_shard.unpack(), self.query_labels, self.retrieval_labels, k))
+        if self.calc_map_k is not calc_map_k:
+            # an injected calc_map_k sees what the reference's would: the complete code matrices on every rank
+            # (runners/base.py:259-264 gathers them), at the price of the gather the built-in sharded scan avoids
+            lo, hi = self._shard(self.retrieval_num)
+            full = self._gather_packed(r_shard, self.retrieval_num)
+            return float(self.calc_map_k(q.unpack(), full.unpack(), self.query_labels, self.retrieval_labels, k))
         ops = sharded.HipShardOps(q, self._qlab, r_shard, self._rlab, C)
         return float(sharded.map_k_sharded(ops, k)[0].item())
 
@@ -338,9 +350,19 @@ class BaseTrainer:
     def _is_writer(self):
         return not self.distributed or self.rank == 0
 
+    def _gather_packed_to_writer(self, p: R.PackedCodes, length: int):
+        """the complete packed code set on rank 0 only (None elsewhere): the .mat writer is the only consumer"""
+        if not self.distributed:
+            return p
+        b = sharded.shard_bounds(length, self.world_size)
+        counts = [b[r + 1] - b[r] for r in range(self.world_size)]
+        bits = sharded.gather_rows_to(p.bits, counts, dst=0)
+        zero = sharded.gather_rows_to(p.zero, counts, dst=0) if p.zero is not None else None     # zero planes are global (reduce_flags)
+        return R.PackedCodes(bits, zero, p.K, p.flags) if bits is not None else None
+
     def _save_codes(self, codes, save_file):
         q_img, q_txt, r_img, r_txt = codes
-        r_img, r_txt = self._gather_packed(r_img, self.retrieval_num), self._gather_packed(r_txt, self.retrieval_num)
+        r_img, r_txt = self._gather_packed_to_writer(r_img, self.retrieval_num), self._gather_packed_to_writer(r_txt, self.retrieval_num)
         if self._is_writer():
             self.save_mat(q_img.unpack(), q_txt.unpack(), self.query_labels, r_img.unpack(), r_txt.unpack(), self.retrieval_labels, save_file=save_file)
 

@@ -179,10 +179,67 @@ def _map_k_blocks(blocks, k, rank, group):
 
 def merge_topk(dists: torch.Tensor, idxs: torch.Tensor, k: int):
     """Host merge of per-shard exact top-k lists (north_star: 'partial top-k lists merged on the host').
-    dists/idxs: [world, Q, k] (any device).  Order key = (distance, global index); unused slots carry
-    idx -1 and are pushed to the end."""
-    d = dists.to("cpu").to(torch.int64).permute(1, 0, 2).reshape(dists.shape[1], -1)
+    dists/idxs: [world, Q, k] (any device; int16 distances are the uint16 bit patterns xmh_hamming_topk writes).
+    Order key = (distance, global index); unused slots carry idx -1 and are pushed to the end."""
+    d = dists.to("cpu").to(torch.int64)
+    if dists.dtype == torch.int16:
+        d = d & 0xFFFF
+    d = d.permute(1, 0, 2).reshape(dists.shape[1], -1)
     i = idxs.to("cpu").to(torch.int64).permute(1, 0, 2).reshape(idxs.shape[1], -1)
     key = torch.where(i < 0, torch.full_like(d, 1 << 62), (d << 32) | i)
     order = torch.argsort(key, dim=1)[:, :k]
     return torch.gather(d, 1, order).to(torch.int32), torch.gather(i, 1, order).to(torch.int32)
+
+
+def reduce_flags(flags: torch.Tensor, group=None) -> torch.Tensor:
+    """bitwise OR of the quantiser's value flags (int32 [1]: bit0 = an exact 0 was seen, bit1 = a value outside
+    {-1,0,+1}) over all ranks, in place.  Every rank must rank its shard in the SAME mode: a zero seen on one rank only
+    would otherwise leave that rank with 2K+1 half-unit buckets and the others with K+1, and the histogram all-gather
+    with mismatched shapes.  RCCL has no bitwise reductions: the bits travel as separate MAX lanes."""
+    lanes = torch.stack([(flags.reshape(-1)[0] >> b) & 1 for b in range(2)]).to(torch.int32)
+    dist.all_reduce(lanes, op=dist.ReduceOp.MAX, group=group)
+    flags.reshape(-1)[0] = lanes[0] | (lanes[1] << 1)
+    return flags
+
+
+def gather_rows_to(t: torch.Tensor, counts: Sequence[int], dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """like all_gather_rows, but only ``dst`` receives the concatenation (others get None): the .mat writer needs the
+    whole retrieval set on one rank only."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    m = max(counts)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
+def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
+    """north_star retrieval mode over a sharded gallery: exact top-k of every query on this rank's shard (global indices
+    = base_index + row), ONE all-gather of the [Q, k] (distance, index) lists, k-way merge on the host.  Returns
+    (dist int32 [Q,k], idx int32 [Q,k]) CPU tensors, identical on every rank; unused slots (fewer than k rows in all)
+    carry idx -1.  ``topk_fn(q, r_shard, k, base_index) -> (dist, idx)`` defaults to the HIP op; a rank without gallery
+    rows contributes empty lists."""
+    world = dist.get_world_size(group)
+    n_rows = r_shard.n if hasattr(r_shard, "n") else len(r_shard)
+    nq = q.n if hasattr(q, "n") else len(q)
+    if topk_fn is None:
+        from . import retrieval as R
+        topk_fn = R.hamming_topk
+        dev = q.bits.device
+    else:
+        dev = torch.device("cpu")
+    if n_rows == 0:
+        d = torch.full((nq, k), -1, dtype=torch.int16, device=dev)          # 0xFFFF = unused slot
+        i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+    else:
+        d, i = topk_fn(q, r_shard, k, base_index)
+    both = torch.stack([(d.to(torch.int32) & 0xFFFF) if d.dtype == torch.int16 else d.to(torch.int32), i.to(torch.int32)]).contiguous()
+    out = torch.empty((world,) + tuple(both.shape), dtype=torch.int32, device=both.device)
+    if hasattr(dist, "all_gather_into_tensor") and both.is_cuda:
+        dist.all_gather_into_tensor(out, both, group=group)
+    else:
+        dist.all_gather(list(out.unbind(0)), both, group=group)
+    return merge_topk(out[:, 0], out[:, 1], k)

@@ -89,7 +89,7 @@ int xmh_label_sim(const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t
  * Fused ranking scan (a-2): calc_map_k (common/calc_utils.py:58-92) without the [Q,R] intermediates.
  *
  * Canonical order = (distance asc, gallery index asc)  == torch.sort(stable=True).
- * Two streaming passes over the gallery shard, queries one-per-lane, gallery through scalar loads:
+ * Two streaming passes over the gallery shard (a wave owns 64/S queries x S item slots, per-query bucket counters in LDS):
  *   pass 1 (xmh_hamming_hist): per (query, gallery chunk) bucket counts of all / relevant items;
  *   pass 2 (xmh_hamming_ap):   rank of every relevant item = bucket base + running in-bucket count,
  *                              accumulates sum_j j/rank_j for ordinals j <= min(n_rel, k).

@@ -43,15 +43,14 @@ def main():
     for K in (16, 64):
         ref = HashLayer(clip_embed_dim=512, k_bits=K, dropout=0.0, transformer_layers=2, activation="gelu", top_k_label=8, res_mlp_layers=2).eval()
         ref.load_state_dict(mith_state(Wt, ref.state_dict(), K))
-        B = 3
+        B = 40                                            # 640 / 2560 code bits per modality: the "<1 % flips" bound means something
         cls_i = Wt.synth_tensor(SEED, "mith_in.cls_i", (B, 512), 0.6)
         tok_i = Wt.synth_tensor(SEED, "mith_in.tok_i", (49, B, 512), 0.6)
         cls_t = Wt.synth_tensor(SEED, "mith_in.cls_t", (B, 512), 0.6)
         tok_t = Wt.synth_tensor(SEED, "mith_in.tok_t", (32, B, 512), 0.6)
         mask = torch.zeros(B, 32, dtype=torch.bool)
-        mask[0, 9:] = True
-        mask[1, 20:] = True
-        mask[2, 4:] = True
+        for b in range(B):
+            mask[b, 4 + (7 * b) % 27:] = True             # caption lengths 4..30 (tests/test_oracle_encode.py: mith_inputs)
         with torch.no_grad():
             _, ch_i, th_i, _ = ref.encode_img(cls_i, tok_i)
             _, ch_t, th_t, _ = ref.encode_txt(cls_t, tok_t, mask)

@@ -198,7 +198,8 @@ def test_bench_sharded_path_over_rccl_single_rank():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in a
-    assert a["roofline"]["bound"] in ("hbm", "mfma") and "frac" in a["roofline"] and "workload" in a["config"]
+    assert a["roofline"]["bound"] in ("valu", "hbm", "mfma") and "frac" in a["roofline"] and "workload" in a["config"]
+    assert a["roofline"]["hbm"]["bound"] == "hbm" and a["rccl_ranks"] == 1 and b["rccl_ranks"] == 1
 
 
 def test_runner_distributed_code_path_world_size_1(tmp_path):

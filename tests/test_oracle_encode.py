@@ -135,9 +135,10 @@ def mith_params(W, seed, K):
 
 
 def mith_inputs(W, seed):
-    B = 3
+    B = 40
     mask = torch.zeros(B, 32, dtype=torch.bool)
-    mask[0, 9:], mask[1, 20:], mask[2, 4:] = True, True, True
+    for b in range(B):
+        mask[b, 4 + (7 * b) % 27:] = True                 # as in oracle/make_golden_mith.py
     return (W.synth_tensor(seed, "mith_in.cls_i", (B, 512), 0.6), W.synth_tensor(seed, "mith_in.tok_i", (49, B, 512), 0.6),
             W.synth_tensor(seed, "mith_in.cls_t", (B, 512), 0.6), W.synth_tensor(seed, "mith_in.tok_t", (32, B, 512), 0.6), mask)
 

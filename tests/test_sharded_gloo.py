@@ -101,3 +101,76 @@ def test_world_size_2_sharded_map_and_topk(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def _worker_flags_topk(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "clip-based-cross-modal-hash_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        from oracle import c_oracle as co
+        from xmh import sharded
+        # only rank 1's shard saw an exact 0 (flag bit0), only rank 0 saw an un-quantised value (bit1): after the
+        # reduction every rank holds the OR, so every rank keeps / drops its zero planes alike (same bucket count everywhere)
+        flags = torch.tensor([2 if rank == 0 else 1], dtype=torch.int32)
+        sharded.reduce_flags(flags)
+        assert int(flags.item()) == 3
+        flags = torch.zeros(1, dtype=torch.int32)
+        sharded.reduce_flags(flags)
+        assert int(flags.item()) == 0
+        # gather to the writer only
+        b = sharded.shard_bounds(11, world)
+        mine = torch.arange(b[rank], b[rank + 1], dtype=torch.int32).reshape(-1, 1).repeat(1, 3)
+        full = sharded.gather_rows_to(mine, [b[r + 1] - b[r] for r in range(world)], dst=0)
+        if rank == 0:
+            assert full.shape == (11, 3) and torch.equal(full[:, 0], torch.arange(11, dtype=torch.int32))
+        else:
+            assert full is None
+        # topk_sharded: shard lists -> one all-gather -> host merge == global top-k; second round: rank 1 owns no rows at all
+        rng = np.random.default_rng(7)
+        Q, R, K, kk = 9, 700, 64, 25
+        qb = rng.integers(0, 2**32, size=(Q, 2), dtype=np.uint32)
+        rb = rng.integers(0, 2**32, size=(R, 2), dtype=np.uint32)[rng.integers(0, 90, size=R)]
+
+        def fn(q, r, k, base):
+            d, i = co.topk(q, r, K + 1, k, base_index=base)
+            return torch.from_numpy(d.view(np.int16).copy()), torch.from_numpy(i)
+        wd, wi = co.topk(qb, rb, K + 1, kk)
+        for bounds in (sharded.shard_bounds(R, world), [0, R, R]):
+            lo, hi = bounds[rank], bounds[rank + 1]
+            md, mi = sharded.topk_sharded(qb, rb[lo:hi], kk, lo, topk_fn=fn)
+            assert np.array_equal(mi.numpy(), wi) and np.array_equal(md.numpy().astype(np.uint16), wd)
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_2_flags_writer_gather_and_topk_sharded(tmp_path):
+    world = 2
+    mp.spawn(_worker_flags_topk, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_n_ranks_dry_run():
+    """`python bench.py --gpus 2` (no RANK/WORLD_SIZE in the environment, the way the round driver calls it) re-executes
+    itself under torch.distributed.run; --dry-run walks the launcher, the rendezvous and one step's collectives over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["ranks_in_group"] == 2
+    # N=1 takes no launcher
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["ranks_in_group"] == 1

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Count the VALU instructions per 64 (query, item) pairs in the steady-state loops of the scan kernels, from the ISA hipcc emits
+for the very sources that are built into libxmh.so (-save-temps).  Writes profiles/<tag>_scan_isa.json (read by bench_roofline.py)
+and profiles/<tag>_scan_isa.txt (the loop bodies themselves, so a reader can check the counts).
+
+    python tools/isa_count.py r02
+
+The hot path of a kernel = the straight run of code (no branch inside) with the most LDS atomics: hipcc emits the unrolled full
+64-item batch that way.  One LDS atomic = one step of a wave = 64 pairs, so VALU per 64 pairs = VALU in the run / atomics in
+the run.  This is a STATIC count of the hot path: per-batch prologue code (loads, staging) and conditionally executed pieces
+that hipcc moved out of the run (pass 2: the credit of the first group of a batch sits behind the `have_prev` test) are not in
+it; the dynamic count per launch is SQ_INSTS_VALU in the rocprofv3 PMC summary (bench_roofline.py reports both)."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "clip-based-cross-modal-hash_amd", "csrc", "xmh_scan.hip")
+
+# json key -> (kernel, template-argument string as mangled by the Itanium ABI)
+#   k_scan_hist_s<W, LW, TERN, S, NW, CACHE>;  k_scan_ap_s<W, LW, TERN, CAPPED, S, P32, MASKED, NW, CACHE>
+KERNELS = {
+    "hist_W2_L3_cache": ("k_scan_hist_s", "ILi2ELi3ELb0ELi4ELi1ELb1EE"),
+    "hist_W2_L3_plain": ("k_scan_hist_s", "ILi2ELi3ELb0ELi4ELi1ELb0EE"),
+    "ap_W2_L3_cache_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb1EE"),
+    "ap_W2_L3_cache_p32": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb1ELb0ELi1ELb1EE"),
+    "ap_W2_L3_plain_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb0EE"),
+    "hist_W4_L3_cache": ("k_scan_hist_s", "ILi4ELi3ELb0ELi8ELi1ELb1EE"),
+    "ap_W4_L3_cache_u64": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb0ELb0ELi1ELb1EE"),
+    "ap_W4_L3_cache_p32": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb1ELb0ELi1ELb1EE"),
+}
+
+
+def kernel_bodies(asm):
+    """mangled name -> list of instruction/label lines"""
+    out, cur, name = {}, None, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):\s", line)
+        if m:
+            name, cur = m.group(1), []
+            out[name] = cur
+            continue
+        if cur is not None:
+            if line.startswith(".Lfunc_end"):                 # (not the first s_endpgm: gated kernels return early)
+                cur = None
+                continue
+            cur.append(line)
+    return out
+
+
+def best_loop(lines):
+    """-> (instruction lines executed per full 64-item batch, LDS atomics among them).
+    hipcc lays the unrolled full-batch path out as one straight run of code (possibly after the loop's own span, jumping back to
+    the loop header), and keeps the ragged-batch path inside the span.  So: the straight run with the most LDS atomics = the hot
+    path; the per-batch prologue = the code from the label its final branch returns to, up to the branch that enters it."""
+    is_label = lambda l: re.match(r"^(\.LBB\d+_\d+):", l)                     # noqa: E731
+    is_branch = lambda l: re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", l)    # noqa: E731
+    is_atomic = lambda l: re.match(r"\s+ds_(add|inc)", l)                      # noqa: E731
+    # straight runs: split at branches only (labels that are merely fall-through targets stay inside a run)
+    runs, start = [], 0
+    for i, l in enumerate(lines):
+        if is_branch(l):
+            runs.append((start, i))
+            start = i + 1
+    runs.append((start, len(lines) - 1))
+    a, b = max(runs, key=lambda r: sum(1 for l in lines[r[0]:r[1] + 1] if is_atomic(l)))
+    natom = sum(1 for l in lines[a:b + 1] if is_atomic(l))
+    if not natom:
+        return None, 0
+    # trim the run to start at the last label before its first atomic that some branch targets (the entry of the hot path)
+    first_atomic = next(i for i in range(a, b + 1) if is_atomic(lines[i]))
+    targets = {is_branch(l).group(1) for l in lines if is_branch(l)}
+    entry = a
+    for i in range(a, first_atomic):
+        m = is_label(lines[i])
+        if m and m.group(1) in targets:
+            entry = i
+    hot = lines[entry:b + 1]
+    entry_label = is_label(lines[entry]).group(1) if is_label(lines[entry]) else None
+    back = is_branch(lines[b]).group(1) if is_branch(lines[b]) else None
+    pro = []
+    if entry_label and back:
+        idx = {is_label(l).group(1): i for i, l in enumerate(lines) if is_label(l)}
+        if back in idx:
+            for i in range(idx[back], len(lines)):
+                pro.append(lines[i])
+                m = is_branch(lines[i])
+                if m and m.group(1) == entry_label:
+                    break
+            else:
+                pro = []
+        if pro and sum(1 for l in pro if is_atomic(l)):
+            pro = []                                           # walked through another path: do not guess
+    return pro + hot, natom
+
+
+def count(body):
+    ops = collections.Counter()
+    for l in body:
+        m = re.match(r"\s+(v_\w+|ds_\w+|s_\w+|global_\w+|buffer_\w+)", l)
+        if m:
+            ops[m.group(1)] += 1
+    return ops
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-save-temps", "-c", SRC,
+                        "-o", os.path.join(tmp, "x.o")], cwd=tmp, check=True, stderr=subprocess.DEVNULL)
+        asm = open([os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]).read()
+    bodies = kernel_bodies(asm)
+    result, text = {}, []
+    for key, (kern, targs) in KERNELS.items():
+        names = [n for n in bodies if kern + targs in n]
+        if not names:
+            continue
+        body, natom = best_loop(bodies[names[0]])
+        if not body or not natom:
+            continue
+        ops = count(body)
+        valu = {re.sub(r"_e(32|64)$|_sdwa$|_dpp$", "", k): 0 for k in ops if k.startswith("v_")}
+        for k, v in ops.items():
+            if k.startswith("v_"):
+                valu[re.sub(r"_e(32|64)$|_sdwa$|_dpp$", "", k)] += v
+        per_step = {k: v / natom for k, v in sorted(valu.items())}
+        result[key] = per_step
+        text.append("=== %s  %s\n    loop: %d instructions, %d LDS atomics (= steps of 64 pairs); VALU per step %.2f, DS per step %.2f, SALU per step %.2f\n"
+                    % (key, names[0], sum(ops.values()), natom, sum(valu.values()) / natom,
+                       sum(v for k, v in ops.items() if k.startswith("ds_")) / natom, sum(v for k, v in ops.items() if k.startswith("s_")) / natom))
+        text.append("    per step: " + ", ".join("%s %.2f" % kv for kv in per_step.items()) + "\n")
+        text.extend(l + "\n" for l in body if l.strip() and not l.strip().startswith(";"))
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(result, open(os.path.join(ROOT, "profiles", "%s_scan_isa.json" % tag), "w"), indent=1, sort_keys=True)
+    open(os.path.join(ROOT, "profiles", "%s_scan_isa.txt" % tag), "w").writelines(text)
+    for k, v in result.items():
+        print("%-22s VALU per 64 pairs: %.2f" % (k, sum(v.values())))
+
+
+if __name__ == "__main__":
+    main()
