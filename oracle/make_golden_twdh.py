@@ -1,8 +1,8 @@
 """Generate tests/golden/encode_twdh.npz by RUNNING the reference's pieces of the TwDH forward (models/TwDH/TwDH.py:66-85):
 the DCMHT HashLayer at long_dim = 512 (models/DCMHT/hash/hash.py) and ``quantization(long_hash.matmul(trans))`` for two
-short lengths, plus the runner's quantiser (runners/DCMHT/runner.py:82-95).  The TwDH class itself cannot be instantiated
-here (it torch.load()s centre / transform files that are not in the tree), so its three-line encode path is driven with
-the reference's own HashLayer and a seeded transform matrix.
+short lengths, plus the runner's quantiser (runners/DCMHT/runner.py:82-95), on a seeded transform matrix (head-level
+golden, B = 24).  The TwDH CLASS itself -- instantiated with the centre / transform matrices the reference ships under
+data/transformer/TwDH/coco -- and TwDHTrainer.get_code / valid are pinned by oracle/make_golden_runner.py -> runner.npz.
 TEST INFRASTRUCTURE ONLY; runs in the build container.   python oracle/make_golden_twdh.py"""
 import os
 import sys

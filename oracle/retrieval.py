@@ -85,6 +85,29 @@ def map_k(qB, rB, query_L, retrieval_L, k=None, stable: bool = True) -> torch.Te
     return acc / Q
 
 
+def map_k_tie_bounds(qB, rB, query_L, retrieval_L, k=None):
+    """(lowest, highest) mAP any tie order can give: the reference's default torch.sort (calc_utils.py:77) leaves the order of
+    equal distances unspecified, so ITS value -- and the canonical (distance, index) value -- must lie between the
+    ranking that puts every irrelevant item of a distance bucket first and the one that puts every relevant item first."""
+    Q = query_L.shape[0]
+    if k is None:
+        k = retrieval_L.shape[0]
+    rel = (query_L.to(torch.float32).mm(retrieval_L.to(torch.float32).t()) > 0)
+    d = hamming_dist(qB.cpu(), rB.cpu())
+    out = []
+    for sign in (+1.0, -1.0):                                   # worst case: relevant last within a tie; best: relevant first
+        key = d.to(torch.float64) * 4.0 + sign * rel.to(torch.float64)
+        order = torch.sort(key, dim=-1, stable=True).indices
+        acc = 0.0
+        for i in range(Q):
+            hits = rel[i][order[i]]
+            n = int(min(int(hits.sum()), k))
+            rank = torch.nonzero(hits)[:n].squeeze(-1).to(torch.float64) + 1.0
+            acc += float((torch.arange(1, n + 1, dtype=torch.float64) / rank).mean()) if n else float("nan")
+        out.append(acc / Q)
+    return out[0], out[1]
+
+
 # --------------------------------------------------------------------------
 # make_hash_code variants (quantisers)
 # --------------------------------------------------------------------------

@@ -98,3 +98,26 @@ def test_ternary_and_float_similarities():
     assert np.allclose(orc.hamming_dist(fq, fr).numpy(), g["float_dist"], atol=1e-5)
     got = float(orc.map_k(fq, fr, torch.from_numpy(g["fqL"]).long(), torch.from_numpy(g["frL"]).long()))
     assert abs(got - float(g["float_map_stable"])) < 1e-6
+
+
+def test_oracle_reproduces_the_reference_runner_log_on_its_own_codes():
+    """runner.npz holds the code buffers and the logged mAPs of the REFERENCE's DCMHTTrainer / MITHTrainer / TwDHTrainer.valid()
+    (oracle/make_golden_runner.py).  The oracle's port with the reference's default sort reproduces every logged value on those
+    codes, and the canonical-order value the HIP path is held to lies in the same tie-order envelope."""
+    import sys
+    from oracle import retrieval as orc
+    from oracle import runner_fixture as RF
+    g = np.load(os.path.join(GOLDEN, "runner.npz"))
+    q, r = RF.datasets()
+    qL, rL = q.get_all_label(), r.get_all_label()
+    pairs = [("q_img", "r_txt"), ("q_txt", "r_img"), ("q_txt", "r_txt"), ("q_img", "r_img")]          # i2t, t2i, t2t, i2i (log order)
+    streams = ["DCMHT", "MITH", "TwDH_long"] + ["TwDH_%d" % int(s) for s in g["TwDH_short_dims"]]
+    for st in streams:
+        logged = g[st + "_maps_i2t_t2i_t2t_i2i"]
+        for ref, (a, b) in zip(logged, pairs):
+            qc, rc = torch.from_numpy(g["%s_%s" % (st, a)]), torch.from_numpy(g["%s_%s" % (st, b)])
+            lo, hi = orc.map_k_tie_bounds(qc, rc, qL, rL)
+            stable = float(orc.map_k(qc, rc, qL, rL, None, stable=True))
+            assert lo - 1e-6 <= ref <= hi + 1e-6 and lo - 1e-6 <= stable <= hi + 1e-6, (st, a, b)
+            if sys.version_info[:2] == (3, 10) and torch.__version__.startswith("2.10"):     # tie order of the default sort is a torch detail
+                assert abs(float(orc.map_k(qc, rc, qL, rL, None, stable=False)) - ref) < 1e-6, (st, a, b)
