@@ -118,7 +118,8 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
 //   below[c][d][q] = (#all, #relevant) items of bucket d in chunks < c of this shard
 //   tot[d][q]      = (#all, #relevant) items of bucket d in this shard
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__ chunk_hist, int qpad, int nb, int nchunk,
+// rel_scale = 0: pass-1 counters are (all | relevant << 16); else all + relevant * rel_scale (the MFMA-evaluated pass 1)
+__global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__ chunk_hist, int qpad, int nb, int nchunk, uint32_t rel_scale,
                                                     uint2* __restrict__ below, uint2* __restrict__ tot) {
     const int lane = threadIdx.x & 63;
     const int d = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -133,15 +134,17 @@ __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             below[((int64_t)(c + j) * nb + d) * qpad + q] = make_uint2(ra, rr);
-            ra += h[j] & 0xffffu;
-            rr += h[j] >> 16;
+            const uint32_t rel = rel_scale ? h[j] / rel_scale : h[j] >> 16;
+            ra += rel_scale ? h[j] - rel * rel_scale : h[j] & 0xffffu;
+            rr += rel;
         }
     }
     for (; c < nchunk; ++c) {
         const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
         below[((int64_t)c * nb + d) * qpad + q] = make_uint2(ra, rr);
-        ra += h & 0xffffu;
-        rr += h >> 16;
+        const uint32_t rel = rel_scale ? h / rel_scale : h >> 16;
+        ra += rel_scale ? h - rel * rel_scale : h & 0xffffu;
+        rr += rel;
     }
     tot[(int64_t)d * qpad + q] = make_uint2(ra, rr);
 }
@@ -616,6 +619,220 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
     if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
 
+
+// ===================================================================================================
+// MFMA-evaluated scan (binary codes of at most 64 bits, at most 128 classes).
+//
+// Hamming distance and label overlap of 16 gallery items x 16 queries are two i8 dot-product tiles -- literally what the
+// reference computes, B1 @ B2^T and query_L @ retrieval_L^T (common/calc_utils.py:51-56, :72) -- so they go to
+// v_mfma_i32_16x16x64_i8 instead of 8 VALU instructions per pair:
+//   * code tile: item bytes +-1, query bytes -+SCALE (SCALE = bytes of one bucket row of the LDS counters); started from the lane's
+//     counter base, the accumulator IS the LDS byte address of counter [distance][query]:  base + SCALE*K/2 - (SCALE/2)*dot;
+//   * label tile: item bytes 127, query bytes 64; pass 1 starts it at 1 so that min(acc, 1 + 8128) is the add operand
+//     1 + relevant * 8128 (counters hold all + relevant * 8128; a chunk has at most 8064 items), pass 2 takes min(acc, 1).
+// Per pair the VALU does ONE instruction in pass 1 (v_min) and the credit arithmetic in pass 2.
+// Geometry = the slotted scheme with S = 4: lane = slot * 16 + query, and MFMA row 4*slot + j of a 16-item group holds item
+// 4*j + slot, so accumulator register j of a lane is its step j and same-query lanes of one LDS instruction are consecutive
+// items in lane order -- exactly what pass 2's returning adds need (lane_order_ok).
+// Operand images (built per call by two small kernels, in the workspace): gallery [64-item batch][16-item group][tile m][lane][16 B],
+// i.e. every MFMA A operand is one contiguous KB = one global_load_lds piece and one conflict-free ds_read_b128 per lane; the
+// NW waves of a block (NW * 16 queries) share each staged batch (2-deep ring, LDS-DMA issued one batch ahead).
+// The LDS atomics are inline asm: hipcc would drain the LDS-DMA (vmcnt(0)) before any LDS atomic it cannot prove disjoint from
+// the ring.  Returning adds are waited for with counted lgkmcnt statements naming their destinations (LDS returns in order).
+// ===================================================================================================
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr uint32_t kRelScale = 127u * 64u;
+constexpr int kMfmaMaxChunk = 8064;                  // < kRelScale, multiple of 64
+
+struct MfmaArgs {
+    const uint4* gimg;
+    const uint4* qimg;
+    const uint32_t* qbits;
+    int Q, R, K, W;
+    int chunk, nchunk, nqt, nb, qpad;
+};
+
+template <int NMC, int NML>
+__device__ __forceinline__ void expand_query_piece(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qlab, int64_t Q, int W, int LW, int K,
+                                                   uint4* __restrict__ out32, int64_t p);
+
+// one launch builds both operand images: blocks [0, gblocks) the gallery image, the rest the query image
+template <int NMC, int NML>
+__global__ __launch_bounds__(256) void k_scan_expand(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int K,
+                                                     uint4* __restrict__ out, int64_t npieces, unsigned gblocks, const uint32_t* __restrict__ qbits,
+                                                     const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces) {
+    constexpr int NM = NMC + NML;
+    if (blockIdx.x >= gblocks) {
+        const int64_t qp = (int64_t)(blockIdx.x - gblocks) * 256 + threadIdx.x;
+        if (qp < qpieces) expand_query_piece<NMC, NML>(qbits, qlab, Q, W, LW, K, qout, qp);
+        return;
+    }
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npieces) return;
+    const int lane = (int)(p & 63);
+    const int m = (int)((p >> 6) % NM);
+    const int64_t grp = (p >> 6) / NM;                             // batch * 4 + group
+    const int rho = lane & 15, c = lane >> 4;
+    const int64_t item = grp * 16 + 4 * (rho & 3) + (rho >> 2);
+    uint32_t by[4] = {0u, 0u, 0u, 0u};
+    if (m < NMC) {                                                 // items past the end: all-zero-bit codes (bytes -1), no labels
+        const int k0 = m * 64 + c * 16;
+        uint32_t bits = 0u;
+        if (item < R && k0 < W * 32) bits = (rbits[item * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((k0 + t < K) ? (((bits >> t) & 1u) ? 0x01u : 0xffu) : 0u) << (8 * (t & 3));
+    } else {
+        const int k0 = (m - NMC) * 64 + c * 16;
+        uint32_t bits = 0u;
+        if (item < R && k0 < LW * 32) bits = (rlab[item * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) by[t >> 2] |= (((bits >> t) & 1u) ? 127u : 0u) << (8 * (t & 3));
+    }
+    out[p] = make_uint4(by[0], by[1], by[2], by[3]);
+}
+
+// query image piece: code bytes -+32 (half the 64-byte bucket row of the 4-byte counters per unit of the dot product), labels 64
+template <int NMC, int NML>
+__device__ __forceinline__ void expand_query_piece(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qlab, int64_t Q, int W, int LW, int K,
+                                                   uint4* __restrict__ out32, int64_t p) {
+    constexpr int NM = NMC + NML;
+    const int lane = (int)(p & 63);
+    const int m = (int)((p >> 6) % NM);
+    const int64_t q = ((p >> 6) / NM) * 16 + (lane & 15);
+    const int c = lane >> 4;
+    uint32_t a[4] = {0u, 0u, 0u, 0u};
+    if (q < Q) {                                                   // queries past the end: all-zero operand (dot = 0 -> their own bucket 0)
+        if (m < NMC) {
+            const int k0 = m * 64 + c * 16;
+            uint32_t bits = 0u;
+            if (k0 < W * 32) bits = (qbits[q * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (k0 + t < K) a[t >> 2] |= (((bits >> t) & 1u) ? 0xe0u : 0x20u) << (8 * (t & 3));       // -32 / +32
+            }
+        } else {
+            const int k0 = (m - NMC) * 64 + c * 16;
+            uint32_t bits = 0u;
+            if (k0 < LW * 32) bits = (qlab[q * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a[t >> 2] |= (((bits >> t) & 1u) ? 64u : 0u) << (8 * (t & 3));
+        }
+    }
+    out32[p] = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+template <int NM, int NW>
+struct MfmaStage {
+    static constexpr int PIECES = 4 * NM;                        // 1 KB pieces per 64-item batch
+    static constexpr int PPW = PIECES / NW;
+    static_assert(PIECES % NW == 0, "pieces per wave");
+    static __device__ __forceinline__ void issue(const uint4* gimg, char* ring, int buf, int64_t batch, int lane, int wave) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = j * NW + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gimg + (batch * PIECES + p) * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(ring + buf * (PIECES * 1024) + p * 1024), 16, 0, 0);
+        }
+    }
+    // this wave's pieces of the batch staged ONE iteration ago have landed (the PPW pieces issued since may still fly)
+    static __device__ __forceinline__ void wait_prev(bool more_in_flight) {
+        if (!more_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (PPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+};
+
+__device__ __forceinline__ bool mfma_map_block(const MfmaArgs& a, int& chunk_id, int& qtile) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, t = b >> 3;
+    qtile = t % a.nqt;
+    chunk_id = xcd + 8 * (t / a.nqt);
+    return chunk_id < a.nchunk;
+}
+
+// CACHE: also leaves the pair cache of k_scan_hist_s (one byte per pair, distance | relevant << 7, 16 bytes per lane and batch in
+// the same lane geometry) so that the cached k_scan_ap_s runs as pass 2.
+template <int NMC, int NML, int NW, bool CACHE>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+    constexpr int NM = NMC + NML;
+    using ST = MfmaStage<NM, NW>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters, then the 2-deep ring
+    int chunk_id, qtile;
+    if (!mfma_map_block(a, chunk_id, qtile)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int q0 = (qtile * NW + wave) * 16;
+    const int q = q0 + ql;
+    const int ncell = a.nb * 16;
+    uint32_t* cnt = lds + wave * ncell;
+    for (int e = lane; e < ncell; e += 64) cnt[e] = 0u;
+    char* ring = reinterpret_cast<char*>(lds + NW * ncell);
+    v4i bq[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) bq[m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(q0 >> 4) * NM + m) * 64 + lane);
+    const bool valid = q < a.Q;
+    const int cinit = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4 + (valid ? 32 * a.K : 0);
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
+    const int lanebase = cinit - (valid ? 32 * a.K : 0);            // address of this lane's bucket-0 counter
+    uint4* crow = CACHE ? pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane : nullptr;
+    ST::issue(a.gimg, ring, 0, bat0, lane, wave);
+    for (int i = 0; i < nbat; ++i) {
+        if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
+        ST::wait_prev(i + 1 < nbat);
+        __builtin_amdgcn_s_barrier();                                // every wave's pieces of batch i are in the ring
+        const char* base = ring + (i & 1) * (ST::PIECES * 1024) + lane * 16;
+        v4i am[4][NM];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
+        }
+        uint32_t cw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4i acc = {cinit, cinit, cinit, cinit};
+#pragma unroll
+            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], acc, 0, 0, 0);
+            v4i lab = {1, 1, 1, 1};
+#pragma unroll
+            for (int m = NMC; m < NM; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], lab, 0, 0, 0);
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t inc = min((uint32_t)lab[j], 1u + kRelScale);        // 1 or 0x1fc1: bit 7 = relevant
+                asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
+                if (CACHE) e[j] = (inc & 0x80u) | ((uint32_t)(acc[j] - lanebase) >> 6);
+            }
+            if (CACHE) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+        }
+        if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
+            uint4* dst = crow + (int64_t)i * 64;
+            __builtin_nontemporal_store(cw[0], &dst->x);
+            __builtin_nontemporal_store(cw[1], &dst->y);
+            __builtin_nontemporal_store(cw[2], &dst->z);
+            __builtin_nontemporal_store(cw[3], &dst->w);
+        }
+        __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
+    }
+    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
+    const int npad = nbat * 64 - (int)(hi - lo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (npad > 0 && slot == 0 && valid) {
+        int dpad = 0;
+        for (int w = 0; w < a.W; ++w) dpad += __popc(a.qbits[(int64_t)q * a.W + w]);
+        cnt[dpad * 16 + ql] -= (uint32_t)npad;
+    }
+    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
+}
+
 // Does the LDS hand out same-address returning adds of one instruction in ascending lane order?  (see the header)
 __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ ok_out) {
     __shared__ unsigned long long c64[256];
@@ -772,8 +989,20 @@ constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
 
 struct WsLayout {
-    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, pair_cache, total;
+    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, pair_cache, gimg, qimg32, total;
 };
+
+// the MFMA-evaluated pass 1 (k_scan_hist_m): binary codes of 33..64 bits, i.e. where the pair cache hands pass 2 the evaluated
+// pairs (measured at Q 5000 x R 117 218, whole step: K=64 0.512 -> 0.489 ms; at K <= 32, where pass 2 evaluates the pairs itself
+// and the VALU pass 1 is cheap, it loses: K=16 0.452 -> 0.471 ms).  XMH_SCAN_MFMA=0 turns it off.
+inline bool mfma_shape(int K, bool ternary) {
+    static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
+    return on && !ternary && K > 32 && K <= 64;
+}
+constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
+// operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
+inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 3 * 1024; }
+inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 3 * 1024; }
 
 // Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
 // pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 4096; 0 = off).
@@ -785,7 +1014,7 @@ size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
 }
 
-WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes) {
+WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes, int64_t R = 0, bool mfma = false) {
     WsLayout L;
     const size_t cells = (size_t)p.nchunk * p.nbuckets * p.qpad;
     size_t o = 0;
@@ -802,6 +1031,8 @@ WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes) {
     L.gate = take(256 + 8 * 4096);           // [0]: nrel_max gate word, [1]: finalize ticket, +256: per-block partial sums (<= 4096 blocks)
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
     L.pair_cache = take(cache_bytes);
+    L.gimg = take(mfma ? mfma_gimg_bytes(R) : 0);
+    L.qimg32 = take(mfma ? mfma_qimg_bytes(p.qpad) : 0);
     L.total = o;
     return L;
 }
@@ -829,19 +1060,29 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 65 && !cache_shape ? 2 : 1);
     int64_t nchunk = rounds * slots / nqt;
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
+    const bool mfma = mfma_shape(K, ternary != 0);
+    if (mfma) {
+        // blocks of kMfmaWaves waves = one 64-query tile x one chunk; 3 blocks fit a CU (pass 1), `rounds` sets of them
+        static const int mr = getenv("XMH_SCAN_MFMA_ROUNDS") ? atoi(getenv("XMH_SCAN_MFMA_ROUNDS")) : 3;
+        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * 3 / nqt;
+    }
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
     int64_t chunk = xmh::ceil_div(R, nchunk);
     if (chunk < kMinChunk) chunk = kMinChunk;
     if (chunk > kMaxChunk) chunk = kMaxChunk;
     chunk = xmh::ceil_div(chunk, 8) * 8;
+    if (mfma) {                                   // batches of 64 items aligned to the gallery image; counters hold all + 8128 * relevant
+        chunk = xmh::ceil_div(chunk, 64) * 64;
+        if (chunk > kMfmaMaxChunk) chunk = kMfmaMaxChunk;
+    }
     nchunk = xmh::ceil_div(R, chunk);
     p->chunk = chunk;
     p->nchunk = nchunk;
     p->nqtile = nqt;
     p->qpad = nqt * 64;
     p->nbuckets = nb;
-    p->ws_bytes = ws_layout(*p, pair_cache_bytes(*p, K, ternary != 0)).total;
+    p->ws_bytes = ws_layout(*p, pair_cache_bytes(*p, K, ternary != 0), R, mfma).total;
     return XMH_OK;
 }
 
@@ -920,6 +1161,45 @@ int raise_lds(KernT kern, size_t lds, const char* who) {
 
 }  // namespace
 
+
+namespace {
+template <int NML>
+int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+                const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    constexpr int NMC = 1, NM = NMC + NML, NW = kMfmaWaves;
+    uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
+    uint4* q32 = reinterpret_cast<uint4*>(base + L.qimg32);
+    const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NM * 64, qpieces = (p.qpad / 16) * NM * 64;
+    const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
+    hipLaunchKernelGGL((k_scan_expand<NMC, NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
+                       q32, qpieces);
+    XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
+    MfmaArgs a{gimg, q32, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * NW)), (int)p.nbuckets, (int)p.qpad};
+    const size_t lds = (size_t)NW * p.nbuckets * 16 * 4 + 2 * 4 * NM * 1024;
+    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
+    xmh::ProfScope prof("scan_hist", st);
+    if (cache) {
+        auto kern = k_scan_hist_m<NMC, NML, NW, true>;
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    } else {
+        auto kern = k_scan_hist_m<NMC, NML, NW, false>;
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    }
+    return XMH_OK;
+}
+
+int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+              const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    return LW <= 2 ? mfma_hist_t<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                   : mfma_hist_t<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+}
+
+}  // namespace
+
 extern "C" int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host) {
     if (!plan_host) return xmh::fail(XMH_EINVAL, "xmh_scan_plan_make: null plan");
     return make_plan(Q, R, K, ternary, plan_host);
@@ -943,13 +1223,20 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     if (rc) return rc;
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
     const size_t cache_bytes = pair_cache_bytes(p, K, tern);
-    const WsLayout L = ws_layout(p, cache_bytes);
+    const bool mfma_plan = mfma_shape(K, tern);
+    const WsLayout L = ws_layout(p, cache_bytes, R, mfma_plan);
     char* base = static_cast<char*>(ws);
     uint32_t* chunk_hist = reinterpret_cast<uint32_t*>(base + L.chunk_hist);
     uint2* below = reinterpret_cast<uint2*>(base + L.below);
     uint2* tot = reinterpret_cast<uint2*>(base + L.tot);
     hipStream_t st = xmh::as_stream(stream);
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
+    const bool use_mfma = mfma_plan && LW <= 4 && lane_order_ok(st);
+    if (use_mfma) {
+        rc = mfma_hist(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist,
+                       cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st);
+        if (rc) return rc;
+    }
     auto launch = [&](auto tern_c) {
         constexpr bool T = decltype(tern_c)::value;
         return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
@@ -978,11 +1265,13 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
             return (int)XMH_OK;
         });
     };
-    rc = tern ? launch(std::true_type{}) : launch(std::false_type{});
-    if (rc) return rc;
+    if (!use_mfma) {
+        rc = tern ? launch(std::true_type{}) : launch(std::false_type{});
+        if (rc) return rc;
+    }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, below, tot);
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelScale : 0u, below, tot);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");
     if (hist_all || hist_rel) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
@@ -1009,7 +1298,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     if (ext != 0 && ext != 3) return xmh::fail(XMH_EINVAL, "xmh_hamming_ap: base_all, base_rel and nrel_total go together");
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
     const size_t cache_bytes = pair_cache_bytes(p, K, tern);
-    const WsLayout L = ws_layout(p, cache_bytes);
+    const bool mfma_plan = mfma_shape(K, tern);
+    const WsLayout L = ws_layout(p, cache_bytes, R, mfma_plan);
     char* base = static_cast<char*>(ws);
     const uint2* below = reinterpret_cast<const uint2*>(base + L.below);
     const uint2* tot = reinterpret_cast<const uint2*>(base + L.tot);
@@ -1031,6 +1321,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool capped = k > 0;
     const bool masked = !lane_order_ok(st);
+
     // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run
     auto launch = [&](auto tern_c, auto cap_c, auto p32_c, auto masked_c) {
         constexpr bool T = decltype(tern_c)::value;

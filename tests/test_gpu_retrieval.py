@@ -293,6 +293,16 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
     assert len(on) == 7 and len(off) == 7
     assert all(x[0] == "True" for x in on) and all(x[0] == "False" for x in off)
     assert [x[1:] for x in on] == [x[1:] for x in off]
+    # the MFMA-evaluated pass 1 (codes of at most 64 bits) against the VALU one: another chunking, so the per-chunk float sums
+    # add in another order -- the caps are equal, the AP sums agree to float rounding
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMH_SCAN_MFMA="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    valu = [l.split()[1:] for l in r.stdout.splitlines() if l.startswith("ROW ")]
+    assert len(valu) == 7
+    for x, y in zip(on, valu):
+        assert x[2] == y[2]
+        a, b = np.frombuffer(bytes.fromhex(x[1]), dtype=np.float64), np.frombuffer(bytes.fromhex(y[1]), dtype=np.float64)
+        assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
 
 
 def test_calc_map_k_label_cache_sees_in_place_edits(cu):
