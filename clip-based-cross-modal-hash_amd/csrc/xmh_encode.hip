@@ -15,6 +15,7 @@
 //   xmh_bitwise_hash      MITH BitwiseHashing (models/MITH/hash/hash.py:68-85)
 // Every one of these is HBM-bound elementwise / row-reduction work; the GEMMs around them dominate the time.
 #include "xmh_common.h"
+#include "xmh_planes.h"
 
 #include <stdlib.h>
 
@@ -61,12 +62,54 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
 }
 
+// D % 4 == 0, 16-byte aligned rows: four consecutive columns per lane, and the result goes out as fp32 and / or as the fp16
+// operand planes of the GEMM that consumes it (xmh_planes.h) -- the same values either way.
+__global__ __launch_bounds__(256) void k_layernorm4(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, float* __restrict__ y, int64_t ldy,
+                                                    xmh::Planes p, int64_t rows, int D) {
+    constexpr int NV = kLnMaxPerLane / 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        v[j] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+            const float o0 = (v[j].x - mean) * rstd * gm.x + bt.x, o1 = (v[j].y - mean) * rstd * gm.y + bt.y;
+            const float o2 = (v[j].z - mean) * rstd * gm.z + bt.z, o3 = (v[j].w - mean) * rstd * gm.w + bt.w;
+            if (y) *reinterpret_cast<float4*>(y + row * ldy + c) = make_float4(o0, o1, o2, o3);
+            if (p.hi) xmh::store_planes4(p, row, c, o0, o1, o2, o3);
+        }
+    }
+}
+
 // ---- small-sequence attention: one block per (batch, head), one thread per query row -------------------
 // qkv: [B, L, 3*H*dh] rows = tokens, columns [q | k | v] each H*dh wide (nn.MultiheadAttention in_proj order).
 // LDS: K and V of this head [L][dh] (float4 rows), scores [L][L+1].
 template <int DH>
 __global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv, int L, int H, int causal, const uint8_t* __restrict__ kpm,
-                            float* __restrict__ out) {
+                            float* __restrict__ out, xmh::Planes pl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * DH;
@@ -132,10 +175,12 @@ __global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv
             o[4 * c + 3] = fmaf(p, vv.w, o[4 * c + 3]);
         }
     }
-    float* orow = out + ((int64_t)b * L + i) * D + h * DH;
+    const int64_t orow_i = (int64_t)b * L + i;
 #pragma unroll
-    for (int c = 0; c < DH / 4; ++c)
-        *reinterpret_cast<float4*>(orow + c * 4) = make_float4(o[4 * c + 0], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+    for (int c = 0; c < DH / 4; ++c) {
+        if (out) *reinterpret_cast<float4*>(out + orow_i * D + h * DH + c * 4) = make_float4(o[4 * c + 0], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+        if (pl.hi) xmh::store_planes4(pl, orow_i, h * DH + c * 4, o[4 * c + 0], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+    }
 }
 
 // ---- the same attention on the fp32 MFMA for L <= 64 (ViT-B/32: L = 50, text: L = 32) ----------------------------
@@ -150,7 +195,7 @@ __global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv
 typedef float attn_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
-                                                         const uint8_t* __restrict__ kpm, float* __restrict__ out) {
+                                                         const uint8_t* __restrict__ kpm, float* __restrict__ out, xmh::Planes pl) {
     constexpr int DH = 64, SP = 68;                                  // score row stride: 16-byte aligned, rows on distinct 16-B slots
     __shared__ __attribute__((aligned(16))) float sS[32 * SP];
     const int nblk = (L + 31) / 32;                                  // 32-row blocks of queries / keys (1 or 2)
@@ -251,7 +296,10 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = ib * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (row < L) out[((int64_t)b * L + row) * D + h * DH + cb * 32 + r] = acc[e];
+                if (row < L) {
+                    if (out) out[((int64_t)b * L + row) * D + h * DH + cb * 32 + r] = acc[e];
+                    if (pl.hi) xmh::store_planes1(pl, (int64_t)b * L + row, h * DH + cb * 32 + r, acc[e]);
+                }
             }
         }
     }
@@ -259,7 +307,7 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
 
 // ---- patch gather: cols[(b*G*G + gy*G + gx)][c*P*P + dy*P + dx] = image[b][c][gy*P+dy][gx*P+dx] --------
 __global__ __launch_bounds__(256) void k_im2col_patch(const float* __restrict__ img, int64_t B, int Cin, int res, int P,
-                                                      float* __restrict__ cols) {
+                                                      float* __restrict__ cols, xmh::Planes pl) {
     const int G = res / P;
     const int64_t kdim = (int64_t)Cin * P * P;
     const int64_t total4 = B * G * G * kdim / 4;
@@ -271,7 +319,8 @@ __global__ __launch_bounds__(256) void k_im2col_patch(const float* __restrict__ 
         const int64_t b = row / (G * G);
         const int g = (int)(row % (G * G)), gy = g / G, gx = g % G;
         const float4 v = *reinterpret_cast<const float4*>(img + ((b * Cin + c) * res + gy * P + dy) * res + gx * P + dx);
-        *reinterpret_cast<float4*>(cols + flat) = v;
+        if (cols) *reinterpret_cast<float4*>(cols + flat) = v;
+        if (pl.hi) xmh::store_planes4(pl, row, k, v.x, v.y, v.z, v.w);
     }
 }
 
@@ -478,26 +527,33 @@ inline int grid1d(int64_t work, int per_block = 256) {
 
 }  // namespace
 
-extern "C" int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
-                                 int64_t ldy, int64_t rows, int D, xmh_stream_t stream) {
-    if (rows < 0 || D <= 0 || D > 64 * kLnMaxPerLane) return xmh::fail(XMH_EINVAL, "xmh_layernorm_f32: bad shape rows=%lld D=%d (D <= %d)", (long long)rows, D, 64 * kLnMaxPerLane);
+namespace xmh {
+
+int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y, int64_t ldy, const Planes& p,
+                     int64_t rows, int D, hipStream_t st) {
+    if (rows < 0 || D <= 0 || D > 64 * kLnMaxPerLane) return fail(XMH_EINVAL, "xmh_layernorm_f32: bad shape rows=%lld D=%d (D <= %d)", (long long)rows, D, 64 * kLnMaxPerLane);
     if (rows == 0) return XMH_OK;
-    if (!x || !gamma || !beta || !y) return xmh::fail(XMH_EINVAL, "xmh_layernorm_f32: null pointer");
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)xmh::ceil_div(rows, 4)), dim3(256), 0, xmh::as_stream(stream), x, ldx, gamma, beta, eps, y, ldy, rows, D);
+    if (!x || !gamma || !beta || (!y && !p.hi)) return fail(XMH_EINVAL, "xmh_layernorm_f32: null pointer");
+    const bool vec = D % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0) && (!p.hi || p.ld % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.hi) | reinterpret_cast<uintptr_t>(p.lo)) % 8 == 0;
+    if (vec) hipLaunchKernelGGL(k_layernorm4, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, p, rows, D);
+    else if (p.hi) return fail(XMH_ENOTSUP, "xmh layernorm: operand planes need D %% 4 == 0 and 16-byte aligned rows (D=%d)", D);
+    else hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, rows, D);
     XMH_LAUNCH_CHECK("xmh_layernorm_f32");
     return XMH_OK;
 }
 
-extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
-                                 float* out, xmh_stream_t stream) {
-    if (B < 0 || L <= 0 || H <= 0) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: bad shape");
+int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
+                     hipStream_t st) {
+    if (B < 0 || L <= 0 || H <= 0) return fail(XMH_EINVAL, "xmh_attention_f32: bad shape");
     if (B == 0) return XMH_OK;
-    if (dh != 64) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
-    if (L > 128) return xmh::fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
-    if (!qkv || !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
+    if (dh != 64) return fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
+    if (L > 128) return fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
+    if (!qkv || (!out && !p.hi)) return fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
     static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
     if (L <= 64 && !valu_only) {                                     // fp32-MFMA kernel: one wave per head
-        hipLaunchKernelGGL(k_attention_mfma64, dim3((unsigned)(B * H)), dim3(64), 0, xmh::as_stream(stream), qkv, L, H, causal, key_padding_mask, out);
+        hipLaunchKernelGGL(k_attention_mfma64, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
         XMH_LAUNCH_CHECK("xmh_attention_f32");
         return XMH_OK;
     }
@@ -506,22 +562,41 @@ extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int 
     auto kern = k_attention<64>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_attention_f32: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(XMH_EHIP, "xmh_attention_f32: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(threads), lds, xmh::as_stream(stream), qkv, L, H, causal, key_padding_mask, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(threads), lds, st, qkv, L, H, causal, key_padding_mask, out, p);
     XMH_LAUNCH_CHECK("xmh_attention_f32");
     return XMH_OK;
 }
 
-extern "C" int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,
-                                xmh_stream_t stream) {
-    if (B < 0 || channels <= 0 || patch <= 0 || resolution % patch || patch % 4) return xmh::fail(XMH_EINVAL, "xmh_im2col_patch: bad geometry res=%d patch=%d", resolution, patch);
+int im2col_planes(const float* image, int64_t B, int channels, int resolution, int patch, float* cols, const Planes& p, hipStream_t st) {
+    if (B < 0 || channels <= 0 || patch <= 0 || resolution % patch || patch % 4) return fail(XMH_EINVAL, "xmh_im2col_patch: bad geometry res=%d patch=%d", resolution, patch);
     if (B == 0) return XMH_OK;
-    if (!image || !cols) return xmh::fail(XMH_EINVAL, "xmh_im2col_patch: null pointer");
+    if (!image || (!cols && !p.hi)) return fail(XMH_EINVAL, "xmh_im2col_patch: null pointer");
     const int64_t total4 = B * channels * resolution * resolution / 4;
-    hipLaunchKernelGGL(k_im2col_patch, dim3(grid1d(total4)), dim3(256), 0, xmh::as_stream(stream), image, B, channels, resolution, patch, cols);
+    hipLaunchKernelGGL(k_im2col_patch, dim3(grid1d(total4)), dim3(256), 0, st, image, B, channels, resolution, patch, cols, p);
     XMH_LAUNCH_CHECK("xmh_im2col_patch");
     return XMH_OK;
+}
+
+}  // namespace xmh
+
+extern "C" int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
+                                 int64_t ldy, int64_t rows, int D, xmh_stream_t stream) {
+    if (rows > 0 && !y) return xmh::fail(XMH_EINVAL, "xmh_layernorm_f32: null pointer");
+    return xmh::layernorm_planes(x, ldx, gamma, beta, eps, y, ldy, xmh::Planes{nullptr, nullptr, 0}, rows, D, xmh::as_stream(stream));
+}
+
+extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
+                                 float* out, xmh_stream_t stream) {
+    if (B > 0 && !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
+    return xmh::attention_planes(qkv, B, L, H, dh, causal, key_padding_mask, out, xmh::Planes{nullptr, nullptr, 0}, xmh::as_stream(stream));
+}
+
+extern "C" int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,
+                                xmh_stream_t stream) {
+    if (B > 0 && !cols) return xmh::fail(XMH_EINVAL, "xmh_im2col_patch: null pointer");
+    return xmh::im2col_planes(image, B, channels, resolution, patch, cols, xmh::Planes{nullptr, nullptr, 0}, xmh::as_stream(stream));
 }
 
 extern "C" int xmh_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,

@@ -7,6 +7,7 @@
 //   text : embed + pos -> blocks (causal [+ key padding]) -> ln_final -> GEMM text_projection -> EOS row
 //   block: LN, GEMM qkv, attention, GEMM out + residual, LN, GEMM c_fc + QuickGELU, GEMM c_proj + residual
 #include "xmh_common.h"
+#include "xmh_planes.h"
 
 namespace {
 
@@ -29,32 +30,66 @@ struct Arena {
     }
 };
 
+// Parity and fast mode keep every GEMM input as fp16 operand planes (xmh_planes.h), written by the kernel that produces it:
+// LayerNorm -> qkv / c_fc, attention -> out_proj, the c_fc epilogue (QuickGELU) -> c_proj.  Only the residual stream x and the
+// qkv rows the attention kernel reads stay fp32.  Exact mode (fp32 MFMA) keeps the fp32 buffers.
 struct BlockScratch {
-    float *h, *qkv, *a, *f;
-    void* half;                                      // fast mode: fp16 image of the current GEMM's activations
+    float *h, *qkv, *a, *f;                          // exact mode: fp32 activations
+    xmh::Planes hP, aP, fP;                          // parity / fast mode
+    xmh::Planes any;                                 // planes of an fp32 activation that was not produced as planes (linear_any)
 };
 
+xmh::Planes carve_planes(Arena& ar, size_t rows, size_t cols, int precision) {
+    xmh::Planes p;
+    p.hi = reinterpret_cast<_Float16*>(ar.take<uint16_t>(rows * cols));
+    p.lo = precision == kPrecParity ? reinterpret_cast<_Float16*>(ar.take<uint16_t>(rows * cols)) : nullptr;
+    p.ld = (int64_t)cols;
+    return p;
+}
+
 BlockScratch carve_blocks(Arena& ar, int64_t M, int width, int precision) {
-    BlockScratch s;
-    s.h = ar.take<float>((size_t)M * width);
+    BlockScratch s{};
     s.qkv = ar.take<float>((size_t)M * width * 3);
-    s.a = ar.take<float>((size_t)M * width);
-    s.f = ar.take<float>((size_t)M * width * 4);
-    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)M * width * 4) : nullptr;
+    if (precision == kPrecExact) {
+        s.h = ar.take<float>((size_t)M * width);
+        s.a = ar.take<float>((size_t)M * width);
+        s.f = ar.take<float>((size_t)M * width * 4);
+    } else {
+        s.hP = carve_planes(ar, (size_t)M, (size_t)width, precision);
+        s.aP = carve_planes(ar, (size_t)M, (size_t)width, precision);
+        s.fP = carve_planes(ar, (size_t)M, (size_t)width * 4, precision);
+        s.any = s.fP;                                // free between blocks: the towers' other GEMMs run before / after the stack
+    }
     return s;
 }
 
-// act(A @ W^T + bias) (+ residual), dispatch as xmh/ops.py:gemm_nt does it
-int linear(const xmh_linear& l, const float* A, int64_t lda, const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M,
-           int act, int precision, void* half, xmh_stream_t st) {
+bool planes_layer(const xmh_linear& l) { return l.w_hi && l.k % 32 == 0; }
+
+// act(A @ W^T + bias) (+ residual) from operand planes; C and / or the result's own planes
+int linear_p(const xmh_linear& l, const xmh::Planes& A, const float* residual, int64_t ldr, float* C, int64_t ldc, const xmh::Planes* out,
+             int64_t M, int act, int precision, xmh_stream_t st) {
+    xmh::GemmPlanes g{};
+    g.A_hi = A.hi; g.A_lo = precision == kPrecParity ? A.lo : nullptr; g.lda = A.ld;
+    g.W_hi = static_cast<const _Float16*>(l.w_hi);
+    g.W_lo = precision == kPrecParity ? static_cast<const _Float16*>(l.w_lo) : nullptr;
+    g.ldw = l.k;
+    g.bias = l.bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc;
+    if (out) g.O = *out;
+    g.M = M; g.N = l.n; g.K = l.k; g.act = act;
+    return xmh::gemm_planes(g, xmh::as_stream(st));
+}
+
+// the same from an fp32 activation: one split pass into `scratch` (rows x K planes), or the fp32 kernels when the layer has no
+// fp16 weights / an unaligned K -- dispatch as xmh/ops.py:gemm_nt does it
+int linear_any(const xmh_linear& l, const float* A, int64_t lda, const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M,
+               int act, int precision, const xmh::Planes& scratch, xmh_stream_t st) {
     const int64_t N = l.n, K = l.k;
-    if (precision == kPrecFast && l.w_hi && K % 32 == 0 && lda == K && (M * K) % 8 == 0 && half) {
-        int rc = xmh_cast_f32_to_f16(A, half, M * K, st);
+    if (precision != kPrecExact && planes_layer(l) && scratch.hi && lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
+        xmh::Planes p{scratch.hi, precision == kPrecParity ? scratch.lo : nullptr, K};
+        int rc = xmh::split_planes(A, lda, M, K, p, xmh::as_stream(st));
         if (rc) return rc;
-        return xmh_gemm_nt_h16(half, K, l.w_hi, K, l.bias, residual, ldr, C, ldc, M, N, K, act, st);
+        return linear_p(l, p, residual, ldr, C, ldc, nullptr, M, act, precision, st);
     }
-    if (precision == kPrecParity && l.w_hi && K % 32 == 0 && lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0)
-        return xmh_gemm_nt_split16(A, lda, l.w_hi, l.w_lo, K, l.bias, residual, ldr, C, ldc, M, N, K, act, st);
     if (!l.w_f32) return xmh::fail(-22, "xmh forward: a %lld x %lld layer needs its fp32 weight for this shape / precision", (long long)N, (long long)K);
     return xmh_gemm_nt_f32(A, lda, l.w_f32, K, l.bias, residual, ldr, C, ldc, M, N, K, act, precision == kPrecFast ? 1 : 0, st);
 }
@@ -63,47 +98,87 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
                const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st) {
     const int64_t M = B * L;
     const int D = width;
+    hipStream_t hs = xmh::as_stream(st);
+    const xmh::Planes none{nullptr, nullptr, 0};
     for (int i = 0; i < layers; ++i) {
         const xmh_clip_block& b = blocks[i];
         if (b.qkv.n != 3 * D || b.qkv.k != D || b.out.n != D || b.out.k != D || b.fc.k != D || b.fc.n != 4 * D || b.proj.n != D || b.proj.k != b.fc.n)
             return xmh::fail(-22, "xmh forward: block %d has layer shapes that do not fit width %d", i, D);
-        int rc = xmh_layernorm_f32(x, D, b.ln1_w, b.ln1_b, kLnEps, s.h, D, M, D, st);
+        int rc;
+        if (precision == kPrecExact) {
+            if (!b.qkv.w_f32 || !b.out.w_f32 || !b.fc.w_f32 || !b.proj.w_f32) return xmh::fail(-22, "xmh forward: block %d lacks fp32 weights (exact mode)", i);
+            rc = xmh_layernorm_f32(x, D, b.ln1_w, b.ln1_b, kLnEps, s.h, D, M, D, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(s.h, D, b.qkv.w_f32, D, b.qkv.bias, nullptr, 0, s.qkv, 3 * D, M, 3 * D, D, kActNone, 0, st);
+            if (rc) return rc;
+            rc = xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(s.a, D, b.out.w_f32, D, b.out.bias, x, D, x, D, M, D, D, kActNone, 0, st);
+            if (rc) return rc;
+            rc = xmh_layernorm_f32(x, D, b.ln2_w, b.ln2_b, kLnEps, s.h, D, M, D, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(s.h, D, b.fc.w_f32, D, b.fc.bias, nullptr, 0, s.f, 4 * D, M, 4 * D, D, kActQuickGelu, 0, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(s.f, 4 * D, b.proj.w_f32, 4 * D, b.proj.bias, x, D, x, D, M, D, 4 * D, kActNone, 0, st);
+            if (rc) return rc;
+            continue;
+        }
+        if (!planes_layer(b.qkv) || !planes_layer(b.out) || !planes_layer(b.fc) || !planes_layer(b.proj))
+            return xmh::fail(-22, "xmh forward: block %d lacks fp16 weights (w_hi) for width %d", i, D);
+        rc = xmh::layernorm_planes(x, D, b.ln1_w, b.ln1_b, kLnEps, nullptr, 0, s.hP, M, D, hs);
         if (rc) return rc;
-        rc = linear(b.qkv, s.h, D, nullptr, 0, s.qkv, 3 * D, M, kActNone, precision, s.half, st);
+        rc = linear_p(b.qkv, s.hP, nullptr, 0, s.qkv, 3 * D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
-        rc = xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
+        rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, hs);
         if (rc) return rc;
-        rc = linear(b.out, s.a, D, x, D, x, D, M, kActNone, precision, s.half, st);
+        rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
-        rc = xmh_layernorm_f32(x, D, b.ln2_w, b.ln2_b, kLnEps, s.h, D, M, D, st);
+        rc = xmh::layernorm_planes(x, D, b.ln2_w, b.ln2_b, kLnEps, nullptr, 0, s.hP, M, D, hs);
         if (rc) return rc;
-        rc = linear(b.fc, s.h, D, nullptr, 0, s.f, b.fc.n, M, kActQuickGelu, precision, s.half, st);
+        rc = linear_p(b.fc, s.hP, nullptr, 0, nullptr, 0, &s.fP, M, kActQuickGelu, precision, st);
         if (rc) return rc;
-        rc = linear(b.proj, s.f, b.fc.n, x, D, x, D, M, kActNone, precision, s.half, st);
+        rc = linear_p(b.proj, s.fP, x, D, x, D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
     }
+    (void)none;
     return 0;
 }
 
 struct TowerScratch {
     BlockScratch blk;
     float *x, *cols, *patches, *row_a, *row_b, *y;
+    xmh::Planes colsP;                               // parity / fast mode: im2col writes the conv1 GEMM's operand planes
     int32_t* eos;
 };
 
 // conv_k > 0: image tower (im2col columns + patch embeddings); out_dim > 0: all tokens go through the final LN + projection
 TowerScratch carve_tower(Arena& ar, int64_t B, int L, int width, int conv_k, int out_dim, int precision) {
-    TowerScratch t;
+    TowerScratch t{};
     const int64_t M = B * L;
     t.blk = carve_blocks(ar, M, width, precision);
     t.x = ar.take<float>((size_t)M * width);
-    t.cols = conv_k > 0 ? ar.take<float>((size_t)B * (L - 1) * conv_k) : nullptr;
+    const bool cols_planes = conv_k > 0 && precision != kPrecExact && conv_k % 32 == 0;
+    if (cols_planes) t.colsP = carve_planes(ar, (size_t)B * (L - 1), (size_t)conv_k, precision);
+    t.cols = conv_k > 0 && !cols_planes ? ar.take<float>((size_t)B * (L - 1) * conv_k) : nullptr;
     t.patches = conv_k > 0 ? ar.take<float>((size_t)B * (L - 1) * width) : nullptr;
     t.row_a = ar.take<float>((size_t)B * width);
     t.row_b = ar.take<float>((size_t)B * width);
     t.y = out_dim > 0 ? ar.take<float>((size_t)M * width) : nullptr;
     t.eos = ar.take<int32_t>((size_t)B);
     return t;
+}
+
+// LayerNorm + projection of `rows` rows (the tail of both towers): planes straight out of the LayerNorm when the layer allows
+int ln_linear(const float* x, int64_t rows, int D, const float* gamma, const float* beta, const xmh_linear& l, float* ytmp, float* C,
+              int precision, const BlockScratch& blk, xmh_stream_t st) {
+    if (precision != kPrecExact && planes_layer(l) && blk.hP.hi) {
+        int rc = xmh::layernorm_planes(x, D, gamma, beta, kLnEps, nullptr, 0, blk.hP, rows, D, xmh::as_stream(st));
+        if (rc) return rc;
+        return linear_p(l, blk.hP, nullptr, 0, C, l.n, nullptr, rows, kActNone, precision, st);
+    }
+    int rc = xmh_layernorm_f32(x, D, gamma, beta, kLnEps, ytmp, D, rows, D, st);
+    if (rc) return rc;
+    return linear_any(l, ytmp, D, nullptr, 0, C, l.n, rows, kActNone, precision, blk.any, st);
 }
 
 int check_precision(int precision) {
@@ -147,27 +222,31 @@ extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image,
     const TowerScratch t = carve_tower(ar, B, L, D, conv_k, out_tokens ? w->out_dim : 0, precision);
     if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_vit_b32_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
     const int64_t M = B * L;
-    int rc = xmh_im2col_patch(image, B, 3, w->resolution, w->patch, t.cols, stream);
-    if (rc) return rc;
-    rc = linear(w->conv1, t.cols, conv_k, nullptr, 0, t.patches, D, B * P, kActNone, precision, t.blk.half, stream);
+    int rc;
+    if (t.colsP.hi && planes_layer(w->conv1)) {
+        rc = xmh::im2col_planes(image, B, 3, w->resolution, w->patch, nullptr, t.colsP, xmh::as_stream(stream));
+        if (rc) return rc;
+        rc = linear_p(w->conv1, t.colsP, nullptr, 0, t.patches, D, nullptr, B * P, kActNone, precision, stream);
+    } else {
+        if (!t.cols) return xmh::fail(-22, "xmh_vit_b32_forward: conv1 lacks fp16 weights (w_hi) for a %d-wide patch row", conv_k);
+        rc = xmh_im2col_patch(image, B, 3, w->resolution, w->patch, t.cols, stream);
+        if (rc) return rc;
+        rc = linear_any(w->conv1, t.cols, conv_k, nullptr, 0, t.patches, D, B * P, kActNone, precision, t.blk.any, stream);
+    }
     if (rc) return rc;
     rc = xmh_vit_assemble(t.patches, w->cls, w->pos, w->ln_pre_w, w->ln_pre_b, kLnEps, t.x, B, P, D, stream);
     if (rc) return rc;
     rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 0, nullptr, precision, t.blk, stream);
     if (rc) return rc;
     if (out_tokens) {                                 // return_patches: ln_post + proj on every token (model.py:257-265)
-        rc = xmh_layernorm_f32(t.x, D, w->ln_post_w, w->ln_post_b, kLnEps, t.y, D, M, D, stream);
-        if (rc) return rc;
-        rc = linear(w->proj, t.y, D, nullptr, 0, out_tokens, w->out_dim, M, kActNone, precision, t.blk.half, stream);
+        rc = ln_linear(t.x, M, D, w->ln_post_w, w->ln_post_b, w->proj, t.y, out_tokens, precision, t.blk, stream);
         if (rc) return rc;
         if (out_cls) rc = xmh_gather_rows(out_tokens, w->out_dim, nullptr, 0, L, out_cls, B, w->out_dim, stream);
         return rc;
     }
     rc = xmh_gather_rows(t.x, D, nullptr, 0, L, t.row_a, B, D, stream);       // the cls row is all the caller keeps
     if (rc) return rc;
-    rc = xmh_layernorm_f32(t.row_a, D, w->ln_post_w, w->ln_post_b, kLnEps, t.row_b, D, B, D, stream);
-    if (rc) return rc;
-    return linear(w->proj, t.row_b, D, nullptr, 0, out_cls, w->out_dim, B, kActNone, precision, t.blk.half, stream);
+    return ln_linear(t.row_a, B, D, w->ln_post_w, w->ln_post_b, w->proj, t.row_b, out_cls, precision, t.blk, stream);
 }
 
 extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
@@ -189,49 +268,45 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
     rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream);
     if (rc) return rc;
     if (out_tokens) {
-        rc = xmh_layernorm_f32(t.x, D, w->ln_final_w, w->ln_final_b, kLnEps, t.y, D, M, D, stream);
-        if (rc) return rc;
-        rc = linear(w->proj, t.y, D, nullptr, 0, out_tokens, w->out_dim, M, kActNone, precision, t.blk.half, stream);
+        rc = ln_linear(t.x, M, D, w->ln_final_w, w->ln_final_b, w->proj, t.y, out_tokens, precision, t.blk, stream);
         if (rc) return rc;
         if (out_eos) rc = xmh_gather_rows(out_tokens, w->out_dim, eos, 0, L, out_eos, B, w->out_dim, stream);
         return rc;
     }
     rc = xmh_gather_rows(t.x, D, eos, 0, L, t.row_a, B, D, stream);
     if (rc) return rc;
-    rc = xmh_layernorm_f32(t.row_a, D, w->ln_final_w, w->ln_final_b, kLnEps, t.row_b, D, B, D, stream);
-    if (rc) return rc;
-    return linear(w->proj, t.row_b, D, nullptr, 0, out_eos, w->out_dim, B, kActNone, precision, t.blk.half, stream);
+    return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
 }
 
 // ---- hash heads ---------------------------------------------------------------------------------------
 
-extern "C" size_t xmh_head_workspace_bytes(int64_t B, int E, int precision) {
-    if (B <= 0 || E <= 0) return 0;
-    Arena ar(nullptr);
-    ar.take<float>((size_t)B * E);
-    ar.take<float>((size_t)B * E);
-    ar.take<float>((size_t)B * E * 2);                   // fc2 / fc output (2K <= 2E is checked) ...
-    ar.take<float>((size_t)B * E * 2);                   // ... and the probabilities when the caller only wants bits
-    if (precision == kPrecFast) ar.take<uint16_t>((size_t)B * E);
-    return ar.used;
-}
-
 namespace {
 struct HeadScratch {
     float *a, *b, *wide, *wide2;
-    void* half;
+    xmh::Planes any;                                 // operand planes of the current GEMM's input (B x E)
 };
-int carve_head(void* workspace, size_t workspace_bytes, int64_t B, int E, int precision, HeadScratch& s, const char* who) {
-    Arena ar(workspace);
+void carve_head_arena(Arena& ar, int64_t B, int E, int precision, HeadScratch& s) {
     s.a = ar.take<float>((size_t)B * E);
     s.b = ar.take<float>((size_t)B * E);
-    s.wide = ar.take<float>((size_t)B * E * 2);
-    s.wide2 = ar.take<float>((size_t)B * E * 2);
-    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)B * E) : nullptr;
+    s.wide = ar.take<float>((size_t)B * E * 2);          // fc2 / fc output (2K <= 2E is checked) ...
+    s.wide2 = ar.take<float>((size_t)B * E * 2);         // ... and the probabilities when the caller only wants bits
+    s.any = precision == kPrecExact ? xmh::Planes{nullptr, nullptr, 0} : carve_planes(ar, (size_t)B, (size_t)E, precision);
+}
+int carve_head(void* workspace, size_t workspace_bytes, int64_t B, int E, int precision, HeadScratch& s, const char* who) {
+    Arena ar(workspace);
+    carve_head_arena(ar, B, E, precision, s);
     if (ar.used > workspace_bytes) return xmh::fail(-12, "%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, ar.used);
     return 0;
 }
 }  // namespace
+
+extern "C" size_t xmh_head_workspace_bytes(int64_t B, int E, int precision) {
+    if (B <= 0 || E <= 0) return 0;
+    Arena ar(nullptr);
+    HeadScratch s;
+    carve_head_arena(ar, B, E, precision, s);
+    return ar.used;
+}
 
 extern "C" int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t B, int precision, float* probs, uint32_t* bits,
                               const int64_t* row_index, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
@@ -244,14 +319,14 @@ extern "C" int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t
         return xmh::fail(-22, "xmh_head_dcmht: layer shapes do not fit (E = %d, fc2 %lld x %lld)", E, (long long)K2, (long long)h->fc2.k);
     HeadScratch s;
     if (int rc = carve_head(workspace, workspace_bytes, B, E, precision, s, "xmh_head_dcmht")) return rc;
-    int rc = linear(h->v_proj, emb, E, nullptr, 0, s.a, E, B, kActNone, precision, s.half, stream);
+    int rc = linear_any(h->v_proj, emb, E, nullptr, 0, s.a, E, B, kActNone, precision, s.any, stream);
     if (rc) return rc;
-    rc = linear(h->out_proj, s.a, E, nullptr, 0, s.b, E, B, kActNone, precision, s.half, stream);
+    rc = linear_any(h->out_proj, s.a, E, nullptr, 0, s.b, E, B, kActNone, precision, s.any, stream);
     if (rc) return rc;
     rc = h->norm_is_batchnorm ? xmh_affine_cols(s.b, h->bn_mean, h->bn_var, h->norm_w, h->norm_b, h->norm_eps, s.a, B, E, stream)
                               : xmh_layernorm_f32(s.b, E, h->norm_w, h->norm_b, h->norm_eps, s.a, E, B, E, stream);
     if (rc) return rc;
-    rc = linear(h->fc2, s.a, E, nullptr, 0, s.wide, K2, B, kActRelu, precision, s.half, stream);
+    rc = linear_any(h->fc2, s.a, E, nullptr, 0, s.wide, K2, B, kActRelu, precision, s.any, stream);
     if (rc) return rc;
     float* p = probs ? probs : s.wide2;
     rc = xmh_pair_softmax(s.wide, p, B, (int)(K2 / 2), stream);
@@ -270,12 +345,12 @@ extern "C" int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, 
     const int64_t K = fc->n;
     if (K > 2 * E) return xmh::fail(-22, "xmh_head_dsph: %lld bits from %d features exceed the workspace layout", (long long)K, E);
     HeadScratch s{};
-    if (!out || precision == kPrecFast) {
+    if (!out || precision != kPrecExact) {
         if (!workspace) return xmh::fail(-22, "xmh_head_dsph: workspace needed");
         if (int rc = carve_head(workspace, workspace_bytes, B, E, precision, s, "xmh_head_dsph")) return rc;
     }
     float* o = out ? out : s.wide;
-    int rc = linear(*fc, emb, E, nullptr, 0, o, K, B, kActTanh, precision, s.half, stream);
+    int rc = linear_any(*fc, emb, E, nullptr, 0, o, K, B, kActTanh, precision, s.any, stream);
     if (rc) return rc;
     if (bits) rc = xmh_pack_sign(o, B, (int)K, row_index, bits, zero, flags, stream);
     return rc;
@@ -286,39 +361,57 @@ extern "C" int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, 
 namespace {
 struct MithScratch {
     float *y, *hbuf, *f, *scores, *m, *ycls, *hcls, *fcls;
+    xmh::Planes hP, fP;                              // parity / fast mode: LayerNorm output and fc1 output as operand planes
     BlockScratch blk;
-    void* half;
 };
 void carve_mith(Arena& ar, int64_t B, int L, int D, int K, int precision, MithScratch& s) {
     const int64_t M = B * L, M2 = B * K;
     s.y = ar.take<float>((size_t)M * D);
-    s.hbuf = ar.take<float>((size_t)M * D);
-    s.f = ar.take<float>((size_t)M * D * 4);
     s.scores = ar.take<float>((size_t)M * K);
     s.m = ar.take<float>((size_t)M2 * D);
     s.ycls = ar.take<float>((size_t)B * D);
-    s.hcls = ar.take<float>((size_t)B * D);
-    s.fcls = ar.take<float>((size_t)B * D * 4);
+    if (precision == kPrecExact) {
+        s.hbuf = ar.take<float>((size_t)M * D);
+        s.f = ar.take<float>((size_t)M * D * 4);
+        s.hcls = ar.take<float>((size_t)B * D);
+        s.fcls = ar.take<float>((size_t)B * D * 4);
+        s.hP = s.fP = xmh::Planes{nullptr, nullptr, 0};
+    } else {
+        s.hbuf = s.f = s.hcls = s.fcls = nullptr;
+        s.hP = carve_planes(ar, (size_t)M, (size_t)D, precision);
+        s.fP = carve_planes(ar, (size_t)M, (size_t)D * 4, precision);
+    }
     s.blk = carve_blocks(ar, M2, D, precision);
-    s.half = precision == kPrecFast ? (void*)ar.take<uint16_t>((size_t)(M > M2 ? M : M2) * D * 4) : nullptr;
 }
 // GlobalConceptLearning on `rows` rows: y = ResidualMLPs(x) (x is not modified), scores = tanh(concept(y))
-int mith_gcl(const xmh_mith_head* h, const float* x, int64_t rows, float* y, float* hb, float* f, float* scores, int precision, void* half,
-             xmh_stream_t st) {
+int mith_gcl(const xmh_mith_head* h, const float* x, int64_t rows, float* y, float* hb, float* f, float* scores, int precision,
+             const MithScratch& s, xmh_stream_t st) {
     const int D = h->width;
     const float* cur = x;
     for (int i = 0; i < h->res_layers; ++i) {
         const xmh_mith_mlp& m = h->mlps[i];
         if (m.fc1.k != D || m.fc2.n != D || m.fc2.k != m.fc1.n || m.fc1.n > 4 * D) return xmh::fail(-22, "xmh_head_mith: MLP %d shapes do not fit width %d", i, D);
-        int rc = xmh_layernorm_f32(cur, D, m.ln_w, m.ln_b, m.ln_eps, hb, D, rows, D, st);
-        if (rc) return rc;
-        rc = linear(m.fc1, hb, D, nullptr, 0, f, m.fc1.n, rows, kActGeluErf, precision, half, st);
-        if (rc) return rc;
-        rc = linear(m.fc2, f, m.fc1.n, cur, D, y, D, rows, kActNone, precision, half, st);       // y = cur + fc2(..): no clone of x needed
-        if (rc) return rc;
+        int rc;
+        if (precision != kPrecExact && planes_layer(m.fc1) && planes_layer(m.fc2)) {
+            rc = xmh::layernorm_planes(cur, D, m.ln_w, m.ln_b, m.ln_eps, nullptr, 0, s.hP, rows, D, xmh::as_stream(st));
+            if (rc) return rc;
+            const xmh::Planes fo{s.fP.hi, s.fP.lo, m.fc1.n};
+            rc = linear_p(m.fc1, s.hP, nullptr, 0, nullptr, 0, &fo, rows, kActGeluErf, precision, st);
+            if (rc) return rc;
+            rc = linear_p(m.fc2, fo, cur, D, y, D, nullptr, rows, kActNone, precision, st);      // y = cur + fc2(..): no clone of x needed
+            if (rc) return rc;
+        } else {
+            if (!hb || !f) return xmh::fail(-22, "xmh_head_mith: MLP %d lacks fp16 weights (w_hi)", i);
+            rc = xmh_layernorm_f32(cur, D, m.ln_w, m.ln_b, m.ln_eps, hb, D, rows, D, st);
+            if (rc) return rc;
+            rc = linear_any(m.fc1, hb, D, nullptr, 0, f, m.fc1.n, rows, kActGeluErf, precision, s.hP, st);
+            if (rc) return rc;
+            rc = linear_any(m.fc2, f, m.fc1.n, cur, D, y, D, rows, kActNone, precision, s.fP, st);
+            if (rc) return rc;
+        }
         cur = y;
     }
-    return linear(h->concept, cur, D, nullptr, 0, scores, h->k_bits, rows, kActTanh, precision, half, st);
+    return linear_any(h->concept, cur, D, nullptr, 0, scores, h->k_bits, rows, kActTanh, precision, s.hP, st);
 }
 }  // namespace
 
@@ -343,9 +436,9 @@ extern "C" int xmh_head_mith(const xmh_mith_head* h, const float* cls, const flo
     MithScratch s;
     carve_mith(ar, B, L, D, K, precision, s);
     if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_head_mith: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
-    int rc = mith_gcl(h, cls, B, s.ycls, s.hcls, s.fcls, cls_hash, precision, s.half, stream);
+    int rc = mith_gcl(h, cls, B, s.ycls, s.hcls, s.fcls, cls_hash, precision, s, stream);
     if (rc) return rc;
-    rc = mith_gcl(h, tokens, B * L, s.y, s.hbuf, s.f, s.scores, precision, s.half, stream);
+    rc = mith_gcl(h, tokens, B * L, s.y, s.hbuf, s.f, s.scores, precision, s, stream);
     if (rc) return rc;
     rc = xmh_lta_aggregate(s.scores, tokens, token_mask, h->pos_enc, s.m, B, L, K, D, h->top_k, stream);
     if (rc) return rc;

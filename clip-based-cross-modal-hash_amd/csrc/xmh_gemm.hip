@@ -17,6 +17,7 @@
 // Bound in practice: L2 -> CU bandwidth (each tile re-reads its operands from L2; 8.5 TB/s measured at both tile sizes,
 // DESIGN.md section 3.4), with the MFMA peak above it.  Algorithmic flops per launch = 2*M*N*K.
 #include "xmh_common.h"
+#include "xmh_planes.h"
 #include <string.h>
 
 #include <stdlib.h>
@@ -324,529 +325,229 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// h16 path: A and W already fp16 in memory (fast mode proper: weights are converted once and cached by the host,
-// activations by one HBM-bound cast pass), BK = 64, LDS row = 64 halves + 8 pad (144 B), no conversion in the loop.
+// g16: the fp16-MFMA GEMM on operand planes (xmh_planes.h), staged by LDS-DMA.
+//
+// Operands are fp16 in memory -- one plane per operand in fast mode; activations as (lo, hi) planes in parity mode, weights
+// as one plane when they are fp16-exact (CLIP as released) or (hi, lo) when not -- produced in that format by whatever kernel
+// computed them, so the k-loop moves bytes and issues MFMAs and nothing else:
+//   * global_load_lds_dwordx4 (1 KB per wave instruction) straight into a double-buffered LDS tile, next tile in flight under the
+//     MFMAs of the current one, ONE barrier per k-step (s_waitcnt vmcnt(0); s_barrier; issue next; compute);
+//   * LDS tile = [rows][BK halves], 16-byte chunk c of row r stored at chunk c ^ ((r / RPB) & (CH-1)) (CH chunks per row, RPB
+//     rows per 256-byte bank row): the 16 lanes of every ds_read_b128 group -- 16 different rows, one k chunk -- cover all 16
+//     slots of the bank row.  LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address (same
+//     128-byte line, chunks swapped) and again on the read;
+//   * v_mfma_f32_32x32x16_f16, slabs of 16 in k order, per slab  acc += a_lo*w_hi; acc += a_hi*w_lo; acc += a_hi*w_hi  (the
+//     terms that exist): every tile shape and BK walks k in the same order, so results do not depend on the dispatch;
+//   * tiles are numbered for the XCD's L2: block -> XCD-contiguous id range, inside it groups of 8 tile rows x all tile columns;
+//   * epilogue through LDS: accumulators -> the wave's own fp32 region -> 16-byte row pieces; bias / activation / residual there,
+//     then fp32 C (dwordx4) and / or the operand planes of the result (8 bytes per plane and lane) for the next GEMM.
+// Measured against the register-staged BK = 32 kernels this replaces (M = 5000 ViT-B/32 shapes): fast mode 190-320 -> 400-640
+// TFLOP/s, parity mode 184-270 -> 260-430 useful TFLOP/s; tools/proto_gemm_glds.hip holds the ablations (what the C store,
+// the staging and the MFMAs each cost) that picked these shapes.
 // ---------------------------------------------------------------------------------------------------
-constexpr int BKH = 32, LDH = 40;          // 32 halves + 8 pad = 80 B rows: 16-lane ds_read_b128 groups hit 16 distinct slots
-
-struct GemmArgsH {
-    const _Float16* A;
-    const _Float16* W;
+struct GArgsP {
+    const _Float16 *A0, *A1;      // A0 = lo plane (or the only plane), A1 = hi plane
+    const _Float16 *W0, *W1;      // W0 = hi plane, W1 = lo plane or null
     const float* bias;
     const float* residual;
     float* C;
-    int64_t lda, ldw, ldr, ldc;
+    _Float16 *O_hi, *O_lo;
+    int64_t lda, ldw, ldr, ldc, ldo;
     int M, N, K, act;
 };
 
-template <int MI>
-__global__ __launch_bounds__(kThreads) void k_gemm_nt_h16(GemmArgsH g) {
-    constexpr int TBM = 64 * MI;
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][TBM * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LDH];
-    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
+template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
+    constexpr int NWAVE = WM * WN;
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr int CH = BK / 8, RPB = 16 / CH, RPP = 64 / CH;        // chunks per row, rows per bank row, rows per 1 KB piece
+    constexpr int ROWB = BK * 2;
+    constexpr int PA = TBM / RPP, PW = TBN / RPP;                   // 1 KB pieces per operand plane
+    constexpr int NPIECE = NA * PA + NW * PW;
+    static_assert(NPIECE % NWAVE == 0, "pieces per wave");
+    constexpr int PPW = NPIECE / NWAVE;
+    constexpr int BUFB = NPIECE * 1024;
+    constexpr int TW = 32 * NJ;                                     // epilogue: the wave's region is [32][TW] fp32
+    static_assert(2 * BUFB >= NWAVE * 32 * TW * 4, "the epilogue regions fit the staging buffers");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
     int tm, tn;
     tile_of_block(nbm, nbn, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * BN;
+    {   // inside the XCD's contiguous id range: groups of kGroupM tile rows x all tile columns, tile rows fastest -- the A rows
+        // of a group and the W panels in flight stay in that XCD's L2 (measured +5-15 % on the ViT shapes)
+        constexpr int kGroupM = 8;
+        const int id = tn * nbm + tm;
+        const int per = kGroupM * nbn;
+        const int grp = id / per, rem = id % per;
+        const int gm0 = grp * kGroupM;
+        const int gsz = nbm - gm0 < kGroupM ? nbm - gm0 : kGroupM;
+        tm = gm0 + rem % gsz;
+        tn = rem / gsz;
+    }
+    const int m0 = tm * TBM, n0 = tn * TBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
-    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 halves = 16 B per thread
-    // named registers (not arrays captured by a lambda): hipcc sends such arrays to scratch, one round trip per K step
-    uint4 ra0, ra1, rw0, rw1;
-    ra0 = ra1 = rw0 = rw1 = make_uint4(0u, 0u, 0u, 0u);
-    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
-    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
-#define XMH_HLOAD(k0)                                                                                               \
-    ra0 = *reinterpret_cast<const uint4*>(g.A + (int64_t)row_a(srow) * g.lda + (k0) + scol);                         \
-    if (MI == 2) ra1 = *reinterpret_cast<const uint4*>(g.A + (int64_t)row_a(srow + 64) * g.lda + (k0) + scol);       \
-    rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                         \
-    rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);
-#define XMH_HWRITE(buf)                                                                                             \
-    *reinterpret_cast<uint4*>(&sA[buf][srow * LDH + scol]) = ra0;                                                    \
-    if (MI == 2) *reinterpret_cast<uint4*>(&sA[buf][(srow + 64) * LDH + scol]) = ra1;                                \
-    *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                    \
-    *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;
-    f32x16 acc[MI][2];
+    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // staging: piece p = j * NWAVE + wave; pieces [0, NA*PA) the A planes, then the W planes
+    const _Float16* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = j * NWAVE + wave;
+        const int prow = lane / CH;
+        int r;
+        const _Float16* base;
+        if (p < NA * PA) {
+            r = (p % PA) * RPP + prow;
+            const int rg = m0 + r < g.M ? m0 + r : g.M - 1;          // clamped rows are never stored
+            base = (p / PA == 0 ? g.A0 : g.A1) + (int64_t)rg * g.lda;
+        } else {
+            const int q = p - NA * PA;
+            r = (q % PW) * RPP + prow;
+            const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
+            base = (q / PW == 0 ? g.W0 : g.W1) + (int64_t)rg * g.ldw;
+        }
+        src[j] = base + ((lane % CH) ^ ((r / RPB) & (CH - 1))) * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = j * NWAVE + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BUFB + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const int nk = g.K / BKH;
-    XMH_HLOAD(0)
-    XMH_HWRITE(0)
-    __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
+
+    const int swz = (fr / RPB) & (CH - 1);      // wm, wn, i*32 are multiples of 32: the swizzle depends on fr only
+    const int nk = g.K / BK;
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) { XMH_HLOAD((kt + 1) * BKH) }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();                              // ... and everyone's; all reads of the other buffer are done
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+        const char* bA = lds + buf * BUFB;
+        const char* bW = bA + NA * PA * 1024;
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {                       // two k-slabs of 16 per BK
-            f16x8 a[MI], b[2];
+        for (int s = 0; s < BK / 16; ++s) {                        // k slabs of 16: lane half fh takes chunk 2s + fh
+            const int coff = ((2 * s + fh) ^ swz) * 16;
+            f16x8 b[NJ], bl[NW == 2 ? NJ : 1], a[MI], ah[NA == 2 ? MI : 1];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(&sA[buf][(wm + i * 32 + fr) * LDH + sl * 16 + fh * 8]);
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + sl * 16 + fh * 8]);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            XMH_HWRITE(buf ^ 1)
-            __syncthreads();
-        }
-    }
-#undef XMH_HLOAD
-#undef XMH_HWRITE
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + j * 32 + fr;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < g.M) {
-                    float v = apply_act(acc[i][j][e] + bv, g.act);
-                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
-                    g.C[(int64_t)row * g.ldc + col] = v;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// split path ("f32s"): fp32 activations x fp16-EXACT weights at fp16-MFMA rate with fp32-grade accuracy.
-// CLIP weights are fp16 values held in fp32 (convert_weights + .float(), reference models/CLIP/model.py:415-436), so W
-// is taken as fp16 without loss.  A is split while it is staged: a = hi + lo + r with hi = a truncated to 11 significant
-// bits, lo = half(a - hi) rounded toward zero, |r| <= 2^-21 |a| (for |a| below 2^-3 the low part is subnormal: absolute
-// error <= 2^-24).  Each fp16 x fp16 product is
-// exact in fp32, so acc += hi*w; acc += lo*w reproduces the fp32 product to 2^-22 relative -- the same order as fp32
-// summation-order noise -- at two fp16 MFMAs per k-slab instead of eight fp32 ones.  Domain |a| < 65504 (fp16 range):
-// true for LayerNorm outputs, attention outputs and QuickGELU activations (the reference's own GPU path computes these in
-// fp16); larger values saturate (finite, inaccurate).  The exact fp32-MFMA kernel stays selectable ("f32x").
-// ---------------------------------------------------------------------------------------------------
-struct GemmArgsS {
-    const float* A;
-    const _Float16* W;
-    const _Float16* Wl;        // low parts of weights that are not fp16-exact (WS kernels), else unused
-    const float* bias;
-    const float* residual;
-    float* C;
-    int64_t lda, ldw, ldr, ldc;
-    int M, N, K, act;
-};
-
-// WS: the weight is split as well (w = wh + wl, both fp16, prepared once by the host) for weights that are NOT fp16-exact
-// -- anything fine-tuned in fp32, e.g. the hash heads or a backbone after training: acc += al*wh + ah*wl + ah*wh, the
-// dropped al*wl term is 2^-22 relative.  Three fp16 MFMAs per product instead of two; 64x128 tiles only (LDS).
-template <int MI, bool WS>
-__global__ __launch_bounds__(kThreads) void k_gemm_nt_s16(GemmArgsS g) {
-    constexpr int TBM = 64 * MI;
-    __shared__ __attribute__((aligned(16))) _Float16 sAh[2][TBM * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 sAl[2][TBM * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 sW[2][BN * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 sWl[WS ? 2 : 1][WS ? BN * LDH : 8];
-    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + BN - 1) / BN;
-    int tm, tn;
-    tile_of_block(nbm, nbn, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
-    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 elements per thread
-    float4 fa0, fa1, fa2, fa3;                                 // named staging registers (see k_gemm_nt_h16)
-    uint4 rw0, rw1, rl0, rl1;
-    fa0 = fa1 = fa2 = fa3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    rw0 = rw1 = rl0 = rl1 = make_uint4(0u, 0u, 0u, 0u);
-    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
-    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
-#define XMH_SLOAD(k0)                                                                                               \
-    {                                                                                                               \
-        const float4* pa = reinterpret_cast<const float4*>(g.A + (int64_t)row_a(srow) * g.lda + (k0) + scol);        \
-        fa0 = pa[0]; fa1 = pa[1];                                                                                   \
-        if (MI == 2) {                                                                                              \
-            const float4* pb = reinterpret_cast<const float4*>(g.A + (int64_t)row_a(srow + 64) * g.lda + (k0) + scol); \
-            fa2 = pb[0]; fa3 = pb[1];                                                                               \
-        }                                                                                                           \
-        rw0 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                     \
-        rw1 = *reinterpret_cast<const uint4*>(g.W + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);                \
-        if (WS) {                                                                                                   \
-            rl0 = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)row_w(srow) * g.ldw + (k0) + scol);                \
-            rl1 = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)row_w(srow + 64) * g.ldw + (k0) + scol);           \
-        }                                                                                                           \
-    }
-// two floats -> packed (hi, hi) and (lo, lo) halves in 6 VALU ops: hi = the float truncated to 11 significant bits (a mask:
-// exactly an fp16 value inside the fp16 exponent range), lo = a - hi (exact in fp32), both packed with
-// v_cvt_pkrtz_f16_f32 (round toward zero: exact for hi, <= 2^-21 |a| for lo, and it saturates at 65504 instead of inf).
-#define XMH_SPLIT2(f0, f1, H, L)                                                                                    \
-    {                                                                                                               \
-        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
-        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
-        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
-        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
-    }
-#define XMH_SPLIT8(VA, VB, hi, lo)                                                                                  \
-    {                                                                                                               \
-        XMH_SPLIT2(VA.x, VA.y, hi.x, lo.x) XMH_SPLIT2(VA.z, VA.w, hi.y, lo.y)                                       \
-        XMH_SPLIT2(VB.x, VB.y, hi.z, lo.z) XMH_SPLIT2(VB.z, VB.w, hi.w, lo.w)                                       \
-    }
-#define XMH_SWRITE(buf)                                                                                             \
-    {                                                                                                               \
-        uint4 h8, l8;                                                                                               \
-        XMH_SPLIT8(fa0, fa1, h8, l8)                                                                                \
-        *reinterpret_cast<uint4*>(&sAh[buf][srow * LDH + scol]) = h8;                                                \
-        *reinterpret_cast<uint4*>(&sAl[buf][srow * LDH + scol]) = l8;                                                \
-        if (MI == 2) {                                                                                              \
-            XMH_SPLIT8(fa2, fa3, h8, l8)                                                                            \
-            *reinterpret_cast<uint4*>(&sAh[buf][(srow + 64) * LDH + scol]) = h8;                                     \
-            *reinterpret_cast<uint4*>(&sAl[buf][(srow + 64) * LDH + scol]) = l8;                                     \
-        }                                                                                                           \
-        *reinterpret_cast<uint4*>(&sW[buf][srow * LDH + scol]) = rw0;                                                \
-        *reinterpret_cast<uint4*>(&sW[buf][(srow + 64) * LDH + scol]) = rw1;                                         \
-        if (WS) {                                                                                                   \
-            *reinterpret_cast<uint4*>(&sWl[buf][srow * LDH + scol]) = rl0;                                           \
-            *reinterpret_cast<uint4*>(&sWl[buf][(srow + 64) * LDH + scol]) = rl1;                                    \
-        }                                                                                                           \
-    }
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const int nk = g.K / BKH;
-    XMH_SLOAD(0)
-    XMH_SWRITE(0)
-    __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) XMH_SLOAD((kt + 1) * BKH)
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {                       // two k-slabs of 16 per BK
-            f16x8 ah[MI], al[MI], b[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(&sAh[buf][(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
-                al[i] = *reinterpret_cast<const f16x8*>(&sAl[buf][(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8*>(&sW[buf][(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + (wm + i * 32 + fr) * ROWB + coff);
             // low parts first: the small terms meet the accumulator before the large ones of this slab
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
-            if (WS) {
-                f16x8 bl[2];
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (NA == 2) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&sWl[buf][(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
+                for (int i = 0; i < MI; ++i) ah[i] = *reinterpret_cast<const f16x8*>(bA + PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+                if (NW == 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bl[j] = *reinterpret_cast<const f16x8*>(bW + PW * 1024 + (wn + j * 32 + fr) * ROWB + coff);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            XMH_SWRITE(buf ^ 1)
-            __syncthreads();
         }
     }
-#undef XMH_SLOAD
-#undef XMH_SPLIT8
-#undef XMH_SPLIT2
-#undef XMH_SWRITE
+
+    // epilogue, 32 accumulator rows at a time: C layout (lane = column, 16 rows) -> LDS -> row pieces of 4 consecutive columns
+    __builtin_amdgcn_s_barrier();                                  // every wave is done with the staging buffers
+    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * TW);
+    constexpr int LPR = TW / 4, RPI = 64 / LPR;                    // lanes per row, rows per pass
+    const int pr = lane / LPR, pc = (lane % LPR) * 4;
+    const int col = n0 + wn + pc;
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
+    const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = col + t < g.N ? g.bias[col + t] : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + j * 32 + fr;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.0f;
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < g.M) {
-                    float v = apply_act(acc[i][j][e] + bv, g.act);
-                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
-                    g.C[(int64_t)row * g.ldc + col] = v;
+            for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * TW + j * 32 + fr] = acc[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int r = it * RPI + pr;
+            const float4 v4 = *reinterpret_cast<const float4*>(reg + r * TW + pc);
+            const int64_t row = m0 + wm + i * 32 + r;
+            if (row >= g.M || col >= g.N) continue;
+            float v[4] = {apply_act(v4.x + bv[0], g.act), apply_act(v4.y + bv[1], g.act), apply_act(v4.z + bv[2], g.act), apply_act(v4.w + bv[3], g.act)};
+            if (vec) {
+                if (g.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + col);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.O_hi) xmh::store_planes4(op, row, col, v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (col + t >= g.N) break;
+                    float x = v[t];
+                    if (g.residual) x += g.residual[row * g.ldr + col + t];
+                    if (g.C) g.C[row * g.ldc + col + t] = x;
+                    if (g.O_hi) xmh::store_planes1(op, row, col + t, x);
                 }
             }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// split path, 128 x 256 block tile (waves 2x2, each 64 x 128 = 2x4 MFMA tiles) for large grids.  The GEMMs are bound by
-// L2 -> CU bandwidth: per k a tile moves 4*TBM + 2*TBN bytes for 2*TBM*TBN flops, so 128x256 carries 64 flop/B
-// against 42.7 at 128x128 and 32 at 64x128.  Needs >= 2 blocks per CU to pay, i.e. M of 16 k rows and more (fused
-// evaluation batches, BaseTrainer.encode_shard).  fp16-exact weights only; 80 KB of dynamic LDS (double-buffered).
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt_s16_wide(GemmArgsS g) {
-    constexpr int TBM = 128, TBN = 256;
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
-    _Float16* sAh = smem_w;                                    // [2][TBM * LDH]
-    _Float16* sAl = sAh + 2 * TBM * LDH;                       // [2][TBM * LDH]
-    _Float16* sW = sAl + 2 * TBM * LDH;                        // [2][TBN * LDH]
-    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
-    int tm, tn;
-    tile_of_block(nbm, nbn, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * TBN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
-    const int srow = tid >> 2, scol = (tid & 3) * 8;           // 64 rows per pass, 8 elements per thread
-    float4 fa0, fa1, fa2, fa3;
-    uint4 rw0, rw1, rw2, rw3;
-    auto row_a = [&](int r) { return m0 + r < g.M ? m0 + r : g.M - 1; };      // clamped rows are never stored
-    auto row_w = [&](int r) { return n0 + r < g.N ? n0 + r : g.N - 1; };
-    const float* pa0 = g.A + (int64_t)row_a(srow) * g.lda + scol;
-    const float* pa1 = g.A + (int64_t)row_a(srow + 64) * g.lda + scol;
-    const _Float16* pw0 = g.W + (int64_t)row_w(srow) * g.ldw + scol;
-    const _Float16* pw1 = g.W + (int64_t)row_w(srow + 64) * g.ldw + scol;
-    const _Float16* pw2 = g.W + (int64_t)row_w(srow + 128) * g.ldw + scol;
-    const _Float16* pw3 = g.W + (int64_t)row_w(srow + 192) * g.ldw + scol;
-#define XMH_WL(k0)                                                                                                  \
-    {                                                                                                               \
-        fa0 = reinterpret_cast<const float4*>(pa0 + (k0))[0]; fa1 = reinterpret_cast<const float4*>(pa0 + (k0))[1]; \
-        fa2 = reinterpret_cast<const float4*>(pa1 + (k0))[0]; fa3 = reinterpret_cast<const float4*>(pa1 + (k0))[1]; \
-        rw0 = *reinterpret_cast<const uint4*>(pw0 + (k0)); rw1 = *reinterpret_cast<const uint4*>(pw1 + (k0));       \
-        rw2 = *reinterpret_cast<const uint4*>(pw2 + (k0)); rw3 = *reinterpret_cast<const uint4*>(pw3 + (k0));       \
-    }
-#define XMH_WS2(f0, f1, H, L)                                                                                       \
-    {                                                                                                               \
-        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
-        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
-        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
-        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
-    }
-#define XMH_WW(buf)                                                                                                 \
-    {                                                                                                               \
-        uint4 h, l;                                                                                                 \
-        XMH_WS2(fa0.x, fa0.y, h.x, l.x) XMH_WS2(fa0.z, fa0.w, h.y, l.y) XMH_WS2(fa1.x, fa1.y, h.z, l.z) XMH_WS2(fa1.z, fa1.w, h.w, l.w) \
-        *reinterpret_cast<uint4*>(&sAh[(buf) * TBM * LDH + srow * LDH + scol]) = h;                                  \
-        *reinterpret_cast<uint4*>(&sAl[(buf) * TBM * LDH + srow * LDH + scol]) = l;                                  \
-        XMH_WS2(fa2.x, fa2.y, h.x, l.x) XMH_WS2(fa2.z, fa2.w, h.y, l.y) XMH_WS2(fa3.x, fa3.y, h.z, l.z) XMH_WS2(fa3.z, fa3.w, h.w, l.w) \
-        *reinterpret_cast<uint4*>(&sAh[(buf) * TBM * LDH + (srow + 64) * LDH + scol]) = h;                           \
-        *reinterpret_cast<uint4*>(&sAl[(buf) * TBM * LDH + (srow + 64) * LDH + scol]) = l;                           \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + srow * LDH + scol]) = rw0;                                 \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rw1;                          \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 128) * LDH + scol]) = rw2;                         \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 192) * LDH + scol]) = rw3;                         \
-    }
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const int nk = g.K / BKH;
-    XMH_WL(0)
-    XMH_WW(0)
-    __syncthreads();
-    const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) XMH_WL((kt + 1) * BKH)
-        const _Float16* cAh = sAh + buf * TBM * LDH;
-        const _Float16* cAl = sAl + buf * TBM * LDH;
-        const _Float16* cW = sW + buf * TBN * LDH;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            f16x8 ah[2], al[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(&cAh[(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
-                al[i] = *reinterpret_cast<const f16x8*>(&cAl[(wm + i * 32 + fr) * LDH + fh * 16 + sl * 8]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[(wn + j * 32 + fr) * LDH + fh * 16 + sl * 8]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            XMH_WW(buf ^ 1)
-            __syncthreads();
-        }
-    }
-#undef XMH_WL
-#undef XMH_WS2
-#undef XMH_WW
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn + j * 32 + fr;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < g.M) {
-                    float v = apply_act(acc[i][j][e] + bv, g.act);
-                    if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
-                    g.C[(int64_t)row * g.ldc + col] = v;
-                }
-            }
+// fp32 [rows][cols] -> operand planes, 8 elements per thread
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols8, xmh::Planes p) {
+    const int64_t total = rows * cols8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / cols8;
+        const int c = (int)(e % cols8) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c), b = *reinterpret_cast<const float4*>(x + row * ldx + c + 4);
+        if (p.lo) {
+            uint4 h, l;
+            xmh::split2(a.x, a.y, h.x, l.x); xmh::split2(a.z, a.w, h.y, l.y);
+            xmh::split2(b.x, b.y, h.z, l.z); xmh::split2(b.z, b.w, h.w, l.w);
+            *reinterpret_cast<uint4*>(p.hi + row * p.ld + c) = h;
+            *reinterpret_cast<uint4*>(p.lo + row * p.ld + c) = l;
+        } else {
+            *reinterpret_cast<uint4*>(p.hi + row * p.ld + c) = make_uint4(xmh::round2(a.x, a.y), xmh::round2(a.z, a.w), xmh::round2(b.x, b.y), xmh::round2(b.z, b.w));
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// split path, A straight from global ("direct A").  Phase probes of k_gemm_nt_s16 (its k-loop with parts removed, 4096^3):
-// MFMAs alone 0.151 ms, + ds_reads and barrier 0.162 ms, everything BUT the MFMAs 0.232 ms, all of it 0.300 ms -- the
-// staging side (global -> registers -> split -> ds_write, then every wave re-reading hi and lo planes) costs more than the
-// matrix work, and a deeper prefetch does not change it: the LDS pipe carries 72 KB per 128x128 k-step against 512 clk
-// of MFMA.  Here the A operand never touches LDS: a wave owns 32 ROWS of the block tile and all of its 32*NJ columns, lane
-// (row, half) loads its row's 16-float half of the k-step (64 contiguous bytes = half a cache line, no duplication
-// between waves) directly in MFMA operand layout and splits it in registers.  The k-sum does not care which k sits in
-// which MFMA slot, so slab s takes elements [8s, 8s+8) of each lane's 16 -- the W fragments are read from LDS with the
-// same permutation (offset half*16 + s*8; the LDS-staged kernels use the same one, so all of them produce identical bits).
-// Only W goes through LDS: 8 / 16 KB written and 4 x 8 / 16 KB read per k-step (NJ = 4 / 8).
-// Outcome: +10-16 % for the three-term product (W split too: the LDS-staged kernel holds four planes), within +-4 % of the
-// LDS-staged kernels otherwise (462 vs 444 TF at 4096^3) -- taking A out of LDS moved the load to the vector memory
-// path: each of the four loads per k-step touches 32 cache lines for 1 KB.  The dispatcher uses it for the former only.
-// ---------------------------------------------------------------------------------------------------
-template <int NJ, bool WS>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_nt_s16_da(GemmArgsS g) {
-    constexpr int TBM = 128, TBN = 32 * NJ, NP = TBN / 64;     // NP staging passes of 64 W rows (2 or 4)
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem_d[];
-    _Float16* sW = smem_d;                                     // [2][TBN * LDH]
-    _Float16* sWl = sW + 2 * TBN * LDH;                        // [2][TBN * LDH], WS only
-    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
-    int tm, tn;
-    tile_of_block(nbm, nbn, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * TBN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int wm = wave * 32;
-    const int arow = m0 + wm + fr < g.M ? m0 + wm + fr : g.M - 1;                 // clamped rows are never stored
-    const float* pA = g.A + (int64_t)arow * g.lda + fh * 16;
-    const int srow = tid >> 2, scol = (tid & 3) * 8;           // W staging: 64 rows per pass, 8 halves per thread
-    // named registers, no arrays: hipcc keeps small arrays of pointers / uint4 in scratch here
-#define XMH_DROW(p) ((int64_t)(n0 + srow + 64 * (p) < g.N ? n0 + srow + 64 * (p) : g.N - 1) * g.ldw + scol)
-    const int64_t ow0 = XMH_DROW(0), ow1 = XMH_DROW(1), ow2 = NP > 2 ? XMH_DROW(2) : 0, ow3 = NP > 2 ? XMH_DROW(3) : 0;
-#undef XMH_DROW
-    float4 an0, an1, an2, an3;                                 // the next k-step's 16 floats of this lane's row
-    uint4 rw0, rw1, rw2, rw3, rl0, rl1;
-    rw2 = rw3 = rl0 = rl1 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 h0, h1, l0, l1;                                      // current k-step: packed hi / lo halves, slab 0 and slab 1
-#define XMH_DS2(f0, f1, H, L)                                                                                       \
-    {                                                                                                               \
-        const float h0_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f0) & 0xffffe000u);                \
-        const float h1_ = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, f1) & 0xffffe000u);                \
-        H = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0_, h1_));                                     \
-        L = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f0 - h0_, f1 - h1_));                           \
+template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
+int launch_g16(const GArgsP& a, hipStream_t st) {
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr size_t lds = (size_t)2 * (NA * TBM + NW * TBN) * BK * 2;
+    auto kern = k_gemm_g16<WM, WN, MI, NJ, NA, NW, BK, MINB>;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return xmh::fail(XMH_EHIP, "xmh gemm: cannot raise dynamic LDS to %zu", lds);
+        raised = true;
     }
-#define XMH_DLOAD(k0)                                                                                               \
-    {                                                                                                               \
-        an0 = reinterpret_cast<const float4*>(pA + (k0))[0]; an1 = reinterpret_cast<const float4*>(pA + (k0))[1];   \
-        an2 = reinterpret_cast<const float4*>(pA + (k0))[2]; an3 = reinterpret_cast<const float4*>(pA + (k0))[3];   \
-        rw0 = *reinterpret_cast<const uint4*>(g.W + ow0 + (k0)); rw1 = *reinterpret_cast<const uint4*>(g.W + ow1 + (k0)); \
-        if (NP > 2) { rw2 = *reinterpret_cast<const uint4*>(g.W + ow2 + (k0)); rw3 = *reinterpret_cast<const uint4*>(g.W + ow3 + (k0)); } \
-        if (WS) { rl0 = *reinterpret_cast<const uint4*>(g.Wl + ow0 + (k0)); rl1 = *reinterpret_cast<const uint4*>(g.Wl + ow1 + (k0)); }  \
-    }
-#define XMH_DWRITE(buf)                                                                                             \
-    {                                                                                                               \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + srow * LDH + scol]) = rw0;                                 \
-        *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rw1;                          \
-        if (NP > 2) {                                                                                               \
-            *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 128) * LDH + scol]) = rw2;                     \
-            *reinterpret_cast<uint4*>(&sW[(buf) * TBN * LDH + (srow + 192) * LDH + scol]) = rw3;                     \
-        }                                                                                                           \
-        if (WS) {                                                                                                   \
-            *reinterpret_cast<uint4*>(&sWl[(buf) * TBN * LDH + srow * LDH + scol]) = rl0;                            \
-            *reinterpret_cast<uint4*>(&sWl[(buf) * TBN * LDH + (srow + 64) * LDH + scol]) = rl1;                     \
-        }                                                                                                           \
-    }
-    static_assert(!WS || NP == 2, "the three-term variant stages two passes of W and W_lo");
-    f32x16 acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
-    const int nk = g.K / BKH;
-    XMH_DLOAD(0)
-    XMH_DWRITE(0)
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        XMH_DS2(an0.x, an0.y, h0.x, l0.x) XMH_DS2(an0.z, an0.w, h0.y, l0.y) XMH_DS2(an1.x, an1.y, h0.z, l0.z) XMH_DS2(an1.z, an1.w, h0.w, l0.w)
-        XMH_DS2(an2.x, an2.y, h1.x, l1.x) XMH_DS2(an2.z, an2.w, h1.y, l1.y) XMH_DS2(an3.x, an3.y, h1.z, l1.z) XMH_DS2(an3.z, an3.w, h1.w, l1.w)
-        if (kt + 1 < nk) XMH_DLOAD((kt + 1) * BKH)
-        const _Float16* cW = sW + buf * TBN * LDH;
-        const _Float16* cL = sWl + buf * TBN * LDH;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, sl == 0 ? h0 : h1), al = __builtin_bit_cast(f16x8, sl == 0 ? l0 : l1);
-#pragma unroll
-            for (int jq = 0; jq < NJ; jq += 4) {                // four column fragments at a time (16 VGPRs of W in flight)
-                f16x8 b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f16x8*>(&cW[((jq + j) * 32 + fr) * LDH + fh * 16 + sl * 8]);
-                // low parts first: the small terms meet the accumulator before the large ones of this slab
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[j], acc[jq + j], 0, 0, 0);
-                if (WS) {
-                    f16x8 bl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f16x8*>(&cL[((jq + j) * 32 + fr) * LDH + fh * 16 + sl * 8]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[jq + j], 0, 0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[jq + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[j], acc[jq + j], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) {
-            XMH_DWRITE(buf ^ 1)
-            __syncthreads();
-        }
-    }
-#undef XMH_DS2
-#undef XMH_DLOAD
-#undef XMH_DWRITE
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + j * 32 + fr;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * fh;
-            if (row < g.M) {
-                float v = apply_act(acc[j][e] + bv, g.act);
-                if (g.residual) v += g.residual[(int64_t)row * g.ldr + col];
-                g.C[(int64_t)row * g.ldc + col] = v;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cast_f32_h16(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n8) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4*>(x)[2 * e], b = reinterpret_cast<const float4*>(x)[2 * e + 1];
-        f16x8 h;
-        h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
-        h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
-        reinterpret_cast<f16x8*>(y)[e] = h;
-    }
+    const int64_t nblk = xmh::ceil_div(a.M, TBM) * xmh::ceil_div(a.N, TBN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a);
+    return XMH_OK;
 }
 
 }  // namespace
@@ -896,46 +597,100 @@ extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int6
     return XMH_OK;
 }
 
+namespace xmh {
+
+bool gemm_planes_ok(int64_t K, int64_t lda, int64_t ldw, const void* A, const void* W) {
+    return K > 0 && K % 32 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
+}
+
+int split_planes(const float* x, int64_t ldx, int64_t rows, int64_t cols, const Planes& p, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return XMH_OK;
+    if (cols % 8 || ldx % 4 || p.ld % 8 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(p.hi) % 16 || reinterpret_cast<uintptr_t>(p.lo) % 16)
+        return fail(XMH_ENOTSUP, "xmh split_planes: needs cols %% 8 == 0 and 16-byte aligned rows (cols=%lld ldx=%lld)", (long long)cols, (long long)ldx);
+    int64_t grid = ceil_div(rows * (cols / 8), 256);
+    const int64_t cap = (int64_t)device_cu_count() * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)grid), dim3(256), 0, st, x, ldx, rows, (int)(cols / 8), p);
+    XMH_LAUNCH_CHECK("xmh split_planes");
+    return XMH_OK;
+}
+
+// Tile shapes (tools/proto_gemm_glds.hip, M = 5000 / 20000 ViT-B/32 shapes, useful TFLOP/s):
+//   fast   128x128, BK 64, 2 blocks per CU: 550-770; 64x128 for grids that leave CUs empty;
+//   parity 128x128, BK 32, 3 blocks per CU: 310-360; 128x256 with 8 waves once there are >= 1.5 such tiles per CU: 370-430;
+//   parity with split weights (three terms): 128x128, BK 32, 2 blocks per CU.
+int gemm_planes(const GemmPlanes& g, hipStream_t st) {
+    if (g.M < 0 || g.N < 0 || g.K <= 0) return fail(XMH_EINVAL, "xmh gemm: bad shape M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+    if (g.M == 0 || g.N == 0) return XMH_OK;
+    if (!g.A_hi || !g.W_hi || (!g.C && !g.O.hi)) return fail(XMH_EINVAL, "xmh gemm: null pointer");
+    if (!gemm_planes_ok(g.K, g.lda, g.ldw, g.A_hi, g.W_hi) || reinterpret_cast<uintptr_t>(g.A_lo) % 16 || reinterpret_cast<uintptr_t>(g.W_lo) % 16)
+        return fail(XMH_ENOTSUP, "xmh gemm: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)g.K, (long long)g.lda, (long long)g.ldw);
+    if (g.W_lo && !g.A_lo) return fail(XMH_EINVAL, "xmh gemm: split weights go with split activations");
+    if (g.lda < g.K || g.ldw < g.K || (g.C && g.ldc < g.N) || (g.residual && g.ldr < g.N) || (g.O.hi && g.O.ld < g.N))
+        return fail(XMH_EINVAL, "xmh gemm: leading dimension too small");
+    if (g.act < 0 || g.act > 4) return fail(XMH_EINVAL, "xmh gemm: unknown activation %d", g.act);
+    if (g.M >= (1ll << 31) || g.N >= (1ll << 31) || g.K >= (1ll << 31)) return fail(XMH_ENOTSUP, "xmh gemm: dimension >= 2^31");
+    const bool vec = g.N % 4 == 0 && (!g.C || g.ldc % 4 == 0) && (!g.residual || g.ldr % 4 == 0) && (!g.O.hi || g.O.ld % 4 == 0);
+    if (vec && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.residual)) % 16 || (reinterpret_cast<uintptr_t>(g.O.hi) | reinterpret_cast<uintptr_t>(g.O.lo)) % 8))
+        return fail(XMH_ENOTSUP, "xmh gemm: C / residual must be 16-byte aligned");
+    GArgsP a;
+    a.A0 = g.A_lo ? g.A_lo : g.A_hi; a.A1 = g.A_hi;
+    a.W0 = g.W_hi; a.W1 = g.W_lo;
+    a.bias = g.bias; a.residual = g.residual; a.C = g.C;
+    a.O_hi = g.O.hi; a.O_lo = g.O.lo;
+    a.lda = g.lda; a.ldw = g.ldw; a.ldr = g.residual ? g.ldr : 0; a.ldc = g.C ? g.ldc : 0; a.ldo = g.O.hi ? g.O.ld : 0;
+    a.M = (int)g.M; a.N = (int)g.N; a.K = (int)g.K; a.act = g.act;
+    const int64_t cus = device_cu_count();
+    const int64_t n128 = ceil_div(g.M, 128) * ceil_div(g.N, 128);
+    int rc;
+    if (!g.A_lo) {
+        ProfScope prof("gemm_f16", st);
+        if (n128 < cus) rc = g.K % 64 ? launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 64, 4>(a, st);
+        else rc = g.K % 64 ? launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st);
+    } else {
+        ProfScope prof("gemm_s16", st);
+        static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
+        if (g.W_lo) rc = n128 < cus ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
+        else if (!no_wide && ceil_div(g.M, 128) * ceil_div(g.N, 256) * 2 >= 3 * cus) rc = launch_g16<2, 4, 2, 2, 2, 1, 32, 1>(a, st);
+        else if (n128 < cus) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
+        else rc = launch_g16<2, 2, 2, 2, 2, 1, 32, 3>(a, st);
+    }
+    if (rc) return rc;
+    XMH_LAUNCH_CHECK("xmh gemm (fp16 MFMA on operand planes)");
+    return XMH_OK;
+}
+
+}  // namespace xmh
+
+namespace {
+// stream-ordered scratch for the entry points that take fp32 activations (the fused forwards carry their planes in the
+// caller's workspace instead)
+struct AsyncScratch {
+    void* p = nullptr;
+    hipStream_t st;
+    explicit AsyncScratch(hipStream_t s) : st(s) {}
+    int get(size_t bytes) { return hipMallocAsync(&p, bytes, st) == hipSuccess ? 0 : xmh::fail(XMH_EHIP, "xmh gemm: hipMallocAsync of %zu bytes failed", bytes); }
+    ~AsyncScratch() { if (p) (void)hipFreeAsync(p, st); }
+};
+}  // namespace
+
 extern "C" int xmh_cast_f32_to_f16(const float* x, void* y_half, int64_t n, xmh_stream_t stream) {
     if (n < 0 || n % 8) return xmh::fail(XMH_EINVAL, "xmh_cast_f32_to_f16: n=%lld must be a non-negative multiple of 8", (long long)n);
     if (n == 0) return XMH_OK;
     if (!x || !y_half) return xmh::fail(XMH_EINVAL, "xmh_cast_f32_to_f16: null pointer");
-    int64_t grid = xmh::ceil_div(n / 8, 256);
-    const int64_t cap = (int64_t)xmh::device_cu_count() * 16;
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_cast_f32_h16, dim3((unsigned)grid), dim3(256), 0, xmh::as_stream(stream), x, static_cast<_Float16*>(y_half), n / 8);
-    XMH_LAUNCH_CHECK("xmh_cast_f32_to_f16");
-    return XMH_OK;
+    return xmh::split_planes(x, n, 1, n, xmh::Planes{static_cast<_Float16*>(y_half), nullptr, n}, xmh::as_stream(stream));
 }
 
 extern "C" int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_half, int64_t ldw, const float* bias,
                                const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                int act, xmh_stream_t stream) {
-    if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: bad shape");
-    if (M == 0 || N == 0) return XMH_OK;
-    if (!A_half || !W_half || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: null pointer");
-    if (K % BKH || lda % 8 || ldw % 8 || ((reinterpret_cast<uintptr_t>(A_half) | reinterpret_cast<uintptr_t>(W_half)) % 16))
-        return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_h16: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)K, (long long)lda, (long long)ldw);
-    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: leading dimension too small");
-    if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: unknown activation %d", act);
-    if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_h16: dimension >= 2^31");
-    GemmArgsH g;
-    g.A = static_cast<const _Float16*>(A_half); g.W = static_cast<const _Float16*>(W_half);
-    g.bias = bias; g.residual = residual; g.C = C;
-    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
-    hipStream_t st = xmh::as_stream(stream);
-    int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
-    const bool small = nblk < 3ll * xmh::device_cu_count();
-    xmh::ProfScope prof("gemm_f16", st);
-    if (small) {
-        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
-        hipLaunchKernelGGL(k_gemm_nt_h16<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    } else {
-        hipLaunchKernelGGL(k_gemm_nt_h16<2>, dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    }
-    XMH_LAUNCH_CHECK("xmh_gemm_nt_h16");
-    return XMH_OK;
+    if (!C && M > 0 && N > 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_h16: null pointer");
+    xmh::GemmPlanes g{};
+    g.A_hi = static_cast<const _Float16*>(A_half); g.lda = lda;
+    g.W_hi = static_cast<const _Float16*>(W_half); g.ldw = ldw;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    return xmh::gemm_planes(g, xmh::as_stream(stream));
 }
 
 extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_half, const void* W_lo_half, int64_t ldw, const float* bias,
@@ -944,53 +699,20 @@ extern "C" int xmh_gemm_nt_split16(const float* A, int64_t lda, const void* W_ha
     if (M < 0 || N < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: bad shape");
     if (M == 0 || N == 0) return XMH_OK;
     if (!A || !W_half || !C) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: null pointer");
-    if (K % BKH || lda % 4 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(W_half) % 16) ||
+    if (K % 32 || lda % 4 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) % 16) || (reinterpret_cast<uintptr_t>(W_half) % 16) ||
         (reinterpret_cast<uintptr_t>(W_lo_half) % 16))
         return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: needs K %% 32 == 0 and 16-byte aligned rows (K=%lld lda=%lld ldw=%lld)", (long long)K, (long long)lda, (long long)ldw);
-    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: leading dimension too small");
-    if (act < 0 || act > 4) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: unknown activation %d", act);
-    if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_nt_split16: dimension >= 2^31");
-    GemmArgsS g;
-    g.A = A; g.W = static_cast<const _Float16*>(W_half); g.Wl = static_cast<const _Float16*>(W_lo_half);
-    g.bias = bias; g.residual = residual; g.C = C;
-    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.act = act;
+    if (lda < K) return xmh::fail(XMH_EINVAL, "xmh_gemm_nt_split16: leading dimension too small");
     hipStream_t st = xmh::as_stream(stream);
-    int64_t nblk = xmh::ceil_div(M, 128) * xmh::ceil_div(N, BN);
-    const bool small = nblk < 3ll * xmh::device_cu_count();
-    xmh::ProfScope prof("gemm_s16", st);
-    const int64_t nwide = xmh::ceil_div(M, 128) * xmh::ceil_div(N, 256);
-    static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-    // direct-A kernels (k_gemm_nt_s16_da): measured +10-16 % for the three-term product (229 vs 198 TF at 20000x2304x768), within
-    // +-4 % of the LDS-staged kernels for fp16-exact weights -- used for the former; XMH_GEMM_DIRECT_A=all routes every large
-    // enough shape through them (experiments, tests), =off none
-    static const char* da_env = getenv("XMH_GEMM_DIRECT_A");
-    static const int da_mode = !da_env ? 1 : (!strcmp(da_env, "all") ? 2 : (!strcmp(da_env, "off") ? 0 : 1));
-    const int64_t n128 = xmh::ceil_div(M, 128) * xmh::ceil_div(N, 128);
-    if (da_mode == 2 && !W_lo_half && nwide * 2 >= 3ll * xmh::device_cu_count()) {
-        hipLaunchKernelGGL((k_gemm_nt_s16_da<8, false>), dim3((unsigned)nwide), dim3(kThreads), (size_t)2 * 256 * LDH * sizeof(_Float16), st, g);
-    } else if (da_mode == 2 && !W_lo_half && n128 >= xmh::device_cu_count()) {
-        hipLaunchKernelGGL((k_gemm_nt_s16_da<4, false>), dim3((unsigned)n128), dim3(kThreads), (size_t)2 * 128 * LDH * sizeof(_Float16), st, g);
-    } else if (da_mode >= 1 && W_lo_half && n128 >= xmh::device_cu_count()) {
-        hipLaunchKernelGGL((k_gemm_nt_s16_da<4, true>), dim3((unsigned)n128), dim3(kThreads), (size_t)4 * 128 * LDH * sizeof(_Float16), st, g);
-    } else if (!W_lo_half && !no_wide && K >= 768 && nwide * 2 >= 3ll * xmh::device_cu_count()) {     // 128x256 tiles: more flops per L2 byte (short K: the epilogue dominates, measured slower)
-        const size_t lds = (size_t)2 * (128 + 128 + 256) * LDH * sizeof(_Float16);
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_s16_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return xmh::fail(XMH_EHIP, "xmh_gemm_nt_split16: cannot raise dynamic LDS to %zu", lds);
-            raised = true;
-        }
-        hipLaunchKernelGGL(k_gemm_nt_s16_wide, dim3((unsigned)nwide), dim3(kThreads), lds, st, g);
-    } else if (W_lo_half) {                                      // three-term product: 64x128 tiles (60 KB of LDS)
-        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
-        hipLaunchKernelGGL((k_gemm_nt_s16<1, true>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    } else if (small) {
-        nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);
-        hipLaunchKernelGGL((k_gemm_nt_s16<1, false>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    } else {
-        hipLaunchKernelGGL((k_gemm_nt_s16<2, false>), dim3((unsigned)nblk), dim3(kThreads), 0, st, g);
-    }
-    XMH_LAUNCH_CHECK("xmh_gemm_nt_split16");
-    return XMH_OK;
+    AsyncScratch sc(st);
+    const size_t plane = ((size_t)M * K * sizeof(_Float16) + 255) & ~size_t(255);
+    if (int rc = sc.get(2 * plane)) return rc;
+    xmh::Planes ap{static_cast<_Float16*>(sc.p), reinterpret_cast<_Float16*>(static_cast<char*>(sc.p) + plane), K};
+    if (int rc = xmh::split_planes(A, lda, M, K, ap, st)) return rc;
+    xmh::GemmPlanes g{};
+    g.A_hi = ap.hi; g.A_lo = ap.lo; g.lda = K;
+    g.W_hi = static_cast<const _Float16*>(W_half); g.W_lo = static_cast<const _Float16*>(W_lo_half); g.ldw = ldw;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    return xmh::gemm_planes(g, st);
 }
