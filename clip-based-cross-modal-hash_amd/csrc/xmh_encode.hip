@@ -285,7 +285,9 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int t = 0; t < 32; ++t) pa[t] *= inv;
-        // O[i][c] = sum_j P[i][j] V[j][c]
+        // O[i][c] = sum_j P[i][j] V[j][c]; the 32 x 64 result goes through the score tile once more (C layout -> rows) so that
+        // every lane stores 4 consecutive columns: 16 lanes cover 256 bytes of one fp32 row / 128 bytes of each fp16 plane
+        __syncthreads();                                             // all softmax reads of sS are done
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             attn_f32x16 acc;
@@ -294,12 +296,18 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
 #pragma unroll
             for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], vb[cb][t], acc, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = ib * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (row < L) {
-                    if (out) out[((int64_t)b * L + row) * D + h * DH + cb * 32 + r] = acc[e];
-                    if (pl.hi) xmh::store_planes1(pl, (int64_t)b * L + row, h * DH + cb * 32 + r, acc[e]);
-                }
+            for (int e = 0; e < 16; ++e) sS[((e & 3) + 8 * (e >> 2) + 4 * kk) * SP + cb * 32 + r] = acc[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
+            const int row = ib * 32 + rr;
+            const float4 v = *reinterpret_cast<const float4*>(&sS[rr * SP + cc]);
+            if (row < L) {
+                const int64_t orow = (int64_t)b * L + row;
+                if (out) *reinterpret_cast<float4*>(out + orow * D + h * DH + cc) = v;
+                if (pl.hi) xmh::store_planes4(pl, orow, h * DH + cc, v.x, v.y, v.z, v.w);
             }
         }
     }

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
 // TFLOP/s, parity mode 184-270 -> 260-430 useful TFLOP/s; tools/proto_gemm_glds.hip holds the ablations (what the C store,
 // the staging and the MFMAs each cost) that picked these shapes.
 // ---------------------------------------------------------------------------------------------------
+
 struct GArgsP {
     const _Float16 *A0, *A1;      // A0 = lo plane (or the only plane), A1 = hi plane
     const _Float16 *W0, *W1;      // W0 = hi plane, W1 = lo plane or null
@@ -355,6 +356,72 @@ struct GArgsP {
     int64_t lda, ldw, ldr, ldc, ldo;
     int M, N, K, act;
 };
+
+template <int ACT>
+__device__ __forceinline__ float act_ct(float x) {
+    if (ACT == ACT_QUICKGELU) return x * (1.0f / (1.0f + expf(-1.702f * x)));
+    if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (ACT == ACT_TANH) return tanhf(x);
+    if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
+    return x;
+}
+
+// the wave's (32 MI) x (32 NJ) accumulators -> memory, 32 rows at a time through the wave's own [32][32 NJ] fp32 LDS region:
+// written in C layout (lane = column, 16 rows per lane), read back as 16-byte row pieces, so that bias / activation / residual
+// and the stores work on 4 consecutive columns: fp32 C as dwordx4, operand planes as 8 bytes per plane.
+template <int ACT, int MI, int NJ>
+__device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][NJ], char* lds, int wave, int lane, int row0, int col0) {
+    constexpr int TW = 32 * NJ, LPR = TW / 4, RPI = 64 / LPR;      // region width, lanes per row, rows per pass
+    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * TW);
+    const float4* reg4 = reinterpret_cast<const float4*>(lds) + wave * (32 * LPR);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int pr = lane / LPR, pq = lane % LPR;
+    const int col = col0 + pq * 4;
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
+    const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) {
+        if (vec && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
+        else {
+            bv.x = col < g.N ? g.bias[col] : 0.0f; bv.y = col + 1 < g.N ? g.bias[col + 1] : 0.0f;
+            bv.z = col + 2 < g.N ? g.bias[col + 2] : 0.0f; bv.w = col + 3 < g.N ? g.bias[col + 3] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * TW + j * 32 + fr] = acc[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int r = it * RPI + pr;
+            const float4 v4 = reg4[r * LPR + pq];
+            const int64_t row = row0 + i * 32 + r;
+            if (row >= g.M || col >= g.N) continue;
+            float4 v = make_float4(act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w));
+            if (vec) {
+                if (g.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + col);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                if (g.O_hi) xmh::store_planes4(op, row, col, v.x, v.y, v.z, v.w);
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (col + t < g.N) {
+                        float x = vv[t];
+                        if (g.residual) x += g.residual[row * g.ldr + col + t];
+                        if (g.C) g.C[row * g.ldc + col + t] = x;
+                        if (g.O_hi) xmh::store_planes1(op, row, col + t, x);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
@@ -369,6 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
     constexpr int BUFB = NPIECE * 1024;
     constexpr int TW = 32 * NJ;                                     // epilogue: the wave's region is [32][TW] fp32
     static_assert(2 * BUFB >= NWAVE * 32 * TW * 4, "the epilogue regions fit the staging buffers");
+    static_assert(TW % 64 == 0 || TW == 32, "epilogue row pieces");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
     int tm, tn;
@@ -470,48 +538,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
 
     // epilogue, 32 accumulator rows at a time: C layout (lane = column, 16 rows) -> LDS -> row pieces of 4 consecutive columns
     __builtin_amdgcn_s_barrier();                                  // every wave is done with the staging buffers
-    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * TW);
-    constexpr int LPR = TW / 4, RPI = 64 / LPR;                    // lanes per row, rows per pass
-    const int pr = lane / LPR, pc = (lane % LPR) * 4;
-    const int col = n0 + wn + pc;
-    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
-    const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv[t] = col + t < g.N ? g.bias[col + t] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * TW + j * 32 + fr] = acc[i][j][e];
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int r = it * RPI + pr;
-            const float4 v4 = *reinterpret_cast<const float4*>(reg + r * TW + pc);
-            const int64_t row = m0 + wm + i * 32 + r;
-            if (row >= g.M || col >= g.N) continue;
-            float v[4] = {apply_act(v4.x + bv[0], g.act), apply_act(v4.y + bv[1], g.act), apply_act(v4.z + bv[2], g.act), apply_act(v4.w + bv[3], g.act)};
-            if (vec) {
-                if (g.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + col);
-                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                }
-                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                if (g.O_hi) xmh::store_planes4(op, row, col, v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (col + t >= g.N) break;
-                    float x = v[t];
-                    if (g.residual) x += g.residual[row * g.ldr + col + t];
-                    if (g.C) g.C[row * g.ldc + col + t] = x;
-                    if (g.O_hi) xmh::store_planes1(op, row, col + t, x);
-                }
-            }
-        }
+    const int row0 = m0 + wm, col0 = n0 + wn;
+    switch (g.act) {                                               // one straight-line epilogue per activation
+        case ACT_QUICKGELU: g16_epilogue<ACT_QUICKGELU, MI, NJ>(g, acc, lds, wave, lane, row0, col0); break;
+        case ACT_GELU_ERF: g16_epilogue<ACT_GELU_ERF, MI, NJ>(g, acc, lds, wave, lane, row0, col0); break;
+        case ACT_TANH: g16_epilogue<ACT_TANH, MI, NJ>(g, acc, lds, wave, lane, row0, col0); break;
+        case ACT_RELU: g16_epilogue<ACT_RELU, MI, NJ>(g, acc, lds, wave, lane, row0, col0); break;
+        default: g16_epilogue<ACT_NONE, MI, NJ>(g, acc, lds, wave, lane, row0, col0); break;
     }
 }
 
@@ -643,16 +676,18 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     const int64_t cus = device_cu_count();
     const int64_t n128 = ceil_div(g.M, 128) * ceil_div(g.N, 128);
     int rc;
+    const bool tiny = 2 * n128 < cus;                 // 64-row tiles only once half the CUs would stay empty (measured: 240 tiles of 128x128 beat 474 of 64x128)
     if (!g.A_lo) {
         ProfScope prof("gemm_f16", st);
-        if (n128 < cus) rc = g.K % 64 ? launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 64, 4>(a, st);
+        if (tiny) rc = g.K % 64 ? launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 64, 4>(a, st);
         else rc = g.K % 64 ? launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st);
     } else {
         ProfScope prof("gemm_s16", st);
         static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-        if (g.W_lo) rc = n128 < cus ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
+        if (g.W_lo) rc = tiny ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
         else if (!no_wide && ceil_div(g.M, 128) * ceil_div(g.N, 256) * 2 >= 3 * cus) rc = launch_g16<2, 4, 2, 2, 2, 1, 32, 1>(a, st);
-        else if (n128 < cus) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
+        else if (tiny) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
+        else if (n128 <= cus && g.K >= 2048 && g.K % 64 == 0) rc = launch_g16<2, 2, 2, 2, 2, 1, 64, 1>(a, st);   // one block per CU and a long k-loop: deeper steps (377 vs 325 TF at 5000 x 768 x 3072)
         else rc = launch_g16<2, 2, 2, 2, 2, 1, 32, 3>(a, st);
     }
     if (rc) return rc;
