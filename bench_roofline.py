@@ -148,16 +148,31 @@ def scan_roofline(scan, Q, Rn, K, C, steps=20):
                       "frac_of_measured_mix": pairs * ops / t / 1e9 / peak_mix, "mix": mix})
         return e
     ops_eval = 2 * W + Lw + 1
-    key1 = "hist_W%d_L%d_%s" % (W, Lw, "cache" if cached else "plain")
+    # binary codes of 33..64 bits: pass 1 is k_scan_hist_m (pairs evaluated by the i8 MFMA, xmh_scan.hip mfma_shape)
+    mfma_p1 = (not tern) and 32 < K <= 64 and Lw <= 4 and os.environ.get("XMH_SCAN_MFMA", "1") != "0"
+    key1 = ("histm_L%d_%s" % (Lw, "cache" if cached else "plain")) if mfma_p1 else "hist_W%d_L%d_%s" % (W, Lw, "cache" if cached else "plain")
     key2 = "ap_W%d_L%d_%s_%s" % (W, Lw, "cache" if cached else "plain", "p32" if packed else "u64")
     ap_suffix = ", true, false, 1," if packed else ", false, false, 1,"
-    v1 = pass_entry(key1, ops_eval + 2 + (2 if cached else 0), t_hist, ("k_scan_hist_s<", ""))
+    p1_kernel = "k_scan_hist_m<" if mfma_p1 else "k_scan_hist_s<"
+    v1 = pass_entry(key1, (1 + (5 if cached else 0)) if mfma_p1 else ops_eval + 2 + (2 if cached else 0), t_hist, (p1_kernel, ""))
+    if mfma_p1:
+        nm = 1 + (1 if Lw <= 2 else 2)                            # MFMAs per 16 items x 16 queries: one code tile + the label tiles
+        mf = pmc_counter(p1_kernel, "", "SQ_VALU_MFMA_BUSY_CYCLES")
+        v1["mfma"] = {"instruction": "v_mfma_i32_16x16x64_i8", "per_64_pairs": nm / 4.0, "cycles_each": 16,
+                      "matrix_pipe_frac": pairs / 64.0 * (nm / 4.0) * 16 / (t_hist * CLOCK_HZ * SIMDS),
+                      "note": "SQ_INSTS_VALU counts the MFMAs too; the static VALU count does not"}
+        if mf:
+            v1["mfma"]["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = mf[0]
     v2 = pass_entry(key2, (2 if cached else ops_eval) + 1 + (0 if packed else 1) + 5, t_ap, ("k_scan_ap_s<", ap_suffix))
     dom_is_hist = t_hist > t_ap
     t_dom, n_dom, vd = (t_hist, n_hist, v1) if dom_is_hist else (t_ap, n_ap, v2)
-    traffic = pmc_traffic("k_scan_hist_s<", "") if dom_is_hist else pmc_traffic("k_scan_ap_s<", ap_suffix)
-    name = ("k_scan_hist_s (pass 1 of the fused mAP scan: pair evaluation + bucket histogram%s)" % (" + pair cache" if cached else "")) if dom_is_hist \
-        else ("k_scan_ap_s, %s counters (pass 2 of the fused mAP scan)" % ("packed 32-bit" if packed else "64-bit"))
+    traffic = pmc_traffic(p1_kernel, "") if dom_is_hist else pmc_traffic("k_scan_ap_s<", ap_suffix)
+    if dom_is_hist and mfma_p1:
+        name = "k_scan_hist_m (pass 1 of the fused mAP scan: Hamming distance and label overlap on the i8 MFMA, bucket histogram by LDS atomics%s)" % (" + pair cache" if cached else "")
+    elif dom_is_hist:
+        name = "k_scan_hist_s (pass 1 of the fused mAP scan: pair evaluation + bucket histogram%s)" % (" + pair cache" if cached else "")
+    else:
+        name = "k_scan_ap_s, %s counters (pass 2 of the fused mAP scan)" % ("packed 32-bit" if packed else "64-bit")
     return {
         "kernel": "%s, HIP events around the launch, %d launches" % (name, n_dom),
         "bound": "valu", "achieved": vd["achieved"], "peak": VALU_PEAK_GUIDE, "unit": "G lane-ops/s", "frac": vd["frac_of_guide_peak"],

@@ -649,7 +649,8 @@ int split_planes(const float* x, int64_t ldx, int64_t rows, int64_t cols, const 
 }
 
 // Tile shapes (tools/proto_gemm_glds.hip, M = 5000 / 20000 ViT-B/32 shapes, useful TFLOP/s):
-//   fast   128x128, BK 64, 2 blocks per CU: 550-770; 64x128 for grids that leave CUs empty;
+//   fast   128x128, BK 64, 2 blocks per CU: 550-770; 256x256 (8 waves) once there are >= 0.7 such tiles per CU: 660-1000;
+//          64x128 for grids that leave most CUs empty;
 //   parity 128x128, BK 32, 3 blocks per CU: 310-360; 128x256 with 8 waves once there are >= 1.5 such tiles per CU: 370-430;
 //   parity with split weights (three terms): 128x128, BK 32, 2 blocks per CU.
 int gemm_planes(const GemmPlanes& g, hipStream_t st) {
@@ -679,7 +680,10 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     const bool tiny = 2 * n128 < cus;                 // 64-row tiles only once half the CUs would stay empty (measured: 240 tiles of 128x128 beat 474 of 64x128)
     if (!g.A_lo) {
         ProfScope prof("gemm_f16", st);
+        static const bool no_wide16 = getenv("XMH_GEMM_NO_WIDE") != nullptr;
         if (tiny) rc = g.K % 64 ? launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 64, 4>(a, st);
+        else if (!no_wide16 && g.K % 64 == 0 && ceil_div(g.M, 256) * ceil_div(g.N, 256) * 10 >= 7 * cus)
+            rc = launch_g16<2, 4, 4, 2, 1, 1, 64, 1>(a, st);       // 256 x 256, 8 waves of 128 x 64: half the L2 -> LDS bytes per flop (+7-20 % once the grid fills the chip)
         else rc = g.K % 64 ? launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st);
     } else {
         ProfScope prof("gemm_s16", st);

@@ -29,6 +29,8 @@ KERNELS = {
     "ap_W2_L3_cache_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb1EE"),
     "ap_W2_L3_cache_p32": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb1ELb0ELi1ELb1EE"),
     "ap_W2_L3_plain_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb0EE"),
+    "histm_L3_cache": ("k_scan_hist_m", "ILi1ELi2ELi4ELb1EE"),        # k_scan_hist_m<NMC, NML, NW, CACHE>: the MFMA-evaluated pass 1
+    "histm_L3_plain": ("k_scan_hist_m", "ILi1ELi2ELi4ELb0EE"),
     "hist_W4_L3_cache": ("k_scan_hist_s", "ILi4ELi3ELb0ELi8ELi1ELb1EE"),
     "ap_W4_L3_cache_u64": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb0ELb0ELi1ELb1EE"),
     "ap_W4_L3_cache_p32": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb1ELb0ELi1ELb1EE"),
@@ -123,16 +125,18 @@ def main():
         if not body or not natom:
             continue
         ops = count(body)
-        valu = {re.sub(r"_e(32|64)$|_sdwa$|_dpp$", "", k): 0 for k in ops if k.startswith("v_")}
+        is_valu = lambda k: k.startswith("v_") and not k.startswith("v_mfma")      # noqa: E731  (MFMAs issue to the matrix pipe)
+        valu = {re.sub(r"_e(32|64)$|_sdwa$|_dpp$", "", k): 0 for k in ops if is_valu(k)}
         for k, v in ops.items():
-            if k.startswith("v_"):
+            if is_valu(k):
                 valu[re.sub(r"_e(32|64)$|_sdwa$|_dpp$", "", k)] += v
+        mfma = sum(v for k, v in ops.items() if k.startswith("v_mfma"))
         per_step = {k: v / natom for k, v in sorted(valu.items())}
         result[key] = per_step
         text.append("=== %s  %s\n    loop: %d instructions, %d LDS atomics (= steps of 64 pairs); VALU per step %.2f, DS per step %.2f, SALU per step %.2f\n"
                     % (key, names[0], sum(ops.values()), natom, sum(valu.values()) / natom,
                        sum(v for k, v in ops.items() if k.startswith("ds_")) / natom, sum(v for k, v in ops.items() if k.startswith("s_")) / natom))
-        text.append("    per step: " + ", ".join("%s %.2f" % kv for kv in per_step.items()) + "\n")
+        text.append("    per step: " + ", ".join("%s %.2f" % kv for kv in per_step.items()) + (", MFMA %.3f" % (mfma / natom) if mfma else "") + "\n")
         text.extend(l + "\n" for l in body if l.strip() and not l.strip().startswith(";"))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(result, open(os.path.join(ROOT, "profiles", "%s_scan_isa.json" % tag), "w"), indent=1, sort_keys=True)

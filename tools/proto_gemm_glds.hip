@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
 #pragma unroll
         for (int d = 0; d < ABL - 10; ++d) __builtin_amdgcn_s_sleep(127);
     }
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    if (ABL == 20) t0 = __builtin_readcyclecounter();
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, acc_wait = 0, acc_bar = 0, acc_stage = 0;
+    if (ABL == 20 || ABL == 21) t0 = __builtin_readcyclecounter();
     const int swz = (fr / RPB) & (CH - 1);      // wm, wn, i*32 are multiples of 32: the swizzle depends on fr only
     const int nk = g.K / BK;
     // DEPTH = tiles in flight beyond the one being computed (1: wait for everything each step; 2 needs NBUF >= 3)
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
         if (d < nk) stage(d % NBUF, d * BK);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % NBUF;
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (ABL == 21) ta = __builtin_readcyclecounter();
         if (DEPTH == 1 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (PPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -128,10 +130,45 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
         else if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (PPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ABL == 21) tb = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
+        if (ABL == 21) tc = __builtin_readcyclecounter();
         if (kt + DEPTH < nk && ABL != 2) stage((kt + DEPTH) % NBUF, (kt + DEPTH) * BK);
+        if (ABL == 21) { td = __builtin_readcyclecounter(); acc_wait += tb - ta; acc_bar += tc - tb; acc_stage += td - tc; }
         const char* bA = lds + buf * BUFB;
         const char* bW = bA + NA * PA * 1024;
+        if (ABL == 30) {      // explicit fragment double-buffering: slab s+1 is read while the MFMAs of slab s run
+            constexpr int NS = BK / 16;
+            f16x8 fa[2][NA][MI], fb[2][NJ];
+            auto rd = [&](int s, int w) {
+                const int coff = ((2 * s + fh) ^ swz) * 16;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[w][j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+#pragma unroll
+                for (int pl = 0; pl < NA; ++pl)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[w][pl][i] = *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) rd(s + 1, (s + 1) & 1);
+#pragma unroll
+                for (int pl = 0; pl < NA; ++pl)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][pl][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+            }
+            // pin the order: reads of slab s+1 are issued before the MFMAs of slab s
+            constexpr int NR = NA * MI + NJ, NM = NA * MI * NJ;
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {                        // k slabs of 16: lane half fh takes chunk 2s + fh
             const int coff = ((2 * s + fh) ^ swz) * 16;
@@ -153,7 +190,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
             }
         }
     }
-    if (ABL == 20) t1 = __builtin_readcyclecounter();
+    if (ABL == 20 || ABL == 21) t1 = __builtin_readcyclecounter();
+    if (ABL == 21 && (tid & 63) == 0) {
+        unsigned long long* o = g.tim + (blockIdx.x * 4 + wave) * 4;
+        o[0] = t1 - t0; o[1] = acc_wait; o[2] = acc_bar; o[3] = acc_stage;
+    }
     if (ABL == 7 || ABL == 8) {
         // transposed epilogue: the wave's (32 MI) x (32 NJ) fp32 tile goes through its own LDS region, rows come back as 16-byte
         // pieces: 16 lanes cover 256 bytes of one row (fp32) / 8 lanes cover 128 bytes (fp16)
@@ -294,23 +335,18 @@ int main() {
         hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, A2, (int64_t)M * K, 2u, 0.001f);
         hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, W, (int64_t)N * K, 3u, 1.0f);
         unsigned long long* tim;
-        CK(hipMalloc(&tim, 8192 * 4 * 8));
+        CK(hipMalloc(&tim, 8192 * 16 * 8));
         GArgs g{A, A2, W, C, K, K, N, M, N, K, tim};
         printf("M=%d N=%d K=%d\n", M, N, K);
         const int iters = 20;
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, ref, refrows);
-        run<2, 2, 2, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 2, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 2, 2, 32, 3, 2, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 2, 2, 32, 4, 2, 1, 0, 8>(g, iters, ref, refrows);
-        run<1, 2, 2, 2, 2, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<1, 4, 4, 1, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 2, 2, 2, 32, 3, 2, 1, 0, 8>(g, iters, ref, refrows);
         run<2, 4, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 4, 2, 2, 2, 32, 3, 2, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 4, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run<2, 4, 4, 2, 2, 32, 2, 1, 1, 0, 4>(g, iters, ref, refrows);
+        run<4, 2, 2, 4, 2, 32, 2, 1, 1, 0, 4>(g, iters, ref, refrows);
+        run<4, 2, 2, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run<4, 2, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run<2, 4, 2, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(ref));
     }
     return 0;
