@@ -111,6 +111,28 @@ def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), e
             ops.set_precision("f32")
     fused["workload"] = "the same towers at batch %d (4 fused loader batches, what valid() runs)" % (4 * batch)
     out["fused_batches"] = fused
+    # image + caption pairs with the text tower on a second HIP stream under the image tower (xmh/towers.py: what the runners'
+    # generate_hash does) against the two towers back to back
+    from xmh import towers
+    pairs = {}
+    for tag, im, tx, n in (("b%d" % batch, image, ids, batch), ("b%d" % (4 * batch), big_img, big_ids, 4 * batch)):
+        def both():
+            a, b = towers.run_both(lambda: model.encode_image(im), lambda: model.encode_text(tx))
+            R.pack_pair_argmax(a)
+            R.pack_pair_argmax(b)
+        for env in ("1", "0"):
+            os.environ["XMH_TOWER_STREAMS"] = env
+            for _ in range(3):
+                both()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                both()
+            torch.cuda.synchronize()
+            pairs["pairs_per_s_%s_%s" % (tag, "two_streams" if env == "1" else "one_stream")] = n * steps / (time.perf_counter() - t0)
+    os.environ.pop("XMH_TOWER_STREAMS", None)
+    pairs["workload"] = "image + caption pairs through both towers and the DCMHT head, parity mode"
+    out["both_towers"] = pairs
     out["roofline"] = {"kernel": "k_gemm_g16 with two activation planes (parity mode: all GEMM launches of one image forward, HIP events per launch)", "bound": "mfma",
                        "achieved": ach, "peak": PEAK["f32"], "unit": "TFLOP/s", "frac": ach / PEAK["f32"], "traffic": None,
                        "note": "useful flops; parity mode issues two fp16 MFMAs per product (hi and lo activation planes), so its ceiling is half the 2.5 PFLOP/s fp16 peak",

@@ -11,7 +11,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, towers
 from .._lib import check, current_stream, lib, ptr
 from ..common.register import registry
 from . import clip as _clip
@@ -177,7 +177,8 @@ class MITH(BaseModel):
     def forward(self, image, text, key_padding_mask=None, labels=None, indexs=None, return_loss=False):
         if return_loss:
             return self.object_function()
-        return (*self.encode_image(image), *self.encode_text(text, key_padding_mask=key_padding_mask))
+        img, txt = towers.run_both(lambda: self.encode_image(image), lambda: self.encode_text(text, key_padding_mask=key_padding_mask))
+        return (*img, *txt)
 
     def object_function(self, *a, **k):
         raise NotImplementedError("training losses are outside the encode-and-retrieve path (SURVEY 2.1 #8)")

@@ -24,6 +24,7 @@ from torch.utils.data import DataLoader, Sampler
 
 from .. import retrieval as R
 from .. import sharded
+from .. import towers
 from ..common.calc_utils import calc_map_k
 from ..common.register import registry
 from ..utils.logger import get_color_logger
@@ -190,7 +191,7 @@ class BaseTrainer:
 
     # ---- encode ------------------------------------------------------------------------------------------
     def generate_hash(self, image, text, key_padding_mask=None):
-        return self.model.encode_image(image), self.model.encode_text(text)
+        return towers.run_both(lambda: self.model.encode_image(image), lambda: self.model.encode_text(text))
 
     @classmethod
     def make_hash_code(cls, code):

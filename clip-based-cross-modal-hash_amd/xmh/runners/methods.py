@@ -10,6 +10,7 @@ import os
 import torch
 
 from .. import retrieval as R
+from .. import towers
 from ..common.register import registry
 from .base import BaseTrainer
 
@@ -94,8 +95,8 @@ class TwDHTrainer(DCMHTTrainer):
             self.best_epoch_short[str(item)] = {"i2t": 0, "t2i": 0}
 
     def generate_hash(self, image, text, key_padding_mask=None):
-        long_image_hash, short_image_hash = self.model.encode_image(image)
-        long_text_hash, short_text_hash = self.model.encode_text(text)
+        (long_image_hash, short_image_hash), (long_text_hash, short_text_hash) = towers.run_both(
+            lambda: self.model.encode_image(image), lambda: self.model.encode_text(text))
         return long_image_hash, short_image_hash, long_text_hash, short_text_hash
 
     def generate_hashes(self, image, text, key_padding_mask=None):
