@@ -371,22 +371,27 @@ __device__ __forceinline__ float act_ct(float x) {
 // and the stores work on 4 consecutive columns: fp32 C as dwordx4, operand planes as 8 bytes per plane.
 template <int ACT, int MI, int NJ>
 __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][NJ], char* lds, int wave, int lane, int row0, int col0) {
-    constexpr int TW = 32 * NJ, LPR = TW / 4, RPI = 64 / LPR;      // region width, lanes per row, rows per pass
+    constexpr int TW = 32 * NJ, LPR = TW / 4;                      // region width in floats, 16-byte pieces per row
+    constexpr bool kFixedCol = 64 % LPR == 0;                      // every pass of the 64 lanes covers whole rows: a lane keeps its columns
     float* reg = reinterpret_cast<float*>(lds) + wave * (32 * TW);
     const float4* reg4 = reinterpret_cast<const float4*>(lds) + wave * (32 * LPR);
     const int fr = lane & 31, fh = lane >> 5;
-    const int pr = lane / LPR, pq = lane % LPR;
-    const int col = col0 + pq * 4;
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
     const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) {
-        if (vec && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
-        else {
-            bv.x = col < g.N ? g.bias[col] : 0.0f; bv.y = col + 1 < g.N ? g.bias[col + 1] : 0.0f;
-            bv.z = col + 2 < g.N ? g.bias[col + 2] : 0.0f; bv.w = col + 3 < g.N ? g.bias[col + 3] : 0.0f;
+    auto bias_at = [&](int col) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) {
+            if (vec && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
+            else {
+                bv.x = col < g.N ? g.bias[col] : 0.0f; bv.y = col + 1 < g.N ? g.bias[col + 1] : 0.0f;
+                bv.z = col + 2 < g.N ? g.bias[col + 2] : 0.0f; bv.w = col + 3 < g.N ? g.bias[col + 3] : 0.0f;
+            }
         }
-    }
+        return bv;
+    };
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kFixedCol) bv = bias_at(col0 + (lane % LPR) * 4);
+    constexpr int NIT = 32 * LPR / 64;                             // passes of the 64 lanes over one 32-row slab
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -394,11 +399,13 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][
 #pragma unroll
             for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * TW + j * 32 + fr] = acc[i][j][e];
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int r = it * RPI + pr;
-            const float4 v4 = reg4[r * LPR + pq];
+        for (int it = 0; it < NIT; ++it) {                         // the region is contiguous: piece f of the slab = float4 f
+            const int f = it * 64 + lane;
+            const int r = f / LPR, col = col0 + (f % LPR) * 4;
+            const float4 v4 = reg4[f];
             const int64_t row = row0 + i * 32 + r;
             if (row >= g.M || col >= g.N) continue;
+            if (!kFixedCol) bv = bias_at(col);
             float4 v = make_float4(act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w));
             if (vec) {
                 if (g.residual) {
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
     constexpr int BUFB = NPIECE * 1024;
     constexpr int TW = 32 * NJ;                                     // epilogue: the wave's region is [32][TW] fp32
     static_assert(2 * BUFB >= NWAVE * 32 * TW * 4, "the epilogue regions fit the staging buffers");
-    static_assert(TW % 64 == 0 || TW == 32, "epilogue row pieces");
+    static_assert((32 * TW / 4) % 64 == 0, "epilogue: whole passes of 64 lanes");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
     int tm, tn;
@@ -677,21 +684,32 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     const int64_t cus = device_cu_count();
     const int64_t n128 = ceil_div(g.M, 128) * ceil_div(g.N, 128);
     int rc;
-    const bool tiny = 2 * n128 < cus;                 // 64-row tiles only once half the CUs would stay empty (measured: 240 tiles of 128x128 beat 474 of 64x128)
+    // Tile shape by how the grid fills the chip (every shape walks k in the same order, so this never changes a result):
+    //   grids that leave more than half the CUs without a 128x128 tile: 64-row tiles (with the prototype's bare epilogue they also won
+    //   at one tile per CU, with bias / residual / planes they lose there: 63.6 vs 80.7 us at 5000 x 768 x 3072 parity);
+    //   a grid that needs a second, mostly empty round of 128x128 tiles: 192x128 (fast) / 128x192 (parity) when those fit one round
+    //   (5000 x 2304 x 768 parity 53.4 -> 51.5 us);
+    //   large grids: 256x256 (fast), 128x256 with 8 waves (parity).
+    static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
+    static const int tile_rules = getenv("XMH_GEMM_TILE_RULES") ? atoi(getenv("XMH_GEMM_TILE_RULES")) : 2;     // bit 0: 64-row tiles already for grids of <= one 128x128 tile per CU (measured slower with the real epilogues: off), bit 1: 192-wide tiles
+    const bool under = (tile_rules & 1) ? n128 <= cus : 2 * n128 < cus;
+    const bool k64 = g.K % 64 == 0;
     if (!g.A_lo) {
         ProfScope prof("gemm_f16", st);
-        static const bool no_wide16 = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-        if (tiny) rc = g.K % 64 ? launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 64, 4>(a, st);
-        else if (!no_wide16 && g.K % 64 == 0 && ceil_div(g.M, 256) * ceil_div(g.N, 256) * 10 >= 7 * cus)
+        const int64_t n192 = ceil_div(g.M, 192) * ceil_div(g.N, 128);
+        if (under) rc = k64 ? launch_g16<1, 2, 2, 2, 1, 1, 64, 3>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st);
+        else if (!no_wide && k64 && ceil_div(g.M, 256) * ceil_div(g.N, 256) * 10 >= 7 * cus)
             rc = launch_g16<2, 4, 4, 2, 1, 1, 64, 1>(a, st);       // 256 x 256, 8 waves of 128 x 64: half the L2 -> LDS bytes per flop (+7-20 % once the grid fills the chip)
-        else rc = g.K % 64 ? launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st);
+        else if ((tile_rules & 2) && !no_wide && k64 && n128 > 2 * cus && n128 < 3 * cus && n192 <= 2 * cus) rc = launch_g16<2, 2, 3, 2, 1, 1, 64, 2>(a, st);
+        else rc = k64 ? launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st);
     } else {
         ProfScope prof("gemm_s16", st);
-        static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-        if (g.W_lo) rc = tiny ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
+        const int64_t n192 = ceil_div(g.M, 128) * ceil_div(g.N, 192);
+        if (g.W_lo) rc = 2 * n128 < cus ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
         else if (!no_wide && ceil_div(g.M, 128) * ceil_div(g.N, 256) * 2 >= 3 * cus) rc = launch_g16<2, 4, 2, 2, 2, 1, 32, 1>(a, st);
-        else if (tiny) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
-        else if (n128 <= cus && g.K >= 2048 && g.K % 64 == 0) rc = launch_g16<2, 2, 2, 2, 2, 1, 64, 1>(a, st);   // one block per CU and a long k-loop: deeper steps (377 vs 325 TF at 5000 x 768 x 3072)
+        else if (under) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
+        else if ((tile_rules & 2) && !no_wide && n128 > 2 * cus && n192 <= 2 * cus) rc = launch_g16<2, 2, 2, 3, 2, 1, 32, 2>(a, st);
+        else if (!(tile_rules & 1) && n128 <= cus && g.K >= 2048 && k64) rc = launch_g16<2, 2, 2, 2, 2, 1, 64, 1>(a, st);
         else rc = launch_g16<2, 2, 2, 2, 2, 1, 32, 3>(a, st);
     }
     if (rc) return rc;

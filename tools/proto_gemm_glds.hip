@@ -128,6 +128,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
         else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (PPW == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else if (PPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ABL == 21) tb = __builtin_readcyclecounter();
@@ -340,13 +342,18 @@ int main() {
         printf("M=%d N=%d K=%d\n", M, N, K);
         const int iters = 20;
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
+        run<2, 2, 2, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 3, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 3, 1, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 3, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 1, 1, 64, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 1, 2, 1, 64, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, ref, refrows);
-        run<2, 4, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 4, 4, 2, 2, 32, 2, 1, 1, 0, 4>(g, iters, ref, refrows);
-        run<4, 2, 2, 4, 2, 32, 2, 1, 1, 0, 4>(g, iters, ref, refrows);
-        run<4, 2, 2, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 4, 2, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 2, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 3, 2, 32, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 3, 2, 2, 32, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 1, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 1, 2, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(ref));
     }
     return 0;
