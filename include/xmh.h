@@ -352,6 +352,18 @@ int xmh_affine_inplace(float* x, int64_t n, float alpha, float beta, xmh_stream_
 int xmh_float_rank_ap(const float* dist, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C,
                       int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Loss forward of the DCMHT objective (forward only, the backward pass is out of scope).
+ * ------------------------------------------------------------------------------------------- */
+/* similarity_loss (models/DCMHT/DCMHT.py:72-98) of one pair of code matrices a, b [B, D] with packed multi-hot labels lab
+ * [B][ceil(C/32)] (label_sim = calc_label_sim(labels, labels), common/calc_utils.py:8-10).  cosine == 0: euclidean branch with
+ * max_value = sqrt(2 K vartheta) (:81-88); cosine != 0: the cosine branch with `threshold` (:92-95).
+ * out2 (device, 2 doubles) = (positive_loss, negative_loss). */
+int xmh_pair_similarity_loss(const float* a, const float* b, int64_t B, int D, const uint32_t* lab, int C, int cosine,
+                             float max_value, float threshold, double* out2, xmh_stream_t stream);
+/* soft_argmax_hash_loss (models/DCMHT/DCMHT.py:100-105): out (device, 1 double) = 1 - mean((2 code - 1)^2) over n elements */
+int xmh_quant_loss(const float* code, int64_t n, double* out, xmh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
