@@ -263,6 +263,119 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
     }
 }
 
+// producer / consumer specialisation: WM*WN compute waves (ds_read + MFMA only) and LW loader waves (LDS-DMA only), one barrier
+// per k-step for everyone.  The DMA issue (~90 cycles per instruction under load) no longer blocks the waves that feed the MFMA pipe.
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int LW, int MINB, int GM>
+__global__ __launch_bounds__(64 * (WM * WN + LW), MINB) void k_gemm_spec(GArgs g) {
+    constexpr int NCW = WM * WN;
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr int CH = BK / 8, RPB = 16 / CH, RPP = 64 / CH;
+    constexpr int ROWB = BK * 2;
+    constexpr int PA = TBM / RPP, PW = TBN / RPP;
+    constexpr int NPIECE = NA * PA + PW;
+    static_assert(NPIECE % LW == 0, "pieces per loader wave");
+    constexpr int PPL = NPIECE / LW;
+    constexpr int BUFB = NPIECE * 1024;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, tm, tn);
+    if (GM > 0) {
+        const int id = tn * nbm + tm;
+        const int per = GM * nbn;
+        const int grp = id / per, rem = id % per;
+        const int gm0 = grp * GM;
+        const int gsz = nbm - gm0 < GM ? nbm - gm0 : GM;
+        tm = gm0 + rem % gsz;
+        tn = rem / gsz;
+    }
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = g.K / BK;
+    if (wave >= NCW) {                                                  // ---- loader waves
+        const int lw = wave - NCW;
+        const _Float16* src[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int p = j * LW + lw;
+            const int prow = lane / CH;
+            int r;
+            const _Float16* base;
+            if (p < NA * PA) {
+                const int pl = p / PA;
+                r = (p % PA) * RPP + prow;
+                const int rg = m0 + r < g.M ? m0 + r : g.M - 1;
+                base = (pl == 0 ? g.A : g.A2) + (int64_t)rg * g.lda;
+            } else {
+                r = (p - NA * PA) * RPP + prow;
+                const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
+                base = g.W + (int64_t)rg * g.ldw;
+            }
+            src[j] = base + ((lane % CH) ^ ((r / RPB) & (CH - 1))) * 8;
+        }
+        auto stage = [&](int buf, int k0) {
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int p = j * LW + lw;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * BUFB + p * 1024), 16, 0, 0);
+            }
+        };
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        }
+        return;
+    }
+    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int swz = (fr / RPB) & (CH - 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const char* bA = lds + (kt & 1) * BUFB;
+        const char* bW = bA + NA * PA * 1024;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int coff = ((2 * s + fh) ^ swz) * 16;
+            f16x8 b[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+#pragma unroll
+            for (int pl = 0; pl < NA; ++pl) {
+                f16x8 a[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) g.C[(int64_t)row * g.ldc + col] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 __global__ void k_ref(GArgs g, int na, float* out, int rows) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)rows * g.N) return;
@@ -322,6 +435,44 @@ float run(const GArgs& g, int iters, float* ref, int refrows) {
     return ms;
 }
 
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int LW, int MINB, int GM>
+float run_spec(const GArgs& g, int iters, float* ref, int refrows) {
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr size_t ldsb = (size_t)2 * (NA * TBM + TBN) * BK * 2;
+    auto kern = k_gemm_spec<WM, WN, MI, NJ, NA, BK, LW, MINB, GM>;
+    char name[128];
+    snprintf(name, sizeof name, "SPEC %dx%d w%dx%d(%dx%d) NA%d BK%d lw%d mb%d gm%d", TBM, TBN, WM, WN, MI, NJ, NA, BK, LW, MINB, GM);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int nblk = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    const int nthr = 64 * (WM * WN + LW);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(g.C, 0, (size_t)g.M * g.ldc * 4));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), ldsb, 0, g);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), ldsb, 0, g);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    std::vector<float> hc((size_t)g.M * g.N), hr((size_t)refrows * g.N);
+    CK(hipMemcpy(hc.data(), g.C, hc.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0;
+    for (int r = 0; r < refrows; ++r) {
+        const int m = r * (g.M / refrows);
+        for (int n = 0; n < g.N; ++n) {
+            maxerr = std::max(maxerr, (double)fabsf(hc[(size_t)m * g.N + n] - hr[(size_t)r * g.N + n]));
+            maxref = std::max(maxref, (double)fabsf(hr[(size_t)r * g.N + n]));
+        }
+    }
+    const double tf = 2.0 * g.M * g.N * g.K * NA / ms / 1e9;
+    printf("  %-40s %4d blocks  %8.4f ms  %8.1f TF (MFMA work; useful %.1f)  rel err %.2e\n", name, nblk, ms, tf, tf / NA, maxerr / maxref);
+    return ms;
+}
+
 int main() {
     const int shapes[][3] = {{5000, 2304, 768}, {5000, 768, 768}, {5000, 3072, 768}, {5000, 768, 3072}, {20000, 2304, 768}, {20000, 768, 768},
                              {20000, 3072, 768}, {20000, 768, 3072}, {3200, 1536, 512}, {3200, 512, 2048}, {4096, 4096, 4096}, {8192, 8192, 8192}};
@@ -343,17 +494,20 @@ int main() {
         const int iters = 20;
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
         run<2, 2, 2, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 3, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 3, 1, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 3, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 1, 1, 64, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 1, 2, 1, 64, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 1, 64, 4, 2, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 1, 64, 2, 2, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 1, 64, 1, 2, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 1, 32, 4, 3, 8>(g, iters, ref, refrows);
+        run<2, 4, 4, 2, 1, 64, 2, 1, 1, 0, 4>(g, iters, ref, refrows);
+        run_spec<2, 4, 4, 2, 1, 64, 4, 1, 4>(g, iters, ref, refrows);
+        run_spec<2, 4, 4, 2, 1, 64, 8, 1, 4>(g, iters, ref, refrows);
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, ref, refrows);
         run<2, 2, 2, 2, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 3, 2, 32, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 3, 2, 2, 32, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 1, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 1, 2, 2, 32, 2, 1, 3, 0, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 2, 32, 4, 2, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 2, 32, 2, 3, 8>(g, iters, ref, refrows);
+        run_spec<2, 2, 2, 2, 2, 64, 4, 1, 8>(g, iters, ref, refrows);
+        run<2, 4, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run_spec<2, 4, 2, 2, 2, 32, 4, 1, 8>(g, iters, ref, refrows);
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(ref));
     }
     return 0;
