@@ -1152,9 +1152,13 @@ inline int scan_grid(const xmh_scan_plan& p) { return (int)(8 * p.nqtile * xmh::
 
 template <typename KernT>
 int raise_lds(KernT kern, size_t lds, const char* who) {
-    if (lds > 64 * 1024) {
+    static const void* raised_for = nullptr;                     // (kernel, size) of the last raise: the attribute call is kept off
+    static size_t raised = 0;                                    // the launch path of repeated calls
+    if (lds > 64 * 1024 && !(raised_for == reinterpret_cast<const void*>(kern) && lds <= raised)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return xmh::fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, lds, hipGetErrorString(e));
+        raised_for = reinterpret_cast<const void*>(kern);
+        raised = lds;
     }
     return XMH_OK;
 }
