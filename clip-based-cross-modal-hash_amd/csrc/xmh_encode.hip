@@ -193,6 +193,53 @@ __global__ __launch_bounds__(128) void k_attention(const float* __restrict__ qkv
 // columns [32*part, 32*part+32) with one cross-half exchange -- and the probabilities it then holds are exactly the A
 // operand of the PV product (row r, k-half part), so they never go back to memory.
 typedef float attn_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
+
+// S16: the same dataflow on the fp16 MFMA with split operands (the GEMMs' parity scheme, xmh_planes.h): every operand register
+// set is converted once to packed (hi, lo) halves -- x = hi + lo to 22 mantissa bits -- and every product becomes
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate, each fp16 x fp16 product exact; the dropped lo*lo term is
+// 2^-22 relative).  12 MFMAs of 32 cycles per 32x32 block instead of 32 of 64: the matrix time of a head drops 5.3x, which is
+// what bounds this kernel (one wave per head, two waves per SIMD).  The slab structure is the same trick as above: lane (r, kk)
+// owns k in [32 kk, 32 kk + 32) of its row, slab s takes its elements [8 s, 8 s + 8).
+struct AttnSplit {
+    uint32_t hi[16], lo[16];
+    __device__ __forceinline__ void set(const float (&f)[32]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xmh::split2(f[2 * t], f[2 * t + 1], hi[t], lo[t]);
+    }
+    __device__ __forceinline__ void set4(int c, float x, float y, float z, float w) {      // elements 4c .. 4c+3
+        xmh::split2(x, y, hi[2 * c], lo[2 * c]);
+        xmh::split2(z, w, hi[2 * c + 1], lo[2 * c + 1]);
+    }
+    __device__ __forceinline__ void set2(int t, float x, float y) { xmh::split2(x, y, hi[t], lo[t]); }                // elements 2t, 2t+1
+    __device__ __forceinline__ attn_f16x8 h(int s) const { return __builtin_bit_cast(attn_f16x8, make_uint4(hi[4 * s], hi[4 * s + 1], hi[4 * s + 2], hi[4 * s + 3])); }
+    __device__ __forceinline__ attn_f16x8 l(int s) const { return __builtin_bit_cast(attn_f16x8, make_uint4(lo[4 * s], lo[4 * s + 1], lo[4 * s + 2], lo[4 * s + 3])); }
+};
+__device__ __forceinline__ attn_f32x16 attn_mm_split(const AttnSplit& a, const AttnSplit& b) {
+    attn_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                                    // low parts first: the small terms meet the accumulator first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l(s), b.h(s), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h(s), b.l(s), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h(s), b.h(s), acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ attn_f32x16 attn_mm_f32(const float (&a)[32], const float (&b)[32]) {
+    attn_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    return acc;
+}
+
+// Both variants keep the head's K and V blocks resident in registers (S16: as packed hi / lo halves, converted as they arrive) and
+// run two waves per SIMD.  Reloading the K / V block per product to fit three or four waves was measured: 54.8 us against 20.1 us
+// per ViT layer (the V operand is 32 strided loads per block and lane).
+template <bool S16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
                                                          const uint8_t* __restrict__ kpm, float* __restrict__ out, xmh::Planes pl) {
@@ -205,53 +252,70 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
     const float* base = qkv + (int64_t)b * L * 3 * D + h * DH;
     const float scale = rsqrtf((float)DH);
 
-    // B operands that every query block shares: K rows (columns of S) and V columns.  All loads are unconditional on a
-    // clamped row and zeroed by a select afterwards: a branch per load costs more than the load.
-    float kb[2][32], vb[2][32];
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    // K rows (columns of S) and V columns.  All loads are unconditional on a clamped row and zeroed by a select afterwards: a
+    // branch per load costs more than the load.
+    auto load_k = [&](int jb, float (&kf)[S16 ? 1 : 32], AttnSplit& ksp) {
         const int j = jb * 32 + r;
         const bool ok = j < L;
         const float4* p = reinterpret_cast<const float4*>(base + (int64_t)(ok ? j : L - 1) * 3 * D + D + 32 * kk);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float4 v = p[c];
-            kb[jb][4 * c] = ok ? v.x : 0.0f; kb[jb][4 * c + 1] = ok ? v.y : 0.0f;
-            kb[jb][4 * c + 2] = ok ? v.z : 0.0f; kb[jb][4 * c + 3] = ok ? v.w : 0.0f;
+            const float x = ok ? v.x : 0.0f, y = ok ? v.y : 0.0f, z = ok ? v.z : 0.0f, w = ok ? v.w : 0.0f;
+            if constexpr (S16) ksp.set4(c, x, y, z, w);              // converted as it arrives: no fp32 copy of the operand is kept
+            else { kf[4 * c] = x; kf[4 * c + 1] = y; kf[4 * c + 2] = z; kf[4 * c + 3] = w; }
         }
-    }
+    };
+    auto load_v = [&](int cb, float (&vf)[S16 ? 1 : 32], AttnSplit& vsp) {
+#pragma unroll
+        for (int t = 0; t < 32; t += 2) {
+            float pair[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 32 * kk + t + u;
+                const int jc = j < L ? j : L - 1;
+                const float v0 = base[(int64_t)jc * 3 * D + 2 * D + cb * 32 + r];
+                pair[u] = j < L ? v0 : 0.0f;                         // key index = k of the PV product
+            }
+            if constexpr (S16) vsp.set2(t / 2, pair[0], pair[1]);
+            else { vf[t] = pair[0]; vf[t + 1] = pair[1]; }
+        }
+    };
     uint32_t dead_keys = 0;                                          // bit t: key 32*kk + t is padding or masked for this batch row
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const int j = 32 * kk + t;
-        const int jc = j < L ? j : L - 1;
-        const float v0 = base[(int64_t)jc * 3 * D + 2 * D + r], v1 = base[(int64_t)jc * 3 * D + 2 * D + 32 + r];
-        vb[0][t] = j < L ? v0 : 0.0f;                                // key index = k of the PV product
-        vb[1][t] = j < L ? v1 : 0.0f;
-        const uint32_t m = kpm ? (uint32_t)kpm[(int64_t)b * L + jc] : 0u;
+        const uint32_t m = (kpm && j < L) ? (uint32_t)kpm[(int64_t)b * L + j] : 0u;
         dead_keys |= ((j >= L || m != 0u) ? 1u : 0u) << t;
+    }
+    float kb[2][S16 ? 1 : 32], vb[2][S16 ? 1 : 32];
+    AttnSplit ks[S16 ? 2 : 1], vs[S16 ? 2 : 1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        load_k(t, kb[t], ks[S16 ? t : 0]);
+        load_v(t, vb[t], vs[S16 ? t : 0]);
     }
 
     for (int ib = 0; ib < nblk; ++ib) {
         const int i = ib * 32 + r;                                   // this lane's query row (A operand / softmax row)
-        float qa[32];
+        float qa[S16 ? 1 : 32];
+        AttnSplit qs;
         {
             const float4* p = reinterpret_cast<const float4*>(base + (int64_t)(i < L ? i : L - 1) * 3 * D + 32 * kk);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {                            // PyTorch scales q before QK^T; rows >= L are never stored
                 const float4 v = p[c];
-                qa[4 * c] = v.x * scale; qa[4 * c + 1] = v.y * scale; qa[4 * c + 2] = v.z * scale; qa[4 * c + 3] = v.w * scale;
+                if constexpr (S16) qs.set4(c, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+                else { qa[4 * c] = v.x * scale; qa[4 * c + 1] = v.y * scale; qa[4 * c + 2] = v.z * scale; qa[4 * c + 3] = v.w * scale; }
             }
         }
-        __syncthreads();                                             // previous block's softmax reads are done
+        __syncthreads();                                             // previous block's reads of the score tile are done
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             if (jb >= nblk) break;
             attn_f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[jb][t], acc, 0, 0, 0);
+            if constexpr (S16) acc = attn_mm_split(qs, ks[jb]);
+            else acc = attn_mm_f32(qa, kb[jb]);
 #pragma unroll
             for (int e = 0; e < 16; ++e) sS[((e & 3) + 8 * (e >> 2) + 4 * kk) * SP + jb * 32 + r] = acc[e];
         }
@@ -283,18 +347,22 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
         }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        AttnSplit ps;
+        if constexpr (S16) {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) pa[t] *= inv;
+            for (int t = 0; t < 16; ++t) ps.set2(t, pa[2 * t] * inv, pa[2 * t + 1] * inv);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 32; ++t) pa[t] *= inv;
+        }
         // O[i][c] = sum_j P[i][j] V[j][c]; the 32 x 64 result goes through the score tile once more (C layout -> rows) so that
         // every lane stores 4 consecutive columns: 16 lanes cover 256 bytes of one fp32 row / 128 bytes of each fp16 plane
         __syncthreads();                                             // all softmax reads of sS are done
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             attn_f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], vb[cb][t], acc, 0, 0, 0);
+            if constexpr (S16) acc = attn_mm_split(ps, vs[cb]);
+            else acc = attn_mm_f32(pa, vb[cb]);
 #pragma unroll
             for (int e = 0; e < 16; ++e) sS[((e & 3) + 8 * (e >> 2) + 4 * kk) * SP + cb * 32 + r] = acc[e];
         }
@@ -553,7 +621,7 @@ int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const floa
 }
 
 int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
-                     hipStream_t st) {
+                     bool split16, hipStream_t st) {
     if (B < 0 || L <= 0 || H <= 0) return fail(XMH_EINVAL, "xmh_attention_f32: bad shape");
     if (B == 0) return XMH_OK;
     if (dh != 64) return fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
@@ -561,7 +629,8 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
     if (!qkv || (!out && !p.hi)) return fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
     static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
     if (L <= 64 && !valu_only) {                                     // fp32-MFMA kernel: one wave per head
-        hipLaunchKernelGGL(k_attention_mfma64, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
+        if (split16) hipLaunchKernelGGL(k_attention_mfma64<true>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
+        else hipLaunchKernelGGL(k_attention_mfma64<false>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
         XMH_LAUNCH_CHECK("xmh_attention_f32");
         return XMH_OK;
     }
@@ -598,7 +667,13 @@ extern "C" int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma
 extern "C" int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
                                  float* out, xmh_stream_t stream) {
     if (B > 0 && !out) return xmh::fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
-    return xmh::attention_planes(qkv, B, L, H, dh, causal, key_padding_mask, out, xmh::Planes{nullptr, nullptr, 0}, xmh::as_stream(stream));
+    return xmh::attention_planes(qkv, B, L, H, dh, causal, key_padding_mask, out, xmh::Planes{nullptr, nullptr, 0}, false, xmh::as_stream(stream));
+}
+
+extern "C" int xmh_attention_split16(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
+                                     float* out, xmh_stream_t stream) {
+    if (B > 0 && !out) return xmh::fail(XMH_EINVAL, "xmh_attention_split16: null pointer");
+    return xmh::attention_planes(qkv, B, L, H, dh, causal, key_padding_mask, out, xmh::Planes{nullptr, nullptr, 0}, true, xmh::as_stream(stream));
 }
 
 extern "C" int xmh_im2col_patch(const float* image, int64_t B, int channels, int resolution, int patch, float* cols,

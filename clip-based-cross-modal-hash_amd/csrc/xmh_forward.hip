@@ -129,7 +129,7 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
         if (rc) return rc;
         rc = linear_p(b.qkv, s.hP, nullptr, 0, s.qkv, 3 * D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
-        rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, hs);
+        rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, true, hs);
         if (rc) return rc;
         rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;

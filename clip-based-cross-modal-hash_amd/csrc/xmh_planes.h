@@ -92,8 +92,9 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st);
 // p.hi may be null when only fp32 is wanted
 int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y, int64_t ldy, const Planes& p,
                      int64_t rows, int D, hipStream_t st);
+// split16: the products on the fp16 MFMA with hi/lo split operands (parity / fast mode) instead of the fp32 MFMA (exact mode)
 int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
-                     hipStream_t st);
+                     bool split16, hipStream_t st);
 int im2col_planes(const float* image, int64_t B, int channels, int resolution, int patch, float* cols, const Planes& p, hipStream_t st);
 
 }  // namespace xmh

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "xmh_cast_f32_to_f16": (i32, [vp, vp, i64, vp]),
     "xmh_layernorm_f32": (i32, [vp, i64, vp, vp, C.c_float, vp, i64, i64, i32, vp]),
     "xmh_attention_f32": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
+    "xmh_attention_split16": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp]),
     "xmh_image_preprocess_u8": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "xmh_im2col_patch": (i32, [vp, i64, i32, i32, i32, vp, vp]),
     "xmh_vit_assemble": (i32, [vp, vp, vp, vp, vp, C.c_float, vp, i64, i32, i32, vp]),

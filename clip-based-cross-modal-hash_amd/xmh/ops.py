@@ -131,7 +131,8 @@ def attention(qkv: torch.Tensor, heads: int, causal: bool = False, key_padding_m
     if key_padding_mask is not None:
         kpm = key_padding_mask.to(device=qkv.device, dtype=torch.uint8).contiguous()
     out = torch.empty(B, L, D, dtype=torch.float32, device=qkv.device)
-    check(lib.xmh_attention_f32(ptr(qkv), B, L, heads, D // heads, int(causal), ptr(kpm), ptr(out), current_stream()), "xmh_attention_f32")
+    fn = lib.xmh_attention_f32 if _precision == PREC_F32X else lib.xmh_attention_split16      # exact mode keeps fp32 products
+    check(fn(ptr(qkv), B, L, heads, D // heads, int(causal), ptr(kpm), ptr(out), current_stream()), "xmh_attention")
     return out
 
 

@@ -197,6 +197,11 @@ int xmh_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const flo
  * key_padding_mask [B, L] bytes (non-zero = ignore key) or NULL. */
 int xmh_attention_f32(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
                       float* out, xmh_stream_t stream);
+/* The same attention with the two products on the fp16 MFMA and hi/lo split operands (x = hi + lo, 22 mantissa bits; the scheme of
+ * xmh_gemm_nt_split16): product error 2^-22, 5x less matrix time.  What parity and fast mode use; xmh_attention_f32 (exact fp32
+ * products) is exact mode.  L > 64 runs the same fp32 kernel as xmh_attention_f32. */
+int xmh_attention_split16(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask,
+                          float* out, xmh_stream_t stream);
 /* Evaluation image transform (reference dataset/transformer_dataset.py:38-42: torchvision Resize((r, r), BICUBIC) +
  * ToTensor + Normalize on a PIL image), bit-exact with Pillow's two-pass 8-bit resample.  images [B][H][W][3] u8 RGB.
  * bounds_x [out][2] = (first input index, count), kk_x [out][ksize_x] = 22-bit fixed-point coefficients (device; built
