@@ -833,6 +833,130 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
 }
 
+// Pass 2 on the same operand images: the MFMA emits the counter address and the label overlap, ONE returning ds_add per pair
+// advances {rank, ordinal} of (bucket, query) and hands back the pair's own rank and ordinal (same-address lanes of one
+// instruction resolve in ascending lane = item order, lane_order_ok), relevant pairs are credited ordinal / rank one group of
+// 16 items later, so the returns are never waited for.  No pair cache: pass 1 then runs without the 5 packing instructions per
+// pair and the 600 MB round trip.  Counters as in k_scan_ap_s: P32 packs {rank | ordinal << rank_bits} in 32 bits when the
+// device word nrel_max says it fits (bucket rows of 64 bytes, the query image's -+32 scaling lands on them directly), else
+// 64-bit {rank, ordinal} (rows of 128 bytes: the accumulator runs at half scale and is doubled, one shift per pair).
+// The atomics and their waits are inline asm naming the destination registers (hipcc would drain the LDS-DMA before an LDS
+// atomic it cannot prove disjoint from the ring, and does not know that an asm's result arrives later).
+template <int NMC, int NML, int NW, bool P32, bool CAPPED>
+__global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+                                                       const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
+                                                       const uint32_t* __restrict__ nrel_max, int rank_bits) {
+    using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
+    constexpr int NM = NMC + NML, CW = (int)(sizeof(CT) / 4);
+    using ST = MfmaStage<NM, NW>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] counters, then the 2-deep ring
+    int chunk_id, qtile;
+    if (!mfma_map_block(a, chunk_id, qtile)) return;
+    {
+        const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
+        if (P32 != fits32) return;                                   // the other variant takes this call
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15;
+    const int q0 = (qtile * NW + wave) * 16;
+    const int q = q0 + ql;
+    const int ncell = a.nb * 16;
+    CT* cnt = reinterpret_cast<CT*>(lds + wave * ncell * CW);
+    {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+        const uint2* __restrict__ pd = dpre + q0;
+        for (int e = lane; e < ncell; e += 64) {
+            const int64_t at = (int64_t)(e >> 4) * a.qpad + (e & 15);
+            const uint2 x = pb[at], y = pd[at];
+            if (P32) cnt[e] = (CT)((x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits));
+            else cnt[e] = (CT)((unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32));
+        }
+    }
+    char* ring = reinterpret_cast<char*>(lds + NW * ncell * CW);
+    v4i bq[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) bq[m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(q0 >> 4) * NM + m) * 64 + lane);
+    const bool valid = q < a.Q;
+    const int cbase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)reinterpret_cast<uint32_t*>(cnt);
+    const int cinit = (P32 ? cbase : (cbase >> 1)) + ql * 4 + (valid ? 32 * a.K : 0);
+    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
+    const uint32_t rmask = P32 ? (1u << rank_bits) - 1u : 0xffffffffu;
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    const int64_t bat0 = lo >> 6;
+    float apsum = 0.0f;
+    auto credit = [&](CT old, uint32_t hit) {
+        uint32_t rank, ord;
+        if (P32) { rank = (uint32_t)old & rmask; ord = (uint32_t)old >> rank_bits; }
+        else { rank = (uint32_t)old; ord = (uint32_t)((unsigned long long)old >> 32); }
+        if (CAPPED) hit = ord <= cap ? hit : 0u;
+        const float of = (float)__umul24(ord, hit);
+        apsum = fmaf(of, __builtin_amdgcn_rcpf((float)rank), apsum);
+    };
+    CT oldp[4];
+    uint32_t hitp[4];
+    bool have_prev = false;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // counters are in place (own wave's region only)
+    ST::issue(a.gimg, ring, 0, bat0, lane, wave);
+    for (int i = 0; i < nbat; ++i) {
+        if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
+        ST::wait_prev(i + 1 < nbat);
+        __builtin_amdgcn_s_barrier();                                // every wave's pieces of batch i are in the ring
+        const char* base = ring + (i & 1) * (ST::PIECES * 1024) + lane * 16;
+        v4i am[4][NM];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4i acc = {cinit, cinit, cinit, cinit};
+#pragma unroll
+            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], acc, 0, 0, 0);
+            v4i lab = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = NMC; m < NM; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], lab, 0, 0, 0);
+            CT oldn[4];
+            uint32_t hit[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hit[j] = min((uint32_t)lab[j], 1u);
+                if (P32) {
+                    const uint32_t v = (hit[j] << rank_bits) + 1u;
+                    uint32_t o;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(acc[j]), "v"(v) : "memory");
+                    oldn[j] = (CT)o;
+                } else {
+                    const unsigned long long v = 1ull | ((unsigned long long)hit[j] << 32);
+                    const int addr = acc[j] << 1;
+                    unsigned long long o;
+                    asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(o) : "v"(addr), "v"(v) : "memory");
+                    oldn[j] = (CT)o;
+                }
+            }
+            if (have_prev) {                                         // the previous group's returns: 4 newer LDS operations are in flight
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3])::"memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) credit(oldp[j], hitp[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { oldp[j] = oldn[j]; hitp[j] = hit[j]; }
+            have_prev = true;
+        }
+        __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
+    }
+    if (have_prev) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3])::"memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) credit(oldp[j], hitp[j]);
+    }
+    apsum += __shfl_xor(apsum, 16, 64);
+    apsum += __shfl_xor(apsum, 32, 64);
+    if (lane < 16) ap_part[(int64_t)chunk_id * a.qpad + q] = apsum;
+}
+
 // Does the LDS hand out same-address returning adds of one instruction in ascending lane order?  (see the header)
 __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ ok_out) {
     __shared__ unsigned long long c64[256];
@@ -999,6 +1123,14 @@ inline bool mfma_shape(int K, bool ternary) {
     static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
     return on && !ternary && K > 32 && K <= 64;
 }
+// MFMA-evaluated pass 2 (k_scan_ap_m) instead of the pair cache + cached k_scan_ap_s: XMH_SCAN_MFMA_AP=1.  Bit-identical results,
+// measured at Q 5000 x R 117 218, K = 64: pass 1 without the cache 0.239 -> 0.196 ms, but pass 2 0.195 -> 0.349 ms (64-bit returning
+// atomics behind a staged ring with two barriers per batch at 2 waves per SIMD, against a cache reader with no staging and no
+// barrier): whole step 0.491 -> 0.595 ms.  Off by default; kept for the 65..128-bit shapes it may suit once tuned.
+inline bool mfma_ap_on() {                           // read per call (tests toggle it in one process); a histogram / ap call pair
+    const char* e = getenv("XMH_SCAN_MFMA_AP");       // must of course see the same value
+    return e && atoi(e) != 0;
+}
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 3 * 1024; }
@@ -1007,8 +1139,10 @@ inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 3 * 1
 // Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
 // pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 4096; 0 = off).
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
-    static const long long cap_mb = getenv("XMH_SCAN_CACHE_MB") ? atoll(getenv("XMH_SCAN_CACHE_MB")) : 4096;
+    const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call, like XMH_SCAN_MFMA_AP
+    const long long cap_mb = cap_env ? atoll(cap_env) : 4096;
     if (ternary || K <= 32 || K > 256 || cap_mb <= 0) return 0;
+    if (mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
@@ -1361,6 +1495,34 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             return (int)XMH_OK;
         });
     };
+    if (mfma_plan && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
+        MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
+                    (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)), (int)p.nbuckets, (int)p.qpad};
+        const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));
+        auto launch_m = [&](auto nml_c, auto p32_c, auto cap_c) {
+            constexpr int NML = decltype(nml_c)::value;
+            constexpr bool P32 = decltype(p32_c)::value, CP = decltype(cap_c)::value;
+            auto kern = k_scan_ap_m<1, NML, kMfmaWaves, P32, CP>;
+            const size_t lds = (size_t)kMfmaWaves * p.nbuckets * 16 * (P32 ? 4 : 8) + 2 * 4 * (1 + NML) * 1024;
+            const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
+            if (r2) return r2;
+            xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
+            hipLaunchKernelGGL(kern, grid, dim3(64 * kMfmaWaves), lds, st, ma, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+                               (const uint32_t*)nrel_max, rank_bits);
+            return (int)XMH_OK;
+        };
+        auto by_shape = [&](auto p32_c) {
+            if (LW <= 2) return capped ? launch_m(std::integral_constant<int, 1>{}, p32_c, std::true_type{}) : launch_m(std::integral_constant<int, 1>{}, p32_c, std::false_type{});
+            return capped ? launch_m(std::integral_constant<int, 2>{}, p32_c, std::true_type{}) : launch_m(std::integral_constant<int, 2>{}, p32_c, std::false_type{});
+        };
+        if (rank_bits) {
+            rc = by_shape(std::true_type{});
+            if (rc) return rc;
+        }
+        rc = by_shape(std::false_type{});
+        if (rc) return rc;
+        XMH_LAUNCH_CHECK("xmh_hamming_ap (MFMA)");
+    } else {
     using T1 = std::true_type;
     using T0 = std::false_type;
     auto launch_width = [&](auto p32_c) {
@@ -1376,6 +1538,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     rc = launch_width(T0{});
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
+    }
     const unsigned nred = (unsigned)xmh::ceil_div(Q, 256);
     if (map_out && nred <= 4096) {                                   // reduce + mean in one launch (last-ticket block finalises)
         hipLaunchKernelGGL(k_ap_reduce_map, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, (const int32_t*)cap, ap_sum,

@@ -305,6 +305,23 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
         assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
 
 
+def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
+    """XMH_SCAN_MFMA_AP=1 (pass 2 evaluated on the MFMA, no pair cache) against the default path: same ap sums, caps and capped
+    sums bit for bit."""
+    Q, R, K, C = 150, 9001, 64, 80
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=11, p=0.06)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("XMH_SCAN_MFMA_AP", flag)
+        scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+        scan.histograms(False)
+        ap, cap = scan.ap_sums(None)
+        ap9, cap9 = scan.ap_sums(9)
+        outs.append((ap.clone(), cap.clone(), ap9.clone(), cap9.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_calc_map_k_label_cache_sees_in_place_edits(cu):
     orc = _orc()
     qB, rB, qL, rL = _synth(12, 900, 64, 10, seed=4)
@@ -527,45 +544,37 @@ def test_full_size_nuswide_shape_sharded_eight_ways(xr):
     assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)                          # fp32 credits, summed per chunk: order differs
 
 
-def test_full_size_long_gallery_256bit_uncached_scan(xr):
+def test_full_size_long_gallery_256bit_uncached_scan(xr, monkeypatch):
     """BASELINE configs[4] per-GPU shard (10 M / 8 = 1.25 M rows x 256 bit) through the mAP scan: at Q 5000 the pair cache would
-    exceed its cap, so this is the path without it -- checked here at Q 192 with the cache switched off (fresh process) against
-    the oracle on a query subsample, plus the size-independent properties."""
-    import subprocess
-    import sys
-    code = """
-import sys, numpy as np, torch
-sys.path[:0] = [%r, %r]
-from xmh import retrieval as xr
-sys.path.insert(0, %r)
-from oracle import retrieval as orc
-Q, R, K, C = 192, 1250000, 256, 24
-g = torch.Generator().manual_seed(4114)
-proto = torch.sign(torch.randn(C, K, generator=g))
-rL = (torch.rand(R, C, generator=g) < 0.06).float(); rL[torch.arange(R), torch.randint(0, C, (R,), generator=g)] = 1
-qL = (torch.rand(Q, C, generator=g) < 0.06).float(); qL[torch.arange(Q), torch.randint(0, C, (Q,), generator=g)] = 1
-rB = torch.sign(rL @ proto + 2.5 * torch.randn(R, K, generator=g)); rB[rB == 0] = 1
-qB = torch.sign(qL @ proto + 2.5 * torch.randn(Q, K, generator=g)); qB[qB == 0] = 1
-q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
-r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
-scan = xr.RankingScan(q, ql, r, rl, C)
-ha, hr = scan.histograms()
-assert (ha.to(torch.int64).sum(1) == R).all()
-ap, cap = scan.ap_sums(None)
-assert torch.equal(hr.to(torch.int64).sum(1).to(torch.int32), cap)
-u32 = lambda t: t.cpu().numpy().view(np.uint32)
-sub = np.arange(0, Q, 13)[:12]
-dist = orc.hamming_packed(u32(q.bits)[sub], u32(r.bits))
-rel = orc.relevance_packed(u32(ql)[sub], u32(rl))
-assert np.array_equal(cap.cpu().numpy()[sub], rel.sum(-1))
-assert np.allclose(ap.cpu().numpy()[sub], orc.ap_from_ranking(dist, rel), rtol=3e-6)
-ap2, cap2 = scan.ap_sums(1000)
-assert (cap2 <= 1000).all() and (ap2 <= ap + 1e-9).all()
-print("OK")
-""" % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"), ROOT)
-    env = dict(os.environ, XMH_SCAN_CACHE_MB="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    exceed its cap, so this is the path without it -- checked here at Q 192 with the cache switched off against the oracle on a
+    query subsample, plus the size-independent properties."""
+    monkeypatch.setenv("XMH_SCAN_CACHE_MB", "0")
+    orc = _orc()
+    Q, R, K, C = 192, 1250000, 256, 24
+    g = torch.Generator().manual_seed(4114)
+    proto = torch.sign(torch.randn(C, K, generator=g))
+    rL = (torch.rand(R, C, generator=g) < 0.06).float()
+    rL[torch.arange(R), torch.randint(0, C, (R,), generator=g)] = 1
+    qL = (torch.rand(Q, C, generator=g) < 0.06).float()
+    qL[torch.arange(Q), torch.randint(0, C, (Q,), generator=g)] = 1
+    rB = torch.sign(rL @ proto + 2.5 * torch.randn(R, K, generator=g))
+    rB[rB == 0] = 1
+    qB = torch.sign(qL @ proto + 2.5 * torch.randn(Q, K, generator=g))
+    qB[qB == 0] = 1
+    q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+    r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+    scan = xr.RankingScan(q, ql, r, rl, C)
+    ha, hr = scan.histograms()
+    assert (ha.to(torch.int64).sum(1) == R).all()
+    ap, cap = scan.ap_sums(None)
+    assert torch.equal(hr.to(torch.int64).sum(1).to(torch.int32), cap)
+    sub = np.arange(0, Q, 13)[:12]
+    dist = orc.hamming_packed(_u32(q.bits)[sub], _u32(r.bits))
+    rel = orc.relevance_packed(_u32(ql)[sub], _u32(rl))
+    assert np.array_equal(cap.cpu().numpy()[sub], rel.sum(-1))
+    assert np.allclose(ap.cpu().numpy()[sub], orc.ap_from_ranking(dist, rel), rtol=3e-6)
+    ap2, cap2 = scan.ap_sums(1000)
+    assert (cap2 <= 1000).all() and (ap2 <= ap + 1e-9).all()
 
 
 # ------------------------------------------------------------------------------------------------
