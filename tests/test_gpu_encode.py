@@ -367,35 +367,32 @@ def test_head_entry_points_equal_the_primitive_chain_and_pack(ops):
         ops.set_precision(before)
 
 
-_DIRECT_A_CHILD = r"""
-import os, sys, torch
-sys.path[:0] = [os.environ["XMH_ROOT"], os.path.join(os.environ["XMH_ROOT"], "clip-based-cross-modal-hash_amd")]
-from xmh import ops
-g = torch.Generator().manual_seed(5)
-for (M, N, K) in ((33000, 256, 64), (4100, 1024, 96), (40000, 768, 64), (3000, 2304, 160)):
-    A = (torch.randn(M, K, generator=g) * 2).cuda()
-    for exact in (True, False):
-        W = (torch.randn(N, K, generator=g) * 0.1)
-        W = (W.half().float() if exact else W).cuda()
-        b, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
-        out = ops.gemm_nt(A, W, b, residual=res, act=ops.ACT_QUICKGELU)
-        rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).cuda()
-        z = A[rows].double() @ W.double().t() + b.double()
-        ref = z * torch.sigmoid(1.702 * z) + res[rows].double()
-        err = float((out[rows].double() - ref).abs().max() / ref.abs().max())
-        assert err < 2e-6, (M, N, K, exact, err)
-        ops.set_precision("f32")
-print("direct-a ok")
-"""
-
-
-def test_direct_a_split_gemm_variants_in_a_child_process(ops):
-    """XMH_GEMM_DIRECT_A=all routes fp16-exact weights through the direct-A kernels too (128x128 and 128x256 tiles; by default
-    only the three-term product uses them): ragged M / N edges, bias + residual + activation epilogue, against float64."""
-    import subprocess, sys
-    env = dict(os.environ, XMH_GEMM_DIRECT_A="all", XMH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", _DIRECT_A_CHILD], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "direct-a ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("mode,M,N,K", [("f16", 4096, 3072, 768),       # 256 x 256 tiles (8 waves)
+                                         ("f16", 5000, 2304, 768),       # 192 x 128
+                                         ("f16", 5000, 768, 3072),       # 128 x 128, BK 64
+                                         ("f16", 300, 512, 96),          # BK 32 (K % 64 != 0), 64-row tiles
+                                         ("f32", 5000, 2304, 768),       # 128 x 192, two activation planes
+                                         ("f32", 5000, 768, 3072),       # 128 x 128, BK 64, one block per CU
+                                         ("f32", 5000, 3072, 768),       # 128 x 256 (8 waves)
+                                         ("f32", 3200, 512, 2048)])      # 64-row tiles
+def test_gemm_tile_shapes_share_one_k_order(ops, mode, M, N, K):
+    """Every tile shape of the fp16-MFMA GEMM (k_gemm_g16) walks k in the same order: the first rows of a large product -- which
+    picks the large-grid tile of its mode -- equal the same rows computed alone (a small grid, another tile shape) BIT FOR BIT,
+    with bias + QuickGELU + residual in the epilogue; and the large product matches float64."""
+    gen = g_(M + N + K)
+    A = torch.randn(M, K, generator=gen)
+    W = (torch.randn(N, K, generator=gen) * 0.05).half().float()
+    bias, res = torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+    prec = ops._NAMES[mode]
+    Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), res.cuda()
+    big = ops.gemm_nt(Ad, Wd, bd, residual=rd, act=ops.ACT_QUICKGELU, precision=prec)
+    rows = 130
+    small = ops.gemm_nt(Ad[:rows].contiguous(), Wd, bd, residual=rd[:rows].contiguous(), act=ops.ACT_QUICKGELU, precision=prec)
+    assert torch.equal(big[:rows], small)
+    Aref = A.half().double() if mode == "f16" else A.double()
+    pre = (Aref[:512] @ W.double().t() + bias.double()).float()
+    want = (pre * torch.sigmoid(1.702 * pre)).double() + res[:512].double()
+    assert rel(big[:512], want) < (2e-5 if mode == "f16" else 3e-6)
 
 
 def test_clip_state_dict_keys_are_the_reference_contract(clip_models):
