@@ -1227,9 +1227,10 @@ int lane_order_ok(hipStream_t st) {
     static bool have[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (getenv("XMH_SCAN_MASKED") != nullptr) return 0;           // read per call: the self-check test runs both paths in one process
     if (have[dev]) return cached[dev];
     int ok = 0;
-    if (getenv("XMH_SCAN_MASKED") == nullptr) {
+    {
         uint32_t* flag = nullptr;
         if (hipMalloc(&flag, 4) == hipSuccess) {
             uint32_t h = 0;

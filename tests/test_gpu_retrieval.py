@@ -264,6 +264,25 @@ def test_scan_masked_fallback_in_a_fresh_process():
     assert abs(outs[0] - outs[1]) < 1e-9 and abs(outs[0] - outs[2]) < 1e-9, outs
 
 
+def test_scan_masked_self_check_at_full_size(xr, monkeypatch):
+    """The fast pass 2 relies on same-address LDS atomics of one instruction resolving in ascending lane order (probed once per
+    process); the masked variant does not.  Self-check at the BASELINE configs[1] shape, every chunk and query tile
+    under full load: both give the same ap sums and caps bit for bit."""
+    Q, R, K, C = 5000, 117218, 64, 80
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=1814, p=0.04)
+    q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+    r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+    outs = []
+    for masked in (False, True):
+        if masked:
+            monkeypatch.setenv("XMH_SCAN_MASKED", "1")
+        scan = xr.RankingScan(q, ql, r, rl, C)
+        scan.histograms(False)
+        ap, cap = scan.ap_sums(None)
+        outs.append((ap.clone(), cap.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_scan_pair_cache_on_and_off_give_identical_bits():
     """The pair cache (pass 1 leaves distance | relevant per pair for pass 2; XMH_SCAN_CACHE_MB, read once per process)
     must not change a single bit: same counter adds in the same order.  Code lengths of both entry widths, ragged
