@@ -378,6 +378,11 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][
     const int fr = lane & 31, fh = lane >> 5;
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
     const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
+    // C and residual are the same buffer in the blocks' x += ... GEMMs.  Every lane reads exactly the addresses it then writes and
+    // each store takes its value from that load, so letting hipcc treat the two as disjoint only frees it to issue the residual loads
+    // of later passes above the stores of earlier ones (otherwise: one exposed memory latency per pass).
+    const float* __restrict__ resid = g.residual;
+    float* __restrict__ cout = g.C;
     auto bias_at = [&](int col) {
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias) {
@@ -408,11 +413,11 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][
             if (!kFixedCol) bv = bias_at(col);
             float4 v = make_float4(act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w));
             if (vec) {
-                if (g.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + col);
+                if (resid) {
+                    const float4 rr = *reinterpret_cast<const float4*>(resid + row * g.ldr + col);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
-                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                if (cout) *reinterpret_cast<float4*>(cout + row * g.ldc + col) = v;
                 if (g.O_hi) xmh::store_planes4(op, row, col, v.x, v.y, v.z, v.w);
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
