@@ -93,3 +93,13 @@ def test_load_backbone_from_checkpoint_file_and_weight_rounding(tmp_path):
     assert not any(p.requires_grad for p in model.parameters())
     model.unfreezen()
     assert all(p.requires_grad for p in model.parameters())
+
+
+def test_tower_helper_runs_back_to_back_without_a_gpu(monkeypatch):
+    """xmh.towers.run_both: image tower first, text tower second, results in (image, text) order; XMH_TOWER_STREAMS=0 (and a machine
+    without HIP) selects the single-stream path."""
+    from xmh import towers
+    order = []
+    monkeypatch.setenv("XMH_TOWER_STREAMS", "0")
+    out = towers.run_both(lambda: order.append("image") or "I", lambda: order.append("text") or "T")
+    assert out == ("I", "T") and order == ["image", "text"]
