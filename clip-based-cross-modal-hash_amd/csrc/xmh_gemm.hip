@@ -696,7 +696,7 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     //   (5000 x 2304 x 768 parity 53.4 -> 51.5 us);
     //   large grids: 256x256 (fast), 128x256 with 8 waves (parity).
     static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-    static const int tile_rules = getenv("XMH_GEMM_TILE_RULES") ? atoi(getenv("XMH_GEMM_TILE_RULES")) : 14;    // bit 3: 64x128 tiles of 8 waves for grids of at most two 128x128 tiles per CU; bit 0: 64-row tiles already for grids of <= one 128x128 tile per CU (measured slower with the real epilogues: off), bit 1: 192-wide tiles, bit 2: 8-wave 128x128 tiles
+    static const int tile_rules = getenv("XMH_GEMM_TILE_RULES") ? atoi(getenv("XMH_GEMM_TILE_RULES")) : 30;    // bit 4: 8-wave tiles for the three-term product; bit 3: 64x128 tiles of 8 waves for grids of at most two 128x128 tiles per CU; bit 0: 64-row tiles already for grids of <= one 128x128 tile per CU (measured slower with the real epilogues: off), bit 1: 192-wide tiles, bit 2: 8-wave 128x128 tiles
     const bool under = (tile_rules & 1) ? n128 <= cus : 2 * n128 < cus;
     const bool k64 = g.K % 64 == 0;
     if (!g.A_lo) {
@@ -712,7 +712,8 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     } else {
         ProfScope prof("gemm_s16", st);
         const int64_t n192 = ceil_div(g.M, 128) * ceil_div(g.N, 192);
-        if (g.W_lo) rc = 2 * n128 < cus ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
+        if (g.W_lo && (tile_rules & 16)) rc = n128 <= 2 * cus ? launch_g16<2, 4, 1, 1, 2, 2, 32, 2>(a, st) : launch_g16<4, 2, 1, 2, 2, 2, 32, 2>(a, st);   // 8 waves per tile here too
+        else if (g.W_lo) rc = 2 * n128 < cus ? launch_g16<1, 2, 2, 2, 2, 2, 32, 2>(a, st) : launch_g16<2, 2, 2, 2, 2, 2, 32, 2>(a, st);
         else if (!no_wide && ceil_div(g.M, 128) * ceil_div(g.N, 256) * 2 >= 3 * cus) rc = launch_g16<2, 4, 2, 2, 2, 1, 32, 1>(a, st);
         else if ((tile_rules & 8) && k64 && n128 <= 2 * cus) rc = launch_g16<2, 4, 1, 1, 2, 1, 64, 2>(a, st);  // small grids: 64 x 128 as 8 waves of 32 x 32 (3200 x 512 x 2048: 34.6 -> 24.8 us)
         else if (under) rc = launch_g16<1, 2, 2, 2, 2, 1, 32, 3>(a, st);
