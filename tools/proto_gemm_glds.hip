@@ -493,16 +493,12 @@ int main() {
         printf("M=%d N=%d K=%d\n", M, N, K);
         const int iters = 20;
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
-        hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, ref, refrows);
-        run<4, 2, 1, 2, 2, 64, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 1, 2, 2, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 1, 2, 2, 32, 2, 1, 4, 0, 8>(g, iters, ref, refrows);
-        run<2, 4, 1, 1, 2, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 2, 1, 2, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
         run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<2, 2, 1, 2, 1, 64, 2, 1, 4, 0, 8>(g, iters, ref, refrows);
-        run<2, 4, 1, 1, 1, 64, 2, 1, 4, 0, 8>(g, iters, ref, refrows);
+        run<4, 2, 1, 2, 1, 32, 2, 1, 4, 0, 8>(g, iters, ref, refrows);
+        run<4, 2, 1, 2, 1, 32, 3, 2, 3, 0, 8>(g, iters, ref, refrows);
+        run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 4>(g, iters, ref, refrows);
+        run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 16>(g, iters, ref, refrows);
+        run<2, 4, 2, 1, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(ref));
     }
     return 0;
