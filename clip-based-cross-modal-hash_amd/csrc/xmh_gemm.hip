@@ -2,20 +2,19 @@
 // W is in nn.Linear layout (row n = output feature n), i.e. an "NT" GEMM -- what every Linear / in_proj /
 // out_proj / c_fc / c_proj of the reference's CLIP (models/CLIP/model.py:167-197) and hash heads computes.
 //
-// MFMA paths, same tiling (128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32; 64x128 tiles
-// for small grids):
-//   s16   k_gemm_nt_s16: "parity mode" -- fp32 activations split hi/lo into two fp16 terms while staged, weights as one
-//         (fp16-exact) or two fp16 parts, v_mfma_f32_32x32x16_f16 with fp32 accumulate: every product exact in fp32,
-//         2^-22 relative error per product, 2-3 MFMAs per product (see the comment at the kernel);
+// Kernels:
+//   g16   k_gemm_g16: the fp16-MFMA GEMM of parity and fast mode.  Operands are fp16 "planes" in memory (xmh_planes.h), staged by
+//         LDS-DMA into a swizzled, double-buffered LDS tile; parity mode = two activation planes (x = hi + lo) x one or two
+//         weight planes, every fp16 x fp16 product exact in fp32, 2^-22 relative error per product, 2-3 MFMAs per product;
+//         fast mode = one plane per operand.  Peak 2.5 PFLOP/s (1.25 useful in parity mode).  See the comment at the kernel.
 //   f32   k_gemm_nt_f32, v_mfma_f32_32x32x2_f32: exact fp32 products -- "exact mode" and unaligned shapes; peak 157 TFLOP/s;
-//   h16   k_gemm_nt_h16 / k_gemm_nt_f16, v_mfma_f32_32x32x16_f16 on operands rounded to fp16 -- "fast mode"; peak 2.5 PFLOP/s.
-// LDS tiles are [rows][BK] with rows padded so that the ds_read_b128 of a 16-lane group lands on 16 distinct
-// 16-byte slots (guide section 2 / Guideline 4).  k-order inside a BK slab is permuted identically for A and
-// W (lane half h reads the contiguous k range h*BK/2 ...), which lets every lane fetch its MFMA operands with
-// two b128 reads instead of eight b32 reads; a sum over k does not care about the order of k.
+//         register-staged, LDS rows padded so that the ds_read_b128 of a 16-lane group lands on 16 distinct 16-byte slots.
+//   f16   k_gemm_nt_f16: fp32 operands rounded to fp16 while staged -- fast mode for shapes the planes kernel does not take (K % 32).
+// In all of them the k-order inside a slab is permuted identically for A and W (a sum over k does not care), which lets every
+// lane fetch its MFMA operands with 16-byte LDS reads.
 //
-// Bound in practice: L2 -> CU bandwidth (each tile re-reads its operands from L2; 8.5 TB/s measured at both tile sizes,
-// DESIGN.md section 3.4), with the MFMA peak above it.  Algorithmic flops per launch = 2*M*N*K.
+// Bound in practice: the L2 -> LDS path (about 18 TB/s at 128x128 tiles), with the MFMA peak above it;
+// bytes per flop (tile size) and waves per tile are the levers.  Algorithmic flops per launch = 2*M*N*K.
 #include "xmh_common.h"
 #include "xmh_planes.h"
 #include <string.h>

@@ -165,7 +165,7 @@ int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, in
 #define XMH_ACT_GELU_ERF 2    /* nn.GELU() of the MITH ResidualMLPs, models/MITH/hash/hash.py:22 */
 #define XMH_ACT_TANH 3
 #define XMH_ACT_RELU 4
-#define XMH_PREC_F32 0        /* v_mfma_f32_32x32x2_f32: exact fp32 products ("parity mode") */
+#define XMH_PREC_F32 0        /* v_mfma_f32_32x32x2_f32: exact fp32 products */
 #define XMH_PREC_F16 1        /* operands rounded to fp16, fp32 accumulate ("fast mode")     */
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]).  W in nn.Linear layout.  bias / residual may
@@ -179,8 +179,10 @@ int xmh_gemm_nt_h16(const void* A_half, int64_t lda, const void* W_half, int64_t
                     const float* residual, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                     int act, xmh_stream_t stream);
 int xmh_cast_f32_to_f16(const float* x, void* y_half, int64_t n, xmh_stream_t stream);
-/* Parity-grade contraction at fp16-MFMA rate: fp32 A is split into two fp16 terms while it is staged (a = hi + lo, 22
- * mantissa bits); every fp16 x fp16 product is exact in fp32, accumulation is fp32.
+/* Parity-grade contraction at fp16-MFMA rate: fp32 A is split into two fp16 planes (a = hi + lo, 22 mantissa bits) by a pass
+ * into stream-ordered scratch (hipMallocAsync) and multiplied by the LDS-DMA staged plane kernel; every fp16 x fp16 product is
+ * exact in fp32, accumulation is fp32.  (The whole-tower entry points below never take this route: there the producing kernel
+ * writes the planes.)
  *   W_lo_half == NULL: W_half must hold fp16-EXACT weights (true for CLIP weights after convert_weights,
  *                      models/CLIP/model.py:415-436): two MFMAs per product, relative error 2^-22;
  *   W_lo_half != NULL: any fp32 weight, given as w = W_half + W_lo_half (host: hi = half(w), lo = half(w - hi)): three MFMAs
