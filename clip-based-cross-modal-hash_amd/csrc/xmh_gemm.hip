@@ -703,8 +703,9 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
         const int64_t n192 = ceil_div(g.M, 192) * ceil_div(g.N, 128);
         if ((tile_rules & 8) && k64 && n128 <= cus) rc = launch_g16<2, 4, 1, 1, 1, 1, 64, 2>(a, st);          // small grids: 64 x 128 as 8 waves of 32 x 32 (up to one 128 x 128 tile per CU; at two the 128 x 128 tile is ahead in fast mode)
         else if (under) rc = k64 ? launch_g16<1, 2, 2, 2, 1, 1, 64, 3>(a, st) : launch_g16<1, 2, 2, 2, 1, 1, 32, 4>(a, st);
-        else if (!no_wide && k64 && ceil_div(g.M, 256) * ceil_div(g.N, 256) * 10 >= 7 * cus)
-            rc = launch_g16<2, 4, 4, 2, 1, 1, 64, 1>(a, st);       // 256 x 256, 8 waves of 128 x 64: half the L2 -> LDS bytes per flop (+7-20 % once the grid fills the chip)
+        else if (!no_wide && k64 && g.K >= 2048 && ceil_div(g.M, 256) * ceil_div(g.N, 256) * 10 >= 7 * cus)
+            rc = launch_g16<2, 4, 4, 2, 1, 1, 64, 1>(a, st);       // 256 x 256, 8 waves of 128 x 64: half the L2 -> LDS bytes per flop.  Long k only: one block per CU
+                                                                   // leaves the CU idle while it stores C, which at K = 768 costs more than the bytes save
         else if ((tile_rules & 2) && !no_wide && k64 && n128 > 2 * cus && n128 < 3 * cus && n192 <= 2 * cus) rc = launch_g16<2, 2, 3, 2, 1, 1, 64, 2>(a, st);
         else if (k64 && (tile_rules & 4)) rc = launch_g16<4, 2, 1, 2, 1, 1, 64, 2>(a, st);      // 128 x 128 as 8 waves of 32 x 64: twice the waves per tile hide more of the staging (5-12 % over 4 waves of 64 x 64)
         else rc = k64 ? launch_g16<2, 2, 2, 2, 1, 1, 64, 2>(a, st) : launch_g16<2, 2, 2, 2, 1, 1, 32, 4>(a, st);

@@ -1,0 +1,18 @@
+import sys, os, time
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "clip-based-cross-modal-hash_amd")]
+import torch
+from xmh import ops, retrieval as R
+from xmh.models.dcmht import DCMHT
+from xmh.utils.config import Config
+from xmh.models import weights as W
+model = DCMHT.from_config(Config({"clip_path": "synthetic:1814"}), output_dim=64).cuda().eval()
+for B in (100, 400):
+    image = W.synth_images(5, 100).cuda().repeat(B // 100, 1, 1, 1)
+    for mode in ("f16", "f32"):
+        ops.set_precision(mode)
+        fn = lambda: R.pack_pair_argmax(model.encode_image(image))
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        print("B=%d %s %.0f img/s" % (B, mode, B * 20 / (time.perf_counter() - t0)))
