@@ -33,9 +33,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3, ACT_RELU = 4 };
 
+// x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)) on v_exp_f32 and v_rcp_f32 (1 ulp each: relative error 3e-7, the level of the
+// split product itself) -- 5 VALU instructions; expf + an IEEE division cost 12 us of a 53 us c_fc GEMM (5000 x 3072 x 768, fast mode)
+__device__ __forceinline__ float quick_gelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
-        case ACT_QUICKGELU: return x * (1.0f / (1.0f + expf(-1.702f * x)));   // x * sigmoid(1.702 x), model.py:162-164
+        case ACT_QUICKGELU: return quick_gelu(x);                              // x * sigmoid(1.702 x), model.py:162-164
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
         case ACT_TANH: return tanhf(x);
         case ACT_RELU: return x > 0.0f ? x : 0.0f;
@@ -358,7 +364,7 @@ struct GArgsP {
 
 template <int ACT>
 __device__ __forceinline__ float act_ct(float x) {
-    if (ACT == ACT_QUICKGELU) return x * (1.0f / (1.0f + expf(-1.702f * x)));
+    if (ACT == ACT_QUICKGELU) return quick_gelu(x);
     if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     if (ACT == ACT_TANH) return tanhf(x);
     if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
