@@ -342,7 +342,9 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
         float sum = 0.0f;
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
-            pa[t] = expf(pa[t] - mx);
+            // S16: e^x as 2^(x log2 e) on v_exp_f32 (1 ulp; the arguments are <= 0 and, for weights that matter, small): the split
+            // product that follows carries 2^-22 itself.  The fp32 variant keeps expf.
+            pa[t] = S16 ? __builtin_amdgcn_exp2f((pa[t] - mx) * 1.4426950408889634f) : expf(pa[t] - mx);
             sum += pa[t];
         }
         sum += __shfl_xor(sum, 32, 64);
