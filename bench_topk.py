@@ -82,6 +82,30 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
     t *= 1e-3
     _lib.prof_enable(False)
     alg = R * W * 4 + Q * W * 4 + Q * 4                 # gallery read once + queries + thresholds
+    # the robust path alone (what a call costs when a candidate list overflows or the sample misjudges): XMH_TOPK_ROBUST_ONLY
+    # makes the library skip the fast path; same call, same outputs
+    os.environ["XMH_TOPK_ROBUST_ONLY"] = "1"
+    try:
+        for _ in range(2):
+            d2, i2 = X.hamming_topk(q, r, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            d2, i2 = X.hamming_topk(q, r, k)
+        e1.record()
+        torch.cuda.synchronize()
+        t_robust = e0.elapsed_time(e1) / 5 * 1e-3
+        same = bool(torch.equal(d2, d) and torch.equal(i2, i))
+    finally:
+        os.environ.pop("XMH_TOPK_ROBUST_ONLY", None)
+    robust_only = {"whole_call_ms": t_robust * 1e3, "whole_call_GBps": alg / t_robust / 1e9, "equals_fast_path": same}
+    out = _result(alg, t, t_call, launches, R, K, Q, k, kind)
+    out["robust_path_alone"] = robust_only
+    return out
+
+
+def _result(alg, t, t_call, launches, R, K, Q, k, kind):
     return {"kernel": "k_topk_filter (streaming pass of xmh_hamming_topk), HIP events around the launch, %d launches" % launches,
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
             "traffic": _traffic(), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
@@ -107,7 +131,7 @@ def measure_structured(R=10_000_000, K=256, k=100):
     for kind in ("structured", "duplicates"):
         for Q in (1, 8):
             m = measure(R=R, K=K, Q=Q, k=k, iters=10, kind=kind)
-            out["%s_Q%d" % (kind, Q)] = {x: m[x] for x in ("whole_call_ms", "whole_call_GBps", "avg_launch_ms", "achieved", "workload", "robust_path_launches")}
+            out["%s_Q%d" % (kind, Q)] = {x: m[x] for x in ("whole_call_ms", "whole_call_GBps", "avg_launch_ms", "achieved", "workload", "robust_path_launches", "robust_path_alone")}
     return out
 
 
