@@ -330,7 +330,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),   # "nccl" is RCCL on ROCm
+                                timeout=datetime.timedelta(minutes=5))          # every collective here is sub-second: fail fast, do not hang
         ranks_in_group = dist.get_world_size()
         if ranks_in_group != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus %d" % (ranks_in_group, args.gpus))
