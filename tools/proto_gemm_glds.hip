@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
                 f16x8 a[MI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>((ABL == 3 ? lds : bA) + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + (ABL == 3 ? 0 : coff));
+                if (ABL == 31) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
                         if (ABL == 4) { asm volatile("" ::"v"(a[i]), "v"(b[j])); }
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
                     }
+                if (ABL == 31) __builtin_amdgcn_s_setprio(0);
             }
         }
     }
@@ -494,11 +496,12 @@ int main() {
         const int iters = 20;
         hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, ref, refrows);
         run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 1, 2, 1, 32, 2, 1, 4, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 1, 2, 1, 32, 3, 2, 3, 0, 8>(g, iters, ref, refrows);
-        run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 4>(g, iters, ref, refrows);
-        run<4, 2, 1, 2, 1, 64, 2, 1, 2, 0, 16>(g, iters, ref, refrows);
-        run<2, 4, 2, 1, 1, 64, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<4, 2, 1, 2, 1, 64, 2, 1, 2, 31, 8>(g, iters, ref, refrows);
+        hipLaunchKernelGGL(k_ref, dim3((refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, ref, refrows);
+        run<2, 4, 2, 2, 2, 32, 2, 1, 1, 0, 8>(g, iters, ref, refrows);
+        run<2, 4, 2, 2, 2, 32, 2, 1, 1, 31, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 3, 2, 32, 2, 1, 2, 0, 8>(g, iters, ref, refrows);
+        run<2, 2, 2, 3, 2, 32, 2, 1, 2, 31, 8>(g, iters, ref, refrows);
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(ref));
     }
     return 0;
