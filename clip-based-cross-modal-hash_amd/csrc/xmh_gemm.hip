@@ -39,10 +39,25 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
 }
 
+// nn.GELU() = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. <= 1.5e-7 relative on
+// the factor 1 + erf in [1, 2] and <= 1.5e-7 |x| / 2 absolute where it is near 0): branch-free, one v_rcp_f32 and one v_exp_f32 --
+// libm's erff costs 14 us of a 55 us GEMM epilogue (5000 x 3072 x 768), this 9; measured |error| <= 4.6e-7 over [-12, 12]
+// (tools/check_gelu_erf.py)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case ACT_QUICKGELU: return quick_gelu(x);                              // x * sigmoid(1.702 x), model.py:162-164
-        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_GELU_ERF: return gelu_erf(x);
         case ACT_TANH: return tanhf(x);
         case ACT_RELU: return x > 0.0f ? x : 0.0f;
         default: return x;
@@ -365,7 +380,7 @@ struct GArgsP {
 template <int ACT>
 __device__ __forceinline__ float act_ct(float x) {
     if (ACT == ACT_QUICKGELU) return quick_gelu(x);
-    if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (ACT == ACT_GELU_ERF) return gelu_erf(x);
     if (ACT == ACT_TANH) return tanhf(x);
     if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
     return x;
