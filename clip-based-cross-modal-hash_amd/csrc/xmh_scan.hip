@@ -119,39 +119,103 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
 //   tot[d][q]      = (#all, #relevant) items of bucket d in this shard
 // ---------------------------------------------------------------------------------------------------
 // rel_scale = 0: pass-1 counters are (all | relevant << 16); else all + relevant * rel_scale (the MFMA-evaluated pass 1)
+// The block that finishes a 64-query tile LAST (ticket per tile, zeroed ahead of the launch) also writes what the unsharded pass 2
+// needs from the totals -- dpre[d][q] = exclusive prefix of tot over d, nrel[q], the nrel_max gate word -- which used to be a
+// launch of its own between the passes (k_scan_dpre: 9 us + a launch gap; kept for the sharded call and the histogram export).
 __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__ chunk_hist, int qpad, int nb, int nchunk, uint32_t rel_scale,
-                                                    uint2* __restrict__ below, uint2* __restrict__ tot) {
-    const int lane = threadIdx.x & 63;
-    const int d = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                    uint2* __restrict__ below, uint2* __restrict__ tot, uint32_t* __restrict__ tickets, int Q,
+                                                    uint2* __restrict__ dpre, uint32_t* __restrict__ nrel_ws, uint32_t* __restrict__ nrel_max) {
+    __shared__ uint2 part[4][64];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int d = blockIdx.y * 4 + wq;
     const int q = blockIdx.x * 64 + lane;
-    if (d >= nb) return;
-    uint32_t ra = 0, rr = 0;
-    int c = 0;
-    for (; c + 4 <= nchunk; c += 4) {
-        uint32_t h[4];
+    if (d < nb) {
+        uint32_t ra = 0, rr = 0;
+        int c = 0;
+        for (; c + 4 <= nchunk; c += 4) {
+            uint32_t h[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = chunk_hist[((int64_t)(c + j) * nb + d) * qpad + q];
+            for (int j = 0; j < 4; ++j) h[j] = chunk_hist[((int64_t)(c + j) * nb + d) * qpad + q];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            below[((int64_t)(c + j) * nb + d) * qpad + q] = make_uint2(ra, rr);
-            const uint32_t rel = rel_scale ? h[j] / rel_scale : h[j] >> 16;
-            ra += rel_scale ? h[j] - rel * rel_scale : h[j] & 0xffffu;
+            for (int j = 0; j < 4; ++j) {
+                below[((int64_t)(c + j) * nb + d) * qpad + q] = make_uint2(ra, rr);
+                const uint32_t rel = rel_scale ? h[j] / rel_scale : h[j] >> 16;
+                ra += rel_scale ? h[j] - rel * rel_scale : h[j] & 0xffffu;
+                rr += rel;
+            }
+        }
+        for (; c < nchunk; ++c) {
+            const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
+            below[((int64_t)c * nb + d) * qpad + q] = make_uint2(ra, rr);
+            const uint32_t rel = rel_scale ? h / rel_scale : h >> 16;
+            ra += rel_scale ? h - rel * rel_scale : h & 0xffffu;
             rr += rel;
         }
+        // agent-scope store (sc1: written through this XCD's L2): the totals are the one thing another block of this launch reads
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(tot + (int64_t)d * qpad + q), (unsigned long long)ra | ((unsigned long long)rr << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (; c < nchunk; ++c) {
-        const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
-        below[((int64_t)c * nb + d) * qpad + q] = make_uint2(ra, rr);
-        const uint32_t rel = rel_scale ? h / rel_scale : h >> 16;
-        ra += rel_scale ? h - rel * rel_scale : h & 0xffffu;
-        rr += rel;
+    if (!tickets) return;
+    // hand-off without fences (an agent-scope release writes back the whole L2 of the XCD -- with 84 MB of `below` in flight that
+    // made this kernel 22 -> 152 us): the totals go out as agent-scope stores, every wave waits for their acknowledgement
+    // (vmcnt(0)) before the barrier, then one thread takes the tile's ticket; the block that draws the last ticket reads the
+    // totals with agent-scope loads, which do not hit in a stale L1 / L2 line.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.y - 1;
     }
-    tot[(int64_t)d * qpad + q] = make_uint2(ra, rr);
+    __syncthreads();
+    if (!last) return;
+    auto tot_at = [&](int dd) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(tot + (int64_t)dd * qpad + q), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    // 64 queries, the bucket axis split over the 4 waves: quarter sums, prefixed through LDS, then the exclusive prefixes
+    const int nbq = (nb + 3) / 4;
+    const int d0 = wq * nbq, d1 = (d0 + nbq < nb) ? d0 + nbq : nb;
+    uint32_t sa = 0, sr = 0;
+    for (int dd = d0; dd < d1; dd += 8) {
+        uint2 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = dd + j < d1 ? tot_at(dd + j) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa += t[j].x; sr += t[j].y; }
+    }
+    part[wq][lane] = make_uint2(sa, sr);
+    __syncthreads();
+    uint32_t ra = 0, rr = 0, tr = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint2 pw = part[w][lane];
+        if (w < wq) { ra += pw.x; rr += pw.y; }
+        tr += pw.y;
+    }
+    for (int dd = d0; dd < d1; dd += 8) {
+        uint2 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = dd + j < d1 ? tot_at(dd + j) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (dd + j < d1) {
+                dpre[(int64_t)(dd + j) * qpad + q] = make_uint2(ra, rr);
+                ra += t[j].x;
+                rr += t[j].y;
+            }
+        }
+    }
+    if (wq == 0) {
+        nrel_ws[q] = tr;
+        if (q < Q) atomicMax(nrel_max, tr);
+    }
 }
 
 //   dpre[d][q] = rank offset of bucket d from outside this shard's bucket d: all lower buckets
 //                (locally: exclusive prefix of tot; sharded: the caller's base_all/base_rel)
-//   cap[q]     = min(n_rel, k)
+//   nrel_ws[q] = relevant items of query q over all shards (pass 2 caps at min(nrel, k) itself), cap_out[q] = min(nrel, k)
 __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot, int Q, int qpad, int nb,
                                                    const uint32_t* __restrict__ base_all,
                                                    const uint32_t* __restrict__ base_rel,
@@ -205,8 +269,8 @@ __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot
     if (cap_ws && wq == 0) {
         const uint32_t nrel = nrel_total ? (qok ? nrel_total[q] : 0u) : tr;
         const uint32_t cap = (kcap > 0 && (uint64_t)kcap < (uint64_t)nrel) ? (uint32_t)kcap : nrel;
-        cap_ws[q] = cap;
-        if (qok) cap_out[q] = (int32_t)cap;
+        cap_ws[q] = nrel;
+        if (qok && cap_out) cap_out[q] = (int32_t)cap;
         if (qok && nrel_max) atomicMax(nrel_max, nrel);
     }
     (void)ta;
@@ -422,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
 template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                  const uint32_t* __restrict__ nrel_max, int rank_bits) {
+                                                  const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap) {
     using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using SG = SlotGeom<S>;
@@ -465,7 +529,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
             cnt[e] = pack(pb[at], pd[at]);
         }
     }
-    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
+    const uint32_t cap = CAPPED ? min(cap_ws[q], kcap) : 0u;      // cap_ws[q] = relevant items of query q
     const uint32_t rmask = P32 ? (1u << rank_bits) - 1u : 0xffffffffu;
 
     QueryRegs<W, LW, TERN> qr;
@@ -845,7 +909,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
 template <int NMC, int NML, int NW, bool P32, bool CAPPED>
 __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                        const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                       const uint32_t* __restrict__ nrel_max, int rank_bits) {
+                                                       const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap) {
     using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
     constexpr int NM = NMC + NML, CW = (int)(sizeof(CT) / 4);
     using ST = MfmaStage<NM, NW>;
@@ -879,7 +943,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
     const bool valid = q < a.Q;
     const int cbase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)reinterpret_cast<uint32_t*>(cnt);
     const int cinit = (P32 ? cbase : (cbase >> 1)) + ql * 4 + (valid ? 32 * a.K : 0);
-    const uint32_t cap = CAPPED ? cap_ws[q] : 0u;
+    const uint32_t cap = CAPPED ? min(cap_ws[q], kcap) : 0u;      // cap_ws[q] = relevant items of query q
     const uint32_t rmask = P32 ? (1u << rank_bits) - 1u : 0xffffffffu;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
@@ -1023,53 +1087,92 @@ __global__ __launch_bounds__(64) void k_shard_offsets(const uint32_t* __restrict
     if (lane == 0) nrel_total[q] = carry_r;
 }
 
-__global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
-                                                   double* __restrict__ ap_sum) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= Q) return;
+// Sum of a query's per-chunk credits.  A block takes 64 queries; its 4 waves take a quarter of the chunks each (all loads of a
+// thread are issued together: one dependent load per chunk was a 13 us chain of misses for 32 chunks) and the quarters are added
+// in a fixed order -- the same order in the sharded and the unsharded reduction, whatever the grid.
+__device__ __forceinline__ double ap_chunk_sum(const float* __restrict__ ap_part, int qpad, int nchunk, int q, double (*quarter)[64]) {
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int per = (nchunk + 3) / 4;
+    const int c0 = wq * per, c1 = (c0 + per < nchunk) ? c0 + per : nchunk;
     double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += (double)ap_part[(int64_t)c * qpad + q];
-    ap_sum[q] = s;
+    for (int c = c0; c < c1; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = c + j < c1 ? ap_part[(int64_t)(c + j) * qpad + q] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c + j < c1) s += (double)v[j];
+    }
+    quarter[wq][lane] = s;
+    __syncthreads();
+    return ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
 }
 
-// k_ap_reduce + k_map_finalize in one launch (unsharded evaluation): every block also leaves the sum of ap/cap over its 256
+// nrel_ws != null (unsharded call): cap_out[q] = min(nrel_ws[q], kcap) is written here; else the caller's cap_out is read.
+// grid = qpad / 64 blocks of 256 threads.
+__global__ __launch_bounds__(256) void k_ap_reduce(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
+                                                   double* __restrict__ ap_sum, const uint32_t* __restrict__ nrel_ws, uint32_t kcap,
+                                                   int32_t* __restrict__ cap_out) {
+    __shared__ double quarter[4][64];
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63);
+    const double s = ap_chunk_sum(ap_part, qpad, nchunk, q, quarter);
+    if (threadIdx.x >= 64 || q >= Q) return;
+    ap_sum[q] = s;
+    if (nrel_ws) cap_out[q] = (int32_t)min(nrel_ws[q], kcap);
+}
+
+// k_ap_reduce + k_map_finalize in one launch (unsharded evaluation): every block also leaves the sum of ap/cap over its 64
 // queries in part[], takes a ticket, and the block that draws the last ticket adds the partials IN BLOCK ORDER (deterministic)
-// into the mean.  Hand-off per the gfx950 rule: plain stores, vmcnt(0), one agent-scope release before the ticket, one
-// agent-scope acquire in the last block before it reads the other blocks' partials; the ticket word is zeroed by the
-// hipMemsetAsync ahead of the launch.  (One block doing all of it was tried: 40 us -- a single block cannot pull 1 MB fast.)
+// into the mean.  Hand-off as in k_scan_below: the partial goes out as an agent-scope store, vmcnt(0), then the ticket; the last
+// block reads the partials with agent-scope loads, one per thread (a thread walking them was a chain of 20 dependent misses);
+// no fence: a release would write back the XCD's whole L2.  The ticket word is zeroed by
+// xmh_hamming_hist and put back to zero by the last block, so several evaluations can follow one pass 1.
+// (One block doing all of it was tried: 40 us -- a single block cannot pull 1 MB fast.)
 __global__ __launch_bounds__(256) void k_ap_reduce_map(const float* __restrict__ ap_part, int Q, int qpad, int nchunk,
-                                                       const int32_t* __restrict__ cap, double* __restrict__ ap_sum,
-                                                       double* __restrict__ part, uint32_t* __restrict__ ticket,
+                                                       const uint32_t* __restrict__ nrel_ws, uint32_t kcap, int32_t* __restrict__ cap_out,
+                                                       double* __restrict__ ap_sum, double* __restrict__ part, uint32_t* __restrict__ ticket,
                                                        double* __restrict__ map_out) {
-    __shared__ double red[256];
+    __shared__ double quarter[4][64];
+    __shared__ double red[64];
     __shared__ int last;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    double term = 0.0;
-    if (q < Q) {
-        double s = 0.0;
-        for (int c = 0; c < nchunk; ++c) s += (double)ap_part[(int64_t)c * qpad + q];
-        ap_sum[q] = s;
-        term = s / (double)cap[q];                                   // cap == 0 -> NaN (0/0), like the reference
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 64 + lane;
+    const double s = ap_chunk_sum(ap_part, qpad, nchunk, q, quarter);
+    if (threadIdx.x < 64) {
+        double term = 0.0;
+        if (q < Q) {
+            const int32_t cap = (int32_t)min(nrel_ws[q], kcap);
+            ap_sum[q] = s;
+            cap_out[q] = cap;
+            term = s / (double)cap;                                  // cap == 0 -> NaN (0/0), like the reference
+        }
+        red[lane] = term;
     }
-    red[threadIdx.x] = term;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        part[blockIdx.x] = red[0];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        double b = 0.0;
+        for (int j = 0; j < 64; ++j) b += red[j];                    // in query order
+        __hip_atomic_store(&part[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = t == gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            double m = 0.0;
-            for (unsigned b = 0; b < gridDim.x; ++b) m += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            map_out[0] = m / (double)Q;
+    }
+    __syncthreads();
+    if (!last) return;
+    double m = 0.0;                                                  // <= 4096 blocks: 16 rounds of 256 parallel loads, added in block order
+    for (unsigned b0 = 0; b0 < gridDim.x; b0 += 256) {
+        const unsigned b = b0 + threadIdx.x;
+        __syncthreads();
+        reinterpret_cast<double*>(quarter)[threadIdx.x] = b < gridDim.x ? __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned n = gridDim.x - b0 < 256u ? gridDim.x - b0 : 256u;
+            for (unsigned j = 0; j < n; ++j) m += reinterpret_cast<double*>(quarter)[j];
         }
+    }
+    if (threadIdx.x == 0) {
+        map_out[0] = m / (double)Q;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1113,7 +1216,7 @@ constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
 
 struct WsLayout {
-    size_t chunk_hist, below, tot, dpre, cap, gate, ap_part, pair_cache, gimg, qimg32, total;
+    size_t chunk_hist, below, tot, dpre, cap, tick, gate, ap_part, pair_cache, gimg, qimg32, total;
 };
 
 // the MFMA-evaluated pass 1 (k_scan_hist_m): binary codes of 33..64 bits, i.e. where the pair cache hands pass 2 the evaluated
@@ -1162,6 +1265,7 @@ WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes, int64_t R = 0, bo
     L.tot = take((size_t)p.nbuckets * p.qpad * 8);
     L.dpre = take((size_t)p.nbuckets * p.qpad * 8);
     L.cap = take((size_t)p.qpad * 4);
+    L.tick = take((size_t)p.nqtile * 4);     // k_scan_below tickets, one per 64-query tile; ends where `gate` starts: one memset clears both
     L.gate = take(256 + 8 * 4096);           // [0]: nrel_max gate word, [1]: finalize ticket, +256: per-block partial sums (<= 4096 blocks)
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
     L.pair_cache = take(cache_bytes);
@@ -1371,6 +1475,8 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     hipStream_t st = xmh::as_stream(stream);
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool use_mfma = mfma_plan && LW <= 4 && lane_order_ok(st);
+    // the tile tickets of k_scan_below, the nrel_max gate word and the finalize ticket of the evaluation calls on this workspace
+    XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // whole 256-byte units: one fill kernel
     if (use_mfma) {
         rc = mfma_hist(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist,
                        cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st);
@@ -1410,7 +1516,9 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelScale : 0u, below, tot);
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelScale : 0u, below, tot,
+                       reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
+                       reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate));
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");
     if (hist_all || hist_rel) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
@@ -1450,13 +1558,19 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // packed 32-bit counters apply to a single shard when rank fits rank_bits and the largest relevant count fits the rest
     int rank_bits = 0;
     if (!base_all && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
-        while ((1ll << rank_bits) < R + 2) ++rank_bits;
+        // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
+        // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
+        const int64_t rank_max = (mfma_plan && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
+        while ((1ll << rank_bits) < rank_max) ++rank_bits;
         if (rank_bits > 24) rank_bits = 0;
     }
-    XMH_HIP(hipMemsetAsync(nrel_max, 0, 8, st));                     // gate word + the finalize ticket next to it
-    hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
-                       base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, rank_bits ? nrel_max : (uint32_t*)nullptr);
-    XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
+    // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
+    if (base_all) {
+        hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
+                           base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
+    }
+    const uint32_t kcap = k > 0 && k < (int64_t)0xffffffffll ? (uint32_t)k : 0xffffffffu;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool capped = k > 0;
     const bool masked = !lane_order_ok(st);
@@ -1484,7 +1598,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
                     if (r3) return r3;
                     as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
                     hipLaunchKernelGGL(kc, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws,
-                                       ap_part, (const uint32_t*)nrel_max, rank_bits);
+                                       ap_part, (const uint32_t*)nrel_max, rank_bits, kcap);
                     return (int)XMH_OK;
                 }
             }
@@ -1492,7 +1606,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rank_bits);
+                               (const uint32_t*)nrel_max, rank_bits, kcap);
             return (int)XMH_OK;
         });
     };
@@ -1509,7 +1623,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             if (r2) return r2;
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
             hipLaunchKernelGGL(kern, grid, dim3(64 * kMfmaWaves), lds, st, ma, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rank_bits);
+                               (const uint32_t*)nrel_max, rank_bits, kcap);
             return (int)XMH_OK;
         };
         auto by_shape = [&](auto p32_c) {
@@ -1540,14 +1654,15 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     if (rc) return rc;
     XMH_LAUNCH_CHECK("xmh_hamming_ap");
     }
-    const unsigned nred = (unsigned)xmh::ceil_div(Q, 256);
+    const unsigned nred = (unsigned)xmh::ceil_div(Q, 64);
     if (map_out && nred <= 4096) {                                   // reduce + mean in one launch (last-ticket block finalises)
-        hipLaunchKernelGGL(k_ap_reduce_map, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, (const int32_t*)cap, ap_sum,
-                           reinterpret_cast<double*>(base + L.gate + 256), nrel_max + 1, map_out);
+        hipLaunchKernelGGL(k_ap_reduce_map, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, (const uint32_t*)cap_ws, kcap,
+                           cap, ap_sum, reinterpret_cast<double*>(base + L.gate + 256), nrel_max + 1, map_out);
         XMH_LAUNCH_CHECK("xmh_hamming_map reduce+finalize");
         return XMH_OK;
     }
-    hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum);
+    hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum,
+                       base_all ? (const uint32_t*)nullptr : (const uint32_t*)cap_ws, kcap, cap);
     XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
     if (map_out) {
         hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);

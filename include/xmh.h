@@ -112,7 +112,9 @@ int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* 
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 
 /* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).
- * qzero / rzero NULL => binary codes. */
+ * qzero / rzero NULL => binary codes.
+ * Also leaves in the workspace what a single-shard pass 2 needs from the totals (per-bucket rank offsets, the relevant count
+ * of every query), so that xmh_hamming_ap / xmh_hamming_map with NULL offsets launch pass 2 and the reduction only. */
 int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,
                      const uint32_t* rbits, const uint32_t* rzero, const uint32_t* rlab,
                      int64_t Q, int64_t R, int K, int C, void* ws, size_t ws_bytes,
@@ -121,7 +123,9 @@ int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_
 /* pass 2 (needs the workspace pass 1 filled for the same inputs).
  *   base_all / base_rel [Q][nbuckets] u32 and nrel_total [Q] u32: rank offsets contributed by items
  *   OUTSIDE this shard (all lower buckets anywhere + same bucket on lower-ranked shards) and the global
- *   relevant count; all three NULL => single shard, derived locally.
+ *   relevant count; all three NULL => single shard, the offsets xmh_hamming_hist left in the workspace are used.
+ *   (A call WITH offsets overwrites them: run xmh_hamming_hist again before a single-shard evaluation on that workspace.)
+ *   Any number of evaluations (different k) may follow one xmh_hamming_hist.
  *   k <= 0 means "all" (k = None in the reference).
  *   ap_sum[Q] (f64) = sum over this shard's relevant items of ordinal/rank, for ordinal <= cap;
  *   cap[Q] (i32)    = min(n_rel, k)  (the divisor, common/calc_utils.py:81). */

@@ -326,19 +326,20 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
 
 def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
     """XMH_SCAN_MFMA_AP=1 (pass 2 evaluated on the MFMA, no pair cache) against the default path: same ap sums, caps and capped
-    sums bit for bit."""
-    Q, R, K, C = 150, 9001, 64, 80
-    qB, rB, qL, rL = _synth(Q, R, K, C, seed=11, p=0.06)
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("XMH_SCAN_MFMA_AP", flag)
-        scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
-        scan.histograms(False)
-        ap, cap = scan.ap_sums(None)
-        ap9, cap9 = scan.ap_sums(9)
-        outs.append((ap.clone(), cap.clone(), ap9.clone(), cap9.clone()))
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    sums bit for bit -- including ragged last batches whose padding items the MFMA pass also counts (R = 2 and R = 8157 are
+    the shapes where the packed rank field used to wrap)."""
+    for (Q, R, K, C, p, k) in ((150, 9001, 64, 80, 0.06, 9), (16, 2, 40, 64, 0.5, 1), (64, 8157, 48, 32, 0.5, 85), (127, 62, 64, 1, 0.01, 199)):
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=11, p=p)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("XMH_SCAN_MFMA_AP", flag)
+            scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+            scan.histograms(False)
+            ap, cap = scan.ap_sums(None)
+            apk, capk = scan.ap_sums(k)
+            outs.append((ap.clone(), cap.clone(), apk.clone(), capk.clone()))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (Q, R, K, C)
 
 
 def test_calc_map_k_label_cache_sees_in_place_edits(cu):

@@ -9,8 +9,8 @@ python - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_scan/t/**/s_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# find the timed steps: sequences starting with k_scan_hist_s
-idx = [i for i, r in enumerate(rows) if "k_scan_hist_s" in r["Kernel_Name"]]
+# the timed steps: from one pass-1 kernel to the next
+idx = [i for i, r in enumerate(rows) if "k_scan_hist_" in r["Kernel_Name"]]
 i0 = idx[4]                                  # a steady-state step
 i1 = idx[5]
 prev_end = None
