@@ -724,8 +724,11 @@ __device__ __forceinline__ void expand_query_piece(const uint32_t* __restrict__ 
 template <int NMC, int NML>
 __global__ __launch_bounds__(256) void k_scan_expand(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int K,
                                                      uint4* __restrict__ out, int64_t npieces, unsigned gblocks, const uint32_t* __restrict__ qbits,
-                                                     const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces) {
+                                                     const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces,
+                                                     uint32_t* __restrict__ ctl, int ctl_words) {
     constexpr int NM = NMC + NML;
+    if (blockIdx.x == gridDim.x - 1)                               // the control words of this call (tile tickets, gate, finalize ticket):
+        for (int e = threadIdx.x; e < ctl_words; e += 256) ctl[e] = 0u;   // this launch precedes their users, so no memset launch
     if (blockIdx.x >= gblocks) {
         const int64_t qp = (int64_t)(blockIdx.x - gblocks) * 256 + threadIdx.x;
         if (qp < qpieces) expand_query_piece<NMC, NML>(qbits, qlab, Q, W, LW, K, qout, qp);
@@ -1415,7 +1418,7 @@ int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbi
     const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NM * 64, qpieces = (p.qpad / 16) * NM * 64;
     const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
     hipLaunchKernelGGL((k_scan_expand<NMC, NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
-                       q32, qpieces);
+                       q32, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
     XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
     MfmaArgs a{gimg, q32, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * NW)), (int)p.nbuckets, (int)p.qpad};
     const size_t lds = (size_t)NW * p.nbuckets * 16 * 4 + 2 * 4 * NM * 1024;
@@ -1476,7 +1479,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool use_mfma = mfma_plan && LW <= 4 && lane_order_ok(st);
     // the tile tickets of k_scan_below, the nrel_max gate word and the finalize ticket of the evaluation calls on this workspace
-    XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // whole 256-byte units: one fill kernel
+    if (!use_mfma) XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // (the MFMA path clears them in k_scan_expand)
     if (use_mfma) {
         rc = mfma_hist(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist,
                        cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st);
