@@ -450,6 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
 constexpr int kCandCap = 8192;        // candidates kept per query (keys of 8 B)
 constexpr int kSampleBlocks = 256;
 constexpr int kSamplePerBlock = 1024;
+constexpr int kFoldPickQ = 16;        // up to this many queries the last sample block picks the thresholds (no pick launch)
 
 struct FastWs {
     uint32_t* hist;            // [Q][nb]  sample histogram
@@ -467,12 +468,68 @@ __device__ __forceinline__ int dist_words(const Rec<W>& r, const uint32_t* __res
     return acc;
 }
 
-// sample histogram: block b reads kSamplePerBlock consecutive rows starting at b*stride (whole gallery if small)
+// t_est = smallest distance whose sampled cumulative count reaches `target` (nb-1 if it never does), by one wave: lanes take
+// 64 consecutive buckets, wave prefix sum, first lane over the target wins (a thread per query walking the buckets one
+// dependent load at a time took 13 us -- a quarter of the Q=1 filter pass).  The row is left ZEROED for the next call on this
+// workspace.  COHERENT: the counts were added by other blocks of the SAME launch (agent-scope loads).
+template <bool COHERENT>
+__device__ __forceinline__ int pick_row(uint32_t* __restrict__ row, int nb, uint32_t target, int lane) {
+    uint32_t carry = 0;
+    int t = nb - 1;
+    bool found = false;
+    for (int base = 0; base < nb; base += 512) {                    // 8 segments of 64 buckets per round, their loads issued together
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = base + j * 64 + lane;
+            v[j] = 0u;
+            if (d < nb) v[j] = COHERENT ? __hip_atomic_load(row + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[d];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = base + j * 64 + lane;
+            if (d < nb) row[d] = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d0 = base + j * 64;
+            if (found || d0 >= nb) continue;
+            uint32_t s = v[j];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(s, o, 64);
+                if (lane >= o) s += u;
+            }
+            const unsigned long long over = __ballot(d0 + lane < nb && carry + s >= target);
+            if (over) {
+                t = d0 + __ffsll((long long)over) - 1;
+                found = true;
+            }
+            carry += __shfl(s, 63, 64);
+        }
+    }
+    return t;
+}
+
+// Control words at the head of the fast-path workspace.  Contract (xmh_topk_ws_init / xmh_hamming_topk_prepared): zero on entry,
+// zero again on exit, like the sample histogram -- every kernel that consumes one of them puts it back.
+struct TopkCtl {
+    uint32_t sample_ticket;
+    uint32_t filter_ticket;
+    uint32_t robust_ticket;
+};
+
+// sample histogram: block b reads kSamplePerBlock consecutive rows starting at b*stride (whole gallery if small).
+// FOLD (few queries): the block that finishes last (ticket) also picks the thresholds and resets the per-call state, so the
+// call needs neither a memset nor a pick launch.
 template <int W>
 __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
                                                           int Q, int64_t R, int nb, int64_t stride, int per_block,
-                                                          uint32_t* __restrict__ hist) {
+                                                          uint32_t* __restrict__ hist, int fold, uint32_t target,
+                                                          TopkCtl* __restrict__ ctl, uint32_t* __restrict__ t_est,
+                                                          uint32_t* __restrict__ cnt, int* __restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];     // [qg][nb]
+    __shared__ int last;
     constexpr int QG = 16;
     const int64_t lo = (int64_t)blockIdx.x * stride;
     const int64_t hi = (lo + per_block < R) ? lo + per_block : R;
@@ -480,44 +537,59 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
         const int nq = (Q - q0 < QG) ? Q - q0 : QG;
         for (int e = threadIdx.x; e < nq * nb; e += kThreads) sh[e] = 0u;
         __syncthreads();
-        for (int64_t it = lo + threadIdx.x; it < hi; it += kThreads) {
-            Rec<W> r;
-            load_rec<W>(r, rbits, it, true);
-            for (int q = 0; q < nq; ++q) atomicAdd(&sh[q * nb + dist_words<W>(r, qbits + (int64_t)(q0 + q) * W)], 1u);
+        constexpr int NB = W <= 8 ? 4 : (W <= 16 ? 2 : 1);          // records in flight per thread (one dependent miss per record otherwise)
+        for (int64_t it0 = lo + threadIdx.x; it0 < hi; it0 += (int64_t)NB * kThreads) {
+            Rec<W> r[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int64_t it = it0 + (int64_t)j * kThreads;
+                load_rec<W>(r[j], rbits, it < hi ? it : lo, true);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (it0 + (int64_t)j * kThreads < hi)
+                    for (int q = 0; q < nq; ++q) atomicAdd(&sh[q * nb + dist_words<W>(r[j], qbits + (int64_t)(q0 + q) * W)], 1u);
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nq * nb; e += kThreads)
             if (sh[e]) atomicAdd(&hist[(int64_t)q0 * nb + e], sh[e]);
         __syncthreads();
     }
+    if (!fold) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this block's adds have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&ctl->sample_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    const int lane = lane_id();
+    for (int q = wave_id(); q < Q; q += kWaves) {
+        const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane);
+        if (lane == 0) {
+            t_est[q] = (uint32_t)t;
+            cnt[q] = 0u;
+        }
+    }
+    if (threadIdx.x == 0) {
+        *fail = 0;
+        __hip_atomic_store(&ctl->sample_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// t_est[q] = smallest distance whose sampled cumulative count reaches `target` (nb-1 if it never does).
-// One wave per query: lanes take 64 consecutive buckets, wave prefix sum, first lane over the target wins (a thread per
-// query walking the buckets one dependent load at a time took 13 us -- a quarter of the Q=1 filter pass).
-__global__ __launch_bounds__(64) void k_topk_pick(const uint32_t* __restrict__ hist, int Q, int nb, uint32_t target,
-                                                  uint32_t* __restrict__ t_est) {
+// many queries: one wave per query after the sample launch; also resets the per-call state (candidate counts, fail flag)
+__global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, int Q, int nb, uint32_t target,
+                                                  uint32_t* __restrict__ t_est, uint32_t* __restrict__ cnt, int* __restrict__ fail) {
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= Q) return;
-    uint32_t carry = 0;
-    int t = nb - 1;
-    for (int d0 = 0; d0 < nb; d0 += 64) {
-        const int d = d0 + lane;
-        const uint32_t v = d < nb ? hist[(int64_t)q * nb + d] : 0u;
-        uint32_t s = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(s, o, 64);
-            if (lane >= o) s += u;
-        }
-        const unsigned long long over = __ballot(d < nb && carry + s >= target);
-        if (over) {
-            t = d0 + __ffsll((long long)over) - 1;
-            break;
-        }
-        carry += __shfl(s, 63, 64);
+    const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane);
+    if (lane == 0) {
+        t_est[q] = (uint32_t)t;
+        cnt[q] = 0u;
+        if (q == 0) *fail = 0;
     }
-    if (lane == 0) t_est[q] = (uint32_t)t;
 }
 
 // rare path of the filter, kept out of line so the streaming loop stays small: wave-aggregated append
@@ -609,7 +681,41 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
     }
 }
 
-// one block per query: verify, bitonic-sort the candidate keys, write the first k
+// block-wide search: first bin b of hist[0..n) whose cumulative count reaches `need` (1 <= need <= total) -> out[0] = b,
+// out[1] = count below b.  Every thread sums a contiguous segment, wave scan, cross-wave offsets through LDS, the owning
+// thread walks its segment (one wave stepping through 64 bins at a time was 16 dependent rounds for the 1024 index bins).
+__device__ __forceinline__ void block_find(const uint32_t* hist, int n, uint32_t need, int* out, uint32_t* wtot) {
+    const int per = (n + kThreads - 1) / kThreads;
+    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t mine = 0;
+    for (int d = lo; d < hi; ++d) mine += hist[d];
+    uint32_t incl = mine;
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wave_id()] = incl;
+    __syncthreads();
+    uint32_t excl = incl - mine;
+    for (int w = 0; w < wave_id(); ++w) excl += wtot[w];
+    if (excl < need && need <= excl + mine) {                       // exactly one thread
+        uint32_t run = excl;
+        for (int d = lo; d < hi; ++d) {
+            const uint32_t h = hist[d];
+            if (run + h >= need) {
+                out[0] = d;
+                out[1] = (int)run;
+                break;
+            }
+            run += h;
+        }
+    }
+    __syncthreads();
+}
+
+// one block per query: verify the candidate list, radix-select its k smallest (distance, index) keys, write them in order
 __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ cnt,
                                                           int64_t R, int k, int nb, int64_t base_index, uint16_t* __restrict__ out_d,
                                                           int32_t* __restrict__ out_i, int* __restrict__ fail) {
@@ -618,8 +724,12 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     unsigned long long* surv = key + kCandCap;
     uint32_t* hist = reinterpret_cast<uint32_t*>(surv + 1024);
     const int nh = nb > 2048 ? nb : 2048;                       // >= 8 KB: reused as a list of 1024 keys
-    int* sc = reinterpret_cast<int*>(hist + nh);               // [0] d*, [1] count below d*, [2] bin*, [3] count below bin*, [4] survivors, [5] keys in the last bin
+    int* sc = reinterpret_cast<int*>(hist + nh);               // [0] d*, [1] count below d*, [2] bin*, [3] count below bin*, [4] survivors, [5] keys in the last bin, [8..11] wave totals
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(sc + 8);
     const int q = blockIdx.x;
+    // the first 512 keys are requested together with the count (lists are a few hundred keys: one miss latency instead of two)
+    const unsigned long long* cq = cand + (int64_t)q * kCandCap;
+    const unsigned long long k0 = cq[threadIdx.x], k1 = cq[threadIdx.x + kThreads];
     const uint32_t n = cnt[q];
     const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
     if (n > (uint32_t)kCandCap || n < want) {
@@ -630,35 +740,15 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     // Radix selection instead of sorting all candidates: a distance histogram finds the bucket d* where the k-th result lies;
     // everything below it survives, inside it a histogram over the top 10 index bits finds the bin, and only the (few)
     // candidates of that last bin are ranked against each other.  The <= k survivors are then placed by counting.
-    for (int p = threadIdx.x; p < (int)n; p += kThreads) key[p] = cand[(int64_t)q * kCandCap + p];
-    for (int e = threadIdx.x; e < nh; e += kThreads) hist[e] = 0u;
+    key[threadIdx.x] = k0;
+    key[threadIdx.x + kThreads] = k1;
+    for (int p = threadIdx.x + 2 * kThreads; p < (int)n; p += kThreads) key[p] = cq[p];
+    for (int e = threadIdx.x; e < nb; e += kThreads) hist[e] = 0u;
     if (threadIdx.x == 0) sc[4] = 0;
     __syncthreads();
     for (int p = threadIdx.x; p < (int)n; p += kThreads) atomicAdd(&hist[(uint32_t)(key[p] >> 32)], 1u);
     __syncthreads();
-    if (threadIdx.x < 64) {                                     // first bucket where the cumulative count reaches kk
-        const int lane = threadIdx.x;
-        uint32_t carry = 0;
-        for (int d0 = 0; d0 < nb; d0 += 64) {
-            const int d = d0 + lane;
-            uint32_t sfx = d < nb ? hist[d] : 0u;
-            const uint32_t own = sfx;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(sfx, o, 64);
-                if (lane >= o) sfx += u;
-            }
-            const unsigned long long over = __ballot(d < nb && carry + sfx >= (uint32_t)kk);
-            if (over) {
-                const int win = __ffsll((long long)over) - 1;
-                const uint32_t below = carry + __shfl(sfx - own, win, 64);
-                if (lane == 0) { sc[0] = d0 + win; sc[1] = (int)below; }
-                break;
-            }
-            carry += __shfl(sfx, 63, 64);
-        }
-    }
-    __syncthreads();
+    block_find(hist, nb, (uint32_t)kk, sc, wtot);               // first bucket where the cumulative count reaches kk
     const uint32_t dstar = (uint32_t)sc[0];
     const int need = kk - sc[1];                               // results still to come from bucket d*
     int shift = 0;
@@ -668,28 +758,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     for (int p = threadIdx.x; p < (int)n; p += kThreads)
         if ((uint32_t)(key[p] >> 32) == dstar) atomicAdd(&hist[(uint32_t)key[p] >> shift], 1u);
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        uint32_t carry = 0;
-        for (int d0 = 0; d0 < 1024; d0 += 64) {
-            uint32_t sfx = hist[d0 + lane];
-            const uint32_t own = sfx;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(sfx, o, 64);
-                if (lane >= o) sfx += u;
-            }
-            const unsigned long long over = __ballot(carry + sfx >= (uint32_t)need);
-            if (over) {
-                const int win = __ffsll((long long)over) - 1;
-                const uint32_t below = carry + __shfl(sfx - own, win, 64);
-                if (lane == 0) { sc[2] = d0 + win; sc[3] = (int)below; }
-                break;
-            }
-            carry += __shfl(sfx, 63, 64);
-        }
-    }
-    __syncthreads();
+    block_find(hist, 1024, (uint32_t)need, sc + 2, wtot);
     const uint32_t bstar = (uint32_t)sc[2];
     const int need2 = need - sc[3];                            // results still to come from (d*, bin*)
     unsigned long long* grp = reinterpret_cast<unsigned long long*>(hist);      // the histogram is done: its space lists the last bin
@@ -734,7 +803,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
 struct TopkPlan {
     int W, ipt, tile, nblocks, tiles_per_block, nqg;
     Layout L, Lm;
-    size_t robust_bytes, off_hist, off_test, off_cnt, off_fail, off_cand;
+    size_t robust_bytes, off_ctl, off_hist, off_test, off_cnt, off_fail, off_cand;
     size_t ws_bytes;
 };
 
@@ -775,7 +844,8 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
         o += (bytes + 255) & ~(size_t)255;
         return at;
     };
-    p->off_hist = take((size_t)Q * (K + 1) * 4);      // hist, t_est, cnt, fail are contiguous: one memset clears them
+    p->off_ctl = take(256);                           // ctl, hist, t_est, cnt, fail are contiguous: one memset clears them
+    p->off_hist = take((size_t)Q * (K + 1) * 4);
     p->off_test = take((size_t)Q * 4);
     p->off_cnt = take((size_t)Q * 4);
     p->off_fail = take(256);
@@ -807,9 +877,19 @@ extern "C" size_t xmh_topk_ws_bytes(int64_t Q, int64_t R, int K, int k) {
     return p.ws_bytes;
 }
 
-extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
-                                int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
-                                xmh_stream_t stream) {
+extern "C" int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_bytes, xmh_stream_t stream) {
+    TopkPlan p;
+    int rc = plan_topk(Q, R, K, k, &p);
+    if (rc) return rc;
+    if (!ws) return xmh::fail(XMH_EINVAL, "xmh_topk_ws_init: null workspace");
+    if (ws_bytes < p.ws_bytes) return xmh::fail(XMH_EINVAL, "xmh_topk_ws_init: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+    XMH_HIP(hipMemsetAsync(static_cast<char*>(ws) + p.off_ctl, 0, p.off_cand - p.off_ctl, xmh::as_stream(stream)));
+    return XMH_OK;
+}
+
+namespace {
+int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes,
+              uint16_t* dist, int32_t* idx, xmh_stream_t stream, bool prepared) {
     TopkPlan p;
     int rc = plan_topk(Q, R, K, k, &p);
     if (rc) return rc;
@@ -825,11 +905,15 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
     f.cnt = reinterpret_cast<uint32_t*>(wsb + p.off_cnt);
     f.fail = reinterpret_cast<int*>(wsb + p.off_fail);
     f.cand = reinterpret_cast<unsigned long long*>(wsb + p.off_cand);
+    TopkCtl* ctl = reinterpret_cast<TopkCtl*>(wsb + p.off_ctl);
     const bool robust_only = getenv("XMH_TOPK_ROBUST_ONLY") != nullptr;   // test hook: skip the fast path
     const int* gate = nullptr;
     if (!robust_only) {
         // ---- fast path: sample -> threshold -> filter -> select (all stream-ordered, no host sync) ----
-        XMH_HIP(hipMemsetAsync(wsb + p.off_hist, 0, p.off_cand - p.off_hist, st));
+        // The control words and the sample histogram are zero on entry and left zero on exit (each consumer puts its word back):
+        // a prepared workspace needs no memset launch.
+        if (!prepared) XMH_HIP(hipMemsetAsync(wsb + p.off_ctl, 0, p.off_cand - p.off_ctl, st));
+        const int fold_pick = Q <= kFoldPickQ;            // few queries: the last sample block picks the thresholds itself
         const int nb = K + 1;
         int sblocks = kSampleBlocks;
         int64_t stride = R / sblocks;
@@ -846,9 +930,9 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
 #define XMH_FAST(WW, II)                                                                                                   \
         {                                                                                                                  \
             hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
-                               per_block, f.hist);                                                                         \
-            hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, (const uint32_t*)f.hist, (int)Q, nb, \
-                               target, f.t_est);                                                                           \
+                               per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
+            if (!fold_pick)                                                                                                \
+                hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
             const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
             const int qmax = WW >= 64 ? 1 : (WW >= 32 ? 2 : (WW >= 16 ? 4 : 8));      /* query words live in VGPRs */     \
             const int qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));       \
@@ -920,4 +1004,15 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
     }
     XMH_LAUNCH_CHECK("xmh_hamming_topk merge");
     return XMH_OK;
+}
+}  // namespace
+
+extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws,
+                                size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
+    return topk_call(qbits, rbits, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, false);
+}
+
+extern "C" int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index,
+                                         void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
+    return topk_call(qbits, rbits, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, true);
 }

@@ -115,6 +115,8 @@ PROTOTYPES = {
     "xmh_quant_loss": (i32, [vp, i64, vp, vp]),
     "xmh_topk_ws_bytes": (sz, [i64, i64, i32, i32]),
     "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
+    "xmh_topk_ws_init": (i32, [i64, i64, i32, i32, vp, sz, vp]),
+    "xmh_hamming_topk_prepared": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -279,10 +279,25 @@ def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch
     return scan.map_all(k)[0]
 
 
-def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0):
+class TopkWorkspace:
+    """A prepared top-k workspace for one (Q, R, K, k) shape on one device: initialised once (xmh_topk_ws_init), then every call
+    through it leaves its control words clean for the next one -- a query loop over a fixed gallery pays no memset launch.
+    Use it from one stream at a time."""
+
+    def __init__(self, Q: int, R: int, K: int, k: int, device):
+        self.shape = (int(Q), int(R), int(K), int(k))
+        self.bytes = lib.xmh_topk_ws_bytes(*self.shape)
+        if self.bytes == 0:
+            check(lib.xmh_hamming_topk(None, None, Q, R, K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        check(lib.xmh_topk_ws_init(*self.shape, ptr(self.buf), self.bytes, current_stream()), "xmh_topk_ws_init")
+
+
+def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, workspace: Optional[TopkWorkspace] = None):
     """Exact top-k of every query over this gallery shard under (distance, index) order.
     Returns (dist int16-storage [Q,k] (uint16 bit pattern, 0xFFFF = unused slot), idx int32 [Q,k] global
-    indices = base_index + row, -1 = unused slot when the shard has fewer than k rows)."""
+    indices = base_index + row, -1 = unused slot when the shard has fewer than k rows).
+    ``workspace``: a TopkWorkspace of this shape (see there); without one a scratch workspace is allocated and cleared per call."""
     _require_cuda(q.bits, r.bits)
     if q.K != r.K:
         raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
@@ -291,6 +306,15 @@ def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0):
     q, r = widened(q), widened(r)
     Q, R = q.n, r.n
     dev = q.bits.device
+    if workspace is not None:
+        if workspace.shape != (Q, R, q.K, int(k)) or workspace.buf.device != dev:
+            raise ValueError("top-k workspace was prepared for %r on %s, call is %r on %s"
+                             % (workspace.shape, workspace.buf.device, (Q, R, q.K, int(k)), dev))
+        dist = torch.empty(Q, k, dtype=torch.int16, device=dev)
+        idx = torch.empty(Q, k, dtype=torch.int32, device=dev)
+        check(lib.xmh_hamming_topk_prepared(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(workspace.buf), workspace.bytes,
+                                            ptr(dist), ptr(idx), current_stream()), "xmh_hamming_topk_prepared")
+        return dist, idx
     need = lib.xmh_topk_ws_bytes(Q, R, q.K, k)
     if need == 0:
         check(lib.xmh_hamming_topk(None, None, Q, R, q.K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")

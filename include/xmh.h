@@ -159,6 +159,13 @@ size_t xmh_topk_ws_bytes(int64_t Q, int64_t R, int K, int k);
 int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
                      int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
                      xmh_stream_t stream);
+/* The same call on a PREPARED workspace: xmh_topk_ws_init zeroes the control words and the sample histogram at the head of the
+ * workspace once, every xmh_hamming_topk_prepared call on it (same Q, R, K, k; one stream at a time) finds them zero and leaves
+ * them zero, so a repeated query loop pays no memset launch.  xmh_hamming_topk == init + prepared call. */
+int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_bytes, xmh_stream_t stream);
+int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
+                              int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
+                              xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder primitives (a-9 .. a-12).  fp32 activations, token-major [B, L, D].  The Python model classes

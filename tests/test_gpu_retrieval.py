@@ -694,6 +694,30 @@ def test_topk_full_size_sample_path(xr):
     _topk_check(xr, 4, 1_500_000, 256, 10, seed=22)
 
 
+def test_topk_prepared_workspace_stays_clean_over_calls(xr):
+    """xmh_topk_ws_init once, then a query loop through xmh_hamming_topk_prepared: every call finds the control words and the sample
+    histogram zero and leaves them zero -- few queries (thresholds picked by the last sample block), many queries (pick kernel),
+    a duplicate-heavy gallery whose lists overflow (robust path recomputes), then ordinary queries again on the same workspace."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(31)
+    for (Q, R, K, k) in ((1, 600_000, 256, 100), (8, 400_000, 64, 50), (40, 300_000, 64, 10), (3, 5000, 128, 20)):
+        W = (K + 31) // 32
+        rb = rng.integers(0, 2**32, size=(R, W), dtype=np.uint32)
+        rdup = rb[rng.integers(0, 4, size=R)]                     # 4 distinct codes: every candidate list overflows
+        ws = xr.TopkWorkspace(Q, R, K, k, "cuda")
+        r = xr.PackedCodes(torch.from_numpy(rb.view(np.int32)).cuda(), None, K)
+        rd = xr.PackedCodes(torch.from_numpy(rdup.view(np.int32)).cuda(), None, K)
+        for rnd, (gal, gal_np) in enumerate(((r, rb), (r, rb), (rd, rdup), (r, rb), (rd, rdup), (r, rb))):
+            qb = rng.integers(0, 2**32, size=(Q, W), dtype=np.uint32)
+            q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+            d, i = xr.hamming_topk(q, gal, k, base_index=7 * rnd, workspace=ws)
+            wd, wi = co.topk(qb, gal_np, K + 1, k, 7 * rnd)
+            assert np.array_equal(i.cpu().numpy(), wi), (Q, R, K, k, rnd)
+            assert np.array_equal(d.cpu().numpy().view(np.uint16), wd), (Q, R, K, k, rnd)
+    with pytest.raises(ValueError):
+        xr.hamming_topk(q, r, k + 1, workspace=ws)
+
+
 def test_float_similarities_and_float_code_fallback(cu):
     """cosine / euclidean / calc_hammingDist / calc_map_k on un-quantised float inputs vs the goldens."""
     g = np.load(os.path.join(GOLDEN, "calc_utils_ternary_float.npz"))
