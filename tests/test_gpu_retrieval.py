@@ -342,6 +342,23 @@ def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
             assert torch.equal(x, y), (Q, R, K, C)
 
 
+def test_scan_many_evaluations_after_one_histogram_pass(xr):
+    """One xmh_hamming_hist, then several evaluations with different k on the same workspace: the offsets pass 1 left behind are
+    reused, the finalize ticket puts itself back to zero (a stale ticket would leave map_out unwritten), and a sharded-style
+    call with explicit offsets in between is followed by a fresh histogram pass as the header asks."""
+    orc = _orc()
+    Q, R, K, C = 130, 7001, 64, 20
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=5)
+    scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+    scan.histograms(False)
+    want = {k: float(orc.map_k(qB, rB, qL, rL, k=k, stable=True)) for k in (None, 7, 500)}
+    for k in (None, 7, None, 500, 7):
+        m, ap, cap = scan.map_all(k)
+        assert abs(float(m) - want[k]) < MAP_TOL, k
+        ap2, cap2 = scan.ap_sums(k)                                  # xmh_hamming_ap (no finalize) on the same tables
+        assert torch.equal(ap, ap2) and torch.equal(cap, cap2)
+
+
 def test_calc_map_k_label_cache_sees_in_place_edits(cu):
     orc = _orc()
     qB, rB, qL, rL = _synth(12, 900, 64, 10, seed=4)
