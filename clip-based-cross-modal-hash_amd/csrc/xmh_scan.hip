@@ -1559,8 +1559,12 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     hipStream_t st = xmh::as_stream(stream);
     uint32_t* nrel_max = reinterpret_cast<uint32_t*>(base + L.gate);
     // packed 32-bit counters apply to a single shard when rank fits rank_bits and the largest relevant count fits the rest
+    // Measured at Q 5000 x R 117 218, sparse relevance (the packed width applies), pass 2 packed / 64-bit: K=16 0.275 / 0.251 ms,
+    // K=32 0.278 / 0.253, K=64 0.199 / 0.195, K=128 0.274 / 0.286, K=256 0.347 / 0.412 -- packed counters pay from 65 bits on;
+    // below that only the 64-bit kernel is launched (and no gated launch returns at once); XMH_SCAN_PACK32_ALL=1 brings the packed
+    // kernels back for every length (tests).
     int rank_bits = 0;
-    if (!base_all && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
+    if (!base_all && (K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
         // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
         // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
         const int64_t rank_max = (mfma_plan && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;

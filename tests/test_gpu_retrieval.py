@@ -236,7 +236,12 @@ def test_scan_wide_counters_and_heavy_collisions(xr, cu, monkeypatch, Q, R, K, C
     rB = rB[torch.randint(0, 5, (R,), generator=torch.Generator().manual_seed(K))]      # 5 distinct gallery codes
     want = orc.map_k(qB, rB, qL, rL, stable=True)
     want7 = orc.map_k(qB, rB, qL, rL, 7, stable=True)
+    monkeypatch.setenv("XMH_SCAN_PACK32_ALL", "1")                 # packed counters at every length (default: from 65 bits on)
     packed = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))
+    packed7 = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), 7))
+    assert abs(packed7 - float(want7)) < MAP_TOL
+    monkeypatch.delenv("XMH_SCAN_PACK32_ALL")
+    assert abs(float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())) - float(want)) < MAP_TOL      # the default choice
     monkeypatch.setenv("XMH_SCAN_NO_PACK32", "1")
     wide = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))
     wide7 = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), 7))
@@ -394,10 +399,12 @@ def test_scan_fuzz_shapes_lengths_and_caps(cu, monkeypatch):
         qL[:, 0] = 1
         rL[0, 0] = 1
         k = None if case % 2 else int(rng.integers(1, 40))
+        monkeypatch.delenv("XMH_SCAN_NO_PACK32", raising=False)
+        monkeypatch.delenv("XMH_SCAN_PACK32_ALL", raising=False)
         if case % 5 == 4:
             monkeypatch.setenv("XMH_SCAN_NO_PACK32", "1")
-        else:
-            monkeypatch.delenv("XMH_SCAN_NO_PACK32", raising=False)
+        elif case % 5 in (1, 2):
+            monkeypatch.setenv("XMH_SCAN_PACK32_ALL", "1")           # the packed kernels at 64 bits and less (default: from 65 on)
         want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))
         got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), k))
         assert abs(got - want) < MAP_TOL, (case, Q, R, K, C, k, ternary)
