@@ -1298,7 +1298,8 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     // (K=64: 0.640 -> 0.624 ms, K=16: 0.502 -> 0.476), costs at 257 (K=256: 1.45 -> 1.54)
     // with the pair cache (binary codes of 33..64 bits) the passes are shorter and the tables weigh more: one set (0.543 -> 0.536 ms)
     const bool cache_shape = !ternary && K > 32 && K <= 64 && !(getenv("XMH_SCAN_CACHE_MB") && atoll(getenv("XMH_SCAN_CACHE_MB")) <= 0);
-    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 65 && !cache_shape ? 2 : 1);
+    // codes of 32 bits and less: three sets (Q 5000 x R 117 218, rounds 2 / 3 / 4: K=16 0.438 / 0.421 / 0.428 ms, K=32 0.461 / 0.444 / 0.451)
+    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 33 ? 3 : (nb <= 65 && !cache_shape ? 2 : 1));
     int64_t nchunk = rounds * slots / nqt;
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     const bool mfma = mfma_shape(K, ternary != 0);
