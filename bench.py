@@ -221,6 +221,12 @@ class ShardedQueries:
         self.q_full, self.ql_full = q, ql                     # the gathered rows are written into these (same values)
 
     def gather(self):
+        if len(set(self.counts)) == 1 and hasattr(dist, "all_gather_into_tensor") and self.q_loc.is_cuda:
+            # equal slices (Q % world == 0): the two collectives write the full buffers in place, no pad / cat / copy kernels
+            # (the ragged form below costs ~10 small launches = 85 us of a 0.56 ms step)
+            dist.all_gather_into_tensor(self.q_full.bits, self.q_loc)
+            dist.all_gather_into_tensor(self.ql_full, self.ql_loc)
+            return
         self.q_full.bits.copy_(self.sharded.all_gather_rows(self.q_loc, self.counts))
         self.ql_full.copy_(self.sharded.all_gather_rows(self.ql_loc, self.counts))
 
@@ -259,7 +265,7 @@ def strong_legs(args, world, rank, barrier):
 
     def step():
         sq.gather()
-        return sharded.map_k_sharded(ops, None)[0]
+        return sharded.map_k_sharded(ops, None, map_only=True)[0]
     for _ in range(10):
         step()
     steps = max(20, args.steps // 4)
@@ -359,7 +365,7 @@ def main():
             scan.histograms(False)
             return scan.map_all(None)[0]
         sq.gather()                                            # packed query codes + labels over RCCL, inside the timed step
-        return sharded.map_k_sharded(piped if piped is not None else ops, None)[0]
+        return sharded.map_k_sharded(piped if piped is not None else ops, None, map_only=True)[0]
 
     def barrier():
         if use_dist:

@@ -124,7 +124,8 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
 // launch of its own between the passes (k_scan_dpre: 9 us + a launch gap; kept for the sharded call and the histogram export).
 __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__ chunk_hist, int qpad, int nb, int nchunk, uint32_t rel_scale,
                                                     uint2* __restrict__ below, uint2* __restrict__ tot, uint32_t* __restrict__ tickets, int Q,
-                                                    uint2* __restrict__ dpre, uint32_t* __restrict__ nrel_ws, uint32_t* __restrict__ nrel_max) {
+                                                    uint2* __restrict__ dpre, uint32_t* __restrict__ nrel_ws, uint32_t* __restrict__ nrel_max,
+                                                    uint32_t* __restrict__ hist_all, uint32_t* __restrict__ hist_rel) {
     __shared__ uint2 part[4][64];
     __shared__ int last;
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
@@ -202,6 +203,8 @@ __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__
         for (int j = 0; j < 8; ++j) {
             if (dd + j < d1) {
                 dpre[(int64_t)(dd + j) * qpad + q] = make_uint2(ra, rr);
+                if (hist_all && q < Q) hist_all[(int64_t)q * nb + dd + j] = t[j].x;      // the shard totals a sharded evaluation gathers
+                if (hist_rel && q < Q) hist_rel[(int64_t)q * nb + dd + j] = t[j].y;
                 ra += t[j].x;
                 rr += t[j].y;
             }
@@ -1090,6 +1093,54 @@ __global__ __launch_bounds__(64) void k_shard_offsets(const uint32_t* __restrict
     if (lane == 0) nrel_total[q] = carry_r;
 }
 
+// The sharded call's offsets in one launch, from the all-gathered TOTALS TABLES of the shards in the workspace's own layout
+// (tot_g[world][nb][qpad] {all, relevant}: what k_scan_below leaves behind, gathered as it is -- no export pass, no transposed
+// copy): dpre[d][q] = items of lower buckets on any shard + items of bucket d on lower shards, cap_ws[q] = relevant items on all
+// shards, cap_out[q] = min(that, k).  64 queries per block (lanes, coalesced), the bucket axis split over the 4 waves as in
+// k_scan_dpre.
+__global__ __launch_bounds__(256) void k_shard_offsets_dpre(const uint2* __restrict__ tot_g, int world, int rank, int Q, int qpad, int nb,
+                                                            int64_t kcap, uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
+                                                            int32_t* __restrict__ cap_out) {
+    __shared__ uint2 part[4][64];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int64_t plane = (int64_t)nb * qpad;
+    const int nbq = (nb + 3) / 4;
+    const int d0 = wq * nbq, d1 = (d0 + nbq < nb) ? d0 + nbq : nb;
+    uint32_t sa = 0, sr = 0;
+    for (int d = d0; d < d1; ++d) {
+        for (int w = 0; w < world; ++w) {
+            const uint2 t = tot_g[(int64_t)w * plane + (int64_t)d * qpad + q];
+            sa += t.x;
+            sr += t.y;
+        }
+    }
+    part[wq][lane] = make_uint2(sa, sr);
+    __syncthreads();
+    uint32_t ra = 0, rr = 0, tr = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint2 pw = part[w][lane];
+        if (w < wq) { ra += pw.x; rr += pw.y; }
+        tr += pw.y;
+    }
+    for (int d = d0; d < d1; ++d) {
+        uint32_t ta = 0, tr2 = 0, la = 0, lr = 0;
+        for (int w = 0; w < world; ++w) {
+            const uint2 t = tot_g[(int64_t)w * plane + (int64_t)d * qpad + q];       // second walk: L2 hits
+            ta += t.x; tr2 += t.y;
+            if (w < rank) { la += t.x; lr += t.y; }
+        }
+        dpre[(int64_t)d * qpad + q] = make_uint2(ra + la, rr + lr);
+        ra += ta;
+        rr += tr2;
+    }
+    if (wq == 0) {
+        cap_ws[q] = tr;
+        if (q < Q) cap_out[q] = (int32_t)((kcap > 0 && (uint64_t)kcap < (uint64_t)tr) ? (uint32_t)kcap : tr);
+    }
+}
+
 // Sum of a query's per-chunk credits.  A block takes 64 queries; its 4 waves take a quarter of the chunks each (all loads of a
 // thread are issued together: one dependent load per chunk was a 13 us chain of misses for 32 chunks) and the quarters are added
 // in a fixed order -- the same order in the sharded and the unsharded reduction, whatever the grid.
@@ -1522,14 +1573,8 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
                        (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelScale : 0u, below, tot,
                        reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
-                       reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate));
+                       reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate), hist_all, hist_rel);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");
-    if (hist_all || hist_rel) {
-        hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, (const uint2*)tot, (int)Q, (int)p.qpad, (int)p.nbuckets,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int64_t)0,
-                           (uint2*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, hist_all, hist_rel, (uint32_t*)nullptr);
-        XMH_LAUNCH_CHECK("xmh_hamming_hist totals");
-    }
     return XMH_OK;
 }
 
@@ -1537,7 +1582,8 @@ namespace {
 int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
                     const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                     size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
-                    const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream) {
+                    const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream,
+                    const uint32_t* hist_g = nullptr, int world = 0, int rank = 0) {
     const bool tern = qzero != nullptr;
     xmh_scan_plan p;
     int rc = make_plan(Q, R, K, tern, &p);
@@ -1565,7 +1611,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // below that only the 64-bit kernel is launched (and no gated launch returns at once); XMH_SCAN_PACK32_ALL=1 brings the packed
     // kernels back for every length (tests).
     int rank_bits = 0;
-    if (!base_all && (K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
+    const bool sharded = base_all != nullptr || hist_g != nullptr;
+    if (!sharded && (K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
         // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
         // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
         const int64_t rank_max = (mfma_plan && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
@@ -1573,7 +1620,11 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         if (rank_bits > 24) rank_bits = 0;
     }
     // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
-    if (base_all) {
+    if (hist_g) {                                                    // offsets straight from the gathered totals tables of the shards
+        hipLaunchKernelGGL(k_shard_offsets_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, reinterpret_cast<const uint2*>(hist_g), world, rank,
+                           (int)Q, (int)p.qpad, (int)p.nbuckets, k, dpre, cap_ws, cap);
+        XMH_LAUNCH_CHECK("xmh_hamming_map_sharded offsets");
+    } else if (base_all) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
                            base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
         XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
@@ -1670,7 +1721,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         return XMH_OK;
     }
     hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum,
-                       base_all ? (const uint32_t*)nullptr : (const uint32_t*)cap_ws, kcap, cap);
+                       sharded ? (const uint32_t*)nullptr : (const uint32_t*)cap_ws, kcap, cap);
     XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
     if (map_out) {
         hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);
@@ -1694,6 +1745,24 @@ extern "C" int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, con
     if (!map_out) return xmh::fail(XMH_EINVAL, "xmh_hamming_map: null output");
     return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_out,
                            stream);
+}
+
+extern "C" size_t xmh_scan_totals_offset(int64_t Q, int64_t R, int K, int ternary, size_t* bytes) {
+    xmh_scan_plan p;
+    if (make_plan(Q, R, K, ternary, &p)) return (size_t)-1;
+    const WsLayout L = ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0));
+    if (bytes) *bytes = (size_t)p.nbuckets * p.qpad * 8;
+    return L.tot;
+}
+
+extern "C" int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                                       const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                                       size_t ws_bytes, const uint32_t* hist_gathered, int world, int rank, int64_t k, double* ap_sum,
+                                       int32_t* cap, double* map_partial, xmh_stream_t stream) {
+    if (!hist_gathered || !map_partial) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded: null pointer");
+    if (world <= 0 || rank < 0 || rank >= world) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded: bad world=%d rank=%d", world, rank);
+    return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_partial,
+                           stream, hist_gathered, world, rank);
 }
 
 extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream) {

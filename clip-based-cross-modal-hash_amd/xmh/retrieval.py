@@ -251,6 +251,40 @@ class RankingScan:
         return out, ap, cap
 
 
+def _totals(self) -> torch.Tensor:
+    """this shard's totals table as pass 1 left it in the workspace: int32 view [nbuckets, qpad, 2] {all, relevant} -- what a
+    sharded evaluation all-gathers (no export pass, no copy).  Valid until the next histograms() on this object."""
+    nbytes = C.c_size_t(0)
+    off = lib.xmh_scan_totals_offset(self.q.n, self.r.n, self.q.K, 1 if self.qz is not None else 0, C.byref(nbytes))
+    if off == C.c_size_t(-1).value:
+        check(1, "xmh_scan_totals_offset")
+    return self.ws[off:off + nbytes.value].view(torch.int32).view(self.plan.nbuckets, self.plan.qpad, 2)
+
+
+def _map_sharded(self, k, totals_gathered: torch.Tensor, rank: int):
+    """pass 2 of ONE SHARD from the all-gathered totals tables of the shards ([world, nbuckets, qpad, 2] int32) with this shard's
+    share of the mean folded in -> (map_partial float64 [1], ap_sum [Q] of this shard, cap [Q] global).  The mAP is the sum of
+    map_partial over the shards."""
+    if (totals_gathered.dim() != 4 or tuple(totals_gathered.shape[1:]) != (self.plan.nbuckets, self.plan.qpad, 2)
+            or totals_gathered.dtype != torch.int32 or not totals_gathered.is_contiguous()):
+        raise ValueError("map_sharded: expected a contiguous int32 [world, %d, %d, 2] tensor" % (self.plan.nbuckets, self.plan.qpad))
+    world = totals_gathered.shape[0]
+    dev = self.ws.device
+    ap = torch.empty(self.q.n, dtype=torch.float64, device=dev)
+    cap = torch.empty(self.q.n, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    kk = 0 if k is None else int(k)
+    if k is not None and kk <= 0:
+        raise ValueError("k must be positive or None")
+    check(lib.xmh_hamming_map_sharded(*self._common(), ptr(totals_gathered), world, int(rank), kk, ptr(ap), ptr(cap), ptr(out),
+                                      current_stream()), "xmh_hamming_map_sharded")
+    return out, ap, cap
+
+
+RankingScan.totals = _totals
+RankingScan.map_sharded = _map_sharded
+
+
 def map_finalize(ap_sum: torch.Tensor, cap: torch.Tensor) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.float64, device=ap_sum.device)
     check(lib.xmh_map_finalize(ptr(ap_sum), ptr(cap), ap_sum.shape[0], ptr(out), current_stream()), "xmh_map_finalize")

@@ -338,7 +338,7 @@ class BaseTrainer:
             full = self._gather_packed(r_shard, self.retrieval_num)
             return float(self.calc_map_k(q.unpack(), full.unpack(), self.query_labels, self.retrieval_labels, k))
         ops = sharded.HipShardOps(q, self._qlab, r_shard, self._rlab, C)
-        return float(sharded.map_k_sharded(ops, k)[0].item())
+        return float(sharded.map_k_sharded(ops, k, map_only=True)[0].item())
 
     def _evaluate(self, k):
         self._qlab = self._rlab = None

@@ -62,6 +62,24 @@ class HipShardOps:
     def finalize(self, ap, cap):
         return self._R.map_finalize(ap, cap)
 
+    def totals(self):
+        """pass 1 on the local shard; returns its totals table [nbuckets, qpad, 2] int32 (a view of the scan workspace) -- what
+        the fused sharded evaluation all-gathers instead of exported [Q, nbuckets] histograms"""
+        if self.empty:
+            p = self._R.scan_plan(self.q.n, 1, self.q.K, self._ternary)
+            return torch.zeros(p.nbuckets, p.qpad, 2, dtype=torch.int32, device=self.q.bits.device)
+        self.scan.histograms(False)
+        return self.scan.totals()
+
+    def map_partial(self, k, totals_gathered, rank):
+        """this shard's share of the mAP (offsets + pass 2 + reduction in one library call; the shares add up over the shards)"""
+        if self.empty:
+            nrel = totals_gathered[:, :, : self.q.n, 1].sum(dim=(0, 1))
+            cap = nrel if k is None else torch.clamp(nrel, max=int(k))
+            z = torch.zeros(self.q.n, dtype=torch.float64, device=totals_gathered.device)
+            return (z / cap.to(torch.float64)).sum().reshape(1) / self.q.n      # cap == 0 -> NaN, like every other rank
+        return self.scan.map_sharded(k, totals_gathered, rank)[0]
+
 
 def all_gather_rows(t: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
     """all_gather of row-ragged tensors (rank i contributes counts[i] rows) -> concatenated rows."""
@@ -122,14 +140,29 @@ class QueryBlocks:
         return QueryBlocks([HipShardOps(q.rows(lo, hi), qlab[lo:hi], r, rlab, C) for lo, hi in zip(bounds[:-1], bounds[1:])])
 
 
-def map_k_sharded(ops, k: Optional[int] = None, group=None):
+def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = False):
     """mAP over a gallery sharded across ``group``.  ``ops`` wraps this rank's shard (HipShardOps or a test
     double) and already holds the FULL (all-gathered) query set.  Returns (map float64 tensor [1], ap_sum,
     cap) -- identical on every rank.  Per call: pass 1, ONE all-gather of the [2, Q, nb] histograms (2.6 MB/rank at
-    Q=5000, K=64), one offsets kernel, pass 2, one all-reduce of [Q] f64, one finalize kernel."""
+    Q=5000, K=64), one offsets kernel, pass 2, one all-reduce of [Q] f64, one finalize kernel.
+    ``map_only``: the caller wants the mean alone -> (map, None, None): the shards' totals tables are gathered as pass 1 left
+    them in the workspace (no export pass), every rank folds its own share of the mean into pass 2's reduction
+    (ops.map_partial: offsets, pass 2 and reduction are three launches of one library call) and ONE 8-byte all-reduce adds the
+    shares; no [Q] all-reduce, no finalize launch."""
     rank = dist.get_rank(group)
     if isinstance(ops, QueryBlocks):
         return _map_k_blocks(ops.blocks, k, rank, group)
+    if map_only and hasattr(ops, "totals"):
+        t = ops.totals()                                         # pass 1; the shard's totals table where pass 1 left it
+        world = dist.get_world_size(group)
+        g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
+            dist.all_gather_into_tensor(g, t, group=group)       # [world, nb, qpad, 2]
+        else:
+            dist.all_gather(list(g.unbind(0)), t, group=group)
+        m = ops.map_partial(k, g, rank)                          # offsets, pass 2, this shard's share of the mean
+        dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)    # [1] f64
+        return m, None, None
     ha, hr = ops.histograms()                                    # pass 1 on the local shard
     g = _gather_hist_pair(ha, hr, group)                         # [world, 2, Q, nb]
     if hasattr(ops, "offsets"):

@@ -149,6 +149,18 @@ int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double
  * items in lower buckets on any shard + items of the same bucket on lower ranks; nrel_total [Q]. */
 int xmh_shard_offsets(const uint32_t* hist_gathered, int world, int rank, int64_t Q, int nbuckets, uint32_t* base_all,
                       uint32_t* base_rel, uint32_t* nrel_total, xmh_stream_t stream);
+/* Sharded evaluation without an export pass.  xmh_hamming_hist leaves this shard's totals table in the workspace:
+ * [nbuckets][qpad] pairs of u32 {all items, relevant items} at byte offset xmh_scan_totals_offset() (*bytes = its size; the
+ * offset depends on Q, K and ternary only through the plan of THIS shard, the table's shape on Q and K alone).  All-gather those
+ * tables as they are -> totals_gathered[world][nbuckets][qpad][2], then xmh_hamming_map_sharded = offsets + pass 2 + this
+ * shard's share of the mean (three launches): ap_sum[Q] = this shard's credits, cap[Q] = the global divisor,
+ * map_partial[0] = (1/Q) sum_q ap_sum[q] / cap[q].  The mAP is the SUM of map_partial over the shards (one 8-byte all-reduce
+ * instead of a [Q] f64 one and a finalize launch). */
+size_t xmh_scan_totals_offset(int64_t Q, int64_t R, int K, int ternary, size_t* bytes);
+int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                            const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                            size_t ws_bytes, const uint32_t* totals_gathered, int world, int rank, int64_t k, double* ap_sum,
+                            int32_t* cap, double* map_partial, xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-query top-k (north_star: "fused bit-packed XOR-popcount + per-query top-k kernel").

@@ -494,6 +494,8 @@ def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():
         "    m0, a0, c0 = whole.map_all(k)\n"
         "    m1, a1, c1 = sharded.map_k_sharded(sharded.HipShardOps(q, ql, r, rl, C), k)\n"
         "    assert torch.equal(c0, c1) and torch.allclose(a0, a1, rtol=1e-12) and abs(float(m0) - float(m1)) < 1e-12\n"
+        "    m3, a3, c3 = sharded.map_k_sharded(sharded.HipShardOps(q, ql, r, rl, C), k, map_only=True)\n"
+        "    assert a3 is None and abs(float(m0) - float(m3)) < 1e-12\n"
         "    for nb in (2, 3, 200):\n"
         "        m2, a2, c2 = sharded.map_k_sharded(sharded.QueryBlocks.split(q, ql, r, rl, C, nb), k)\n"
         "        assert torch.equal(c0, c2) and torch.allclose(a0, a2, rtol=1e-9) and abs(float(m0) - float(m2)) < 1e-9, (Q, K, nb)\n"
@@ -525,6 +527,18 @@ def test_sharded_ops_with_an_empty_shard(xr):
         assert torch.equal(cap, cap_ref)
         ap += part
     assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)
+    # the fused form (offsets + pass 2 + this shard's share of the mean in one call): the shares add up to the mean
+    want = float((ap / cap_ref.double()).mean())                # from the same per-shard credits (fp32 credits: the unsharded
+    tg = torch.stack([o.totals() for o in shards]).contiguous()                  # scan adds them in another order, 1e-6)
+    assert torch.equal(tg[:, :, :Q, 0].transpose(1, 2), gathered[:, 0]) and torch.equal(tg[:, :, :Q, 1].transpose(1, 2), gathered[:, 1])
+    shares = [o.map_partial(9, tg, s) for s, o in enumerate(shards)]
+    got = sum(float(x) for x in shares)
+    assert abs(got - want) < 1e-12 and abs(got - float((ap_ref / cap_ref.double()).mean())) < 1e-6
+    for s, o in enumerate(shards):
+        if not o.empty:
+            m_s, ap_s, cap_s = o.scan.map_sharded(9, tg, s)
+            part, cap = o.ap_sums(9, *o.offsets(gathered, s))
+            assert torch.equal(cap_s, cap_ref) and torch.equal(ap_s, part)
 
 
 def test_full_size_properties_coco_shape(xr):

@@ -36,6 +36,20 @@ class OracleShardOps:
                        nrel_total.numpy().view(np.uint32))
         return torch.from_numpy(s), torch.from_numpy(cap)
 
+    def totals(self):
+        """the shard's totals table in the layout the HIP workspace keeps it: [nbuckets, qpad (= Q here), 2] {all, relevant}"""
+        ha, hr = self.histograms()
+        return torch.stack([ha.t(), hr.t()], dim=2).contiguous()
+
+    def map_partial(self, k, totals_gathered, rank):
+        """what HipShardOps.map_partial does in one library call: offsets from the gathered tables, pass 2, this shard's share"""
+        from xmh import sharded
+        ha = totals_gathered[..., 0].transpose(1, 2).contiguous()     # [world, Q, nb]
+        hr = totals_gathered[..., 1].transpose(1, 2).contiguous()
+        base_a, base_r, nrel = sharded.rank_offsets(ha, hr, rank)
+        ap, cap = self.ap_sums(k, base_a, base_r, nrel)
+        return (ap / cap.to(torch.float64)).sum().reshape(1) / ap.shape[0]
+
 
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -72,6 +86,8 @@ def _worker(rank, world, port, tmp):
             assert np.array_equal(cap.numpy(), want_cap)
             assert np.allclose(ap.numpy(), want_s, rtol=1e-12)
             assert abs(float(m) - float(np.mean(want_s / want_cap))) < 1e-12
+            m1, ap1, cap1 = sharded.map_k_sharded(ops, k, map_only=True)      # shares of the mean, one scalar all-reduce
+            assert ap1 is None and cap1 is None and abs(float(m1) - float(m)) < 1e-12
         # the same over query blocks (asynchronous gathers, one per block): identical results
         for nblk in (2, 3):
             qbl = sharded.shard_bounds(Q, nblk)
