@@ -209,15 +209,17 @@ def dry_run(args, world, rank):
 
 
 class ShardedQueries:
-    """This rank's slice of the packed query set plus persistent full-size buffers the scan objects point at: gather() is
-    the all-gather runners/base.py performs after encoding (packed codes <= 40 KB, packed labels <= 60 KB in all)."""
+    """This rank's slice of the packed query CODES plus the persistent full-size buffer the scan objects point at: gather() is
+    the all-gather runners/base.py performs after encoding (packed codes <= 40 KB in all).  The query LABELS are not gathered:
+    every rank holds the whole label matrices, as in the reference (runners/base.py keeps query_labels / retrieval_labels complete
+    on each rank and xmh/runners/base.py packs them locally)."""
 
     def __init__(self, q, ql, world, rank):
         from xmh import sharded
         self.sharded = sharded
         b = sharded.shard_bounds(q.n, world)
         self.counts = [b[r + 1] - b[r] for r in range(world)]
-        self.q_loc, self.ql_loc = q.bits[b[rank]:b[rank + 1]].clone(), ql[b[rank]:b[rank + 1]].clone()
+        self.q_loc = q.bits[b[rank]:b[rank + 1]].clone()
         self.q_full, self.ql_full = q, ql                     # the gathered rows are written into these (same values)
 
     def gather(self):
@@ -225,10 +227,8 @@ class ShardedQueries:
             # equal slices (Q % world == 0): the two collectives write the full buffers in place, no pad / cat / copy kernels
             # (the ragged form below costs ~10 small launches = 85 us of a 0.56 ms step)
             dist.all_gather_into_tensor(self.q_full.bits, self.q_loc)
-            dist.all_gather_into_tensor(self.ql_full, self.ql_loc)
             return
         self.q_full.bits.copy_(self.sharded.all_gather_rows(self.q_loc, self.counts))
-        self.ql_full.copy_(self.sharded.all_gather_rows(self.ql_loc, self.counts))
 
 
 def timed(step, barrier, steps, use_dist):
