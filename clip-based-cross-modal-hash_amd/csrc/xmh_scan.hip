@@ -851,7 +851,14 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     const int nbat = (int)((hi - lo + 63) >> 6);
     const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
     const int lanebase = cinit - (valid ? 32 * a.K : 0);            // address of this lane's bucket-0 counter
-    uint4* crow = CACHE ? pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane : nullptr;
+    // NMC == 1 (33..64 bits): the cached pass 2 has this kernel's lane geometry (4 slots x 16 queries), a lane stores its 16 one-byte
+    // entries of a batch.  NMC == 2 (65..128 bits): the cached pass 2 runs 8 slots x 8 queries with 16-bit entries, lane
+    // (slot8, query) taking item 8t + slot8 at step t.  This lane (slot4, query) holds items 16g + 4j + slot4: its even j are
+    // exactly the 8 steps of lane (slot4, query) there, its odd j those of lane (slot4 + 4, query) -- no exchange between lanes,
+    // two 16-byte records per batch, 32 uint4 apart in the row of the query's 8-query tile.
+    uint4* crow = nullptr;
+    if (CACHE && NMC == 1) crow = pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane;
+    if (CACHE && NMC == 2) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
     ST::issue(a.gimg, ring, 0, bat0, lane, wave);
     for (int i = 0; i < nbat; ++i) {
         if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
@@ -864,7 +871,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
 #pragma unroll
             for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
         }
-        uint32_t cw[4];
+        uint32_t cw[4], cw2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             v4i acc = {cinit, cinit, cinit, cinit};
@@ -878,16 +885,32 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
             for (int j = 0; j < 4; ++j) {
                 const uint32_t inc = min((uint32_t)lab[j], 1u + kRelScale);        // 1 or 0x1fc1: bit 7 = relevant
                 asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
-                if (CACHE) e[j] = (inc & 0x80u) | ((uint32_t)(acc[j] - lanebase) >> 6);
+                if (CACHE && NMC == 1) e[j] = (inc & 0x80u) | ((uint32_t)(acc[j] - lanebase) >> 6);
+                if (CACHE && NMC == 2) e[j] = ((inc & 0x80u) << 8) | ((uint32_t)(acc[j] - lanebase) >> 6);     // 16-bit entry: distance | relevant << 15
             }
-            if (CACHE) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+            if (CACHE && NMC == 1) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+            if (CACHE && NMC == 2) {                                 // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
+                cw[g] = e[0] | (e[2] << 16);
+                cw2[g] = e[1] | (e[3] << 16);
+            }
         }
-        if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
+        if (CACHE && NMC == 1) {                                     // streamed once each way: non-temporal (see k_scan_hist_s)
             uint4* dst = crow + (int64_t)i * 64;
             __builtin_nontemporal_store(cw[0], &dst->x);
             __builtin_nontemporal_store(cw[1], &dst->y);
             __builtin_nontemporal_store(cw[2], &dst->z);
             __builtin_nontemporal_store(cw[3], &dst->w);
+        }
+        if (CACHE && NMC == 2) {
+            uint4* dst = crow + (int64_t)i * 64;
+            __builtin_nontemporal_store(cw[0], &dst->x);
+            __builtin_nontemporal_store(cw[1], &dst->y);
+            __builtin_nontemporal_store(cw[2], &dst->z);
+            __builtin_nontemporal_store(cw[3], &dst->w);
+            __builtin_nontemporal_store(cw2[0], &dst[32].x);
+            __builtin_nontemporal_store(cw2[1], &dst[32].y);
+            __builtin_nontemporal_store(cw2[2], &dst[32].z);
+            __builtin_nontemporal_store(cw2[3], &dst[32].w);
         }
         __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
     }
@@ -1273,12 +1296,17 @@ struct WsLayout {
     size_t chunk_hist, below, tot, dpre, cap, tick, gate, ap_part, pair_cache, gimg, qimg32, total;
 };
 
+// 65..128 bits (two code tiles per group, 129 bucket rows, 2 blocks per CU; round 2): Q 5000 x R 117 218, K = 128: pass 1 0.427 -> 0.325 ms,
+// whole step 0.759 -> 0.663 ms; the pair cache is written in the layout of the 8-slot cached pass 2 (see k_scan_hist_m).  XMH_SCAN_MFMA128=0
+// turns it off.
 // the MFMA-evaluated pass 1 (k_scan_hist_m): binary codes of 33..64 bits, i.e. where the pair cache hands pass 2 the evaluated
 // pairs (measured at Q 5000 x R 117 218, whole step: K=64 0.512 -> 0.489 ms; at K <= 32, where pass 2 evaluates the pairs itself
 // and the VALU pass 1 is cheap, it loses: K=16 0.452 -> 0.471 ms).  XMH_SCAN_MFMA=0 turns it off.
 inline bool mfma_shape(int K, bool ternary) {
     static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
-    return on && !ternary && K > 32 && K <= 64;
+    const char* e128 = getenv("XMH_SCAN_MFMA128");                 // read per call (tests switch it)
+    const bool on128 = !(e128 && atoi(e128) == 0);
+    return on && !ternary && K > 32 && (K <= 64 || (on128 && K <= 128));
 }
 // MFMA-evaluated pass 2 (k_scan_ap_m) instead of the pair cache + cached k_scan_ap_s: XMH_SCAN_MFMA_AP=1.  Bit-identical results,
 // measured at Q 5000 x R 117 218, K = 64: pass 1 without the cache 0.239 -> 0.196 ms, but pass 2 0.195 -> 0.349 ms (64-bit returning
@@ -1290,8 +1318,8 @@ inline bool mfma_ap_on() {                           // read per call (tests tog
 }
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
-inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 3 * 1024; }
-inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 3 * 1024; }
+inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 4 * 1024; }      // up to 2 code + 2 label tiles per group
+inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 4 * 1024; }
 
 // Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
 // pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 4096; 0 = off).
@@ -1299,7 +1327,7 @@ size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call, like XMH_SCAN_MFMA_AP
     const long long cap_mb = cap_env ? atoll(cap_env) : 4096;
     if (ternary || K <= 32 || K > 256 || cap_mb <= 0) return 0;
-    if (mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
+    if (K <= 64 && mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
@@ -1357,7 +1385,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (mfma) {
         // blocks of kMfmaWaves waves = one 64-query tile x one chunk; 3 blocks fit a CU (pass 1), `rounds` sets of them
         static const int mr = getenv("XMH_SCAN_MFMA_ROUNDS") ? atoi(getenv("XMH_SCAN_MFMA_ROUNDS")) : 3;
-        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * 3 / nqt;
+        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : 2) / nqt;     // 65..128 bits: 129 bucket rows, 2 blocks per CU
     }
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
@@ -1461,10 +1489,10 @@ int raise_lds(KernT kern, size_t lds, const char* who) {
 
 
 namespace {
-template <int NML>
+template <int NMC, int NML>
 int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
                 const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    constexpr int NMC = 1, NM = NMC + NML, NW = kMfmaWaves;
+    constexpr int NM = NMC + NML, NW = kMfmaWaves;
     uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
     uint4* q32 = reinterpret_cast<uint4*>(base + L.qimg32);
     const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NM * 64, qpieces = (p.qpad / 16) * NM * 64;
@@ -1492,8 +1520,11 @@ int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbi
 
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    return LW <= 2 ? mfma_hist_t<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                   : mfma_hist_t<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    if (K <= 64)
+        return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                       : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    return LW <= 2 ? mfma_hist_t<2, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                   : mfma_hist_t<2, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
 }
 
 }  // namespace
@@ -1615,7 +1646,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     if (!sharded && (K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
         // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
         // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
-        const int64_t rank_max = (mfma_plan && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
+        const int64_t rank_max = (mfma_plan && K <= 64 && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
         while ((1ll << rank_bits) < rank_max) ++rank_bits;
         if (rank_bits > 24) rank_bits = 0;
     }
@@ -1669,7 +1700,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             return (int)XMH_OK;
         });
     };
-    if (mfma_plan && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
+    if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
         MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
                     (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)), (int)p.nbuckets, (int)p.qpad};
         const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));

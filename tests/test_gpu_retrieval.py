@@ -347,6 +347,24 @@ def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
             assert torch.equal(x, y), (Q, R, K, C)
 
 
+def test_scan_mfma_pass1_for_128_bit_codes_matches_the_valu_pass1(xr, monkeypatch):
+    """65..128-bit codes: pass 1 on the MFMA writes the pair cache in the layout of the 8-slot cached pass 2 (two 16-byte records per
+    lane and batch).  Against the VALU pass 1 (XMH_SCAN_MFMA128=0): same histograms and caps bit for bit, same credits up to the
+    order of the per-chunk partial sums (the two plans cut the gallery into different chunks)."""
+    for (Q, R, K, C, p, k) in ((150, 9001, 128, 80, 0.06, 9), (17, 130, 128, 5, 0.3, 3), (64, 8157, 96, 33, 0.2, 85), (33, 4096, 65, 128, 0.05, None)):
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R, p=p)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("XMH_SCAN_MFMA128", flag)
+            q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+            scan = xr.RankingScan(q, xr.pack_labels(qL.cuda()), r, xr.pack_labels(rL.cuda()), C)
+            ha, hr = scan.histograms(True)
+            ap, cap = scan.ap_sums(k)
+            outs.append((ha.clone(), hr.clone(), cap.clone(), ap.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), (Q, R, K, C)
+        assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-6, atol=1e-9), (Q, R, K, C)
+
+
 def test_scan_many_evaluations_after_one_histogram_pass(xr):
     """One xmh_hamming_hist, then several evaluations with different k on the same workspace: the offsets pass 1 left behind are
     reused, the finalize ticket puts itself back to zero (a stale ticket would leave map_out unwritten), and a sharded-style
