@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
 
 
 // ===================================================================================================
-// MFMA-evaluated scan (binary codes of at most 64 bits, at most 128 classes).
+// MFMA-evaluated scan (binary codes of 33..128 bits in pass 1, at most 64 in pass 2; at most 128 classes).
 //
 // Hamming distance and label overlap of 16 gallery items x 16 queries are two i8 dot-product tiles -- literally what the
 // reference computes, B1 @ B2^T and query_L @ retrieval_L^T (common/calc_utils.py:51-56, :72) -- so they go to
