@@ -811,6 +811,7 @@ struct MfmaStage {
         else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -852,13 +853,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
     const int lanebase = cinit - (valid ? 32 * a.K : 0);            // address of this lane's bucket-0 counter
     // NMC == 1 (33..64 bits): the cached pass 2 has this kernel's lane geometry (4 slots x 16 queries), a lane stores its 16 one-byte
-    // entries of a batch.  NMC == 2 (65..128 bits): the cached pass 2 runs 8 slots x 8 queries with 16-bit entries, lane
+    // entries of a batch.  NMC >= 2 (65..256 bits): the cached pass 2 runs 8 slots x 8 queries with 16-bit entries, lane
     // (slot8, query) taking item 8t + slot8 at step t.  This lane (slot4, query) holds items 16g + 4j + slot4: its even j are
     // exactly the 8 steps of lane (slot4, query) there, its odd j those of lane (slot4 + 4, query) -- no exchange between lanes,
     // two 16-byte records per batch, 32 uint4 apart in the row of the query's 8-query tile.
     uint4* crow = nullptr;
     if (CACHE && NMC == 1) crow = pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane;
-    if (CACHE && NMC == 2) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
+    if (CACHE && NMC >= 2) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
     ST::issue(a.gimg, ring, 0, bat0, lane, wave);
     for (int i = 0; i < nbat; ++i) {
         if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
@@ -886,10 +887,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
                 const uint32_t inc = min((uint32_t)lab[j], 1u + kRelScale);        // 1 or 0x1fc1: bit 7 = relevant
                 asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
                 if (CACHE && NMC == 1) e[j] = (inc & 0x80u) | ((uint32_t)(acc[j] - lanebase) >> 6);
-                if (CACHE && NMC == 2) e[j] = ((inc & 0x80u) << 8) | ((uint32_t)(acc[j] - lanebase) >> 6);     // 16-bit entry: distance | relevant << 15
+                if (CACHE && NMC >= 2) e[j] = ((inc & 0x80u) << 8) | ((uint32_t)(acc[j] - lanebase) >> 6);     // 16-bit entry: distance | relevant << 15
             }
             if (CACHE && NMC == 1) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
-            if (CACHE && NMC == 2) {                                 // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
+            if (CACHE && NMC >= 2) {                                 // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
                 cw[g] = e[0] | (e[2] << 16);
                 cw2[g] = e[1] | (e[3] << 16);
             }
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
             __builtin_nontemporal_store(cw[2], &dst->z);
             __builtin_nontemporal_store(cw[3], &dst->w);
         }
-        if (CACHE && NMC == 2) {
+        if (CACHE && NMC >= 2) {
             uint4* dst = crow + (int64_t)i * 64;
             __builtin_nontemporal_store(cw[0], &dst->x);
             __builtin_nontemporal_store(cw[1], &dst->y);
@@ -1305,8 +1306,9 @@ struct WsLayout {
 inline bool mfma_shape(int K, bool ternary) {
     static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
     const char* e128 = getenv("XMH_SCAN_MFMA128");                 // read per call (tests switch it)
-    const bool on128 = !(e128 && atoi(e128) == 0);
-    return on && !ternary && K > 32 && (K <= 64 || (on128 && K <= 128));
+    const char* e256 = getenv("XMH_SCAN_MFMA256");
+    const bool on128 = !(e128 && atoi(e128) == 0), on256 = !(e256 && atoi(e256) == 0);
+    return on && !ternary && K > 32 && (K <= 64 || (on128 && K <= 128) || (on128 && on256 && K <= 256));
 }
 // MFMA-evaluated pass 2 (k_scan_ap_m) instead of the pair cache + cached k_scan_ap_s: XMH_SCAN_MFMA_AP=1.  Bit-identical results,
 // measured at Q 5000 x R 117 218, K = 64: pass 1 without the cache 0.239 -> 0.196 ms, but pass 2 0.195 -> 0.349 ms (64-bit returning
@@ -1318,8 +1320,8 @@ inline bool mfma_ap_on() {                           // read per call (tests tog
 }
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
-inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 4 * 1024; }      // up to 2 code + 2 label tiles per group
-inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 4 * 1024; }
+inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
+inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
 
 // Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
 // pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 4096; 0 = off).
@@ -1385,7 +1387,8 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (mfma) {
         // blocks of kMfmaWaves waves = one 64-query tile x one chunk; 3 blocks fit a CU (pass 1), `rounds` sets of them
         static const int mr = getenv("XMH_SCAN_MFMA_ROUNDS") ? atoi(getenv("XMH_SCAN_MFMA_ROUNDS")) : 3;
-        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : 2) / nqt;     // 65..128 bits: 129 bucket rows, 2 blocks per CU
+        // 65..128 bits: 129 bucket rows, 2 blocks per CU; 129..256 bits: 257 rows, one block per CU
+        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
     }
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
@@ -1395,7 +1398,10 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     chunk = xmh::ceil_div(chunk, 8) * 8;
     if (mfma) {                                   // batches of 64 items aligned to the gallery image; counters hold all + 8128 * relevant
         chunk = xmh::ceil_div(chunk, 64) * 64;
-        if (chunk > kMfmaMaxChunk) chunk = kMfmaMaxChunk;
+        if (chunk > kMfmaMaxChunk) {                              // capped: whole XCD groups of equal chunks again
+            nchunk = xmh::ceil_div(xmh::ceil_div(R, (int64_t)kMfmaMaxChunk), 8) * 8;
+            chunk = xmh::ceil_div(xmh::ceil_div(R, nchunk), 64) * 64;
+        }
     }
     nchunk = xmh::ceil_div(R, chunk);
     p->chunk = chunk;
@@ -1523,8 +1529,11 @@ int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits
     if (K <= 64)
         return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    return LW <= 2 ? mfma_hist_t<2, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                   : mfma_hist_t<2, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    if (K <= 128)
+        return LW <= 2 ? mfma_hist_t<2, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                       : mfma_hist_t<2, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    return LW <= 2 ? mfma_hist_t<4, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                   : mfma_hist_t<4, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
 }
 
 }  // namespace

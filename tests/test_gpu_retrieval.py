@@ -347,15 +347,16 @@ def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
             assert torch.equal(x, y), (Q, R, K, C)
 
 
-def test_scan_mfma_pass1_for_128_bit_codes_matches_the_valu_pass1(xr, monkeypatch):
+def test_scan_mfma_pass1_for_65_to_256_bit_codes_matches_the_valu_pass1(xr, monkeypatch):
     """65..128-bit codes: pass 1 on the MFMA writes the pair cache in the layout of the 8-slot cached pass 2 (two 16-byte records per
     lane and batch).  Against the VALU pass 1 (XMH_SCAN_MFMA128=0): same histograms and caps bit for bit, same credits up to the
     order of the per-chunk partial sums (the two plans cut the gallery into different chunks)."""
-    for (Q, R, K, C, p, k) in ((150, 9001, 128, 80, 0.06, 9), (17, 130, 128, 5, 0.3, 3), (64, 8157, 96, 33, 0.2, 85), (33, 4096, 65, 128, 0.05, None)):
+    for (Q, R, K, C, p, k) in ((150, 9001, 128, 80, 0.06, 9), (17, 130, 128, 5, 0.3, 3), (64, 8157, 96, 33, 0.2, 85), (33, 4096, 65, 128, 0.05, None),
+                               (70, 9100, 256, 80, 0.06, None), (20, 700, 160, 24, 0.2, 11)):      # 129..256 bits: four code tiles, one block per CU
         qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R, p=p)
         outs = []
         for flag in ("0", "1"):
-            monkeypatch.setenv("XMH_SCAN_MFMA128", flag)
+            monkeypatch.setenv("XMH_SCAN_MFMA128", flag)               # 0 turns the MFMA pass 1 off for everything above 64 bits
             q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
             scan = xr.RankingScan(q, xr.pack_labels(qL.cuda()), r, xr.pack_labels(rL.cuda()), C)
             ha, hr = scan.histograms(True)
