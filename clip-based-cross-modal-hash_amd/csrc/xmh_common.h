@@ -41,6 +41,11 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int device_cu_count();
 
+// Opt `kern` in to `bytes` (> 64 KB) of dynamic LDS on the CURRENT device.  hipFuncSetAttribute applies to the current device only
+// and costs a few microseconds, so the (device, kernel) -> size pairs already raised are remembered (mutex-guarded: host threads and
+// devices may interleave) and repeated calls stay off the launch path.  Returns XMH_OK or XMH_EHIP with the error text set.
+int raise_dynamic_lds(const void* kern, size_t bytes, const char* who);
+
 // Optional per-kernel timing for bench.py (xmh_prof_enable): HIP events recorded on the launch stream right
 // around ONE kernel launch, keyed by a short name.  Disabled by default: no events, no overhead.
 struct ProfScope {

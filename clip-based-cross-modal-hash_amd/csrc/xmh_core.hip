@@ -3,6 +3,9 @@
 
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 namespace xmh {
 
 static thread_local char g_err[512] = {0};
@@ -22,6 +25,24 @@ int device_cu_count() {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
     cached = n;
     return n;
+}
+
+int raise_dynamic_lds(const void* kern, size_t bytes, const char* who) {
+    if (bytes <= 64 * 1024) return XMH_OK;
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> raised[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(XMH_EHIP, "%s: no current device", who);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < kMaxDev) {
+        auto it = raised[dev].find(kern);
+        if (it != raised[dev].end() && bytes <= it->second) return XMH_OK;
+    }
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, bytes, hipGetErrorString(e));
+    if (dev >= 0 && dev < kMaxDev) raised[dev][kern] = bytes;
+    return XMH_OK;
 }
 
 // ---- per-kernel event timing (bench only) ----------------------------------------------------------

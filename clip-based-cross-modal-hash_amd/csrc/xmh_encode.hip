@@ -639,10 +639,7 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
     const size_t lds = ((size_t)2 * L * dh + (size_t)L * (L + 1)) * 4;
     const int threads = L <= 64 ? 64 : 128;
     auto kern = k_attention<64>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(XMH_EHIP, "xmh_attention_f32: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    }
+    if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_attention_f32")) return rl;
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(threads), lds, st, qkv, L, H, causal, key_padding_mask, out, p);
     XMH_LAUNCH_CHECK("xmh_attention_f32");
     return XMH_OK;
@@ -741,10 +738,7 @@ extern "C" int xmh_lta_aggregate(const float* scores, const float* tokens, const
     if (!scores || !tokens || !out) return xmh::fail(XMH_EINVAL, "xmh_lta_aggregate: null pointer");
     const size_t lds = ((size_t)L * (K + 1) + L) * 4;
     if (lds > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "xmh_lta_aggregate: L*K too large for LDS");
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lta_aggregate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_lta_aggregate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    }
+    if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(k_lta_aggregate), lds, "xmh_lta_aggregate")) return rl;
     hipLaunchKernelGGL(k_lta_aggregate, dim3((unsigned)B, (unsigned)xmh::ceil_div(D, 64)), dim3(256), lds, xmh::as_stream(stream), scores, tokens, token_mask, pos_enc, out, L, K, D, top_k);
     XMH_LAUNCH_CHECK("xmh_lta_aggregate");
     return XMH_OK;

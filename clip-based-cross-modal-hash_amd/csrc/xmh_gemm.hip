@@ -604,12 +604,7 @@ int launch_g16(const GArgsP& a, hipStream_t st) {
     constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
     constexpr size_t lds = (size_t)2 * (NA * TBM + NW * TBN) * BK * 2;
     auto kern = k_gemm_g16<WM, WN, MI, NJ, NA, NW, BK, MINB>;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return xmh::fail(XMH_EHIP, "xmh gemm: cannot raise dynamic LDS to %zu", lds);
-        raised = true;
-    }
+    if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh gemm")) return rl;
     const int64_t nblk = xmh::ceil_div(a.M, TBM) * xmh::ceil_div(a.N, TBN);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a);
     return XMH_OK;
@@ -638,13 +633,10 @@ extern "C" int xmh_gemm_nt_f32(const float* A, int64_t lda, const float* W, int6
         const bool fast = aligned && K % BK32 == 0;
         const bool small = nblk < 2ll * xmh::device_cu_count();          // fewer than two 128x128 blocks per CU -> 64x128 tiles
         const size_t lds = (size_t)2 * ((small ? 64 : 128) + BN) * LD32 * 4;
-        static bool raised = false;
-        if (!raised) {
-            const size_t big = (size_t)2 * (128 + BN) * LD32 * 4;        // 73,728 B: above the 64 KB default, opt in once
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_f32<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
-            if (e1 != hipSuccess || e2 != hipSuccess) return xmh::fail(XMH_EHIP, "xmh_gemm_nt_f32: cannot raise dynamic LDS to %zu", big);
-            raised = true;
+        {
+            const size_t big = (size_t)2 * (128 + BN) * LD32 * 4;        // 73,728 B: above the 64 KB default, opt in once per device
+            if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(k_gemm_nt_f32<true, 2>), big, "xmh_gemm_nt_f32")) return rl;
+            if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(k_gemm_nt_f32<false, 2>), big, "xmh_gemm_nt_f32")) return rl;
         }
         if (small) {
             nblk = xmh::ceil_div(M, 64) * xmh::ceil_div(N, BN);

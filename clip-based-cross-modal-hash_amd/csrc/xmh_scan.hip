@@ -118,7 +118,9 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
 //   below[c][d][q] = (#all, #relevant) items of bucket d in chunks < c of this shard
 //   tot[d][q]      = (#all, #relevant) items of bucket d in this shard
 // ---------------------------------------------------------------------------------------------------
-// rel_scale = 0: pass-1 counters are (all | relevant << 16); else all + relevant * rel_scale (the MFMA-evaluated pass 1)
+// rel_scale = 0: pass-1 counters are (all | relevant << 16); kRelHi16: (all << 16 | relevant) (k_scan_hist_m2); else all + relevant * rel_scale
+// (k_scan_hist_m)
+constexpr uint32_t kRelHi16 = 0xffffffffu;
 // The block that finishes a 64-query tile LAST (ticket per tile, zeroed ahead of the launch) also writes what the unsharded pass 2
 // needs from the totals -- dpre[d][q] = exclusive prefix of tot over d, nrel[q], the nrel_max gate word -- which used to be a
 // launch of its own between the passes (k_scan_dpre: 9 us + a launch gap; kept for the sharded call and the histogram export).
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int d = blockIdx.y * 4 + wq;
     const int q = blockIdx.x * 64 + lane;
+    const bool hi16 = rel_scale == kRelHi16;
     if (d < nb) {
         uint32_t ra = 0, rr = 0;
         int c = 0;
@@ -141,16 +144,16 @@ __global__ __launch_bounds__(256) void k_scan_below(const uint32_t* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 below[((int64_t)(c + j) * nb + d) * qpad + q] = make_uint2(ra, rr);
-                const uint32_t rel = rel_scale ? h[j] / rel_scale : h[j] >> 16;
-                ra += rel_scale ? h[j] - rel * rel_scale : h[j] & 0xffffu;
+                const uint32_t rel = hi16 ? h[j] & 0xffffu : (rel_scale ? h[j] / rel_scale : h[j] >> 16);
+                ra += hi16 ? h[j] >> 16 : (rel_scale ? h[j] - rel * rel_scale : h[j] & 0xffffu);
                 rr += rel;
             }
         }
         for (; c < nchunk; ++c) {
             const uint32_t h = chunk_hist[((int64_t)c * nb + d) * qpad + q];
             below[((int64_t)c * nb + d) * qpad + q] = make_uint2(ra, rr);
-            const uint32_t rel = rel_scale ? h / rel_scale : h >> 16;
-            ra += rel_scale ? h - rel * rel_scale : h & 0xffffu;
+            const uint32_t rel = hi16 ? h & 0xffffu : (rel_scale ? h / rel_scale : h >> 16);
+            ra += hi16 ? h >> 16 : (rel_scale ? h - rel * rel_scale : h & 0xffffu);
             rr += rel;
         }
         // agent-scope store (sc1: written through this XCD's L2): the totals are the one thing another block of this launch reads
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
 
-    // cache entry: EB bits = distance | relevant << (EB-1); a lane's QW steps of a batch fill exactly 16 bytes (8-bit entries at
+    // cache entry: EB bits = distance << 1 | relevant; a lane's QW steps of a batch fill exactly 16 bytes (8-bit entries at
     // 16 steps: codes up to 64 bits; 16-bit entries at 8 steps: 65..256 bits), each group of G steps two dwords
     constexpr int EB = 128 / QW, EPW = 32 / EB;
     static_assert(!CACHE || (NW == 1 && (S == 4 || S == 8) && NG == 2 && G == 2 * EPW), "pair cache geometry: 16 bytes per lane and batch, two groups");
@@ -414,9 +417,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
         if (CACHE) {                                                 // append an entry per step: w = entry << (32 - EB) | w >> EB
             // (counters indexed by that byte, so that the add is a constant 1, were tried: 3x the LDS per wave, pass 1 0.27 -> 0.31 ms)
 #pragma unroll
-            for (int u = 0; u < G / 2; ++u) wa = __builtin_amdgcn_alignbyte((hit[u] << (EB - 1)) | (uint32_t)d[u], wa, EB / 8);
+            for (int u = 0; u < G / 2; ++u) wa = __builtin_amdgcn_alignbyte(((uint32_t)d[u] << 1) | hit[u], wa, EB / 8);
 #pragma unroll
-            for (int u = G / 2; u < G; ++u) wb = __builtin_amdgcn_alignbyte((hit[u] << (EB - 1)) | (uint32_t)d[u], wb, EB / 8);
+            for (int u = G / 2; u < G; ++u) wb = __builtin_amdgcn_alignbyte(((uint32_t)d[u] << 1) | hit[u], wb, EB / 8);
         }
     };
     const int nbatch = (a.chunk + 63) >> 6;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
                     int d;
                     uint32_t hit;
                     rec_eval01<W, LW, TERN>(qr, r, a.K, d, hit);
-                    b = (hit << (EB - 1)) | (uint32_t)d;
+                    b = ((uint32_t)d << 1) | hit;
                     if (t * S + slot < cntb) atomicAdd(&cnt[d * QW + ql], (hit << 16) + 1u);
                 }
                 uint32_t& w = t < EPW ? cw0 : (t < 2 * EPW ? cw1 : (t < 3 * EPW ? cw2 : cw3));
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const uint32_t w = u < EPW ? wa : wb;
-                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (u % EPW), EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (u % EPW) + EB - 1, 1);
+                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (u % EPW) + 1, EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (u % EPW), 1);
                 hitp[u] = hit;
                 old[u] = atomicAdd(&cnt[d * QW + ql], inc(hit));      // same-address lanes resolve in lane = item order
             }
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         for (int t = 0; t < QW; ++t) {
             if (t * S + slot < cntb) {
                 const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
-                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (t % EPW), EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + EB - 1, 1);
+                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + 1, EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (t % EPW), 1);
                 const CT o = atomicAdd(&cnt[d * QW + ql], inc(hit));
                 credit(o, hit);
             }
@@ -886,8 +889,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
             for (int j = 0; j < 4; ++j) {
                 const uint32_t inc = min((uint32_t)lab[j], 1u + kRelScale);        // 1 or 0x1fc1: bit 7 = relevant
                 asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
-                if (CACHE && NMC == 1) e[j] = (inc & 0x80u) | ((uint32_t)(acc[j] - lanebase) >> 6);
-                if (CACHE && NMC >= 2) e[j] = ((inc & 0x80u) << 8) | ((uint32_t)(acc[j] - lanebase) >> 6);     // 16-bit entry: distance | relevant << 15
+                if (CACHE) e[j] = ((inc >> 7) & 1u) | ((uint32_t)(acc[j] - lanebase) >> 5);     // entry: distance << 1 | relevant (8 or 16 bits)
             }
             if (CACHE && NMC == 1) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
             if (CACHE && NMC >= 2) {                                 // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
@@ -925,6 +927,244 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     }
     uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
     for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_scan_hist_m2: pass 1 for binary codes of at most 64 bits (round 3).  Same idea as k_scan_hist_m -- the MFMA emits the LDS
+// address of counter [distance][query] -- rebuilt around what limited that kernel (no unit above 0.4 busy, two barriers per
+// batch, 8.2 VALU instructions per pair of which 5 packed the pair-cache byte, 2 moved MFMA results out of the AGPRs):
+//   * VGPR-form MFMAs (inline asm): results are consumed where they land, no v_accvgpr_read.  Every instruction that touches
+//     an MFMA result is asm volatile in program order, software-pipelined one (item group, query group) behind its MFMAs, so
+//     the MFMA -> VALU / DS read hazard (8 wait states, hipcc inserts them only for its own instructions) is covered by the 12
+//     consumer instructions of the previous group that sit in between.
+//   * the pair-cache byte comes out of the matrix pipe too: a second code chain with query bytes -+1 started at K IS
+//     2 * distance, and the label chain counts into (all << 16 | relevant) counters -- item and query label bytes 1, started at
+//     0x10000, min(acc, 0x10001) is the add operand and its low byte the relevance bit -- so one SDWA OR per pair
+//     (byte0(2d) | byte0(inc) written to byte j of the cache word) replaces five instructions: 2 VALU per pair in all.
+//   * a 3-deep LDS ring with ONE barrier per batch: the LDS-DMA of batch i + 2 is issued after the barrier of batch i, by when
+//     every wave has consumed batch i - 1, whose buffer it overwrites.
+//   * NQ query groups of 16 per wave: every A operand read from the ring (ds_read_b128) feeds NQ MFMAs, and a block covers
+//     NW * NQ * 16 queries per staged batch -- the L2 -> LDS traffic of the launch, R * 64 * (1 + NML) bytes per block row of
+//     queries (1.8 GB at configs[1] with 64 queries per block), halves with 128.
+// Counter rows are 64 bytes (16 queries x u32) as in k_scan_hist_m; chunks may now hold up to 32768 items (16-bit halves).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ v4i mfma_i8_vgpr(v4i a, v4i b, v4i c) {
+    v4i d;
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// operand images of k_scan_hist_m2: gallery [64-item batch][16-item group][tile: code, labels...][lane][16 B] with code bytes +-1 and
+// label bytes 1; queries [16-query tile][tile: code -+32, code -+1, labels...][lane][16 B]
+template <int NML>
+__global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int K,
+                                                      uint4* __restrict__ out, int64_t npieces, unsigned gblocks, const uint32_t* __restrict__ qbits,
+                                                      const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces,
+                                                      uint32_t* __restrict__ ctl, int ctl_words) {
+    constexpr int NMI = 1 + NML, NMQ = 2 + NML;
+    if (blockIdx.x == gridDim.x - 1)                               // the control words of this call (see k_scan_expand)
+        for (int e = threadIdx.x; e < ctl_words; e += 256) ctl[e] = 0u;
+    if (blockIdx.x >= gblocks) {
+        const int64_t p = (int64_t)(blockIdx.x - gblocks) * 256 + threadIdx.x;
+        if (p >= qpieces) return;
+        const int lane = (int)(p & 63);
+        const int m = (int)((p >> 6) % NMQ);
+        const int64_t q = ((p >> 6) / NMQ) * 16 + (lane & 15);
+        const int c = lane >> 4;
+        uint32_t a[4] = {0u, 0u, 0u, 0u};
+        if (q < Q) {                                               // queries past the end: all-zero operands
+            const int k0 = c * 16 + (m >= 2 ? (m - 2) * 64 : 0);
+            uint32_t bits = 0u;
+            if (m < 2) {
+                if (k0 < W * 32) bits = (qbits[q * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+                const uint32_t set = m == 0 ? 0xe0u : 0xffu, clr = m == 0 ? 0x20u : 0x01u;      // -32 / +32 (address), -1 / +1 (2 * distance)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (k0 + t < K) a[t >> 2] |= (((bits >> t) & 1u) ? set : clr) << (8 * (t & 3));
+                }
+            } else {
+                if (k0 < LW * 32) bits = (qlab[q * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a[t >> 2] |= ((bits >> t) & 1u) << (8 * (t & 3));
+            }
+        }
+        qout[p] = make_uint4(a[0], a[1], a[2], a[3]);
+        return;
+    }
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npieces) return;
+    const int lane = (int)(p & 63);
+    const int m = (int)((p >> 6) % NMI);
+    const int64_t grp = (p >> 6) / NMI;                            // batch * 4 + group
+    const int rho = lane & 15, c = lane >> 4;
+    const int64_t item = grp * 16 + 4 * (rho & 3) + (rho >> 2);
+    uint32_t by[4] = {0u, 0u, 0u, 0u};
+    if (m == 0) {                                                  // items past the end: all-zero-bit codes (bytes -1), no labels
+        const int k0 = c * 16;
+        uint32_t bits = 0u;
+        if (item < R && k0 < W * 32) bits = (rbits[item * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((k0 + t < K) ? (((bits >> t) & 1u) ? 0x01u : 0xffu) : 0u) << (8 * (t & 3));
+    } else {
+        const int k0 = (m - 1) * 64 + c * 16;
+        uint32_t bits = 0u;
+        if (item < R && k0 < LW * 32) bits = (rlab[item * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((bits >> t) & 1u) << (8 * (t & 3));
+    }
+    out[p] = make_uint4(by[0], by[1], by[2], by[3]);
+}
+
+template <int NML, int NW, int NQ, bool CACHE>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+    constexpr int NMI = 1 + NML, NMQ = 2 + NML;
+    constexpr int PIECES = 4 * NMI;                                  // 1 KB pieces per 64-item batch
+    constexpr int PPW = (PIECES + NW - 1) / NW;                      // LDS-DMA pieces a wave issues per batch
+    constexpr int NST = CACHE ? NQ : 0;                              // cache stores a wave issues per batch (they share vmcnt)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters, then the 3-deep ring
+    int chunk_id, qtile;
+    if (!mfma_map_block(a, chunk_id, qtile)) return;                 // a.nqt counts tiles of NW * NQ * 16 queries here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int t16 = (qtile * NW + wave) * NQ;                        // first 16-query tile of this wave
+    const int ncell = a.nb * 16;
+    uint32_t* cnt = lds + (wave * NQ) * ncell;
+    for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
+    char* ring = reinterpret_cast<char*>(lds + NW * NQ * ncell);
+    v4i bq[NQ][NMQ], cq[NQ];
+    bool valid[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+#pragma unroll
+        for (int m = 0; m < NMQ; ++m) bq[h][m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(t16 + h) * NMQ + m) * 64 + lane);
+        valid[h] = (t16 + h) * 16 + ql < a.Q;
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 32 * a.K : 0);
+        cq[h] = v4i{c0, c0, c0, c0};
+    }
+    const v4i kq = {a.K, a.K, a.K, a.K}, lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
+    uint4* crow[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h)
+        crow[h] = CACHE ? pair_cache + ((int64_t)chunk_id * (a.qpad >> 4) + (t16 + h)) * ((a.chunk + 63) >> 6) * 64 + lane : nullptr;
+    auto stage = [&](int buf, int64_t batch) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = (j * NW + wave) < PIECES ? j * NW + wave : PIECES - 1;     // surplus slots repeat the last piece (same bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.gimg + (batch * PIECES + p) * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(ring + buf * (PIECES * 1024) + p * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, bat0);
+    if (nbat > 1) stage(1, bat0 + 1);
+    int buf = 0;
+    for (int i = 0; i < nbat; ++i) {
+        // this wave's pieces of batch i have landed: newer in flight are the pieces of batch i + 1 and the cache stores of batch i - 1
+        if (i + 1 >= nbat) wait_vmcnt<0>();
+        else if (i == 0) wait_vmcnt<PPW>();
+        else wait_vmcnt<PPW + NST>();
+        __builtin_amdgcn_s_barrier();                                // all pieces of batch i are in; every wave is done with batch i - 1
+        if (i + 2 < nbat) stage(buf >= 1 ? buf - 1 : 2, bat0 + i + 2);      // (i + 2) % 3 == (i - 1) % 3
+        const char* base = ring + buf * (PIECES * 1024) + lane * 16;
+        buf = buf == 2 ? 0 : buf + 1;
+        v4i am[4][NMI];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int m = 0; m < NMI; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NMI + m) * 1024);
+        }
+        uint32_t cw[NQ][4];
+        v4i addr_p, d2_p, lab_p;                                     // results of the previous (group, query group), consumed now
+        // One asm statement per stage: hipcc pads every inline-asm result with s_nop before an inline-asm reader (it assumes a dst_sel
+        // forwarding hazard and does not count asm statements as wait states), so the hazards INSIDE a statement are handled here:
+        // the SDWA byte inserts into w (a real dst_sel forwarding hazard: one wait state before the next reader of w) alternate with
+        // the adds; MFMA -> MFMA srcC dependencies are interlocked in hardware.
+        auto consume = [&](const v4i& addr, const v4i& d2, const v4i& lab, uint32_t& w) {
+            uint32_t i0, i1, i2, i3;
+            if (CACHE) {
+                asm volatile(
+                    "v_min_u32 %1, 0x10001, %5\n\tv_min_u32 %2, 0x10001, %6\n\tv_min_u32 %3, 0x10001, %7\n\tv_min_u32 %4, 0x10001, %8\n\t"
+                    "v_or_b32_sdwa %0, %9, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    "ds_add_u32 %13, %1\n\t"
+                    "v_or_b32_sdwa %0, %10, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    "ds_add_u32 %14, %2\n\t"
+                    "v_or_b32_sdwa %0, %11, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    "ds_add_u32 %15, %3\n\t"
+                    "v_or_b32_sdwa %0, %12, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    "ds_add_u32 %16, %4"
+                    : "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]), "v"(addr[0]), "v"(addr[1]),
+                      "v"(addr[2]), "v"(addr[3])
+                    : "memory");
+            } else {
+                asm volatile(
+                    "v_min_u32 %0, 0x10001, %4\n\tv_min_u32 %1, 0x10001, %5\n\tv_min_u32 %2, 0x10001, %6\n\tv_min_u32 %3, 0x10001, %7\n\t"
+                    "ds_add_u32 %8, %0\n\tds_add_u32 %9, %1\n\tds_add_u32 %10, %2\n\tds_add_u32 %11, %3"
+                    : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+                    : "memory");
+            }
+        };
+        // the chained label MFMA sits right behind its producer; the two independent MFMAs after it keep later VALU writes (which may
+        // reuse its dead registers) out of its operand-read window
+        auto evaluate = [&](int g, int h, v4i& addr, v4i& d2, v4i& lab) {
+            if (NML == 2) {
+                asm volatile(
+                    "v_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\tv_mfma_i32_16x16x64_i8 %0, %6, %7, %0\n\t"
+                    "v_mfma_i32_16x16x64_i8 %1, %8, %9, %10\n\tv_mfma_i32_16x16x64_i8 %2, %8, %11, %12"
+                    : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                    : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]),
+                      "v"(bq[h][1]), "v"(kq));
+            } else {
+                asm volatile(
+                    "v_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\t"
+                    "v_mfma_i32_16x16x64_i8 %1, %6, %7, %8\n\tv_mfma_i32_16x16x64_i8 %2, %6, %9, %10"
+                    : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                    : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
+            }
+        };
+#pragma unroll
+        for (int pidx = 0; pidx < 4 * NQ; ++pidx) {
+            v4i addr, d2, lab;
+            evaluate(pidx / NQ, pidx % NQ, addr, d2, lab);
+            if (pidx > 0) consume(addr_p, d2_p, lab_p, cw[(pidx - 1) % NQ][(pidx - 1) / NQ]);
+            addr_p = addr; d2_p = d2; lab_p = lab;
+        }
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
+        consume(addr_p, d2_p, lab_p, cw[NQ - 1][3]);
+        if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                uint4* dst = crow[h] + (int64_t)i * 64;
+                __builtin_nontemporal_store(cw[h][0], &dst->x);
+                __builtin_nontemporal_store(cw[h][1], &dst->y);
+                __builtin_nontemporal_store(cw[h][2], &dst->z);
+                __builtin_nontemporal_store(cw[h][3], &dst->w);
+            }
+        }
+    }
+    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
+    const int npad = nbat * 64 - (int)(hi - lo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (npad > 0 && slot == 0) {
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            if (!valid[h]) continue;
+            const int64_t q = (int64_t)(t16 + h) * 16 + ql;
+            int dpad = 0;
+            for (int w = 0; w < a.W; ++w) dpad += __popc(a.qbits[q * a.W + w]);
+            cnt[h * ncell + dpad * 16 + ql] -= (uint32_t)npad << 16;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + (t16 + h) * 16;
+        for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[h * ncell + e];
+    }
 }
 
 // Pass 2 on the same operand images: the MFMA emits the counter address and the label overlap, ONE returning ds_add per pair
@@ -1319,6 +1559,13 @@ inline bool mfma_ap_on() {                           // read per call (tests tog
     return e && atoi(e) != 0;
 }
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
+// k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
+// two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
+constexpr int kM2Waves = 4, kM2Groups = 2, kM2Queries = kM2Waves * kM2Groups * 16;
+inline bool m2_shape(int K, bool ternary) {
+    const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
+    return !(e && atoi(e) == 0) && mfma_shape(K, ternary) && K <= 64 && !mfma_ap_on();
+}
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
 inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
@@ -1370,7 +1617,9 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const int S64 = slots_for(Wc, ternary != 0, 8);
     const int64_t lds_ap = nb * (64 / S64) * 8;
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
-    const int64_t nqt = xmh::ceil_div(Q, 64);
+    const bool m2 = m2_shape(K, ternary != 0);
+    int64_t nqt = xmh::ceil_div(Q, 64);
+    if (m2) nqt = xmh::ceil_div(nqt * 64, (int64_t)kM2Queries) * (kM2Queries / 64);      // whole blocks of k_scan_hist_m2
     const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
     // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
@@ -1389,6 +1638,10 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
         static const int mr = getenv("XMH_SCAN_MFMA_ROUNDS") ? atoi(getenv("XMH_SCAN_MFMA_ROUNDS")) : 3;
         // 65..128 bits: 129 bucket rows, 2 blocks per CU; 129..256 bits: 257 rows, one block per CU
         nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
+        if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
+            static const int m2r = getenv("XMH_SCAN_M2_ROUNDS") ? atoi(getenv("XMH_SCAN_M2_ROUNDS")) : 2;
+            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * 2 / (nqt * 64 / kM2Queries);
+        }
     }
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 8) nchunk = (nchunk + 4) / 8 * 8;      // whole XCD groups: every XCD gets the same number of chunks
@@ -1398,7 +1651,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     chunk = xmh::ceil_div(chunk, 8) * 8;
     if (mfma) {                                   // batches of 64 items aligned to the gallery image; counters hold all + 8128 * relevant
         chunk = xmh::ceil_div(chunk, 64) * 64;
-        if (chunk > kMfmaMaxChunk) {                              // capped: whole XCD groups of equal chunks again
+        if (!m2 && chunk > kMfmaMaxChunk) {                       // capped: whole XCD groups of equal chunks again
             nchunk = xmh::ceil_div(xmh::ceil_div(R, (int64_t)kMfmaMaxChunk), 8) * 8;
             chunk = xmh::ceil_div(xmh::ceil_div(R, nchunk), 64) * 64;
         }
@@ -1479,17 +1732,7 @@ ScanArgs make_args(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
 inline int scan_grid(const xmh_scan_plan& p) { return (int)(8 * p.nqtile * xmh::ceil_div(p.nchunk, 8)); }
 
 template <typename KernT>
-int raise_lds(KernT kern, size_t lds, const char* who) {
-    static const void* raised_for = nullptr;                     // (kernel, size) of the last raise: the attribute call is kept off
-    static size_t raised = 0;                                    // the launch path of repeated calls
-    if (lds > 64 * 1024 && !(raised_for == reinterpret_cast<const void*>(kern) && lds <= raised)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, lds, hipGetErrorString(e));
-        raised_for = reinterpret_cast<const void*>(kern);
-        raised = lds;
-    }
-    return XMH_OK;
-}
+int raise_lds(KernT kern, size_t lds, const char* who) { return xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, who); }
 
 }  // namespace
 
@@ -1524,8 +1767,40 @@ int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbi
     return XMH_OK;
 }
 
+template <int NML>
+int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+                 const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    constexpr int NMI = 1 + NML, NMQ = 2 + NML, NW = kM2Waves, NQ = kM2Groups;
+    uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
+    uint4* qimg = reinterpret_cast<uint4*>(base + L.qimg32);
+    const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NMI * 64, qpieces = (p.qpad / 16) * NMQ * 64;
+    const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
+    hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
+                       qimg, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
+    XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
+    MfmaArgs a{gimg, qimg, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / kM2Queries), (int)p.nbuckets, (int)p.qpad};
+    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
+    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
+    xmh::ProfScope prof("scan_hist", st);
+    if (cache) {
+        auto kern = k_scan_hist_m2<NML, NW, NQ, true>;
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    } else {
+        auto kern = k_scan_hist_m2<NML, NW, NQ, false>;
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    }
+    return XMH_OK;
+}
+
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    if (m2_shape(K, false))
+        return LW <= 2 ? mfma_hist2_t<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                       : mfma_hist2_t<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
     if (K <= 64)
         return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
@@ -1611,7 +1886,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelScale : 0u, below, tot,
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) ? kRelHi16 : kRelScale) : 0u, below, tot,
                        reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
                        reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate), hist_all, hist_rel);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");

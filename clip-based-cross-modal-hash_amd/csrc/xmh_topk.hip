@@ -854,20 +854,9 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     return XMH_OK;
 }
 
-// opt a kernel in to more than 64 KB of dynamic LDS, once per kernel and size (the attribute call sits on the launch path of
-// every top-k call otherwise)
+// opt a kernel in to more than 64 KB of dynamic LDS, once per (device, kernel) and size (xmh::raise_dynamic_lds)
 template <typename KernT>
-int raise_lds(KernT kern, size_t bytes, const char* who) {
-    static const void* raised_for = nullptr;                     // KernT is a function-pointer TYPE shared by all kernels of one
-    static size_t raised = 0;                                    // signature: remember the last (kernel, size) pair
-    if (bytes > 64 * 1024 && !(raised_for == reinterpret_cast<const void*>(kern) && bytes <= raised)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return xmh::fail(XMH_EHIP, "%s: cannot raise dynamic LDS to %zu: %s", who, bytes, hipGetErrorString(e));
-        raised_for = reinterpret_cast<const void*>(kern);
-        raised = bytes;
-    }
-    return XMH_OK;
-}
+int raise_lds(KernT kern, size_t bytes, const char* who) { return xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), bytes, who); }
 
 }  // namespace
 
