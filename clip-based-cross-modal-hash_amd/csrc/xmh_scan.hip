@@ -49,7 +49,7 @@ struct ScanArgs {
     const uint32_t* rlab;
     int Q, R, K;
     int chunk, nchunk, nqt, qpad, nb;
-    uint4* pair_cache;      // pass 1 -> pass 2: (distance | relevant << 7) of every pair, see k_scan_hist_s; null = recompute
+    uint4* pair_cache;      // pass 1 -> pass 2: (distance << 1 | relevant) of every pair, see k_scan_hist_s; null = recompute
 };
 
 // blockIdx -> (chunk, query tile).  Block b runs on XCD b%8 (observed, speed only): pin chunk c to XCD c%8
@@ -375,7 +375,7 @@ template <int S> struct SlotGeom {
 // NW = waves per block.  1 except for S = 64 (one query per wave): there every wave would stream its whole chunk for a
 // single query -- the gallery re-read Q times from L2 / Infinity Cache (measured 6.5 TB/s, 10x the VALU time) -- so NW = 8
 // waves (8 queries) share ONE staged batch: each wave loads an eighth of it, two barriers per batch.
-// CACHE (S = 4, one wave per block, codes of at most 127 bits): pass 1 also writes one byte per pair, distance | relevant << 7,
+// CACHE (S = 4, one wave per block, codes of at most 127 bits): pass 1 also writes one byte per pair, distance << 1 | relevant,
 // so that pass 2 does not evaluate the pair again (XOR / popcount / label AND: 8 of its 15 VALU instructions) nor stage the
 // gallery: lane l of the wave of (chunk, query tile) owns 16 consecutive bytes = its 16 steps of a 64-item batch, a wave
 // stores 1 KB per batch.  Q x R bytes in all (593 MB at the COCO shape), streamed once each way while both passes are VALU-bound.
@@ -828,7 +828,7 @@ __device__ __forceinline__ bool mfma_map_block(const MfmaArgs& a, int& chunk_id,
     return chunk_id < a.nchunk;
 }
 
-// CACHE: also leaves the pair cache of k_scan_hist_s (one byte per pair, distance | relevant << 7, 16 bytes per lane and batch in
+// CACHE: also leaves the pair cache of k_scan_hist_s (one byte per pair, distance << 1 | relevant, 16 bytes per lane and batch in
 // the same lane geometry) so that the cached k_scan_ap_s runs as pass 2.
 template <int NMC, int NML, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 32 * a.K : 0);
         cq[h] = v4i{c0, c0, c0, c0};
     }
-    const v4i kq = {a.K, a.K, a.K, a.K}, lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
+    v4i kq = {a.K, a.K, a.K, a.K}, lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
+    asm volatile("" : "+v"(kq), "+v"(lab0));                        // opaque: kept in VGPRs, not re-materialised from SGPRs inside the loop
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) asm volatile("" : "+v"(cq[h]));
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     const int nbat = (int)((hi - lo + 63) >> 6);
@@ -1083,7 +1086,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         // forwarding hazard and does not count asm statements as wait states), so the hazards INSIDE a statement are handled here:
         // the SDWA byte inserts into w (a real dst_sel forwarding hazard: one wait state before the next reader of w) alternate with
         // the adds; MFMA -> MFMA srcC dependencies are interlocked in hardware.
-        auto consume = [&](const v4i& addr, const v4i& d2, const v4i& lab, uint32_t& w) {
+        // `live`: the A tiles of the MFMAs issued just before -- named as (unused) inputs so that none of this statement's results is
+        // allocated on top of them: an MFMA reads its A / B operands over its first cycles, and a VALU write landing on them two or
+        // three instructions later corrupted the last MFMA's operand (wrong cache bytes from the second batch on; the atomics' address
+        // chain, issued one MFMA earlier, was already safe)
+        auto consume = [&](const v4i& addr, const v4i& d2, const v4i& lab, uint32_t& w, const v4i (&live)[NMI]) {
             uint32_t i0, i1, i2, i3;
             if (CACHE) {
                 asm volatile(
@@ -1098,44 +1105,56 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     "ds_add_u32 %16, %4"
                     : "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
                     : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]), "v"(addr[0]), "v"(addr[1]),
-                      "v"(addr[2]), "v"(addr[3])
+                      "v"(addr[2]), "v"(addr[3]), "v"(live[0]), "v"(live[1]), "v"(live[NMI - 1])
                     : "memory");
             } else {
                 asm volatile(
                     "v_min_u32 %0, 0x10001, %4\n\tv_min_u32 %1, 0x10001, %5\n\tv_min_u32 %2, 0x10001, %6\n\tv_min_u32 %3, 0x10001, %7\n\t"
                     "ds_add_u32 %8, %0\n\tds_add_u32 %9, %1\n\tds_add_u32 %10, %2\n\tds_add_u32 %11, %3"
                     : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(live[0]), "v"(live[1]),
+                      "v"(live[NMI - 1])
                     : "memory");
             }
         };
         // the chained label MFMA sits right behind its producer; the two independent MFMAs after it keep later VALU writes (which may
         // reuse its dead registers) out of its operand-read window
+        // ONE statement, opened by wait states: hipcc may place a VALU instruction (a copy, or v_mov_b64 re-materialising one of the
+        // constant accumulator quads from SGPRs) right in front of an asm statement, and an MFMA issued in the very next slot read the
+        // OLD register contents as srcC (seen on hardware: the first batch of the steady-state loop got stale 2 * distance bytes).
+        // hipcc spaces that for its own MFMAs; here it is done by hand.
         auto evaluate = [&](int g, int h, v4i& addr, v4i& d2, v4i& lab) {
-            if (NML == 2) {
-                asm volatile(
-                    "v_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\tv_mfma_i32_16x16x64_i8 %0, %6, %7, %0\n\t"
-                    "v_mfma_i32_16x16x64_i8 %1, %8, %9, %10\n\tv_mfma_i32_16x16x64_i8 %2, %8, %11, %12"
-                    : "=&v"(lab), "=&v"(addr), "=&v"(d2)
-                    : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]),
-                      "v"(bq[h][1]), "v"(kq));
+            if (NML == 2 && CACHE) {
+                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\tv_mfma_i32_16x16x64_i8 %0, %6, %7, %0\n\t"
+                             "v_mfma_i32_16x16x64_i8 %1, %8, %9, %10\n\tv_mfma_i32_16x16x64_i8 %2, %8, %11, %12"
+                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]),
+                               "v"(bq[h][1]), "v"(kq));
+            } else if (NML == 2) {
+                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %2, %3, %4\n\tv_mfma_i32_16x16x64_i8 %0, %5, %6, %0\n\t"
+                             "v_mfma_i32_16x16x64_i8 %1, %7, %8, %9"
+                             : "=&v"(lab), "=&v"(addr)
+                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]));
+            } else if (CACHE) {
+                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\t"
+                             "v_mfma_i32_16x16x64_i8 %1, %6, %7, %8\n\tv_mfma_i32_16x16x64_i8 %2, %6, %9, %10"
+                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
             } else {
-                asm volatile(
-                    "v_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\t"
-                    "v_mfma_i32_16x16x64_i8 %1, %6, %7, %8\n\tv_mfma_i32_16x16x64_i8 %2, %6, %9, %10"
-                    : "=&v"(lab), "=&v"(addr), "=&v"(d2)
-                    : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
+                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %2, %3, %4\n\tv_mfma_i32_16x16x64_i8 %1, %5, %6, %7"
+                             : "=&v"(lab), "=&v"(addr)
+                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]));
             }
         };
 #pragma unroll
         for (int pidx = 0; pidx < 4 * NQ; ++pidx) {
             v4i addr, d2, lab;
             evaluate(pidx / NQ, pidx % NQ, addr, d2, lab);
-            if (pidx > 0) consume(addr_p, d2_p, lab_p, cw[(pidx - 1) % NQ][(pidx - 1) / NQ]);
+            if (pidx > 0) consume(addr_p, d2_p, lab_p, cw[(pidx - 1) % NQ][(pidx - 1) / NQ], am[pidx / NQ]);
             addr_p = addr; d2_p = d2; lab_p = lab;
         }
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
-        consume(addr_p, d2_p, lab_p, cw[NQ - 1][3]);
+        consume(addr_p, d2_p, lab_p, cw[NQ - 1][3], am[3]);
         if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
 #pragma unroll
             for (int h = 0; h < NQ; ++h) {
@@ -1561,7 +1580,13 @@ inline bool mfma_ap_on() {                           // read per call (tests tog
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
 // k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
-constexpr int kM2Waves = 4, kM2Groups = 2, kM2Queries = kM2Waves * kM2Groups * 16;
+struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
+inline M2Geom m2_geom() {                              // XMH_SCAN_M2_GEOM picks one of the instantiated shapes (tuning; read per call)
+    static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}};
+    const char* e = getenv("XMH_SCAN_M2_GEOM");
+    const int g = e ? atoi(e) : 0;
+    return table[g >= 0 && g < 4 ? g : 0];
+}
 inline bool m2_shape(int K, bool ternary) {
     const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
     return !(e && atoi(e) == 0) && mfma_shape(K, ternary) && K <= 64 && !mfma_ap_on();
@@ -1619,7 +1644,8 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const bool m2 = m2_shape(K, ternary != 0);
     int64_t nqt = xmh::ceil_div(Q, 64);
-    if (m2) nqt = xmh::ceil_div(nqt * 64, (int64_t)kM2Queries) * (kM2Queries / 64);      // whole blocks of k_scan_hist_m2
+    const int m2q = m2_geom().queries();
+    if (m2) nqt = xmh::ceil_div(nqt * 64, (int64_t)m2q) * m2q / 64;      // whole blocks of k_scan_hist_m2 (m2q is 128 or 256)
     const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
     // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
@@ -1640,7 +1666,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
         nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
         if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
             static const int m2r = getenv("XMH_SCAN_M2_ROUNDS") ? atoi(getenv("XMH_SCAN_M2_ROUNDS")) : 2;
-            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * 2 / (nqt * 64 / kM2Queries);
+            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * m2_geom().blocks_per_cu / (nqt * 64 / m2q);
         }
     }
     if (nchunk < 1) nchunk = 1;
@@ -1767,10 +1793,10 @@ int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbi
     return XMH_OK;
 }
 
-template <int NML>
+template <int NML, int NW, int NQ>
 int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
                  const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    constexpr int NMI = 1 + NML, NMQ = 2 + NML, NW = kM2Waves, NQ = kM2Groups;
+    constexpr int NMI = 1 + NML, NMQ = 2 + NML;
     uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
     uint4* qimg = reinterpret_cast<uint4*>(base + L.qimg32);
     const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NMI * 64, qpieces = (p.qpad / 16) * NMQ * 64;
@@ -1778,7 +1804,7 @@ int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rb
     hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
                        qimg, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
     XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
-    MfmaArgs a{gimg, qimg, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / kM2Queries), (int)p.nbuckets, (int)p.qpad};
+    MfmaArgs a{gimg, qimg, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
     const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
     xmh::ProfScope prof("scan_hist", st);
@@ -1796,11 +1822,22 @@ int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rb
     return XMH_OK;
 }
 
+template <int NML>
+int mfma_hist2(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    const M2Geom g = m2_geom();
+#define XMH_M2(NWW, NQQ) \
+    if (g.nw == NWW && g.nq == NQQ) return mfma_hist2_t<NML, NWW, NQQ>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    XMH_M2(4, 2) XMH_M2(8, 1) XMH_M2(4, 4) XMH_M2(8, 2)
+#undef XMH_M2
+    return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_m2 instance for %d waves x %d query groups", g.nw, g.nq);
+}
+
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
     if (m2_shape(K, false))
-        return LW <= 2 ? mfma_hist2_t<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                       : mfma_hist2_t<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+        return LW <= 2 ? mfma_hist2<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                       : mfma_hist2<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
     if (K <= 64)
         return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
@@ -1822,6 +1859,12 @@ extern "C" size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ter
     xmh_scan_plan p;
     if (make_plan(Q, R, K, ternary, &p)) return 0;
     return pair_cache_bytes(p, K, ternary != 0);
+}
+
+extern "C" size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary) {
+    xmh_scan_plan p;
+    if (make_plan(Q, R, K, ternary, &p)) return (size_t)-1;
+    return ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0)).pair_cache;
 }
 
 extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,

@@ -106,10 +106,16 @@ typedef struct xmh_scan_plan {
 
 int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host);
 /* Bytes of the workspace (included in plan.ws_bytes) that hold the PAIR CACHE: xmh_hamming_hist leaves one byte per (query,
- * gallery item) pair -- distance | relevant << 7; two bytes for codes of 65..256 bits -- and xmh_hamming_ap reads it instead of
+ * gallery item) pair -- distance << 1 | relevant; two bytes for codes of 65..256 bits -- and xmh_hamming_ap reads it instead of
  * evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 4096 MB;
  * 0 = off); returns 0 when it is not used. */
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
+/* Byte offset of that pair cache inside the workspace ((size_t)-1 on a bad shape) -- for tests and diagnostics, which decode it
+ * and compare every entry with the oracle's distance and relevance.  Layout for codes of at most 64 bits:
+ * [chunk][16-query tile][64-item batch of the chunk][lane 0..63][16 bytes]; lane = slot * 16 + query-in-tile, byte t of a lane
+ * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant.  65..256 bits:
+ * [chunk][8-query tile][batch][lane][8 x u16], lane = slot * 8 + query-in-tile, entry t = item 64 * batch + 8 * t + slot. */
+size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary);
 
 /* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).
  * qzero / rzero NULL => binary codes.

@@ -35,7 +35,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     plan = _lib.ScanPlan()
     assert _lib.lib.xmh_scan_plan_make(0, 10, 64, 0, ctypes.byref(plan)) == -22
     assert _lib.lib.xmh_scan_plan_make(5000, 117218, 64, 0, ctypes.byref(plan)) == 0
-    assert plan.nbuckets == 65 and plan.qpad == 5056 and plan.chunk * plan.nchunk >= 117218
+    assert plan.nbuckets == 65 and plan.qpad == 5120 and plan.chunk * plan.nchunk >= 117218      # whole 128-query blocks of pass 1
     assert _lib.lib.xmh_scan_plan_make(10, 1000, 2048, 0, ctypes.byref(plan)) == 0 and plan.nbuckets == 2049    # long binary codes
     assert _lib.lib.xmh_scan_plan_make(10, 1000, 4096, 0, ctypes.byref(plan)) == -95      # beyond 2048 bits
     assert _lib.lib.xmh_scan_plan_make(10, 1000, 512, 1, ctypes.byref(plan)) == -95       # zero planes only up to 256 bits

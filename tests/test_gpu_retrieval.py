@@ -329,6 +329,52 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
         assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("Q,R,K,C", [(130, 6000, 64, 80), (70, 9100, 64, 33), (300, 20011, 48, 80), (17, 63, 64, 5), (129, 6463, 128, 80),
+                                     (65, 3000, 256, 24)])
+def test_pair_cache_entries_match_oracle(xr, Q, R, K, C):
+    """Every entry pass 1 leaves in the pair cache (distance << 1 | relevant; xmh_scan_pair_cache_offset documents the layout)
+    against the oracle's distance and relevance of that (query, item) pair -- the MFMA-evaluated pass 1 writes the entry from a
+    second accumulator chain, so this checks that chain directly and not only through the mAP it leads to."""
+    from xmh._lib import lib
+    orc = _orc()
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=3 * K + R)
+    q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+    ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
+    scan = xr.RankingScan(q, ql, r, rl, C)
+    nbytes = int(lib.xmh_scan_pair_cache_bytes(Q, R, K, 0))
+    assert nbytes > 0
+    scan.ws.zero_()
+    scan.histograms(False)
+    off = int(lib.xmh_scan_pair_cache_offset(Q, R, K, 0))
+    raw = scan.ws[off:off + nbytes].cpu().numpy()
+    dist = orc.hamming_packed(_u32(q.bits), _u32(r.bits)).astype(np.int64)
+    rel = orc.relevance_packed(_u32(ql), _u32(rl)).astype(np.int64)
+    want = (dist << 1) | rel                                           # [Q, R]
+    pl = scan.plan
+    nbatch = (pl.chunk + 63) // 64
+    S, QW = (4, 16) if K <= 64 else (8, 8)                             # slots x queries of a cache tile; QW entries per lane and batch
+    got = raw.view(np.uint8 if K <= 64 else np.uint16).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
+    lane = np.arange(64)
+    slot, qin = lane // QW, lane % QW
+    t = np.arange(QW)
+    checked = 0
+    for c in range(pl.nchunk):
+        lo, hi = c * pl.chunk, min((c + 1) * pl.chunk, R)
+        item = lo + 64 * np.arange(nbatch)[:, None, None] + S * t[None, None, :] + slot[None, :, None]      # [batch, lane, entry]
+        ok_item = item < hi
+        for tile in range(pl.qpad // QW):
+            qq = tile * QW + qin                                        # [lane]
+            okq = qq < Q
+            if not okq.any():
+                continue
+            m = ok_item & okq[None, :, None]
+            w = want[np.minimum(qq, Q - 1)[None, :, None], np.minimum(item, R - 1)]
+            bad = (got[c, tile] != w) & m
+            assert not bad.any(), (c, tile, np.argwhere(bad)[:5], got[c, tile][bad][:5], w[bad][:5])
+            checked += int(m.sum())
+    assert checked == Q * R
+
+
 def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
     """XMH_SCAN_MFMA_AP=1 (pass 2 evaluated on the MFMA, no pair cache) against the default path: same ap sums, caps and capped
     sums bit for bit -- including ragged last batches whose padding items the MFMA pass also counts (R = 2 and R = 8157 are
