@@ -954,6 +954,17 @@ __device__ __forceinline__ v4i mfma_i8_vgpr(v4i a, v4i b, v4i c) {
     return d;
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// the A tiles of 16-item group G of the staged batch (NMI pieces of 1 KB, 16 bytes per lane) -> registers; asm, so that hipcc neither
+// sees the loads nor waits for them: the caller does, with counted lgkmcnt
+template <int OFF> __device__ __forceinline__ void lds_read128(v4i& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int G, int NMI> __device__ __forceinline__ void lds_read_group(v4i (&A)[NMI], uint32_t abase) {
+    lds_read128<(G * NMI + 0) * 1024>(A[0], abase);
+    if constexpr (NMI > 1) lds_read128<(G * NMI + 1) * 1024>(A[1], abase);
+    if constexpr (NMI > 2) lds_read128<(G * NMI + 2) * 1024>(A[2], abase);
+}
 
 // operand images of k_scan_hist_m2: gallery [64-item batch][16-item group][tile: code, labels...][lane][16 B] with code bytes +-1 and
 // label bytes 1; queries [16-query tile][tile: code -+32, code -+1, labels...][lane][16 B]
@@ -1016,8 +1027,10 @@ __global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict
     out[p] = make_uint4(by[0], by[1], by[2], by[3]);
 }
 
-template <int NML, int NW, int NQ, bool CACHE>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+// STAMP (tools/stamp_m2.hip only): s_memtime stamps around the phases of a batch, summed per wave into stamps[wave id][8]
+template <int NML, int NW, int NQ, bool CACHE, bool STAMP = false>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
+                                                          unsigned long long* __restrict__ stamps = nullptr) {
     constexpr int NMI = 1 + NML, NMQ = 2 + NML;
     constexpr int PIECES = 4 * NMI;                                  // 1 KB pieces per 64-item batch
     constexpr int PPW = (PIECES + NW - 1) / NW;                      // LDS-DMA pieces a wave issues per batch
@@ -1032,6 +1045,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
     uint32_t* cnt = lds + (wave * NQ) * ncell;
     for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
     char* ring = reinterpret_cast<char*>(lds + NW * NQ * ncell);
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     v4i bq[NQ][NMQ], cq[NQ];
     bool valid[NQ];
 #pragma unroll
@@ -1062,99 +1076,194 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                                              (__attribute__((address_space(3))) void*)(ring + buf * (PIECES * 1024) + p * 1024), 16, 0, 0);
         }
     };
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) {                                         // STAMP only: cycles since the previous stamp go to slot k
+        if (!STAMP) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        acc_t[k] += t - t_prev;
+        t_prev = t;
+    };
+    if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     stage(0, bat0);
     if (nbat > 1) stage(1, bat0 + 1);
     int buf = 0;
+    stamp(0);
     for (int i = 0; i < nbat; ++i) {
         // this wave's pieces of batch i have landed: newer in flight are the pieces of batch i + 1 and the cache stores of batch i - 1
         if (i + 1 >= nbat) wait_vmcnt<0>();
         else if (i == 0) wait_vmcnt<PPW>();
         else wait_vmcnt<PPW + NST>();
+        stamp(1);
         __builtin_amdgcn_s_barrier();                                // all pieces of batch i are in; every wave is done with batch i - 1
+        stamp(2);
         if (i + 2 < nbat) stage(buf >= 1 ? buf - 1 : 2, bat0 + i + 2);      // (i + 2) % 3 == (i - 1) % 3
-        const char* base = ring + buf * (PIECES * 1024) + lane * 16;
+        stamp(3);
+        const uint32_t abase = ring_lds + buf * (PIECES * 1024) + lane * 16;      // LDS byte address of this lane's 16 bytes of piece 0
         buf = buf == 2 ? 0 : buf + 1;
-        v4i am[4][NMI];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int m = 0; m < NMI; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NMI + m) * 1024);
-        }
+        // A tiles of item group g live in set g & 1; read (asm: hipcc would wait for ALL outstanding reads at the first use) one group
+        // ahead of the MFMAs that use them, waited for with counted lgkmcnt (LDS operations of a wave complete in order):
+        //   R(0) R(1) | group 0 | R(2) | group 1 | R(3) | group 2 | group 3      with 4 adds per statement behind the first
+        v4i A[2][NMI];
         uint32_t cw[NQ][4];
-        v4i addr_p, d2_p, lab_p;                                     // results of the previous (group, query group), consumed now
-        // One asm statement per stage: hipcc pads every inline-asm result with s_nop before an inline-asm reader (it assumes a dst_sel
-        // forwarding hazard and does not count asm statements as wait states), so the hazards INSIDE a statement are handled here:
-        // the SDWA byte inserts into w (a real dst_sel forwarding hazard: one wait state before the next reader of w) alternate with
-        // the adds; MFMA -> MFMA srcC dependencies are interlocked in hardware.
-        // `live`: the A tiles of the MFMAs issued just before -- named as (unused) inputs so that none of this statement's results is
-        // allocated on top of them: an MFMA reads its A / B operands over its first cycles, and a VALU write landing on them two or
-        // three instructions later corrupted the last MFMA's operand (wrong cache bytes from the second batch on; the atomics' address
-        // chain, issued one MFMA earlier, was already safe)
-        auto consume = [&](const v4i& addr, const v4i& d2, const v4i& lab, uint32_t& w, const v4i (&live)[NMI]) {
+        v4i addr_p, d2_p, lab_p;                                     // results of the previous (group, query group), consumed by the next statement
+        // One asm statement = the MFMAs of (group g, query group h) with the consumer instructions of the PREVIOUS pair between them:
+        // an MFMA occupies the matrix pipe for 16 cycles, the three VALU / DS instructions behind it issue meanwhile, so a wave
+        // keeps the pipe busy by itself (four MFMAs then twelve consumers left it idle half the time: 1830 cycles per batch measured
+        // against 512 of MFMA work per wave).  Inside a statement the hazards are handled by hand (hipcc does not see them):
+        //   * MFMA result -> VALU / DS read needs 8 wait states: the consumers read the PREVIOUS statement's results;
+        //   * the SDWA byte inserts into w have a dst_sel forwarding hazard (one wait state): an add or an MFMA sits between them;
+        //   * a VALU write directly in front of an MFMA was read stale as srcC (seen on hardware with a v_mov_b64 hipcc had placed
+        //     there): every statement opens with s_nop, and the constant accumulator quads are opaque to hipcc (no re-materialising);
+        //   * a VALU write landing on the A / B registers of an MFMA issued two or three instructions earlier corrupted its operand:
+        //     all results are early-clobber outputs of the statement that also names the A tiles as inputs;
+        //   * MFMA -> MFMA srcC dependencies are interlocked in hardware.
+        // The consumers: inc = min(label overlap chain, 0x10001) in place; cache byte j = byte0(2 * distance) | byte0(inc); the add.
+// ablation switches of tools/stamp_m2.hip (-DXMH_ABL_NOADD: the LDS adds become s_nop; -DXMH_ABL_NOMFMA: the MFMAs do): never set in the library build
+#ifdef XMH_ABL_NOADD
+#define XMH_ADD(A, D) "s_nop 0\n\t"
+#else
+#define XMH_ADD(A, D) "ds_add_u32 " A ", " D "\n\t"
+#endif
+#ifdef XMH_ABL_NOMFMA
+#define XMH_MFMA(D, A, B, C) "s_nop 0\n\t"
+#else
+#define XMH_MFMA(D, A, B, C) "v_mfma_i32_16x16x64_i8 " D ", " A ", " B ", " C "\n\t"
+#endif
+#define XMH_SDWA(J) "dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        auto fused = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab, uint32_t& w) {
+            uint32_t i0, i1, i2, i3;                                  // min results: fresh registers (in-place on the MFMA's result tuple made hipcc copy them)
+            if (NML == 2 && CACHE) {
+                asm volatile(
+                    "s_nop 1\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
+                    "v_min_u32 %4, 0x10001, %26\n\tv_min_u32 %5, 0x10001, %27\n\tv_min_u32 %6, 0x10001, %28\n\t"
+                    XMH_MFMA("%0", "%11", "%12", "%0")
+                    "v_min_u32 %7, 0x10001, %29\n\t"
+                    "v_or_b32_sdwa %3, %18, %4 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    XMH_ADD("%22", "%4")
+                    XMH_MFMA("%1", "%13", "%14", "%15")
+                    "v_or_b32_sdwa %3, %19, %5 " XMH_SDWA(1) XMH_ADD("%23", "%5") "v_or_b32_sdwa %3, %20, %6 " XMH_SDWA(2)
+                    XMH_MFMA("%2", "%13", "%16", "%17")
+                    XMH_ADD("%24", "%6") "v_or_b32_sdwa %3, %21, %7 " XMH_SDWA(3) XMH_ADD("%25", "%7")
+                    : "=&v"(lab), "=&v"(addr), "=&v"(d2), "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq),
+                      "v"(d2_p[0]), "v"(d2_p[1]), "v"(d2_p[2]), "v"(d2_p[3]), "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]),
+                      "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
+                    : "memory");
+            } else if (NML == 2) {
+                asm volatile(
+                    "s_nop 1\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
+                    "v_min_u32 %2, 0x10001, %18\n\tv_min_u32 %3, 0x10001, %19\n\tv_min_u32 %4, 0x10001, %20\n\t"
+                    XMH_MFMA("%0", "%9", "%10", "%0")
+                    "v_min_u32 %5, 0x10001, %21\n\t" XMH_ADD("%14", "%2") XMH_ADD("%15", "%3")
+                    XMH_MFMA("%1", "%11", "%12", "%13")
+                    XMH_ADD("%16", "%4") XMH_ADD("%17", "%5")
+                    : "=&v"(lab), "=&v"(addr), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]),
+                      "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]), "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
+                    : "memory");
+            } else if (CACHE) {
+                asm volatile(
+                    "s_nop 1\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
+                    "v_min_u32 %4, 0x10001, %24\n\tv_min_u32 %5, 0x10001, %25\n\tv_min_u32 %6, 0x10001, %26\n\tv_min_u32 %7, 0x10001, %27\n\t"
+                    "v_or_b32_sdwa %3, %16, %4 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    XMH_ADD("%20", "%4")
+                    XMH_MFMA("%1", "%11", "%12", "%13")
+                    "v_or_b32_sdwa %3, %17, %5 " XMH_SDWA(1) XMH_ADD("%21", "%5") "v_or_b32_sdwa %3, %18, %6 " XMH_SDWA(2)
+                    XMH_MFMA("%2", "%11", "%14", "%15")
+                    XMH_ADD("%22", "%6") "v_or_b32_sdwa %3, %19, %7 " XMH_SDWA(3) XMH_ADD("%23", "%7")
+                    : "=&v"(lab), "=&v"(addr), "=&v"(d2), "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq),
+                      "v"(d2_p[0]), "v"(d2_p[1]), "v"(d2_p[2]), "v"(d2_p[3]), "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]),
+                      "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
+                    : "memory");
+            } else {
+                asm volatile(
+                    "s_nop 1\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
+                    "v_min_u32 %2, 0x10001, %16\n\tv_min_u32 %3, 0x10001, %17\n\tv_min_u32 %4, 0x10001, %18\n\tv_min_u32 %5, 0x10001, %19\n\t"
+                    XMH_MFMA("%1", "%9", "%10", "%11")
+                    XMH_ADD("%12", "%2") XMH_ADD("%13", "%3") XMH_ADD("%14", "%4") XMH_ADD("%15", "%5")
+                    : "=&v"(lab), "=&v"(addr), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]),
+                      "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]), "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
+                    : "memory");
+            }
+        };
+        // the first statement of a batch: nothing to consume yet.  Closed by 8 wait states: the next statement's consumers (and any
+        // copy hipcc places in front of it) read these results, and its own MFMA is only one slot away
+        auto evaluate = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab) {
+            if (NML == 2 && CACHE) {
+                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%0", "%6", "%7", "%0")
+                             XMH_MFMA("%1", "%8", "%9", "%10") XMH_MFMA("%2", "%8", "%11", "%12") "s_nop 7"
+                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]),
+                               "v"(bq[h][1]), "v"(kq));
+            } else if (NML == 2) {
+                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%0", "%5", "%6", "%0")
+                             XMH_MFMA("%1", "%7", "%8", "%9") "s_nop 7"
+                             : "=&v"(lab), "=&v"(addr)
+                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]));
+            } else if (CACHE) {
+                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%1", "%6", "%7", "%8")
+                             XMH_MFMA("%2", "%6", "%9", "%10") "s_nop 7"
+                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
+                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
+            } else {
+                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%1", "%5", "%6", "%7") "s_nop 7"
+                             : "=&v"(lab), "=&v"(addr)
+                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]));
+            }
+        };
+        auto consume = [&](uint32_t& w, const v4i (&live)[NMI]) {        // the last pair of a batch (live: see the hazard list above)
             uint32_t i0, i1, i2, i3;
             if (CACHE) {
                 asm volatile(
                     "v_min_u32 %1, 0x10001, %5\n\tv_min_u32 %2, 0x10001, %6\n\tv_min_u32 %3, 0x10001, %7\n\tv_min_u32 %4, 0x10001, %8\n\t"
                     "v_or_b32_sdwa %0, %9, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-                    "ds_add_u32 %13, %1\n\t"
-                    "v_or_b32_sdwa %0, %10, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-                    "ds_add_u32 %14, %2\n\t"
-                    "v_or_b32_sdwa %0, %11, %3 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-                    "ds_add_u32 %15, %3\n\t"
-                    "v_or_b32_sdwa %0, %12, %4 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-                    "ds_add_u32 %16, %4"
+                    XMH_ADD("%13", "%1")
+                    "v_or_b32_sdwa %0, %10, %2 " XMH_SDWA(1) XMH_ADD("%14", "%2") "v_or_b32_sdwa %0, %11, %3 " XMH_SDWA(2)
+                    XMH_ADD("%15", "%3") "v_or_b32_sdwa %0, %12, %4 " XMH_SDWA(3) XMH_ADD("%16", "%4")
                     : "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(d2[0]), "v"(d2[1]), "v"(d2[2]), "v"(d2[3]), "v"(addr[0]), "v"(addr[1]),
-                      "v"(addr[2]), "v"(addr[3]), "v"(live[0]), "v"(live[1]), "v"(live[NMI - 1])
+                    : "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3]), "v"(d2_p[0]), "v"(d2_p[1]), "v"(d2_p[2]), "v"(d2_p[3]), "v"(addr_p[0]),
+                      "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]), "v"(live[0]), "v"(live[1]), "v"(live[NMI - 1])
                     : "memory");
             } else {
                 asm volatile(
                     "v_min_u32 %0, 0x10001, %4\n\tv_min_u32 %1, 0x10001, %5\n\tv_min_u32 %2, 0x10001, %6\n\tv_min_u32 %3, 0x10001, %7\n\t"
-                    "ds_add_u32 %8, %0\n\tds_add_u32 %9, %1\n\tds_add_u32 %10, %2\n\tds_add_u32 %11, %3"
+                    XMH_ADD("%8", "%0") XMH_ADD("%9", "%1") XMH_ADD("%10", "%2") XMH_ADD("%11", "%3")
                     : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-                    : "v"(lab[0]), "v"(lab[1]), "v"(lab[2]), "v"(lab[3]), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(live[0]), "v"(live[1]),
-                      "v"(live[NMI - 1])
+                    : "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3]), "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]), "v"(live[0]),
+                      "v"(live[1]), "v"(live[NMI - 1])
                     : "memory");
             }
         };
-        // the chained label MFMA sits right behind its producer; the two independent MFMAs after it keep later VALU writes (which may
-        // reuse its dead registers) out of its operand-read window
-        // ONE statement, opened by wait states: hipcc may place a VALU instruction (a copy, or v_mov_b64 re-materialising one of the
-        // constant accumulator quads from SGPRs) right in front of an asm statement, and an MFMA issued in the very next slot read the
-        // OLD register contents as srcC (seen on hardware: the first batch of the steady-state loop got stale 2 * distance bytes).
-        // hipcc spaces that for its own MFMAs; here it is done by hand.
-        auto evaluate = [&](int g, int h, v4i& addr, v4i& d2, v4i& lab) {
-            if (NML == 2 && CACHE) {
-                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\tv_mfma_i32_16x16x64_i8 %0, %6, %7, %0\n\t"
-                             "v_mfma_i32_16x16x64_i8 %1, %8, %9, %10\n\tv_mfma_i32_16x16x64_i8 %2, %8, %11, %12"
-                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
-                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]),
-                               "v"(bq[h][1]), "v"(kq));
-            } else if (NML == 2) {
-                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %2, %3, %4\n\tv_mfma_i32_16x16x64_i8 %0, %5, %6, %0\n\t"
-                             "v_mfma_i32_16x16x64_i8 %1, %7, %8, %9"
-                             : "=&v"(lab), "=&v"(addr)
-                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]));
-            } else if (CACHE) {
-                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %5\n\t"
-                             "v_mfma_i32_16x16x64_i8 %1, %6, %7, %8\n\tv_mfma_i32_16x16x64_i8 %2, %6, %9, %10"
-                             : "=&v"(lab), "=&v"(addr), "=&v"(d2)
-                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
-            } else {
-                asm volatile("s_nop 3\n\tv_mfma_i32_16x16x64_i8 %0, %2, %3, %4\n\tv_mfma_i32_16x16x64_i8 %1, %5, %6, %7"
-                             : "=&v"(lab), "=&v"(addr)
-                             : "v"(am[g][1]), "v"(bq[h][2]), "v"(lab0), "v"(am[g][0]), "v"(bq[h][0]), "v"(cq[h]));
-            }
-        };
+#undef XMH_SDWA
+#undef XMH_ADD
+#undef XMH_MFMA
+        auto group = [&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            // the reads of this group have returned: operations issued behind them (see the sequence above), at most 15 countable
+            constexpr int newer = G == 0 ? NMI : (G == 1 ? 4 * (NQ - 1) + NMI : (G == 2 ? 4 * NQ + NMI : 4 * NQ));
+            wait_lgkmcnt<(newer < 15 ? newer : 15)>();
+            if (STAMP && G == 0) stamp(4);
 #pragma unroll
-        for (int pidx = 0; pidx < 4 * NQ; ++pidx) {
-            v4i addr, d2, lab;
-            evaluate(pidx / NQ, pidx % NQ, addr, d2, lab);
-            if (pidx > 0) consume(addr_p, d2_p, lab_p, cw[(pidx - 1) % NQ][(pidx - 1) / NQ], am[pidx / NQ]);
-            addr_p = addr; d2_p = d2; lab_p = lab;
-        }
+            for (int h = 0; h < NQ; ++h) {
+                v4i addr, d2, lab;
+                if (G == 0 && h == 0) evaluate(A[G & 1], h, addr, d2, lab);
+                else fused(A[G & 1], h, addr, d2, lab, cw[(h + NQ - 1) % NQ][h == 0 ? G - 1 : G]);
+                addr_p = addr; d2_p = d2; lab_p = lab;
+            }
+            if (G + 2 < 4) lds_read_group<G + 2, NMI>(A[G & 1], abase);          // this set's MFMAs have been issued (operands are read at issue)
+        };
+        lds_read_group<0, NMI>(A[0], abase);
+        lds_read_group<1, NMI>(A[1], abase);
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
-        consume(addr_p, d2_p, lab_p, cw[NQ - 1][3], am[3]);
+        consume(cw[NQ - 1][3], A[1]);
+        stamp(5);
         if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
 #pragma unroll
             for (int h = 0; h < NQ; ++h) {
@@ -1165,10 +1274,16 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                 __builtin_nontemporal_store(cw[h][3], &dst->w);
             }
         }
+        stamp(7);
     }
     // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
     const int npad = nbat * 64 - (int)(hi - lo);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(6);
+    if (STAMP && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stamps[((int64_t)blockIdx.x * NW + wave) * 8 + k] = acc_t[k];
+    }
     if (npad > 0 && slot == 0) {
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
@@ -1582,10 +1697,10 @@ constexpr int kMfmaWaves = 4;                          // waves (16 queries each
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
 struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
 inline M2Geom m2_geom() {                              // XMH_SCAN_M2_GEOM picks one of the instantiated shapes (tuning; read per call)
-    static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}};
+    static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
     const char* e = getenv("XMH_SCAN_M2_GEOM");
     const int g = e ? atoi(e) : 0;
-    return table[g >= 0 && g < 4 ? g : 0];
+    return table[g >= 0 && g < 7 ? g : 0];
 }
 inline bool m2_shape(int K, bool ternary) {
     const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
@@ -1645,7 +1760,11 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const bool m2 = m2_shape(K, ternary != 0);
     int64_t nqt = xmh::ceil_div(Q, 64);
     const int m2q = m2_geom().queries();
-    if (m2) nqt = xmh::ceil_div(nqt * 64, (int64_t)m2q) * m2q / 64;      // whole blocks of k_scan_hist_m2 (m2q is 128 or 256)
+    if (m2) {                                     // whole blocks of k_scan_hist_m2 AND whole 64-query tiles
+        int64_t l = m2q;
+        while (l % 64) l += m2q;
+        nqt = xmh::ceil_div(nqt * 64, l) * l / 64;
+    }
     const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
     // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
@@ -1812,12 +1931,12 @@ int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rb
         auto kern = k_scan_hist_m2<NML, NW, NQ, true>;
         const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
         if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (unsigned long long*)nullptr);
     } else {
         auto kern = k_scan_hist_m2<NML, NW, NQ, false>;
         const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
         if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (unsigned long long*)nullptr);
     }
     return XMH_OK;
 }
@@ -1828,7 +1947,7 @@ int mfma_hist2(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbit
     const M2Geom g = m2_geom();
 #define XMH_M2(NWW, NQQ) \
     if (g.nw == NWW && g.nq == NQQ) return mfma_hist2_t<NML, NWW, NQQ>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    XMH_M2(4, 2) XMH_M2(8, 1) XMH_M2(4, 4) XMH_M2(8, 2)
+    XMH_M2(4, 2) XMH_M2(8, 1) XMH_M2(4, 4) XMH_M2(8, 2) XMH_M2(4, 1) XMH_M2(6, 1) XMH_M2(5, 2)
 #undef XMH_M2
     return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_m2 instance for %d waves x %d query groups", g.nw, g.nq);
 }

@@ -7,7 +7,7 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('$*', 'ms/step %.4f' % d['ms_per_step'], 'mAP %.8f' % d.get('mAP'), 'pass1 %.4f' % r.get('pass1_avg_launch_ms'), 'pass2 %.4f' % r.get('pass2_avg_launch_ms'))"
 }
-for g in 0 1 2 3; do for r in 2 3; do run XMH_SCAN_M2_GEOM=$g XMH_SCAN_M2_ROUNDS=$r; done; done
+for g in 0 4 5 6; do for r in 2 3; do run XMH_SCAN_M2_GEOM=$g XMH_SCAN_M2_ROUNDS=$r; done; done
 run XMH_SCAN_M2_GEOM=0 XMH_SCAN_CACHE_MB=0
 run XMH_SCAN_M2_GEOM=1 XMH_SCAN_CACHE_MB=0
 run XMH_SCAN_M2=0
