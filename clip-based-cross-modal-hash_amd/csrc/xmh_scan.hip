@@ -38,6 +38,8 @@
 namespace {
 
 constexpr int kMaxChunk = 32768;   // u16 halves of the packed pass-1 counters must not overflow
+constexpr uint32_t kF23 = 0x4B000000u;                  // bits of 2^23 as a float (k_scan_ap_c)
+constexpr int64_t kFloatBitsMaxItems = (1ll << 23) - 3;   // largest gallery (all shards) whose ranks k_scan_ap_c's float-bit counters hold
 constexpr int kMinChunk = 256;
 
 struct ScanArgs {
@@ -489,10 +491,12 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
 // pass 1: the launch is gated by *nrel_max, no host sync), else 64-bit {lo: rank, hi: ordinal}.  Counters are 1-based
 // and start at the global base of (bucket, chunk).  MASKED: see the header (lane-order fallback).
 // CACHE: the pairs come from the byte cache of pass 1 (see k_scan_hist_s) instead of the gallery.
+// items_total (sharded calls that also launch k_scan_ap_c): that kernel takes the call when the gallery over all shards is small enough for it
 template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                  const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap) {
+                                                  const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap,
+                                                  const uint32_t* __restrict__ items_total) {
     using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using SG = SlotGeom<S>;
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
         if (P32 != fits32) return;                                   // the other variant takes this call
     }
+    if (items_total && (int64_t)*items_total <= kFloatBitsMaxItems) return;      // k_scan_ap_c takes this call
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;    // NW waves share the ring, see k_scan_hist_s
     const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
     const int q0 = (qtile * NW + wave) * QW;
@@ -1425,6 +1430,124 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
     if (lane < 16) ap_part[(int64_t)chunk_id * a.qpad + q] = apsum;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_scan_ap_c: pass 2 from the one-byte pair cache (binary codes of at most 64 bits), round 3.  Same counters-in-LDS scheme and
+// the same arithmetic as the cached k_scan_ap_s, so the results are bit-identical; what changed is the VALU work per pair, which
+// bounds this pass (PMC, round 2: VALU busy 86 % of the launch at 10.5 instructions per pair, most of them half-rate):
+//   * the counters hold FLOAT BIT PATTERNS: rank counter = bits(2^23 + rank), ordinal counter = bits(2^24 - 1 - ordinal).  An integer
+//     add of 1 to the bits of a float in [2^23, 2^24) is an add of 1.0 to its value, so the 64-bit add {1, -relevant} still steps
+//     both, and what comes back needs no v_cvt_f32_u32 (half rate) nor the ordinal * relevant product: rank = lo - 2^23 and
+//     ordinal = (2^24 - 1) - hi are full-rate float subtractions, and the relevance mask (0 / ~0, sign-extended straight out of
+//     the cache byte) zeroes the reciprocal with a full-rate AND.  Needs every rank and ordinal below 2^23: galleries of up to
+//     8 388 605 items over all shards (larger ones take k_scan_ap_s);
+//   * the counter address is one v_lshl_add_u32 on a precomputed LDS address (hipcc emitted shift, and, three-operand add);
+//   * the atomics are inline asm on that address, their returns waited for with counted lgkmcnt one group of 8 later.
+// Per pair: 2 bit-field extracts, the address, the pair {1, mask}, ds_add_rtn_u64; sub, rcp, and, sub, fmac.
+// ---------------------------------------------------------------------------------------------------
+template <bool CAPPED>
+__global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+                                                  const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
+                                                  const uint32_t* __restrict__ items_total, uint32_t kcap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][16] 64-bit counters
+    int chunk_id, qtile;
+    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts 16-query tiles here
+    if (items_total && (int64_t)*items_total > kFloatBitsMaxItems) return;      // sharded call: the integer-counter kernel takes it
+    const int lane = threadIdx.x & 63;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int q0 = qtile * 16, q = q0 + ql;
+    const int ncell = a.nb * 16;
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds);
+    {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+        const uint2* __restrict__ pd = dpre + q0;
+        auto pack = [](uint2 x, uint2 y) {
+            return (unsigned long long)(kF23 + x.x + y.x + 1u) | ((unsigned long long)(kF23 + (0x7fffffu - (x.y + y.y + 1u))) << 32);
+        };
+        int e = lane;
+        for (; e + 7 * 64 < ncell; e += 8 * 64) {
+            uint2 x[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ee = e + j * 64;
+                const int64_t at = (int64_t)(ee >> 4) * a.qpad + (ee & 15);
+                x[j] = pb[at];
+                y[j] = pd[at];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt[e + j * 64] = pack(x[j], y[j]);
+        }
+        for (; e < ncell; e += 64) {
+            const int64_t at = (int64_t)(e >> 4) * a.qpad + (e & 15);
+            cnt[e] = pack(pb[at], pd[at]);
+        }
+    }
+    const uint32_t cntbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + ql * 8;
+    const float capf = CAPPED ? (float)min(cap_ws[q], kcap) : 0.0f;   // exact: below 2^23
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    float acc = 0.0f;
+    auto credit = [&](unsigned long long old, uint32_t m) {
+        const float rank = __uint_as_float((uint32_t)old) - 8388608.0f;
+        const float ord = 16777215.0f - __uint_as_float((uint32_t)(old >> 32));
+        if (CAPPED) m = ord <= capf ? m : 0u;
+        acc = fmaf(ord, __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(rank)) & m), acc);
+    };
+    auto issue1 = [&](uint32_t w, int j, unsigned long long& old, uint32_t& m) {
+        m = (uint32_t)__builtin_amdgcn_sbfe((int)w, 8 * j, 1);                    // 0 / ~0
+        const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * j + 1, 7);
+        uint32_t addr;
+        asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(d), "v"(cntbase));
+        const unsigned long long inc = 1ull | ((unsigned long long)m << 32);
+        asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(old) : "v"(addr), "v"(inc) : "memory");     // same-address lanes resolve in lane = item order
+    };
+    unsigned long long oldp[8], oldn[8];
+    uint32_t mp[8], mn[8];
+    bool prev = false;
+    auto group = [&](uint32_t wa, uint32_t wb) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) issue1(u < 4 ? wa : wb, u & 3, oldn[u], mn[u]);
+        if (prev) {                                                   // the previous group's returns: 8 newer LDS operations are in flight
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
+                         "+v"(oldp[7])::"memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u) credit(oldp[u], mp[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { oldp[u] = oldn[u]; mp[u] = mn[u]; }
+        prev = true;
+    };
+    const int nbatch = (a.chunk + 63) >> 6;
+    const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
+    const int nfull = (int)((hi - lo) >> 6);                         // whole batches of this chunk
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the counters are in place before the first asm atomic is counted
+    uint4 cw = crow[0];
+    for (int bi = 0; bi < nfull; ++bi) {
+        const uint4 nw = crow[(int64_t)(bi + 1 < nbatch ? bi + 1 : bi) * 64];      // unconditional: counted vmcnt, no predication
+        group(cw.x, cw.y);
+        group(cw.z, cw.w);
+        cw = nw;
+    }
+    if (prev) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
+                     "+v"(oldp[7])::"memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) credit(oldp[u], mp[u]);
+    }
+    const int cntb = (int)(hi - lo) - nfull * 64;                    // ragged last batch (cw holds its words)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (t * 4 + slot < cntb) {
+            const uint32_t w = t < 4 ? cw.x : (t < 8 ? cw.y : (t < 12 ? cw.z : cw.w));
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, 8 * (t & 3), 1), d = __builtin_amdgcn_ubfe(w, 8 * (t & 3) + 1, 7);
+            const unsigned long long o = atomicAdd(&cnt[d * 16 + ql], 1ull | ((unsigned long long)m << 32));
+            credit(o, m);
+        }
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
+}
+
 // Does the LDS hand out same-address returning adds of one instruction in ascending lane order?  (see the header)
 __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ ok_out) {
     __shared__ unsigned long long c64[256];
@@ -1498,7 +1621,7 @@ __global__ __launch_bounds__(64) void k_shard_offsets(const uint32_t* __restrict
 // k_scan_dpre.
 __global__ __launch_bounds__(256) void k_shard_offsets_dpre(const uint2* __restrict__ tot_g, int world, int rank, int Q, int qpad, int nb,
                                                             int64_t kcap, uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
-                                                            int32_t* __restrict__ cap_out) {
+                                                            int32_t* __restrict__ cap_out, uint32_t* __restrict__ items_total) {
     __shared__ uint2 part[4][64];
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + lane;
@@ -1515,13 +1638,15 @@ __global__ __launch_bounds__(256) void k_shard_offsets_dpre(const uint2* __restr
     }
     part[wq][lane] = make_uint2(sa, sr);
     __syncthreads();
-    uint32_t ra = 0, rr = 0, tr = 0;
+    uint32_t ra = 0, rr = 0, tr = 0, ta_all = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const uint2 pw = part[w][lane];
         if (w < wq) { ra += pw.x; rr += pw.y; }
         tr += pw.y;
+        ta_all += pw.x;
     }
+    if (items_total && blockIdx.x == 0 && threadIdx.x == 0) *items_total = ta_all;      // every query sees every item: the gallery size over all shards
     for (int d = d0; d < d1; ++d) {
         uint32_t ta = 0, tr2 = 0, la = 0, lr = 0;
         for (int w = 0; w < world; ++w) {
@@ -1661,8 +1786,12 @@ constexpr int slots_for(int W, bool tern, int counter_bytes) {
 }
 // the pair cache of k_scan_hist_s: two code words, binary, four slots in both passes and both counter widths
 template <int W, bool TERN>
-constexpr bool kPairCacheShape = !TERN && (W == 2 || W == 4 || W == 8) && slots_for(W, TERN, 4) == (W == 2 ? 4 : 8) &&
-                                 slots_for(W, TERN, 8) == (W == 2 ? 4 : 8);
+constexpr bool kPairCacheShape = !TERN && (W == 1 || W == 2 || W == 4 || W == 8);
+// ... and the slots both passes run with when the cache is in use: 4 x 16 queries with one-byte entries up to 64 bits (for codes of at
+// most 32 bits that is NOT the geometry the uncached kernels pick, 2 x 32), 8 x 8 queries with two-byte entries beyond
+constexpr int cache_slots(int W) { return W <= 2 ? 4 : 8; }
+static_assert(slots_for(2, false, 4) == 4 && slots_for(2, false, 8) == 4 && slots_for(4, false, 4) == 8 && slots_for(4, false, 8) == 8 &&
+              slots_for(8, false, 4) == 8 && slots_for(8, false, 8) == 8, "33..256 bits: the cache geometry is the uncached kernels' own");
 // waves per block: 8 where a wave owns a single query (S = 64), so that 8 queries share each staged gallery batch
 constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
@@ -1677,12 +1806,19 @@ struct WsLayout {
 // the MFMA-evaluated pass 1 (k_scan_hist_m): binary codes of 33..64 bits, i.e. where the pair cache hands pass 2 the evaluated
 // pairs (measured at Q 5000 x R 117 218, whole step: K=64 0.512 -> 0.489 ms; at K <= 32, where pass 2 evaluates the pairs itself
 // and the VALU pass 1 is cheap, it loses: K=16 0.452 -> 0.471 ms).  XMH_SCAN_MFMA=0 turns it off.
+inline bool mfma_ap_on();
+// k_scan_hist_m2 (round 3) also takes codes of at most 32 bits, the pair cache with it: XMH_SCAN_M2=0 brings back k_scan_hist_m for
+// 33..64 bits and the VALU kernels below that
+inline bool m2_enabled() {
+    const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
+    return !(e && atoi(e) == 0) && !mfma_ap_on();
+}
 inline bool mfma_shape(int K, bool ternary) {
     static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
     const char* e128 = getenv("XMH_SCAN_MFMA128");                 // read per call (tests switch it)
     const char* e256 = getenv("XMH_SCAN_MFMA256");
     const bool on128 = !(e128 && atoi(e128) == 0), on256 = !(e256 && atoi(e256) == 0);
-    return on && !ternary && K > 32 && (K <= 64 || (on128 && K <= 128) || (on128 && on256 && K <= 256));
+    return on && !ternary && (K > 32 || m2_enabled()) && (K <= 64 || (on128 && K <= 128) || (on128 && on256 && K <= 256));
 }
 // MFMA-evaluated pass 2 (k_scan_ap_m) instead of the pair cache + cached k_scan_ap_s: XMH_SCAN_MFMA_AP=1.  Bit-identical results,
 // measured at Q 5000 x R 117 218, K = 64: pass 1 without the cache 0.239 -> 0.196 ms, but pass 2 0.195 -> 0.349 ms (64-bit returning
@@ -1696,16 +1832,20 @@ constexpr int kMfmaWaves = 4;                          // waves (16 queries each
 // k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
 struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
-inline M2Geom m2_geom() {                              // XMH_SCAN_M2_GEOM picks one of the instantiated shapes (tuning; read per call)
+inline M2Geom m2_geom(int K) {
+    // XMH_SCAN_M2_GEOM / _BPC pick one of the instantiated shapes / the blocks per CU the chunk count is sized for (tuning; read per call).
+    // Default: 4 waves x 2 query groups, two blocks per CU (70 KB of LDS each at 65 buckets); codes of at most 32 bits have so few
+    // buckets that 4 query groups per wave fit -- half the A-tile reads, LDS-DMA pieces and barriers per pair -- three blocks per CU up
+    // to 16 bits (53 KB), two up to 32 (70 KB).
     static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
     const char* e = getenv("XMH_SCAN_M2_GEOM");
-    const int g = e ? atoi(e) : 0;
-    return table[g >= 0 && g < 7 ? g : 0];
+    M2Geom g = K <= 32 ? M2Geom{4, 4, K <= 16 ? 3 : 2} : table[0];
+    if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
+    const char* b = getenv("XMH_SCAN_M2_BPC");
+    if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
+    return g;
 }
-inline bool m2_shape(int K, bool ternary) {
-    const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
-    return !(e && atoi(e) == 0) && mfma_shape(K, ternary) && K <= 64 && !mfma_ap_on();
-}
+inline bool m2_shape(int K, bool ternary) { return m2_enabled() && mfma_shape(K, ternary) && K <= 64; }
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
 inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
@@ -1715,7 +1855,7 @@ inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call, like XMH_SCAN_MFMA_AP
     const long long cap_mb = cap_env ? atoll(cap_env) : 4096;
-    if (ternary || K <= 32 || K > 256 || cap_mb <= 0) return 0;
+    if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !m2_shape(K, ternary))) return 0;
     if (K <= 64 && mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
@@ -1759,7 +1899,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
     const bool m2 = m2_shape(K, ternary != 0);
     int64_t nqt = xmh::ceil_div(Q, 64);
-    const int m2q = m2_geom().queries();
+    const int m2q = m2_geom(K).queries();
     if (m2) {                                     // whole blocks of k_scan_hist_m2 AND whole 64-query tiles
         int64_t l = m2q;
         while (l % 64) l += m2q;
@@ -1785,7 +1925,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
         nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
         if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
             static const int m2r = getenv("XMH_SCAN_M2_ROUNDS") ? atoi(getenv("XMH_SCAN_M2_ROUNDS")) : 2;
-            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * m2_geom().blocks_per_cu / (nqt * 64 / m2q);
+            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * m2_geom(K).blocks_per_cu / (nqt * 64 / m2q);
         }
     }
     if (nchunk < 1) nchunk = 1;
@@ -1944,7 +2084,7 @@ int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rb
 template <int NML>
 int mfma_hist2(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
                const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    const M2Geom g = m2_geom();
+    const M2Geom g = m2_geom(K);
 #define XMH_M2(NWW, NQQ) \
     if (g.nw == NWW && g.nq == NQQ) return mfma_hist2_t<NML, NWW, NQQ>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
     XMH_M2(4, 2) XMH_M2(8, 1) XMH_M2(4, 4) XMH_M2(8, 2) XMH_M2(4, 1) XMH_M2(6, 1) XMH_M2(5, 2)
@@ -2027,11 +2167,14 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
             xmh::ProfScope prof("scan_hist", st);
             if constexpr (CAN) {
                 if (cache_bytes) {
-                    auto kc = k_scan_hist_s<WW, LL, T, S, NW, true>;
-                    const int r3 = raise_lds(kc, lds, "xmh_hamming_hist");
+                    constexpr int SC = cache_slots(WW);
+                    auto kc = k_scan_hist_s<WW, LL, T, SC, 1, true>;
+                    const size_t ldsc = (((size_t)p.nbuckets * (64 / SC) + 3) & ~(size_t)3) * 4 + aos_ring_bytes(WW, LL, T);
+                    const int r3 = raise_lds(kc, ldsc, "xmh_hamming_hist");
                     if (r3) return r3;
+                    as.nqt = a.nqt * SC;
                     as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
-                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, chunk_hist);
+                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * SC), dim3(64), ldsc, st, as, chunk_hist);
                     return (int)XMH_OK;
                 }
             }
@@ -2099,7 +2242,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
     if (hist_g) {                                                    // offsets straight from the gathered totals tables of the shards
         hipLaunchKernelGGL(k_shard_offsets_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, reinterpret_cast<const uint2*>(hist_g), world, rank,
-                           (int)Q, (int)p.qpad, (int)p.nbuckets, k, dpre, cap_ws, cap);
+                           (int)Q, (int)p.qpad, (int)p.nbuckets, k, dpre, cap_ws, cap, nrel_max + 2);
         XMH_LAUNCH_CHECK("xmh_hamming_map_sharded offsets");
     } else if (base_all) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
@@ -2111,6 +2254,33 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const bool capped = k > 0;
     const bool masked = !lane_order_ok(st);
 
+    // k_scan_ap_c (float-bit counters): one-byte pair cache present, 64-bit counters, lane order holds, and the gallery over ALL
+    // shards small enough -- known here for an unsharded call; for the totals-table form of the sharded call the offsets kernel leaves
+    // the size in a device word and both kernels are launched, each returning at once when it is the other's turn (as for the counter
+    // widths); the explicit-offsets form stays on k_scan_ap_s.  XMH_SCAN_AP_C=0 turns it off.
+    const char* apc_env = getenv("XMH_SCAN_AP_C");
+    const bool apc = cache_bytes && K <= 64 && !tern && !masked && rank_bits == 0 && !(apc_env && atoi(apc_env) == 0) && !base_all &&
+                     (hist_g != nullptr || R <= kFloatBitsMaxItems);
+    const uint32_t* fb_gate = apc && hist_g ? (const uint32_t*)(nrel_max + 2) : nullptr;
+    if (apc) {
+        ScanArgs as = a;
+        as.nqt = a.nqt * 4;
+        as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
+        const size_t lds = (size_t)p.nbuckets * 16 * 8;
+        xmh::ProfScope prof("scan_ap", st);
+        if (capped) {
+            auto kc = k_scan_ap_c<true>;
+            const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
+            if (r3) return r3;
+            hipLaunchKernelGGL(kc, dim3(scan_grid(p) * 4), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
+        } else {
+            auto kc = k_scan_ap_c<false>;
+            const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
+            if (r3) return r3;
+            hipLaunchKernelGGL(kc, dim3(scan_grid(p) * 4), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
+        }
+        XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
+    }
     // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run
     auto launch = [&](auto tern_c, auto cap_c, auto p32_c, auto masked_c) {
         constexpr bool T = decltype(tern_c)::value;
@@ -2128,13 +2298,16 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
             if constexpr (kPairCacheShape<WW, T> && !MK) {
                 if (cache_bytes) {                                    // pass 1 of this call pair left the pairs in the workspace
-                    auto kc = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, true>;
-                    const size_t lds = (P32 ? ((cells + 3) & ~(size_t)3) * 4 : ((cells * 2 + 3) & ~(size_t)3) * 4) * NW;   // counters only: no gallery ring
+                    constexpr int SC = cache_slots(WW);
+                    auto kc = k_scan_ap_s<WW, LL, T, CP, SC, P32, MK, 1, true>;
+                    const size_t cellsc = (size_t)p.nbuckets * (64 / SC);
+                    const size_t lds = P32 ? ((cellsc + 3) & ~(size_t)3) * 4 : ((cellsc * 2 + 3) & ~(size_t)3) * 4;   // counters only: no gallery ring
                     const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
                     if (r3) return r3;
+                    as.nqt = a.nqt * SC;
                     as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
-                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws,
-                                       ap_part, (const uint32_t*)nrel_max, rank_bits, kcap);
+                    hipLaunchKernelGGL(kc, dim3(scan_grid(p) * SC), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws,
+                                       ap_part, (const uint32_t*)nrel_max, rank_bits, kcap, fb_gate);
                     return (int)XMH_OK;
                 }
             }
@@ -2142,11 +2315,13 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rank_bits, kcap);
+                               (const uint32_t*)nrel_max, rank_bits, kcap, (const uint32_t*)nullptr);
             return (int)XMH_OK;
         });
     };
-    if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
+    if (apc && !fb_gate) {
+        // k_scan_ap_c alone takes the call
+    } else if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
         MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
                     (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)), (int)p.nbuckets, (int)p.qpad};
         const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));

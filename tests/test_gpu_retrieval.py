@@ -329,7 +329,7 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
         assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("Q,R,K,C", [(130, 6000, 64, 80), (70, 9100, 64, 33), (300, 20011, 48, 80), (17, 63, 64, 5), (129, 6463, 128, 80),
+@pytest.mark.parametrize("Q,R,K,C", [(130, 6000, 64, 80), (70, 9100, 64, 33), (300, 20011, 48, 80), (17, 63, 64, 5), (129, 6463, 128, 80), (200, 7000, 16, 24), (90, 5001, 32, 80),
                                      (65, 3000, 256, 24)])
 def test_pair_cache_entries_match_oracle(xr, Q, R, K, C):
     """Every entry pass 1 leaves in the pair cache (distance << 1 | relevant; xmh_scan_pair_cache_offset documents the layout)

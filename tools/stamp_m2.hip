@@ -88,7 +88,7 @@ int run(int Q, int R, int K, int C) {
 
 int main() {
     int rc = 0;
-    const M2Geom g = m2_geom();
+    const M2Geom g = m2_geom(64);
     if (g.nw == 4 && g.nq == 2) rc |= run<2, 4, 2>(5000, 117218, 64, 80);
     else if (g.nw == 8 && g.nq == 1) rc |= run<2, 8, 1>(5000, 117218, 64, 80);
     else if (g.nw == 4 && g.nq == 1) rc |= run<2, 4, 1>(5000, 117218, 64, 80);
