@@ -1835,11 +1835,12 @@ struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq 
 inline M2Geom m2_geom(int K) {
     // XMH_SCAN_M2_GEOM / _BPC pick one of the instantiated shapes / the blocks per CU the chunk count is sized for (tuning; read per call).
     // Default: 4 waves x 2 query groups, two blocks per CU (70 KB of LDS each at 65 buckets); codes of at most 32 bits have so few
-    // buckets that 4 query groups per wave fit -- half the A-tile reads, LDS-DMA pieces and barriers per pair -- three blocks per CU up
-    // to 16 bits (53 KB), two up to 32 (70 KB).
+    // buckets that 4 query groups per wave fit -- half the A-tile reads, LDS-DMA pieces and barriers per pair; the chunk count that
+    // measured best there is two blocks of 256 queries per CU in all (Q 5000 x R 117 218, blocks per CU x rounds = 1 / 2 / 3 / 4 / 6:
+    // K=16 0.416 / 0.350 / 0.367 / 0.352 / 0.368 ms per step, K=32 0.426 / 0.362 / 0.385 / 0.375 / 0.393).
     static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
     const char* e = getenv("XMH_SCAN_M2_GEOM");
-    M2Geom g = K <= 32 ? M2Geom{4, 4, K <= 16 ? 3 : 2} : table[0];
+    M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : table[0];
     if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
     const char* b = getenv("XMH_SCAN_M2_BPC");
     if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
@@ -2124,6 +2125,56 @@ extern "C" size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int te
     xmh_scan_plan p;
     if (make_plan(Q, R, K, ternary, &p)) return (size_t)-1;
     return ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0)).pair_cache;
+}
+
+// Which kernel instances an UNSHARDED mAP@all evaluation of this shape launches for the two passes (as rocprofv3 prints them, minus
+// the namespace): bench_roofline.py picks the PMC rows of exactly these -- a prefix match once took the 128-bit kernel's row for
+// the 64-bit headline.  Mirrors the dispatch of xmh_hamming_hist / hamming_ap_impl (lane order assumed to hold).
+extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary, char* out, size_t out_bytes) {
+    if (!out || out_bytes < 64) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
+    xmh_scan_plan p;
+    const int rc = make_plan(Q, R, K, ternary, &p);
+    if (rc) return rc;
+    const bool tern = ternary != 0;
+    const int Wd = (K + 31) / 32, LW = (C + 31) / 32;
+    const int Wc = Wd <= 1 ? 1 : (Wd <= 2 ? 2 : (Wd <= 4 ? 4 : (Wd <= 8 ? 8 : (Wd <= 16 ? 16 : (Wd <= 32 ? 32 : 64)))));
+    const size_t cache = pair_cache_bytes(p, K, tern);
+    const bool use_mfma = mfma_shape(K, tern) && LW <= 4;
+    char p1[160], p2[200];
+    const int NML = LW <= 2 ? 1 : 2;
+    const int S4 = slots_for(Wc, tern, 4), S8 = slots_for(Wc, tern, 8);
+    if (use_mfma && m2_shape(K, tern)) {
+        const M2Geom g = m2_geom(K);
+        snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
+    } else if (use_mfma) {
+        snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false");
+    } else {
+        const bool cached = cache && !tern && Wc <= 8;
+        const int S = cached ? cache_slots(Wc) : S4;
+        snprintf(p1, sizeof(p1), "k_scan_hist_s<%d, %d, %s, %d, %d, %s>", Wc, LW, tern ? "true" : "false", S, S == 64 ? waves_for(Wc, tern) : 1,
+                 cached ? "true" : "false");
+    }
+    const char* apc_env = getenv("XMH_SCAN_AP_C");
+    const bool packable = K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr;
+    if (cache && K <= 64 && !tern && !packable && !(apc_env && atoi(apc_env) == 0) && R <= kFloatBitsMaxItems) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_c<false>");
+    } else if (use_mfma && K <= 64 && mfma_ap_on()) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
+    } else {
+        const bool cached = cache && !tern && Wc <= 8;
+        // codes of 65 bits and more launch both counter widths, a device word picks one: both names, packed first
+        char a32[96] = "";
+        if (packable) {
+            const int S = cached ? cache_slots(Wc) : S4;
+            snprintf(a32, sizeof(a32), "k_scan_ap_s<%d, %d, %s, false, %d, true, false, %d, %s>|", Wc, LW, tern ? "true" : "false", S,
+                     S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
+        }
+        const int S = cached ? cache_slots(Wc) : S8;
+        snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, false, %d, false, false, %d, %s>", a32, Wc, LW, tern ? "true" : "false", S,
+                 S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
+    }
+    if ((size_t)snprintf(out, out_bytes, "pass1=%s;pass2=%s", p1, p2) >= out_bytes) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
+    return XMH_OK;
 }
 
 extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,

@@ -116,6 +116,10 @@ size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
  * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant.  65..256 bits:
  * [chunk][8-query tile][batch][lane][8 x u16], lane = slot * 8 + query-in-tile, entry t = item 64 * batch + 8 * t + slot. */
 size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary);
+/* Diagnostics for the measurement harness: writes "pass1=<kernel instance>;pass2=<kernel instance>[|<second width>]" -- the kernels
+ * an unsharded mAP@all evaluation of this shape launches, spelled as rocprofv3 prints them -- so that a profile row is matched by
+ * its exact name.  out_bytes >= 64. */
+int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary, char* out, size_t out_bytes);
 
 /* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).
  * qzero / rzero NULL => binary codes.
