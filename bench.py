@@ -377,7 +377,7 @@ def main():
     dt, m = timed(step, barrier, args.steps, use_dist)
     map_value = float(m.item())
 
-    roofline = RL.scan_roofline(scan, Q, Rn, K, C, steps=max(args.steps, 10))
+    roofline = RL.scan_roofline(scan, Q, Rn, K, C, steps=max(args.steps, 10), step_s=None if use_dist else dt / args.steps)
 
     out = {
         "metric": "Hamming query x gallery pairs/sec (fused mAP@all pass, DCMHT COCO-shaped 64-bit)",
@@ -398,6 +398,7 @@ def main():
             import bench_topk
             out["roofline_hbm_regime"] = bench_topk.measure(Q=1)
             out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
+            out["roofline_hbm_regime_q64"] = bench_topk.measure(Q=64)
             out["topk_structured_codes"] = bench_topk.measure_structured()
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}
@@ -413,10 +414,12 @@ def main():
         out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
                                      "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
     if rank == 0 and world == 1 and not use_dist and not args.no_extra_configs:
-        try:
-            out["configs3_dsph_128bit"] = RL.extra_scan_leg(synth, Q, Rn, 128, C, args.p_label)
-        except Exception as exc:
-            out["configs3_dsph_128bit"] = {"error": repr(exc)}
+        for name, leg in RL.EXTRA_LEGS.items():
+            try:
+                out[name] = RL.extra_scan_leg(**leg)
+            except Exception as exc:
+                out[name] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not use_dist and not args.no_encode:
         try:
             import bench_encode

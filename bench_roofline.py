@@ -62,36 +62,59 @@ def mix_cycles(mix, cyc):
     return c / n, n
 
 
-def pmc_traffic(kernel_prefix, kernel_suffix=""):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary under profiles/ (collected by
-    tools/profile_round.sh with separate FETCH_SIZE / WRITE_SIZE passes and the gfx950 corrections of
-    MI355X_MICROARCH.md); None if no profile has been committed for it."""
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for name, e in d.get("pmc", {}).items():
-            if name.startswith(kernel_prefix) and kernel_suffix in name and "hbm_bytes_per_launch" in e:
-                best = {"bytes": e["hbm_bytes_per_launch"]["total"], "fetch_raw": e["hbm_bytes_per_launch"]["fetch_raw"],
-                        "write_raw": e["hbm_bytes_per_launch"]["write_raw"], "fetch_correction": e["hbm_bytes_per_launch"]["fetch_correction"],
-                        "source": os.path.relpath(f, ROOT)}
-    return best
+def _norm(name):
+    return re.sub(r"\s+", "", name)
 
 
-def pmc_counter(kernel_prefix, kernel_suffix, counter):
-    """per-launch value of a PMC counter of a kernel from the newest committed rocprofv3 summary, with its source file"""
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary.json"))):
+def _newest_summary():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary.json")))
+    for f in reversed(files):
         try:
-            d = json.load(open(f))
+            return json.load(open(f)), os.path.relpath(f, ROOT)
         except Exception:
             continue
-        for name, e in d.get("pmc", {}).items():
-            if name.startswith(kernel_prefix) and kernel_suffix in name and counter in e.get("per_launch", {}):
-                best = (e["per_launch"][counter], os.path.relpath(f, ROOT))
-    return best
+    return None, None
+
+
+def pmc_row(kernel_instance):
+    """The PMC entry of EXACTLY this kernel instance (e.g. "k_scan_hist_m2<2, 4, 2, true, false>", from xmh_scan_describe) in the
+    newest committed rocprofv3 summary, or (None, source).  Round 2 matched by prefix and kept the last hit, which handed the
+    64-bit headline the 128-bit kernel's counters; an exact name cannot do that, and two rows normalising to one name raise."""
+    d, src = _newest_summary()
+    if not d:
+        return None, None
+    hits = [(n, e) for n, e in d.get("pmc", {}).items() if _norm(n) == _norm(kernel_instance)]
+    if len(hits) > 1:
+        raise RuntimeError("bench_roofline: %d PMC rows match %r in %s" % (len(hits), kernel_instance, src))
+    return (hits[0][1] if hits else None), src
+
+
+def pmc_traffic(kernel_instance):
+    """HBM bytes per launch of a kernel instance (FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md,
+    tools/summarize_profile.py); None if the newest profile has no row for it."""
+    e, src = pmc_row(kernel_instance)
+    if not e or "hbm_bytes_per_launch" not in e:
+        return None
+    h = e["hbm_bytes_per_launch"]
+    return {"bytes": h["total"], "fetch_raw": h["fetch_raw"], "write_raw": h["write_raw"], "fetch_correction": h["fetch_correction"],
+            "kernel": kernel_instance, "source": src}
+
+
+def pmc_counter(kernel_instance, counter):
+    e, src = pmc_row(kernel_instance)
+    if not e or counter not in e.get("per_launch", {}):
+        return None
+    return e["per_launch"][counter], src
+
+
+def scan_kernels(Q, Rn, K, C, tern):
+    """(pass-1 kernel instance, [pass-2 kernel instances]) this shape launches: xmh_scan_describe"""
+    import ctypes
+    from xmh import _lib
+    buf = ctypes.create_string_buffer(1024)
+    _lib.check(_lib.lib.xmh_scan_describe(Q, Rn, K, C, int(tern), buf, 1024), "xmh_scan_describe")
+    parts = dict(x.split("=", 1) for x in buf.value.decode().split(";"))
+    return parts["pass1"], parts["pass2"].split("|")
 
 
 def _pass_times(scan, steps):
@@ -112,93 +135,127 @@ def _pass_times(scan, steps):
     return t_hist * 1e-3, n_hist, t_ap * 1e-3, n_ap, packed
 
 
-def scan_roofline(scan, Q, Rn, K, C, steps=20):
-    """`roofline` object of the headline step: the dominant kernel = the longer of the two passes.  Both passes share every gallery
-    byte between Q=5000 queries, so HBM is idle by construction; what they saturate is VALU issue -- `bound` says so,
-    `frac` is against the guide's 2-cycle issue peak, `valu.frac_of_measured_mix` against what this instruction mix can reach on
-    gfx950 (per-opcode cycles from the committed ubench), and the HBM numbers the contract names stay as side fields."""
+def scan_roofline(scan, Q, Rn, K, C, steps=20, step_s=None):
+    """`roofline` object of the headline step; the dominant kernel = the longer of the two passes.
+
+    Q=5000 queries share every gallery byte, so the step cannot be HBM-bound: the bound is VALU lane-ops.  Two numbers,
+    labelled as what they are:
+      * `frac` / `algorithmic`: SURVEY 8(d)'s per-pair work -- K/32 XOR + K/32 popcount-accumulate + Lw AND/OR = 2W + Lw lane-ops --
+        x pairs per launch / the kernel's HIP-event time / the guide's VALU peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz).  The
+        kernels do that work on the i8 MFMA and with LDS atomics, but the figure stays the reference formulation's.
+      * `issue_utilisation`: the kernel's OWN dynamic instruction count (SQ_INSTS_VALU of exactly this kernel instance in the
+        committed profile) / the same peak -- how busy the VALU issue port is, not an algorithmic fraction.
+    `traffic` = the PMC HBM bytes of that same instance (its own pair cache and bucket tables, not re-reads of the gallery)."""
     from xmh import _lib
     t_hist, n_hist, t_ap, n_ap, packed = _pass_times(scan, steps)
     W, Lw = (K + 31) // 32, (C + 31) // 32
+    tern = scan.qz is not None
     alg_bytes = Rn * 4 * (W + Lw) + Q * 4 * (W + Lw) + Q * 12          # gallery once + queries + ap_sum/cap out
+    alg_ops = (2 * W + Lw) if not tern else (4 * W + Lw)             # ternary: the zero planes double the code-word work
     pl = scan.plan
     table_bytes = (pl.nchunk + 1) * pl.nbuckets * pl.qpad * 8 + pl.nchunk * pl.qpad * 4
-    cache_bytes = int(_lib.lib.xmh_scan_pair_cache_bytes(Q, Rn, K, 0))
-    cached = cache_bytes > 0
+    cache_bytes = int(_lib.lib.xmh_scan_pair_cache_bytes(Q, Rn, K, int(tern)))
     pairs = Q * Rn
+    k1, k2s = scan_kernels(Q, Rn, K, C, tern)
+    k2 = k2s[0] if (packed or len(k2s) == 1) else k2s[-1]              # both counter widths are launched beyond 64 bits: the one that ran
     cyc, cyc_src = ubench_cycles()
-    tern = scan.qz is not None
 
-    def pass_entry(key, fallback_ops, t, pmc_name):
-        mix, src = isa_mix(key)
-        static_ops = sum(mix.values()) if mix else fallback_ops
-        ops = static_ops
-        dyn = pmc_counter(*pmc_name, "SQ_INSTS_VALU")
-        e = {}
+    def isa_key(kernel):
+        m = re.match(r"(k_scan_\w+)<(.*)>", kernel)
+        return (m.group(1) + "<" + re.sub(r"\s+", "", m.group(2)) + ">") if m else kernel
+
+    def pass_entry(kernel, t):
+        e = {"kernel": kernel, "avg_launch_ms": t * 1e3,
+             "algorithmic": {"lane_ops_per_pair": alg_ops, "achieved": pairs * alg_ops / t / 1e9, "unit": "G lane-ops/s", "peak": VALU_PEAK_GUIDE,
+                             "frac": pairs * alg_ops / t / 1e9 / VALU_PEAK_GUIDE}}
+        mix, src = isa_mix(isa_key(kernel))
+        if mix:
+            e["static_hot_path_valu_per_64_pairs"] = sum(mix.values())
+            e["isa_source"] = src
+            e["mix"] = mix
+            if cyc:
+                mean_c, _ = mix_cycles(mix, cyc)
+                e["mean_measured_cycles_per_valu_instruction"] = mean_c
+                e["ubench_source"] = cyc_src
+        dyn = pmc_counter(kernel, "SQ_INSTS_VALU")
         if dyn is not None and (Q, Rn, K, C) == (5000, 117218, 64, 80):      # the committed profile is of the default shape
             ops = dyn[0] / (pairs / 64.0)
-            e.update({"dynamic_valu_per_64_pairs": ops, "dynamic_source": dyn[1] + " (SQ_INSTS_VALU per launch / (pairs / 64))"})
-        e.update({"static_hot_path_valu_per_64_pairs": static_ops})
-        e.update({"lane_ops_per_pair": ops, "isa_source": src, "achieved": pairs * ops / t / 1e9, "unit": "G lane-ops/s",
-             "peak_guide_2cyc": VALU_PEAK_GUIDE, "frac_of_guide_peak": pairs * ops / t / 1e9 / VALU_PEAK_GUIDE})
-        if mix and cyc:
-            mean_c, _ = mix_cycles(mix, cyc)
-            peak_mix = SIMDS * 64 * CLOCK_HZ / mean_c / 1e9
-            e.update({"mean_measured_cycles_per_instruction": mean_c, "ubench_source": cyc_src, "peak_measured_mix": peak_mix,
-                      "frac_of_measured_mix": pairs * ops / t / 1e9 / peak_mix, "mix": mix})
+            e["issue_utilisation"] = {"dynamic_valu_and_mfma_per_64_pairs": ops, "frac_of_guide_peak": pairs * ops / t / 1e9 / VALU_PEAK_GUIDE,
+                                      "source": dyn[1] + ": SQ_INSTS_VALU per launch of this kernel instance / (pairs / 64); counts the MFMAs too",
+                                      "what": "issue-slot utilisation by the kernel's own instruction count, NOT an algorithmic fraction"}
+            for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES",
+                      "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS"):
+                v = pmc_counter(kernel, c)
+                if v is not None:
+                    e["issue_utilisation"][c] = v[0]
         return e
-    ops_eval = 2 * W + Lw + 1
-    # binary codes of 33..64 bits: pass 1 is k_scan_hist_m (pairs evaluated by the i8 MFMA, xmh_scan.hip mfma_shape)
-    mfma_p1 = (not tern) and 32 < K <= 64 and Lw <= 4 and os.environ.get("XMH_SCAN_MFMA", "1") != "0"
-    key1 = ("histm_L%d_%s" % (Lw, "cache" if cached else "plain")) if mfma_p1 else "hist_W%d_L%d_%s" % (W, Lw, "cache" if cached else "plain")
-    key2 = "ap_W%d_L%d_%s_%s" % (W, Lw, "cache" if cached else "plain", "p32" if packed else "u64")
-    ap_suffix = ", true, false, 1," if packed else ", false, false, 1,"
-    p1_kernel = "k_scan_hist_m<" if mfma_p1 else "k_scan_hist_s<"
-    v1 = pass_entry(key1, (1 + (5 if cached else 0)) if mfma_p1 else ops_eval + 2 + (2 if cached else 0), t_hist, (p1_kernel, ""))
-    if mfma_p1:
-        nm = 1 + (1 if Lw <= 2 else 2)                            # MFMAs per 16 items x 16 queries: one code tile + the label tiles
-        mf = pmc_counter(p1_kernel, "", "SQ_VALU_MFMA_BUSY_CYCLES")
-        v1["mfma"] = {"instruction": "v_mfma_i32_16x16x64_i8", "per_64_pairs": nm / 4.0, "cycles_each": 16,
-                      "matrix_pipe_frac": pairs / 64.0 * (nm / 4.0) * 16 / (t_hist * CLOCK_HZ * SIMDS),
-                      "note": "SQ_INSTS_VALU counts the MFMAs too; the static VALU count does not"}
-        if mf:
-            v1["mfma"]["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = mf[0]
-    v2 = pass_entry(key2, (2 if cached else ops_eval) + 1 + (0 if packed else 1) + 5, t_ap, ("k_scan_ap_s<", ap_suffix))
+    v1, v2 = pass_entry(k1, t_hist), pass_entry(k2, t_ap)
+    if k1.startswith("k_scan_hist_m"):
+        nml = 1 if Lw <= 2 else 2
+        nmc = 1 if K <= 64 else (2 if K <= 128 else 4)
+        chains = (2 * nmc if (k1.startswith("k_scan_hist_m2") and cache_bytes) else nmc) + nml
+        v1["mfma"] = {"instruction": "v_mfma_i32_16x16x64_i8", "per_64_pairs": chains / 4.0, "cycles_each": 16,
+                      "matrix_pipe_frac": pairs / 64.0 * (chains / 4.0) * 16 / (t_hist * CLOCK_HZ * SIMDS)}
     dom_is_hist = t_hist > t_ap
-    t_dom, n_dom, vd = (t_hist, n_hist, v1) if dom_is_hist else (t_ap, n_ap, v2)
-    traffic = pmc_traffic(p1_kernel, "") if dom_is_hist else pmc_traffic("k_scan_ap_s<", ap_suffix)
-    if dom_is_hist and mfma_p1:
-        name = "k_scan_hist_m (pass 1 of the fused mAP scan: Hamming distance and label overlap on the i8 MFMA, bucket histogram by LDS atomics%s)" % (" + pair cache" if cached else "")
-    elif dom_is_hist:
-        name = "k_scan_hist_s (pass 1 of the fused mAP scan: pair evaluation + bucket histogram%s)" % (" + pair cache" if cached else "")
-    else:
-        name = "k_scan_ap_s, %s counters (pass 2 of the fused mAP scan)" % ("packed 32-bit" if packed else "64-bit")
+    t_dom, n_dom, vd, kd = (t_hist, n_hist, v1, k1) if dom_is_hist else (t_ap, n_ap, v2, k2)
+    traffic = pmc_traffic(kd)
+    alg = dict(vd["algorithmic"])
+    alg["frac_dominant"] = alg.pop("frac")
+    if step_s:
+        alg["frac_step"] = pairs * alg_ops / step_s / 1e9 / VALU_PEAK_GUIDE
+        alg["step_ms"] = step_s * 1e3
     return {
-        "kernel": "%s, HIP events around the launch, %d launches" % (name, n_dom),
-        "bound": "valu", "achieved": vd["achieved"], "peak": VALU_PEAK_GUIDE, "unit": "G lane-ops/s", "frac": vd["frac_of_guide_peak"],
-        "frac_of_measured_mix": vd.get("frac_of_measured_mix"),
+        "kernel": "%s (pass %d of the fused mAP scan), HIP events around the launch, %d launches" % (kd, 1 if dom_is_hist else 2, n_dom),
+        "bound": "valu", "achieved": alg["achieved"], "peak": VALU_PEAK_GUIDE, "unit": "G lane-ops/s", "frac": alg["frac_dominant"],
+        "algorithmic": alg, "issue_utilisation": vd.get("issue_utilisation"),
         "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,
         "hbm": {"bound": "hbm", "algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
                 "note": "reported because the contract names it: Q=%d queries share every gallery byte, the launch cannot be HBM-bound" % Q},
         "workspace_table_bytes": table_bytes, "pair_cache_bytes": cache_bytes, "avg_launch_ms": t_dom * 1e3, "ternary": tern,
-        "pass1_avg_launch_ms": t_hist * 1e3, "pass2_avg_launch_ms": t_ap * 1e3, "pass1_valu": v1, "pass2_valu": v2,
-        "note": "frac = achieved / the guide's VALU issue peak (2 cycles per wave64 instruction).  frac_of_measured_mix prices the same "
-                "instruction stream at the per-opcode cycles measured on this chip (profiles/*_ubench_valu.txt): most opcodes of these "
-                "loops (v_bcnt, v_and_or, v_lshl_or, v_min, v_alignbyte, v_bfe, v_cvt, v_mul_u24) issue at half rate, v_rcp at an "
-                "eighth.  PMC traffic above the algorithmic bytes is the scheme's own data (bucket tables + the pair cache: one byte "
-                "per pair written by pass 1, read by pass 2), not re-reads of the gallery",
+        "pass1_avg_launch_ms": t_hist * 1e3, "pass2_avg_launch_ms": t_ap * 1e3, "pass1": v1, "pass2": v2,
+        "note": "frac = algorithmic lane-ops (2W + Lw per pair, SURVEY 8d) x pairs / launch time / the guide's VALU peak; "
+                "issue_utilisation is the kernel's own instruction count against the same peak.  PMC traffic above the algorithmic bytes is "
+                "the scheme's own data (bucket tables + the pair cache: one byte per pair written by pass 1, read by pass 2), not re-reads "
+                "of the gallery",
     }
 
 
-def extra_scan_leg(synth, Q, Rn, K, C, p_label, steps=30):
-    """one more driver-visible scan shape (configs[3]: DSPH COCO 128-bit): whole-step time and mAP"""
+def synth_gpu(Q, R, K, C, seed, p=0.04):
+    """SURVEY 8d synthetic inputs (label-correlated +-1 codes, multi-hot labels with >= 1 label per row) generated ON the GPU --
+    the extra legs go up to 1.25 M x 256 bit, which the CPU generator of the headline would spend seconds on.  Returns packed
+    (q, ql, r, rl).  tests/test_gpu_retrieval.py builds the same tensors from the same seed to check the legs against the oracle."""
+    import torch
+    from xmh import retrieval as R_
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    Wm = torch.randn(C, K, generator=g, device="cuda")
+
+    def side(n):
+        codes, labs = [], []
+        for lo in range(0, n, 262144):                               # bounded temporaries
+            m = min(262144, n - lo)
+            L = torch.rand(m, C, generator=g, device="cuda") < p
+            L[torch.arange(m, device="cuda"), torch.randint(0, C, (m,), generator=g, device="cuda")] = True
+            B = (L.float() @ Wm + 0.8 * torch.randn(m, K, generator=g, device="cuda")).sign()
+            B[B == 0] = 1
+            codes.append(R_.pack_sign(B).bits)
+            labs.append(R_.pack_labels(L.to(torch.uint8)))
+        return R_.PackedCodes(torch.cat(codes), None, K), torch.cat(labs)
+    q, ql = side(Q)
+    r, rl = side(R)
+    return q, ql, r, rl
+
+
+def extra_scan_leg(what, Q, Rn, K, C, p_label, seed, steps=30, return_scan=False):
+    """one more driver-visible scan shape: whole-step time, both pass times and the mAP (checked against the oracle on a query
+    subsample by tests/test_gpu_retrieval.py::test_bench_legs_full_shapes_match_the_oracle, which calls this very function)"""
     import time
     import torch
+    from xmh import _lib
     from xmh import retrieval as R
-    qB, qL, rB, rL = synth(Q, Rn, K, C, seed=3814, p=p_label)
-    scan = R.RankingScan(R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda()), C)
-    for _ in range(10):
+    q, ql, r, rl = synth_gpu(Q, Rn, K, C, seed, p_label)
+    scan = R.RankingScan(q, ql, r, rl, C)
+    for _ in range(min(10, steps)):
         scan.histograms(False)
         m = scan.map_all(None)[0]
     torch.cuda.synchronize()
@@ -208,7 +265,23 @@ def extra_scan_leg(synth, Q, Rn, K, C, p_label, steps=30):
         m = scan.map_all(None)[0]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    t_hist, _, t_ap, _, packed = _pass_times(scan, 10)
-    return {"workload": "configs[3] DSPH COCO-shaped %d-bit: Q=%d x R=%d, C=%d, mAP@all" % (K, Q, Rn, C), "ms_per_step": dt * 1e3,
-            "pairs_per_s": Q * Rn / dt, "mAP": float(m.item()), "pass1_ms": t_hist * 1e3, "pass2_ms": t_ap * 1e3,
-            "pass2_counters": "packed 32-bit" if packed else "64-bit"}
+    t_hist, _, t_ap, _, packed = _pass_times(scan, min(10, steps))
+    k1, k2s = scan_kernels(Q, Rn, K, C, False)
+    W, Lw = (K + 31) // 32, (C + 31) // 32
+    out = {"workload": "%s: Q=%d x R=%d, %d bit, C=%d, mAP@all" % (what, Q, Rn, K, C), "ms_per_step": dt * 1e3,
+           "pairs_per_s": Q * Rn / dt, "mAP": float(m.item()), "pass1_ms": t_hist * 1e3, "pass2_ms": t_ap * 1e3,
+           "pass1_kernel": k1, "pass2_kernel": k2s[0] if (packed or len(k2s) == 1) else k2s[-1],
+           "pair_cache_bytes": int(_lib.lib.xmh_scan_pair_cache_bytes(Q, Rn, K, 0)),
+           "algorithmic_frac_step": Q * Rn * (2 * W + Lw) / dt / 1e9 / VALU_PEAK_GUIDE, "seed": seed, "p_label": p_label}
+    return (out, scan) if return_scan else out
+
+
+# the extra N=1 legs of bench.py: BASELINE configs[0] (the reference's default 16-bit codes, MIRFlickr-shaped), the same length at the
+# COCO shape, configs[3] (DSPH COCO 128 bit) and one GPU's shard of configs[4] (10 M x 256 bit / 8) through the mAP scan
+EXTRA_LEGS = {
+    "configs0_dcmht_16bit_mirflickr": dict(what="configs[0] DCMHT MIRFlickr-shaped 16-bit", Q=5000, Rn=20015, K=16, C=24, p_label=0.10, seed=1816, steps=30),
+    "k16_coco_shape": dict(what="16-bit codes at the configs[1] COCO shape", Q=5000, Rn=117218, K=16, C=80, p_label=0.04, seed=1817, steps=30),
+    "configs3_dsph_128bit": dict(what="configs[3] DSPH COCO-shaped 128-bit", Q=5000, Rn=117218, K=128, C=80, p_label=0.04, seed=3814, steps=30),
+    "configs4_shard_scan_256bit": dict(what="configs[4] one GPU's shard (10 M / 8) through the mAP scan, pass 2 uncached", Q=5000, Rn=1250000, K=256, C=80,
+                                       p_label=0.04, seed=4814, steps=4),
+}

@@ -21,10 +21,17 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
-def _traffic():
+def _traffic(K, Q):
+    """PMC HBM bytes of exactly the filter instance this (K, Q) launches: k_topk_filter<words, items per thread, query group>"""
     try:
         import bench_roofline
-        t = bench_roofline.pmc_traffic("k_topk_filter")
+        W = (K + 31) // 32
+        qn = 8 if Q >= 8 else (4 if Q >= 4 else (2 if Q >= 2 else 1))
+        d, _ = bench_roofline._newest_summary()
+        names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter<%d, " % W) and n.endswith(", %d>" % qn)]
+        if len(names) != 1:
+            return None
+        t = bench_roofline.pmc_traffic(names[0])
         return None if t is None else t["bytes"]
     except Exception:
         return None
@@ -121,7 +128,7 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
 def _result(alg, t, t_call, launches, R, K, Q, k, kind):
     return {"kernel": "k_topk_filter (streaming pass of xmh_hamming_topk), HIP events around the launch, %d launches" % launches,
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
-            "traffic": _traffic(), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
+            "traffic": _traffic(K, Q), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
             "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9,
             "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU, %s codes" % (k, Q, R, K, kind),
             "pairs_per_s_whole_call": Q * R / t_call, "robust_path_launches": _robust_launches(launches)}

@@ -667,6 +667,30 @@ def test_full_size_nuswide_shape_sharded_eight_ways(xr):
     assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)                          # fp32 credits, summed per chunk: order differs
 
 
+@pytest.mark.parametrize("leg", ["configs0_dcmht_16bit_mirflickr", "k16_coco_shape", "configs3_dsph_128bit", "configs4_shard_scan_256bit"])
+def test_bench_legs_full_shapes_match_the_oracle(xr, leg):
+    """The extra scan legs of bench.py at their FULL shapes (BASELINE configs[0], 16 bit at the COCO shape, configs[3] through the
+    MFMA pass 1 + 16-bit-entry cache, one GPU's shard of configs[4] with the uncached pass 2), through the very function the bench
+    calls: the mAP the leg prints is the mean of the per-query APs, and those agree with the oracle on a query subsample."""
+    import bench_roofline as RL
+    orc = _orc()
+    cfg = dict(RL.EXTRA_LEGS[leg], steps=1)
+    out, scan = RL.extra_scan_leg(return_scan=True, **cfg)
+    Q, R = cfg["Q"], cfg["Rn"]
+    ha, hr = scan.histograms()
+    assert (ha.to(torch.int64).sum(1) == R).all()
+    ap, cap = scan.ap_sums(None)
+    assert torch.equal(hr.to(torch.int64).sum(1).to(torch.int32), cap)
+    assert abs(out["mAP"] - float((ap / cap.double()).mean())) < 1e-9
+    nsub = 8 if R > 500000 else 32
+    sub = np.arange(0, Q, Q // nsub)[:nsub]
+    dist = orc.hamming_packed(_u32(scan.q.bits)[sub], _u32(scan.r.bits))
+    rel = orc.relevance_packed(_u32(scan.qlab)[sub], _u32(scan.rlab))
+    assert np.array_equal(cap.cpu().numpy()[sub], rel.sum(-1))
+    assert np.allclose(ap.cpu().numpy()[sub], orc.ap_from_ranking(dist, rel), rtol=3e-6)
+    assert (out["pair_cache_bytes"] > 0) == (leg != "configs4_shard_scan_256bit")
+
+
 def test_full_size_long_gallery_256bit_uncached_scan(xr, monkeypatch):
     """BASELINE configs[4] per-GPU shard (10 M / 8 = 1.25 M rows x 256 bit) through the mAP scan: at Q 5000 the pair cache would
     exceed its cap, so this is the path without it -- checked here at Q 192 with the cache switched off against the oracle on a

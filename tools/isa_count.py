@@ -21,20 +21,27 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "clip-based-cross-modal-hash_amd", "csrc", "xmh_scan.hip")
 
-# json key -> (kernel, template-argument string as mangled by the Itanium ABI)
-#   k_scan_hist_s<W, LW, TERN, S, NW, CACHE>;  k_scan_ap_s<W, LW, TERN, CAPPED, S, P32, MASKED, NW, CACHE>
-KERNELS = {
-    "hist_W2_L3_cache": ("k_scan_hist_s", "ILi2ELi3ELb0ELi4ELi1ELb1EE"),
-    "hist_W2_L3_plain": ("k_scan_hist_s", "ILi2ELi3ELb0ELi4ELi1ELb0EE"),
-    "ap_W2_L3_cache_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb1EE"),
-    "ap_W2_L3_cache_p32": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb1ELb0ELi1ELb1EE"),
-    "ap_W2_L3_plain_u64": ("k_scan_ap_s", "ILi2ELi3ELb0ELb0ELi4ELb0ELb0ELi1ELb0EE"),
-    "histm_L3_cache": ("k_scan_hist_m", "ILi1ELi2ELi4ELb1EE"),        # k_scan_hist_m<NMC, NML, NW, CACHE>: the MFMA-evaluated pass 1
-    "histm_L3_plain": ("k_scan_hist_m", "ILi1ELi2ELi4ELb0EE"),
-    "hist_W4_L3_cache": ("k_scan_hist_s", "ILi4ELi3ELb0ELi8ELi1ELb1EE"),
-    "ap_W4_L3_cache_u64": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb0ELb0ELi1ELb1EE"),
-    "ap_W4_L3_cache_p32": ("k_scan_ap_s", "ILi4ELi3ELb0ELb0ELi8ELb1ELb0ELi1ELb1EE"),
-}
+# kernel instances as xmh_scan_describe / rocprofv3 spell them; the json key is the same string without blanks (bench_roofline.py)
+#   k_scan_hist_s<W, LW, TERN, S, NW, CACHE>;  k_scan_ap_s<W, LW, TERN, CAPPED, S, P32, MASKED, NW, CACHE>;
+#   k_scan_hist_m<NMC, NML, NW, CACHE>;  k_scan_hist_m2<NML, NW, NQ, CACHE, STAMP>;  k_scan_ap_c<CAPPED>
+KERNELS = [
+    "k_scan_hist_m2<2, 4, 2, true, false>", "k_scan_hist_m2<2, 4, 2, false, false>", "k_scan_hist_m2<1, 4, 4, true, false>",
+    "k_scan_hist_m2<2, 4, 4, true, false>", "k_scan_ap_c<false>",
+    "k_scan_hist_m<1, 2, 4, true>", "k_scan_hist_m<2, 2, 4, true>", "k_scan_hist_m<4, 2, 4, false>",
+    "k_scan_hist_s<2, 3, false, 4, 1, true>", "k_scan_hist_s<2, 3, false, 4, 1, false>", "k_scan_hist_s<1, 3, false, 2, 1, false>",
+    "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, false>",
+    "k_scan_ap_s<1, 3, false, false, 2, false, false, 1, false>",
+    "k_scan_ap_s<4, 3, false, false, 8, true, false, 1, true>", "k_scan_ap_s<4, 3, false, false, 8, false, false, 1, true>",
+    "k_scan_ap_s<8, 3, false, false, 8, false, false, 1, false>",
+]
+
+
+def mangled(instance):
+    """("k_scan_ap_c", "ILb0EE") for "k_scan_ap_c<false>": the Itanium spelling of integer / bool template arguments"""
+    m = re.match(r"(\w+)<(.*)>", instance)
+    args = [a.strip() for a in m.group(2).split(",")]
+    enc = "".join(("Lb%dE" % (a == "true")) if a in ("true", "false") else "Li%sE" % a for a in args)
+    return m.group(1), "I" + enc + "E"
 
 
 def kernel_bodies(asm):
@@ -110,14 +117,16 @@ def count(body):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-save-temps", "-c", SRC,
                         "-o", os.path.join(tmp, "x.o")], cwd=tmp, check=True, stderr=subprocess.DEVNULL)
         asm = open([os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]).read()
     bodies = kernel_bodies(asm)
     result, text = {}, []
-    for key, (kern, targs) in KERNELS.items():
+    for inst in KERNELS:
+        key = re.sub(r"\s+", "", inst)
+        kern, targs = mangled(inst)
         names = [n for n in bodies if kern + targs in n]
         if not names:
             continue
@@ -142,7 +151,7 @@ def main():
     json.dump(result, open(os.path.join(ROOT, "profiles", "%s_scan_isa.json" % tag), "w"), indent=1, sort_keys=True)
     open(os.path.join(ROOT, "profiles", "%s_scan_isa.txt" % tag), "w").writelines(text)
     for k, v in result.items():
-        print("%-22s VALU per 64 pairs: %.2f" % (k, sum(v.values())))
+        print("%-64s VALU per 64 pairs: %.2f" % (k, sum(v.values())))
 
 
 if __name__ == "__main__":
