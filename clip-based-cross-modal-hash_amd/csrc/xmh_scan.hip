@@ -1664,6 +1664,74 @@ __global__ __launch_bounds__(256) void k_shard_offsets_dpre(const uint2* __restr
     }
 }
 
+// The all-to-all form of the sharded exchange: instead of every rank receiving every shard's whole totals table
+// (world x 2.6 MB at Q 5000, K 64), rank j receives from every shard only the column slice of ITS S = qpad / world queries
+// (tot_s[world][nb][S] {all, relevant}), resolves the offsets of those queries for EVERY shard
+//   out[w][d][s] = items of lower buckets on any shard + items of bucket d on shards < w        (d < nb)
+//   out[w][nb][s] = {relevant items on all shards, items on all shards}
+// and a second all-to-all hands shard w its rows back.  64 queries per block (lanes), the bucket axis split over the 4 waves.
+__global__ __launch_bounds__(256) void k_shard_slice_offsets(const uint2* __restrict__ tot_s, int world, int nb, int S, uint2* __restrict__ out) {
+    __shared__ uint2 part[4][64];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const int s = blockIdx.x * 64 + lane;
+    const bool ok = s < S;
+    const int64_t plane_in = (int64_t)nb * S, plane_out = (int64_t)(nb + 1) * S;
+    const int nbq = (nb + 3) / 4;
+    const int d0 = wq * nbq, d1 = (d0 + nbq < nb) ? d0 + nbq : nb;
+    uint32_t sa = 0, sr = 0;
+    for (int d = d0; d < d1; ++d) {
+        for (int w = 0; w < world; ++w) {
+            const uint2 t = ok ? tot_s[(int64_t)w * plane_in + (int64_t)d * S + s] : make_uint2(0u, 0u);
+            sa += t.x;
+            sr += t.y;
+        }
+    }
+    part[wq][lane] = make_uint2(sa, sr);
+    __syncthreads();
+    uint32_t ra = 0, rr = 0, ta_all = 0, tr_all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint2 pw = part[w][lane];
+        if (w < wq) { ra += pw.x; rr += pw.y; }
+        ta_all += pw.x;
+        tr_all += pw.y;
+    }
+    if (!ok) return;
+    for (int d = d0; d < d1; ++d) {
+        uint32_t la = 0, lr = 0;
+        for (int w = 0; w < world; ++w) {                            // second walk: L2 hits
+            const uint2 t = tot_s[(int64_t)w * plane_in + (int64_t)d * S + s];
+            out[(int64_t)w * plane_out + (int64_t)d * S + s] = make_uint2(ra + la, rr + lr);
+            la += t.x;
+            lr += t.y;
+        }
+        ra += la;
+        rr += lr;
+    }
+    if (wq == 0)
+        for (int w = 0; w < world; ++w) out[(int64_t)w * plane_out + (int64_t)nb * S + s] = make_uint2(tr_all, ta_all);
+}
+
+// ... and on shard w the rows that came back, offs[owner][nb + 1][S], go where pass 2 reads them: dpre[d][q], the relevant count,
+// the cap, and the gallery size over all shards (the gate word of k_scan_ap_c)
+__global__ __launch_bounds__(256) void k_shard_scatter_offsets(const uint2* __restrict__ offs, int nb, int S, int Q, int qpad, int64_t kcap,
+                                                               uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws, int32_t* __restrict__ cap_out,
+                                                               uint32_t* __restrict__ items_total) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpad) return;
+    const int owner = q / S, s = q - owner * S;
+    const uint2* __restrict__ src = offs + (int64_t)owner * (nb + 1) * S + s;
+    const int d = blockIdx.y;
+    if (d < nb) {
+        dpre[(int64_t)d * qpad + q] = src[(int64_t)d * S];
+        return;
+    }
+    const uint2 t = src[(int64_t)nb * S];                           // {relevant items on all shards, items on all shards}
+    cap_ws[q] = t.x;
+    if (q < Q) cap_out[q] = (int32_t)((kcap > 0 && (uint64_t)kcap < (uint64_t)t.x) ? (uint32_t)kcap : t.x);
+    if (q == 0) *items_total = t.y;
+}
+
 // Sum of a query's per-chunk credits.  A block takes 64 queries; its 4 waves take a quarter of the chunks each (all loads of a
 // thread are issued together: one dependent load per chunk was a 13 us chain of misses for 32 chunks) and the quarters are added
 // in a fixed order -- the same order in the sharded and the unsharded reduction, whatever the grid.
@@ -2291,7 +2359,12 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         if (rank_bits > 24) rank_bits = 0;
     }
     // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
-    if (hist_g) {                                                    // offsets straight from the gathered totals tables of the shards
+    if (hist_g && rank < 0) {                                        // the all-to-all form: this shard's offset rows, by slice owner
+        const int S = (int)(p.qpad / world);
+        hipLaunchKernelGGL(k_shard_scatter_offsets, dim3((unsigned)xmh::ceil_div(p.qpad, 256), (unsigned)p.nbuckets + 1), dim3(256), 0, st,
+                           reinterpret_cast<const uint2*>(hist_g), (int)p.nbuckets, S, (int)Q, (int)p.qpad, k, dpre, cap_ws, cap, nrel_max + 2);
+        XMH_LAUNCH_CHECK("xmh_hamming_map_sharded_offsets scatter");
+    } else if (hist_g) {                                             // offsets straight from the gathered totals tables of the shards
         hipLaunchKernelGGL(k_shard_offsets_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, reinterpret_cast<const uint2*>(hist_g), world, rank,
                            (int)Q, (int)p.qpad, (int)p.nbuckets, k, dpre, cap_ws, cap, nrel_max + 2);
         XMH_LAUNCH_CHECK("xmh_hamming_map_sharded offsets");
@@ -2466,6 +2539,28 @@ extern "C" int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qz
     if (world <= 0 || rank < 0 || rank >= world) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded: bad world=%d rank=%d", world, rank);
     return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_partial,
                            stream, hist_gathered, world, rank);
+}
+
+extern "C" int xmh_shard_slice_offsets(const uint32_t* totals_slices, int world, int nbuckets, int slice, uint32_t* offsets_out, xmh_stream_t stream) {
+    if (!totals_slices || !offsets_out) return xmh::fail(XMH_EINVAL, "xmh_shard_slice_offsets: null pointer");
+    if (world <= 0 || nbuckets <= 0 || slice <= 0) return xmh::fail(XMH_EINVAL, "xmh_shard_slice_offsets: bad arguments (world=%d nb=%d slice=%d)", world, nbuckets, slice);
+    hipLaunchKernelGGL(k_shard_slice_offsets, dim3((unsigned)xmh::ceil_div(slice, 64)), dim3(256), 0, xmh::as_stream(stream),
+                       reinterpret_cast<const uint2*>(totals_slices), world, nbuckets, slice, reinterpret_cast<uint2*>(offsets_out));
+    XMH_LAUNCH_CHECK("xmh_shard_slice_offsets");
+    return XMH_OK;
+}
+
+extern "C" int xmh_hamming_map_sharded_offsets(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                                               const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                                               size_t ws_bytes, const uint32_t* offsets, int world, int64_t k, double* ap_sum, int32_t* cap,
+                                               double* map_partial, xmh_stream_t stream) {
+    if (!offsets || !map_partial) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded_offsets: null pointer");
+    xmh_scan_plan p;
+    const int rc = make_plan(Q, R, K, qzero != nullptr, &p);
+    if (rc) return rc;
+    if (world <= 0 || p.qpad % world) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded_offsets: qpad=%lld is not a multiple of world=%d", (long long)p.qpad, world);
+    return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_partial,
+                           stream, offsets, world, -1);
 }
 
 extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream) {

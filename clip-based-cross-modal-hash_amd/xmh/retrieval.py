@@ -281,8 +281,41 @@ def _map_sharded(self, k, totals_gathered: torch.Tensor, rank: int):
     return out, ap, cap
 
 
+def slice_offsets(totals_slices: torch.Tensor) -> torch.Tensor:
+    """all-to-all form of the sharded exchange, the slice owner's part: the columns of this rank's query slice from every shard,
+    int32 [world, nbuckets, slice, 2], -> the offsets of those queries for EVERY shard, int32 [world, nbuckets + 1, slice, 2]
+    (last row: {relevant items, items} over all shards)."""
+    _require_cuda(totals_slices)
+    if totals_slices.dim() != 4 or totals_slices.shape[3] != 2 or totals_slices.dtype != torch.int32 or not totals_slices.is_contiguous():
+        raise ValueError("slice_offsets: expected a contiguous int32 [world, nbuckets, slice, 2] tensor")
+    world, nb, S, _ = totals_slices.shape
+    out = torch.empty(world, nb + 1, S, 2, dtype=torch.int32, device=totals_slices.device)
+    check(lib.xmh_shard_slice_offsets(ptr(totals_slices), world, nb, S, ptr(out), current_stream()), "xmh_shard_slice_offsets")
+    return out
+
+
+def _map_sharded_offsets(self, k, offsets: torch.Tensor):
+    """pass 2 of ONE SHARD from its offset rows as the second all-to-all delivered them ([world (slice owner), nbuckets + 1,
+    slice, 2] int32) -> (map_partial float64 [1], ap_sum [Q] of this shard, cap [Q] global), like map_sharded."""
+    world = offsets.shape[0]
+    if (offsets.dim() != 4 or offsets.shape[1] != self.plan.nbuckets + 1 or offsets.shape[2] * world != self.plan.qpad or offsets.shape[3] != 2
+            or offsets.dtype != torch.int32 or not offsets.is_contiguous()):
+        raise ValueError("map_sharded_offsets: expected a contiguous int32 [world, %d, %d / world, 2] tensor" % (self.plan.nbuckets + 1, self.plan.qpad))
+    dev = self.ws.device
+    ap = torch.empty(self.q.n, dtype=torch.float64, device=dev)
+    cap = torch.empty(self.q.n, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    kk = 0 if k is None else int(k)
+    if k is not None and kk <= 0:
+        raise ValueError("k must be positive or None")
+    check(lib.xmh_hamming_map_sharded_offsets(*self._common(), ptr(offsets), world, kk, ptr(ap), ptr(cap), ptr(out), current_stream()),
+          "xmh_hamming_map_sharded_offsets")
+    return out, ap, cap
+
+
 RankingScan.totals = _totals
 RankingScan.map_sharded = _map_sharded
+RankingScan.map_sharded_offsets = _map_sharded_offsets
 
 
 def map_finalize(ap_sum: torch.Tensor, cap: torch.Tensor) -> torch.Tensor:

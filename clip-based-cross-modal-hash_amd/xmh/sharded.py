@@ -81,6 +81,32 @@ class HipShardOps:
         return self.scan.map_sharded(k, totals_gathered, rank)[0]
 
 
+    def slice_offsets(self, totals_slices):
+        """all-to-all exchange, slice owner's part (one kernel): [world, nb, S, 2] -> [world, nb + 1, S, 2]"""
+        return self._R.slice_offsets(totals_slices)
+
+    def map_partial_offsets(self, k, offsets):
+        """this shard's share of the mAP from its offset rows [world (slice owner), nb + 1, S, 2]"""
+        if self.empty:
+            nrel = offsets[:, -1, :, 0].reshape(-1)[: self.q.n]
+            cap = nrel if k is None else torch.clamp(nrel, max=int(k))
+            z = torch.zeros(self.q.n, dtype=torch.float64, device=offsets.device)
+            return (z / cap.to(torch.float64)).sum().reshape(1) / self.q.n      # cap == 0 -> NaN, like every other rank
+        return self.scan.map_sharded_offsets(k, offsets)[0]
+
+
+def slice_offsets_reference(totals_slices: torch.Tensor) -> torch.Tensor:
+    """torch statement of xmh_shard_slice_offsets (test doubles; the HIP kernel is checked against it on the GPU)"""
+    t = totals_slices.to(torch.int64)                                # [world, nb, S, 2]
+    tot = t.sum(0)                                                   # [nb, S, 2]
+    lower = torch.cumsum(tot, 0) - tot                               # lower buckets on any shard
+    below = torch.cumsum(t, 0) - t                                   # same bucket on lower shards
+    rows = lower.unsqueeze(0) + below                                # [world, nb, S, 2]
+    last = torch.stack([tot[..., 1].sum(0), tot[..., 0].sum(0)], dim=-1)          # {relevant, all} over every shard and bucket
+    last = last.unsqueeze(0).unsqueeze(0).expand(t.shape[0], 1, -1, -1)
+    return torch.cat([rows, last], dim=1).to(torch.int32).contiguous()
+
+
 def all_gather_rows(t: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
     """all_gather of row-ragged tensors (rank i contributes counts[i] rows) -> concatenated rows."""
     world = dist.get_world_size(group)
@@ -140,7 +166,7 @@ class QueryBlocks:
         return QueryBlocks([HipShardOps(q.rows(lo, hi), qlab[lo:hi], r, rlab, C) for lo, hi in zip(bounds[:-1], bounds[1:])])
 
 
-def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = False):
+def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = False, exchange: str = "auto"):
     """mAP over a gallery sharded across ``group``.  ``ops`` wraps this rank's shard (HipShardOps or a test
     double) and already holds the FULL (all-gathered) query set.  Returns (map float64 tensor [1], ap_sum,
     cap) -- identical on every rank.  Per call: pass 1, ONE all-gather of the [2, Q, nb] histograms (2.6 MB/rank at
@@ -148,13 +174,32 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
     ``map_only``: the caller wants the mean alone -> (map, None, None): the shards' totals tables are gathered as pass 1 left
     them in the workspace (no export pass), every rank folds its own share of the mean into pass 2's reduction
     (ops.map_partial: offsets, pass 2 and reduction are three launches of one library call) and ONE 8-byte all-reduce adds the
-    shares; no [Q] all-reduce, no finalize launch."""
+    shares; no [Q] all-reduce, no finalize launch.  ``exchange`` (map_only): "alltoall" = two all-to-alls by query slice (see
+    below), "gather" = the all-gather of whole tables it replaces (kept as the checked reference), "auto" = all-to-all whenever
+    the padded query count divides by the world size.  ``map_only`` is ignored for QueryBlocks (they pipeline the [Q] form)."""
     rank = dist.get_rank(group)
     if isinstance(ops, QueryBlocks):
         return _map_k_blocks(ops.blocks, k, rank, group)
     if map_only and hasattr(ops, "totals"):
         t = ops.totals()                                         # pass 1; the shard's totals table where pass 1 left it
         world = dist.get_world_size(group)
+        nb, qpad = t.shape[0], t.shape[1]
+        if exchange != "gather" and hasattr(ops, "slice_offsets") and qpad % world == 0:
+            # all-to-all by query slice: rank j resolves the offsets of qpad / world queries for every shard.  Per rank 2 x the table
+            # travels (2 x 2.6 MB at Q 5000, K 64) instead of world x (21 MB at 8 ranks), and the offsets are computed once, not
+            # world times.  The column slices are not contiguous in the table: one strided copy each way.
+            S = qpad // world
+            send = t.view(nb, world, S, 2).permute(1, 0, 2, 3).contiguous()      # [world (slice owner), nb, S, 2]
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)      # [world (shard), nb, S, 2]: every shard's columns of MY slice
+            offs = ops.slice_offsets(recv)                       # [world (shard), nb + 1, S, 2]
+            back = torch.empty_like(offs)
+            dist.all_to_all_single(back, offs, group=group)      # [world (slice owner), nb + 1, S, 2]: MY rows for every slice
+            m = ops.map_partial_offsets(k, back)                 # scatter, pass 2, this shard's share of the mean
+            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+            return m, None, None
+        if exchange == "alltoall":
+            raise ValueError("map_k_sharded: the all-to-all exchange needs qpad %% world == 0 (qpad=%d, world=%d)" % (qpad, world))
         g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
             dist.all_gather_into_tensor(g, t, group=group)       # [world, nb, qpad, 2]

@@ -172,6 +172,19 @@ int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qzero, const 
                             size_t ws_bytes, const uint32_t* totals_gathered, int world, int rank, int64_t k, double* ap_sum,
                             int32_t* cap, double* map_partial, xmh_stream_t stream);
 
+/* The same evaluation with an all-to-all exchange (2 x the table size per rank instead of world x): rank j receives from every
+ * shard the columns of ITS slice of `slice` = qpad / world queries -> totals_slices[world][nbuckets][slice][2];
+ * xmh_shard_slice_offsets resolves those queries for EVERY shard -> offsets_out[world][nbuckets + 1][slice][2]
+ * ({lower buckets anywhere + same bucket on lower shards} per bucket; last row {relevant items, items} over all shards); a second
+ * all-to-all returns shard w its rows, ordered by slice owner -> offsets[world][nbuckets + 1][slice][2], which
+ * xmh_hamming_map_sharded_offsets turns into pass 2 + this shard's share of the mean exactly like xmh_hamming_map_sharded.
+ * Needs qpad % world == 0 (qpad is a multiple of 64; 128 for codes of at most 64 bits). */
+int xmh_shard_slice_offsets(const uint32_t* totals_slices, int world, int nbuckets, int slice, uint32_t* offsets_out, xmh_stream_t stream);
+int xmh_hamming_map_sharded_offsets(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                                    const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                                    size_t ws_bytes, const uint32_t* offsets, int world, int64_t k, double* ap_sum, int32_t* cap,
+                                    double* map_partial, xmh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-query top-k (north_star: "fused bit-packed XOR-popcount + per-query top-k kernel").
  * Exact top-k under the canonical order.  dist[Q][k] u16, idx[Q][k] i32 hold GLOBAL indices

@@ -51,6 +51,34 @@ class OracleShardOps:
         return (ap / cap.to(torch.float64)).sum().reshape(1) / ap.shape[0]
 
 
+    def slice_offsets(self, totals_slices):
+        from xmh import sharded
+        return sharded.slice_offsets_reference(totals_slices)
+
+    def map_partial_offsets(self, k, offsets):
+        """what xmh_hamming_map_sharded_offsets does: rows by slice owner -> [Q, nb] offsets, pass 2, this shard's share"""
+        world, nb1, S, _ = offsets.shape
+        rows = offsets.permute(1, 0, 2, 3).reshape(nb1, world * S, 2)            # [nb + 1, qpad, 2]
+        Q = self.a[0].shape[0]
+        base_a = rows[:-1, :Q, 0].t().contiguous()
+        base_r = rows[:-1, :Q, 1].t().contiguous()
+        nrel = rows[-1, :Q, 0].contiguous()
+        ap, cap = self.ap_sums(k, base_a, base_r, nrel)
+        return (ap / cap.to(torch.float64)).sum().reshape(1) / ap.shape[0]
+
+
+class PaddedOracleShardOps(OracleShardOps):
+    """the totals table padded to a multiple of 4 queries, as the HIP plan pads to 64 / 128: the all-to-all exchange needs
+    qpad % world == 0"""
+
+    def totals(self):
+        t = super().totals()
+        qpad = (t.shape[1] + 3) // 4 * 4
+        out = torch.zeros(t.shape[0], qpad, 2, dtype=t.dtype)
+        out[:, : t.shape[1]] = t
+        return out
+
+
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -86,8 +114,16 @@ def _worker(rank, world, port, tmp):
             assert np.array_equal(cap.numpy(), want_cap)
             assert np.allclose(ap.numpy(), want_s, rtol=1e-12)
             assert abs(float(m) - float(np.mean(want_s / want_cap))) < 1e-12
-            m1, ap1, cap1 = sharded.map_k_sharded(ops, k, map_only=True)      # shares of the mean, one scalar all-reduce
+            m1, ap1, cap1 = sharded.map_k_sharded(ops, k, map_only=True, exchange="gather")      # shares of the mean, one scalar all-reduce
             assert ap1 is None and cap1 is None and abs(float(m1) - float(m)) < 1e-12
+            # the all-to-all exchange by query slice against the all-gather it replaces (Q = 37 padded to 40: slices of 20 queries)
+            pops = PaddedOracleShardOps(qb, ql, rb[lo:hi], rl[lo:hi], K + 1)
+            m2, _, _ = sharded.map_k_sharded(pops, k, map_only=True, exchange="alltoall")
+            assert abs(float(m2) - float(m1)) < 1e-12
+            m3, _, _ = sharded.map_k_sharded(pops, k, map_only=True)                          # "auto" picks it: 40 % 2 == 0
+            assert float(m3) == float(m2)
+            with pytest.raises(ValueError):
+                sharded.map_k_sharded(ops, k, map_only=True, exchange="alltoall")             # 37 queries do not split over 2 ranks
         # the same over query blocks (asynchronous gathers, one per block): identical results
         for nblk in (2, 3):
             qbl = sharded.shard_bounds(Q, nblk)
