@@ -386,6 +386,17 @@ def main():
     dt, m = timed(step, barrier, args.steps, use_dist)
     map_value = float(m.item())
 
+    # what the timed step really exchanged: the one-shot form runs map_k_sharded(map_only=True), whose default is the
+    # all-to-all by query slice whenever the padded query count divides by the world size; query blocks pipeline the [Q] form
+    if not use_dist:
+        collectives = []
+    elif piped is not None:
+        collectives = ["all_gather packed query codes", "%d x async all_gather [2,Q/%d,K+1] histograms" % (nqb, nqb), "all_reduce [Q] f64"]
+    elif scan.plan.qpad % world == 0:
+        collectives = ["all_gather packed query codes", "all_to_all totals-table query slices [world,K+1,qpad/world,2] u32",
+                       "all_to_all offset rows [world,K+2,qpad/world,2] u32", "all_reduce [1] f64"]
+    else:
+        collectives = ["all_gather packed query codes", "all_gather totals tables [K+1,qpad,2] u32", "all_reduce [1] f64"]
     roofline = RL.scan_roofline(scan, Q, Rn, K, C, steps=max(args.steps, 10), step_s=None if use_dist else dt / args.steps)
 
     out = {
@@ -397,7 +408,7 @@ def main():
                                "(x%d GPUs, contiguous shards), K=%d bits, C=%d classes, mAP@all" % (Q, Rn, world, K, C),
                    "Q": Q, "R_per_gpu": Rn, "K": K, "C": C, "parallelism": "gallery-shard x%d" % world,
                    "query_blocks": nqb if use_dist else 1,
-                   "collectives_in_step": ["all_gather packed queries", "all_gather [2,Q,K+1] histograms", "all_reduce [Q] f64"] if use_dist else []},
+                   "collectives_in_step": collectives},
         "rccl_ranks": ranks_in_group, "launcher": "torch.distributed.run" if world > 1 else "single process",
         "mAP": map_value, "roofline": roofline,
     }
@@ -461,6 +472,9 @@ def main():
         try:
             out["strong_scaling"] = strong_legs(args, world, rank, barrier)
         except Exception as exc:
+            # a failure on ONE rank leaves the others inside a collective until the process-group timeout (5 minutes, set above);
+            # nothing after this point needs the group again, so the failing rank just records it and every rank falls through to
+            # destroy_process_group
             out["strong_scaling"] = {"error": repr(exc)}
             print("strong-scaling legs failed on rank %d: %r" % (rank, exc), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -73,7 +73,11 @@ class BaseTrainer:
         if not distributed and torch.cuda.is_available() and device is not None:
             # libxmh launches on the CURRENT device's stream: make run.device current (the reference reaches any device
             # through .to(self.device), runners/base.py:105-107)
-            torch.cuda.set_device(torch.device("cuda", device) if isinstance(device, int) else torch.device(device))
+            # "cuda" without an index means the current device; a non-CUDA device (the reference accepts anything .to() does)
+            # is left to the ops, which report that they need a GPU tensor
+            d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            if d.type == "cuda":
+                torch.cuda.set_device(d.index if d.index is not None else torch.cuda.current_device())
         self.output_dim, self.train_num, self.query_num = output_dim, train_num, query_num
         self.epochs, self.display_step, self.top_k = epochs, display_step, top_k
         self.model_state, self.batch_size, self.save_dir = model_state, batch_size, save_dir

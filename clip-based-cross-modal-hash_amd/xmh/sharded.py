@@ -179,7 +179,8 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
     the padded query count divides by the world size.  ``map_only`` is ignored for QueryBlocks (they pipeline the [Q] form)."""
     rank = dist.get_rank(group)
     if isinstance(ops, QueryBlocks):
-        return _map_k_blocks(ops.blocks, k, rank, group)
+        m, ap, cap = _map_k_blocks(ops.blocks, k, rank, group)
+        return (m, None, None) if map_only else (m, ap, cap)     # the blocks pipeline the [Q] form; map_only only trims the result
     if map_only and hasattr(ops, "totals"):
         t = ops.totals()                                         # pass 1; the shard's totals table where pass 1 left it
         world = dist.get_world_size(group)

@@ -28,4 +28,20 @@ def run_both(fn_image, fn_text):
         txt = fn_text()
     img = fn_image()
     cur.wait_stream(side)
+    _record(txt, cur)
     return img, txt
+
+
+def _record(out, stream):
+    """the text tower's outputs were allocated on the side stream and are consumed on the caller's: tell the caching allocator, so
+    that a block freed while the caller's stream still reads it is not handed to the side stream again (the next run_both may
+    run under ANOTHER current stream, whose wait_stream does not fence this one)"""
+    if isinstance(out, torch.Tensor):
+        if out.is_cuda:
+            out.record_stream(stream)
+    elif isinstance(out, (tuple, list)):
+        for o in out:
+            _record(o, stream)
+    elif isinstance(out, dict):
+        for o in out.values():
+            _record(o, stream)

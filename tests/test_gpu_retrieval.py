@@ -536,6 +536,45 @@ def test_sharded_fuzz_random_splits(xr):
         assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9), (case, Q, R, K, world, bounds)
 
 
+@pytest.mark.parametrize("Q,R,K,C,world,k", [(300, 9001, 64, 80, 4, None), (130, 5000, 16, 24, 2, 9), (200, 7000, 128, 40, 8, None),
+                                             (100, 3, 64, 10, 4, None)])
+def test_sharded_all_to_all_exchange_by_query_slice(xr, Q, R, K, C, world, k):
+    """The all-to-all form of the sharded evaluation with the `world` ranks played by one process: every shard's totals table cut
+    into query slices, the slice owner's kernel (xmh_shard_slice_offsets) against its torch statement, the rows handed back to
+    the shards, and the shards' shares (xmh_hamming_map_sharded_offsets) adding up to the unsharded mAP and to the all-gather
+    form (xmh_hamming_map_sharded).  (100, 3, ..., 4): more ranks than gallery rows -- one shard is empty."""
+    from xmh import sharded
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=Q + R + K)
+    qL[:, 0] = 1
+    rL[::3, 0] = 1                                                                    # every query has a relevant item (else the mAP is NaN)
+    q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+    r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+    whole = xr.RankingScan(q, ql, r, rl, C)
+    whole.histograms(False)
+    want = float(whole.map_all(k)[0].item())
+    assert want == want
+    b = sharded.shard_bounds(R, world)
+    shards = [sharded.HipShardOps(q, ql, r.rows(b[i], b[i + 1]), rl[b[i]:b[i + 1]].contiguous(), C) for i in range(world)]
+    tables = [o.totals().clone() for o in shards]                                   # [nb, qpad, 2] each
+    nb, qpad = tables[0].shape[0], tables[0].shape[1]
+    assert qpad % world == 0
+    S = qpad // world
+    sends = [t.view(nb, world, S, 2).permute(1, 0, 2, 3).contiguous() for t in tables]           # [owner, nb, S, 2] per shard
+    offs = []
+    for j in range(world):                                                            # slice owner j
+        recv = torch.stack([sends[w][j] for w in range(world)]).contiguous()         # what all_to_all_single delivers
+        o = xr.slice_offsets(recv)
+        assert torch.equal(o, sharded.slice_offsets_reference(recv))
+        offs.append(o)
+    gathered = torch.stack(tables).contiguous()
+    got = got_gather = 0.0
+    for w in range(world):                                                            # shard w
+        back = torch.stack([offs[j][w] for j in range(world)]).contiguous()          # its rows, by slice owner
+        got += float(shards[w].map_partial_offsets(k, back).item())
+        got_gather += float(shards[w].map_partial(k, gathered, w).item())
+    assert abs(got - want) < 1e-9 and abs(got - got_gather) < 1e-12
+
+
 def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():
     """xmh.sharded.map_k_sharded through a real RCCL process group (world size 1, fresh process): the one-shot form and the
     query-block pipeline (asynchronous gathers) against the unsharded scan."""
@@ -568,6 +607,58 @@ def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():
     ) % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def _two_rank_rccl_worker(rank, world, port, tmp):
+    import sys
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    import torch.distributed as dist
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        from xmh import retrieval as R, sharded
+        g = torch.Generator().manual_seed(21)                                        # identical data on every rank
+        Q, Rn, K, C = 300, 20001, 64, 40
+        qB, rB = torch.randn(Q, K, generator=g).sign(), torch.randn(80, K, generator=g).sign()[torch.randint(0, 80, (Rn,), generator=g)]
+        qL, rL = (torch.rand(Q, C, generator=g) < .1).long(), (torch.rand(Rn, C, generator=g) < .1).long()
+        qL[:, 0] = 1
+        rL[::4, 0] = 1
+        q, ql, r, rl = R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda())
+        whole = R.RankingScan(q, ql, r, rl, C)
+        whole.histograms(False)
+        b = sharded.shard_bounds(Rn, world)
+        ops = sharded.HipShardOps(q, ql, r.rows(b[rank], b[rank + 1]), rl[b[rank]:b[rank + 1]].contiguous(), C)
+        for k in (None, 7):
+            want = float(whole.map_all(k)[0].item())
+            for ex in ("alltoall", "gather"):
+                m = sharded.map_k_sharded(ops, k, map_only=True, exchange=ex)[0]
+                assert abs(float(m.item()) - want) < 1e-9, (k, ex)
+            m, ap, cap = sharded.map_k_sharded(ops, k)
+            assert abs(float(m.item()) - want) < 1e-9
+        d, i = sharded.topk_sharded(q, r.rows(b[rank], b[rank + 1]), 30, b[rank])
+        wd, wi = R.hamming_topk(q, r, 30)
+        assert torch.equal(i, wi.cpu()) and torch.equal(d.to(torch.int16), wd.cpu())
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_over_rccl(tmp_path):
+    """the CUDA branches of the sharded driver (all_to_all_single / all_gather_into_tensor on workspace views, the
+    fused map_only forms, topk_sharded) under a REAL 2-rank RCCL group, against the unsharded scan.  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mp.spawn(_two_rank_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(2))
 
 
 def test_sharded_ops_with_an_empty_shard(xr):

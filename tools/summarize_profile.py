@@ -26,13 +26,18 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
 # bench line's avg_launch_ms must agree with
 steady = {}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    per = collections.defaultdict(list)
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    for k, v in per.items():
+        grid = r.get("Grid_Size") or r.get("Grid_Size_X") or ""
+        per[short(r["Kernel_Name"])][grid].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for k, grids in per.items():
+        # one kernel instance may serve several shapes (k_scan_ap_c<false>: every code length up to 64 bits): the steady figure is of
+        # the grid size launched most often, i.e. the headline shape
+        grid, v = max(grids.items(), key=lambda kv: len(kv[1]))
         v.sort()
         last = [d for _, d in v[-20:]]
-        steady[k] = {"launches": len(v), "steady_avg_ns": sum(last) / len(last), "steady_over": len(last)}
+        steady[k] = {"launches": sum(len(x) for x in grids.values()), "steady_avg_ns": sum(last) / len(last), "steady_over": len(last), "steady_grid": grid,
+                     "grid_sizes_seen": len(grids)}
 for r in res["kernel_stats"]:
     if r["name"] in steady:
         r.update(steady[r["name"]])
