@@ -1444,18 +1444,21 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
 //   * the atomics are inline asm on that address, their returns waited for with counted lgkmcnt one group of 8 later.
 // Per pair: 2 bit-field extracts, the address, the pair {1, mask}, ds_add_rtn_u64; sub, rcp, and, sub, fmac.
 // ---------------------------------------------------------------------------------------------------
-template <bool CAPPED>
+// EB = entry bits of the pair cache: 8 (codes of at most 64 bits: 4 slots x 16 queries, 16 steps per lane and batch) or 16 (65..256 bits:
+// 8 slots x 8 queries, 8 steps)
+template <bool CAPPED, int EB>
 __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ items_total, uint32_t kcap) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][16] 64-bit counters
+    constexpr int QW = 128 / EB, LOG_QW = EB == 8 ? 4 : 3, S = 64 / QW, EPW = 32 / EB;      // queries per tile, slots, entries per cache word
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] 64-bit counters
     int chunk_id, qtile;
-    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts 16-query tiles here
+    if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
     if (items_total && (int64_t)*items_total > kFloatBitsMaxItems) return;      // sharded call: the integer-counter kernel takes it
     const int lane = threadIdx.x & 63;
-    const int ql = lane & 15, slot = lane >> 4;
-    const int q0 = qtile * 16, q = q0 + ql;
-    const int ncell = a.nb * 16;
+    const int ql = lane & (QW - 1), slot = lane >> LOG_QW;
+    const int q0 = qtile * QW, q = q0 + ql;
+    const int ncell = a.nb * QW;
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds);
     {
         const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
@@ -1469,7 +1472,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ee = e + j * 64;
-                const int64_t at = (int64_t)(ee >> 4) * a.qpad + (ee & 15);
+                const int64_t at = (int64_t)(ee >> LOG_QW) * a.qpad + (ee & (QW - 1));
                 x[j] = pb[at];
                 y[j] = pd[at];
             }
@@ -1477,7 +1480,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
             for (int j = 0; j < 8; ++j) cnt[e + j * 64] = pack(x[j], y[j]);
         }
         for (; e < ncell; e += 64) {
-            const int64_t at = (int64_t)(e >> 4) * a.qpad + (e & 15);
+            const int64_t at = (int64_t)(e >> LOG_QW) * a.qpad + (e & (QW - 1));
             cnt[e] = pack(pb[at], pd[at]);
         }
     }
@@ -1493,19 +1496,24 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         acc = fmaf(ord, __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(rank)) & m), acc);
     };
     auto issue1 = [&](uint32_t w, int j, unsigned long long& old, uint32_t& m) {
-        m = (uint32_t)__builtin_amdgcn_sbfe((int)w, 8 * j, 1);                    // 0 / ~0
-        const uint32_t d = __builtin_amdgcn_ubfe(w, 8 * j + 1, 7);
+        m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * j, 1);                   // 0 / ~0
+        const uint32_t d = __builtin_amdgcn_ubfe(w, EB * j + 1, EB - 1);
         uint32_t addr;
-        asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(d), "v"(cntbase));
+        if (EB == 8) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(d), "v"(cntbase));       // rows of 16 queries x 8 bytes
+        else asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(d), "v"(cntbase));
         const unsigned long long inc = 1ull | ((unsigned long long)m << 32);
         asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(old) : "v"(addr), "v"(inc) : "memory");     // same-address lanes resolve in lane = item order
     };
     unsigned long long oldp[8], oldn[8];
     uint32_t mp[8], mn[8];
     bool prev = false;
-    auto group = [&](uint32_t wa, uint32_t wb) {
+    // 8 steps = two cache words of one-byte entries, or all four words of a batch of two-byte entries
+    auto group = [&](uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) issue1(u < 4 ? wa : wb, u & 3, oldn[u], mn[u]);
+        for (int u = 0; u < 8; ++u) {
+            const int wi = u / EPW;
+            issue1(wi == 0 ? wa : (wi == 1 ? wb : (wi == 2 ? wc : wd)), u % EPW, oldn[u], mn[u]);
+        }
         if (prev) {                                                   // the previous group's returns: 8 newer LDS operations are in flight
             asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
                          "+v"(oldp[7])::"memory");
@@ -1523,8 +1531,12 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     uint4 cw = crow[0];
     for (int bi = 0; bi < nfull; ++bi) {
         const uint4 nw = crow[(int64_t)(bi + 1 < nbatch ? bi + 1 : bi) * 64];      // unconditional: counted vmcnt, no predication
-        group(cw.x, cw.y);
-        group(cw.z, cw.w);
+        if (EB == 8) {
+            group(cw.x, cw.y, 0u, 0u);
+            group(cw.z, cw.w, 0u, 0u);
+        } else {
+            group(cw.x, cw.y, cw.z, cw.w);
+        }
         cw = nw;
     }
     if (prev) {
@@ -1535,16 +1547,16 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     }
     const int cntb = (int)(hi - lo) - nfull * 64;                    // ragged last batch (cw holds its words)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        if (t * 4 + slot < cntb) {
-            const uint32_t w = t < 4 ? cw.x : (t < 8 ? cw.y : (t < 12 ? cw.z : cw.w));
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, 8 * (t & 3), 1), d = __builtin_amdgcn_ubfe(w, 8 * (t & 3) + 1, 7);
-            const unsigned long long o = atomicAdd(&cnt[d * 16 + ql], 1ull | ((unsigned long long)m << 32));
+    for (int t = 0; t < QW; ++t) {
+        if (t * S + slot < cntb) {
+            const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * (t % EPW), 1), d = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + 1, EB - 1);
+            const unsigned long long o = atomicAdd(&cnt[d * QW + ql], 1ull | ((unsigned long long)m << 32));
             credit(o, m);
         }
     }
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
+#pragma unroll
+    for (int o = QW; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
 
@@ -2224,8 +2236,9 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     }
     const char* apc_env = getenv("XMH_SCAN_AP_C");
     const bool packable = K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr;
-    if (cache && K <= 64 && !tern && !packable && !(apc_env && atoi(apc_env) == 0) && R <= kFloatBitsMaxItems) {
-        snprintf(p2, sizeof(p2), "k_scan_ap_c<false>");
+    const int apc_mode = apc_env ? atoi(apc_env) : 1;
+    if (cache && !tern && (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256) && R <= kFloatBitsMaxItems) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", K <= 64 ? 8 : 16);
     } else if (use_mfma && K <= 64 && mfma_ap_on()) {
         snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
@@ -2383,26 +2396,29 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // the size in a device word and both kernels are launched, each returning at once when it is the other's turn (as for the counter
     // widths); the explicit-offsets form stays on k_scan_ap_s.  XMH_SCAN_AP_C=0 turns it off.
     const char* apc_env = getenv("XMH_SCAN_AP_C");
-    const bool apc = cache_bytes && K <= 64 && !tern && !masked && rank_bits == 0 && !(apc_env && atoi(apc_env) == 0) && !base_all &&
+    // Beyond 64 bits (two-byte entries, 8 x 8 queries) the same kernel measured no better than k_scan_ap_s (Q 5000 x R 117 218, K=128:
+    // 0.286 against 0.288 ms; K=256, R 60 000: 0.233 against the packed 32-bit counters' 0.204), so it is used there only on request
+    // (XMH_SCAN_AP_C=2; the tests hold it to bit identity with the default).
+    const int apc_mode = apc_env ? atoi(apc_env) : 1;
+    const bool apc = cache_bytes && (K <= 64 ? apc_mode != 0 && rank_bits == 0 : apc_mode == 2 && K <= 256) && !tern && !masked && !base_all &&
                      (hist_g != nullptr || R <= kFloatBitsMaxItems);
     const uint32_t* fb_gate = apc && hist_g ? (const uint32_t*)(nrel_max + 2) : nullptr;
     if (apc) {
+        const int SC = K <= 64 ? 4 : 8;                                  // slots of the cache geometry: 64 / SC queries per wave
         ScanArgs as = a;
-        as.nqt = a.nqt * 4;
+        as.nqt = a.nqt * SC;
         as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
-        const size_t lds = (size_t)p.nbuckets * 16 * 8;
+        const size_t lds = (size_t)p.nbuckets * (64 / SC) * 8;
+        const dim3 grid((unsigned)(scan_grid(p) * SC));
         xmh::ProfScope prof("scan_ap", st);
-        if (capped) {
-            auto kc = k_scan_ap_c<true>;
+        auto go = [&](auto kc) {
             const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
             if (r3) return r3;
-            hipLaunchKernelGGL(kc, dim3(scan_grid(p) * 4), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
-        } else {
-            auto kc = k_scan_ap_c<false>;
-            const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
-            if (r3) return r3;
-            hipLaunchKernelGGL(kc, dim3(scan_grid(p) * 4), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
-        }
+            hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
+            return (int)XMH_OK;
+        };
+        rc = K <= 64 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
+        if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
     }
     // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run

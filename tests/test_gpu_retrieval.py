@@ -375,6 +375,28 @@ def test_pair_cache_entries_match_oracle(xr, Q, R, K, C):
     assert checked == Q * R
 
 
+def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):
+    """k_scan_ap_c (pass 2 with float-bit counters; the default up to 64 bits, XMH_SCAN_AP_C=2 switches it on for the two-byte
+    entries of longer codes) against k_scan_ap_s on the same pair cache: the same credits in the same order, so the per-query sums
+    and caps are equal bit for bit -- mAP@all and mAP@k, ragged last batches, duplicate-heavy galleries."""
+    g = torch.Generator().manual_seed(31)
+    for (Q, Rn, K, C, p, k) in ((70, 5000, 64, 12, .3, None), (33, 4097, 48, 40, .02, 7), (129, 6463, 128, 80, .05, None), (17, 3000, 256, 9, .3, 50),
+                                (200, 9001, 16, 24, .1, None), (5, 63, 32, 3, .5, 2)):
+        qB, rB = torch.randn(Q, K, generator=g).sign(), torch.randn(37, K, generator=g).sign()[torch.randint(0, 37, (Rn,), generator=g)]
+        qL, rL = (torch.rand(Q, C, generator=g) < p).long(), (torch.rand(Rn, C, generator=g) < p).long()
+        qL[:, 0] = 1
+        rL[::3, 0] = 1
+        scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+        scan.histograms(False)
+        outs = []
+        for mode in ("0", "2"):
+            monkeypatch.setenv("XMH_SCAN_AP_C", mode)
+            ap, cap = scan.ap_sums(k)
+            outs.append((ap.clone(), cap.clone()))
+        monkeypatch.delenv("XMH_SCAN_AP_C")
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (Q, Rn, K)
+
+
 def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
     """XMH_SCAN_MFMA_AP=1 (pass 2 evaluated on the MFMA, no pair cache) against the default path: same ap sums, caps and capped
     sums bit for bit -- including ragged last batches whose padding items the MFMA pass also counts (R = 2 and R = 8157 are
@@ -572,7 +594,7 @@ def test_sharded_all_to_all_exchange_by_query_slice(xr, Q, R, K, C, world, k):
         back = torch.stack([offs[j][w] for j in range(world)]).contiguous()          # its rows, by slice owner
         got += float(shards[w].map_partial_offsets(k, back).item())
         got_gather += float(shards[w].map_partial(k, gathered, w).item())
-    assert abs(got - want) < 1e-9 and abs(got - got_gather) < 1e-12
+    assert abs(got - want) < 1e-7 and abs(got - got_gather) < 1e-12          # vs unsharded: fp32 credits summed per chunk, another chunking
 
 
 def test_sharded_driver_over_rccl_world_one_plain_and_query_blocks():

@@ -26,7 +26,7 @@ SRC = os.path.join(ROOT, "clip-based-cross-modal-hash_amd", "csrc", "xmh_scan.hi
 #   k_scan_hist_m<NMC, NML, NW, CACHE>;  k_scan_hist_m2<NML, NW, NQ, CACHE, STAMP>;  k_scan_ap_c<CAPPED>
 KERNELS = [
     "k_scan_hist_m2<2, 4, 2, true, false>", "k_scan_hist_m2<2, 4, 2, false, false>", "k_scan_hist_m2<1, 4, 4, true, false>",
-    "k_scan_hist_m2<2, 4, 4, true, false>", "k_scan_ap_c<false>",
+    "k_scan_hist_m2<2, 4, 4, true, false>", "k_scan_ap_c<false, 8>", "k_scan_ap_c<false, 16>",
     "k_scan_hist_m<1, 2, 4, true>", "k_scan_hist_m<2, 2, 4, true>", "k_scan_hist_m<4, 2, 4, false>",
     "k_scan_hist_s<2, 3, false, 4, 1, true>", "k_scan_hist_s<2, 3, false, 4, 1, false>", "k_scan_hist_s<1, 3, false, 2, 1, false>",
     "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, false>",
@@ -37,7 +37,7 @@ KERNELS = [
 
 
 def mangled(instance):
-    """("k_scan_ap_c", "ILb0EE") for "k_scan_ap_c<false>": the Itanium spelling of integer / bool template arguments"""
+    """("k_scan_ap_c", "ILb0ELi8EE") for "k_scan_ap_c<false, 8>": the Itanium spelling of integer / bool template arguments"""
     m = re.match(r"(\w+)<(.*)>", instance)
     args = [a.strip() for a in m.group(2).split(",")]
     enc = "".join(("Lb%dE" % (a == "true")) if a in ("true", "false") else "Li%sE" % a for a in args)
