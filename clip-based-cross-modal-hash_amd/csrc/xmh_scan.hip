@@ -994,7 +994,11 @@ __global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict
             uint32_t bits = 0u;
             if (m < 2) {
                 if (k0 < W * 32) bits = (qbits[q * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+#ifdef XMH_ABL_SUB2
+                const uint32_t set = m == 0 ? 0xc0u : 0xffu, clr = m == 0 ? 0x40u : 0x01u;      // rows of 128 bytes
+#else
                 const uint32_t set = m == 0 ? 0xe0u : 0xffu, clr = m == 0 ? 0x20u : 0x01u;      // -32 / +32 (address), -1 / +1 (2 * distance)
+#endif
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     if (k0 + t < K) a[t >> 2] |= (((bits >> t) & 1u) ? set : clr) << (8 * (t & 3));
@@ -1046,7 +1050,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & 15, slot = lane >> 4;
     const int t16 = (qtile * NW + wave) * NQ;                        // first 16-query tile of this wave
+#ifdef XMH_ABL_SUB2      // tools/stamp_m2.hip only: one counter copy per slot parity (bank-conflict-free adds) -- timing experiment, totals not merged
+    const int ncell = a.nb * 32;
+#else
     const int ncell = a.nb * 16;
+#endif
     uint32_t* cnt = lds + (wave * NQ) * ncell;
     for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
     char* ring = reinterpret_cast<char*>(lds + NW * NQ * ncell);
@@ -1058,7 +1066,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
 #pragma unroll
         for (int m = 0; m < NMQ; ++m) bq[h][m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(t16 + h) * NMQ + m) * 64 + lane);
         valid[h] = (t16 + h) * 16 + ql < a.Q;
+#ifdef XMH_ABL_SUB2
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (slot & 1) * 64 + (valid[h] ? 64 * a.K : 0);
+#else
         const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 32 * a.K : 0);
+#endif
         cq[h] = v4i{c0, c0, c0, c0};
     }
     v4i kq = {a.K, a.K, a.K, a.K}, lab0 = {0x10000, 0x10000, 0x10000, 0x10000};

@@ -36,7 +36,11 @@ int run(int Q, int R, int K, int C) {
     hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, 0, d_rb, d_rl, (int64_t)R, W, LW, K, gimg, gpieces, gblocks, d_qb, d_ql, (int64_t)Q,
                        qimg, qpieces, reinterpret_cast<uint32_t*>(ws + L.tick), (int)((L.gate + 256 - L.tick) / 4));
     MfmaArgs a{gimg, qimg, d_qb, Q, R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
+#ifdef XMH_ABL_SUB2
+    const size_t lds = (size_t)NW * NQ * p.nbuckets * 32 * 4 + 3 * 4 * NMI * 1024;
+#else
     const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
+#endif
     const unsigned grid = (unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8));
     unsigned long long* d_st;
     CK(hipMalloc(&d_st, (size_t)grid * NW * 8 * 8));
@@ -86,8 +90,10 @@ int run(int Q, int R, int K, int C) {
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     int rc = 0;
+    const int K = argc > 1 ? atoi(argv[1]) : 64;
+    if (K != 64) return run<2, 4, 2>(5000, 117218, K, 80);      // forced 4 x 2 geometry at another code length (XMH_SCAN_M2_GEOM=0 in the environment for the plan)
     const M2Geom g = m2_geom(64);
     if (g.nw == 4 && g.nq == 2) rc |= run<2, 4, 2>(5000, 117218, 64, 80);
     else if (g.nw == 8 && g.nq == 1) rc |= run<2, 8, 1>(5000, 117218, 64, 80);
