@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         //   * MFMA result -> VALU / DS read needs 8 wait states: the consumers read the PREVIOUS statement's results;
         //   * the SDWA byte inserts into w have a dst_sel forwarding hazard (one wait state): an add or an MFMA sits between them;
         //   * a VALU write directly in front of an MFMA was read stale as srcC (seen on hardware with a v_mov_b64 hipcc had placed
-        //     there): every statement opens with s_nop, and the constant accumulator quads are opaque to hipcc (no re-materialising);
+        //     there): every statement opens with s_nop 3, and the constant accumulator quads are opaque to hipcc (no re-materialising);
         //   * a VALU write landing on the A / B registers of an MFMA issued two or three instructions earlier corrupted its operand:
         //     all results are early-clobber outputs of the statement that also names the A tiles as inputs;
         //   * MFMA -> MFMA srcC dependencies are interlocked in hardware.
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
             uint32_t i0, i1, i2, i3;                                  // min results: fresh registers (in-place on the MFMA's result tuple made hipcc copy them)
             if (NML == 2 && CACHE) {
                 asm volatile(
-                    "s_nop 1\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
+                    "s_nop 3\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
                     "v_min_u32 %4, 0x10001, %26\n\tv_min_u32 %5, 0x10001, %27\n\tv_min_u32 %6, 0x10001, %28\n\t"
                     XMH_MFMA("%0", "%11", "%12", "%0")
                     "v_min_u32 %7, 0x10001, %29\n\t"
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     : "memory");
             } else if (NML == 2) {
                 asm volatile(
-                    "s_nop 1\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
+                    "s_nop 3\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
                     "v_min_u32 %2, 0x10001, %18\n\tv_min_u32 %3, 0x10001, %19\n\tv_min_u32 %4, 0x10001, %20\n\t"
                     XMH_MFMA("%0", "%9", "%10", "%0")
                     "v_min_u32 %5, 0x10001, %21\n\t" XMH_ADD("%14", "%2") XMH_ADD("%15", "%3")
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     : "memory");
             } else if (CACHE) {
                 asm volatile(
-                    "s_nop 1\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
+                    "s_nop 3\n\t" XMH_MFMA("%0", "%8", "%9", "%10")
                     "v_min_u32 %4, 0x10001, %24\n\tv_min_u32 %5, 0x10001, %25\n\tv_min_u32 %6, 0x10001, %26\n\tv_min_u32 %7, 0x10001, %27\n\t"
                     "v_or_b32_sdwa %3, %16, %4 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
                     XMH_ADD("%20", "%4")
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     : "memory");
             } else {
                 asm volatile(
-                    "s_nop 1\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
+                    "s_nop 3\n\t" XMH_MFMA("%0", "%6", "%7", "%8")
                     "v_min_u32 %2, 0x10001, %16\n\tv_min_u32 %3, 0x10001, %17\n\tv_min_u32 %4, 0x10001, %18\n\tv_min_u32 %5, 0x10001, %19\n\t"
                     XMH_MFMA("%1", "%9", "%10", "%11")
                     XMH_ADD("%12", "%2") XMH_ADD("%13", "%3") XMH_ADD("%14", "%4") XMH_ADD("%15", "%5")
@@ -1210,23 +1210,23 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         // copy hipcc places in front of it) read these results, and its own MFMA is only one slot away
         auto evaluate = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab) {
             if (NML == 2 && CACHE) {
-                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%0", "%6", "%7", "%0")
+                asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%0", "%6", "%7", "%0")
                              XMH_MFMA("%1", "%8", "%9", "%10") XMH_MFMA("%2", "%8", "%11", "%12") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr), "=&v"(d2)
                              : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]),
                                "v"(bq[h][1]), "v"(kq));
             } else if (NML == 2) {
-                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%0", "%5", "%6", "%0")
+                asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%0", "%5", "%6", "%0")
                              XMH_MFMA("%1", "%7", "%8", "%9") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr)
                              : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]));
             } else if (CACHE) {
-                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%1", "%6", "%7", "%8")
+                asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%1", "%6", "%7", "%8")
                              XMH_MFMA("%2", "%6", "%9", "%10") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr), "=&v"(d2)
                              : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
             } else {
-                asm volatile("s_nop 1\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%1", "%5", "%6", "%7") "s_nop 7"
+                asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%1", "%5", "%6", "%7") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr)
                              : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]));
             }
