@@ -607,16 +607,22 @@ __device__ __noinline__ void append_candidates(int64_t it, int d, bool hit, uint
     }
 }
 
-// queries are processed in groups of QN (blockIdx.y): their words and thresholds are loaded ONCE per block
-// (wave-uniform -> SGPRs) and stay resident over the whole stream, so the tile loop is loads + XOR/popcount only.
-template <int W, int IPT, int QN>
+// queries are processed in groups of QN: their words and thresholds are loaded ONCE per wave and stay resident over the whole
+// stream, so the tile loop is loads + XOR/popcount only.  QG (round 3) = query groups per BLOCK: the block's waves split into QG
+// sub-blocks that walk the SAME tiles, each with its own QN queries -- the second and later readers of a tile hit in the CU's L1
+// instead of every query group streaming the gallery again from L2 / HBM (blockIdx.y alone: 8 passes over the tiles at Q = 64), and at
+// Q = 8 two groups of 4 halve the integer work and the 64 query-word registers per wave that made the VALU co-critical.
+template <int W, int IPT, int QN, int QG>
 __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
                                                           int Q, int64_t R, const uint32_t* __restrict__ t_est,
                                                           uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
-    constexpr int TILE = kThreads * IPT;
-    const int q0 = blockIdx.y * QN;
+    constexpr int SUBT = kThreads / QG;                     // threads (whole waves) per query group
+    static_assert(SUBT % 64 == 0, "query groups are whole waves");
+    constexpr int TILE = SUBT * IPT;
+    const int sub = threadIdx.x / SUBT, tl = threadIdx.x % SUBT;
+    const int q0 = (blockIdx.y * QG + sub) * QN;
     const int64_t ntiles = (R + TILE - 1) / TILE;
-    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * SUBT + tl; };
     uint32_t qw[QN][W];
     int thr[QN];
 #pragma unroll
@@ -922,24 +928,40 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                                per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
-            const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * II);                                                   \
             const int qmax = WW >= 64 ? 1 : (WW >= 32 ? 2 : (WW >= 16 ? 4 : 8));      /* query words live in VGPRs */     \
-            const int qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));       \
-            const unsigned gy = (unsigned)xmh::ceil_div(Q, qn);                                                            \
+            int qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));             \
+            /* query groups per block (they share each tile through L1): Q = 8 runs as 2 x 4, 16 and more queries as up to 4 x 8 */ \
+            int qg = 1;                                                                                                    \
+            if (WW < 16 && Q >= 5 && Q <= 8) { qn = 4; qg = 2; }                                                           \
+            else if (WW < 16 && Q >= 16) qg = Q >= 32 ? 4 : 2;                                                             \
+            if (const char* e_ = getenv("XMH_TOPK_QG")) {                 /* tuning: "<queries per group>x<groups per block>" */ \
+                int a_ = 0, b_ = 0;                                                                                        \
+                if (sscanf(e_, "%dx%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4 || a_ == 8) && a_ <= qmax && (b_ == 1 || b_ == 2 || b_ == 4) && (a_ > 1 || b_ == 1) && WW < 16) { qn = a_; qg = b_; } \
+            }                                                                                                              \
+            const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
+            const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
             int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;     /* 2..32 blocks per CU measured within 5 % */        \
             if (fb < xmh::device_cu_count()) fb = xmh::device_cu_count();                                                  \
             if (fb > ft) fb = ft;                                                                                          \
             xmh::ProfScope prof("topk_filter", st);                                                                        \
+            const dim3 grid_((unsigned)fb, gy);                                                                            \
+            auto go_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, grid_, dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); }; \
             if constexpr (WW < 16) {                                                                                       \
-                if (qn == 8) hipLaunchKernelGGL((k_topk_filter<WW, II, 8>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+                if (qn == 8 && qg == 1) go_(k_topk_filter<WW, II, 8, 1>);                                                   \
+                if (qn == 8 && qg == 2) go_(k_topk_filter<WW, II, 8, 2>);                                                   \
+                if (qn == 8 && qg == 4) go_(k_topk_filter<WW, II, 8, 4>);                                                   \
+                if (qn == 4 && qg == 2) go_(k_topk_filter<WW, II, 4, 2>);                                                   \
+                if (qn == 4 && qg == 4) go_(k_topk_filter<WW, II, 4, 4>);                                                   \
+                if (qn == 2 && qg == 2) go_(k_topk_filter<WW, II, 2, 2>);                                                   \
+                if (qn == 2 && qg == 4) go_(k_topk_filter<WW, II, 2, 4>);                                                   \
             }                                                                                                              \
             if constexpr (WW < 32) {                                                                                       \
-                if (qn == 4) hipLaunchKernelGGL((k_topk_filter<WW, II, 4>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+                if (qn == 4 && qg == 1) go_(k_topk_filter<WW, II, 4, 1>);                                                   \
             }                                                                                                              \
             if constexpr (WW < 64) {                                                                                       \
-                if (qn == 2) hipLaunchKernelGGL((k_topk_filter<WW, II, 2>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+                if (qn == 2 && qg == 1) go_(k_topk_filter<WW, II, 2, 1>);                                                   \
             }                                                                                                              \
-            if (qn == 1) hipLaunchKernelGGL((k_topk_filter<WW, II, 1>), dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); \
+            if (qn == 1) go_(k_topk_filter<WW, II, 1, 1>);                                                                 \
         }
         switch (p.W) {
             case 1: XMH_FAST(1, 8) break;
