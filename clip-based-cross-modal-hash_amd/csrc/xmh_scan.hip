@@ -1024,14 +1024,23 @@ __global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict
         const int k0 = c * 16;
         uint32_t bits = 0u;
         if (item < R && k0 < W * 32) bits = (rbits[item * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
+        // four bits -> four bytes with one multiply (the shifted copies do not overlap: no carries), then 0 / 1 -> -1 / +1
 #pragma unroll
-        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((k0 + t < K) ? (((bits >> t) & 1u) ? 0x01u : 0xffu) : 0u) << (8 * (t & 3));
+        for (int x = 0; x < 4; ++x) {
+            const uint32_t sp = (((bits >> (4 * x)) & 0xfu) * 0x00204081u) & 0x01010101u;
+            by[x] = 0xffffffffu ^ (sp * 0xfeu);
+        }
+        if (k0 + 16 > K) {                                         // the code ends inside these 16 positions: bytes past it are 0
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (k0 + t >= K) by[t >> 2] &= ~(0xffu << (8 * (t & 3)));
+        }
     } else {
         const int k0 = (m - 1) * 64 + c * 16;
         uint32_t bits = 0u;
         if (item < R && k0 < LW * 32) bits = (rlab[item * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((bits >> t) & 1u) << (8 * (t & 3));
+        for (int x = 0; x < 4; ++x) by[x] = (((bits >> (4 * x)) & 0xfu) * 0x00204081u) & 0x01010101u;
     }
     out[p] = make_uint4(by[0], by[1], by[2], by[3]);
 }
