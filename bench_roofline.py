@@ -282,6 +282,6 @@ EXTRA_LEGS = {
     "configs0_dcmht_16bit_mirflickr": dict(what="configs[0] DCMHT MIRFlickr-shaped 16-bit", Q=5000, Rn=20015, K=16, C=24, p_label=0.10, seed=1816, steps=30),
     "k16_coco_shape": dict(what="16-bit codes at the configs[1] COCO shape", Q=5000, Rn=117218, K=16, C=80, p_label=0.04, seed=1817, steps=30),
     "configs3_dsph_128bit": dict(what="configs[3] DSPH COCO-shaped 128-bit", Q=5000, Rn=117218, K=128, C=80, p_label=0.04, seed=3814, steps=30),
-    "configs4_shard_scan_256bit": dict(what="configs[4] one GPU's shard (10 M / 8) through the mAP scan, pass 2 uncached", Q=5000, Rn=1250000, K=256, C=80,
+    "configs4_shard_scan_256bit": dict(what="configs[4] one GPU's shard (10 M / 8) through the mAP scan (12.7 GB pair cache)", Q=5000, Rn=1250000, K=256, C=80,
                                        p_label=0.04, seed=4814, steps=4),
 }

@@ -107,7 +107,7 @@ typedef struct xmh_scan_plan {
 int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host);
 /* Bytes of the workspace (included in plan.ws_bytes) that hold the PAIR CACHE: xmh_hamming_hist leaves one byte per (query,
  * gallery item) pair -- distance << 1 | relevant; two bytes for codes of 65..256 bits -- and xmh_hamming_ap reads it instead of
- * evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 4096 MB;
+ * evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 32768 MB;
  * 0 = off); returns 0 when it is not used. */
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 /* Byte offset of that pair cache inside the workspace ((size_t)-1 on a bad shape) -- for tests and diagnostics, which decode it

@@ -783,7 +783,7 @@ def test_full_size_nuswide_shape_sharded_eight_ways(xr):
 @pytest.mark.parametrize("leg", ["configs0_dcmht_16bit_mirflickr", "k16_coco_shape", "configs3_dsph_128bit", "configs4_shard_scan_256bit"])
 def test_bench_legs_full_shapes_match_the_oracle(xr, leg):
     """The extra scan legs of bench.py at their FULL shapes (BASELINE configs[0], 16 bit at the COCO shape, configs[3] through the
-    MFMA pass 1 + 16-bit-entry cache, one GPU's shard of configs[4] with the uncached pass 2), through the very function the bench
+    MFMA pass 1 + 16-bit-entry cache, one GPU's shard of configs[4] with a 12.7 GB cache), through the very function the bench
     calls: the mAP the leg prints is the mean of the per-query APs, and those agree with the oracle on a query subsample."""
     import bench_roofline as RL
     orc = _orc()
@@ -801,7 +801,7 @@ def test_bench_legs_full_shapes_match_the_oracle(xr, leg):
     rel = orc.relevance_packed(_u32(scan.qlab)[sub], _u32(scan.rlab))
     assert np.array_equal(cap.cpu().numpy()[sub], rel.sum(-1))
     assert np.allclose(ap.cpu().numpy()[sub], orc.ap_from_ranking(dist, rel), rtol=3e-6)
-    assert (out["pair_cache_bytes"] > 0) == (leg != "configs4_shard_scan_256bit")
+    assert out["pair_cache_bytes"] > 0                                                # 12.7 GB for the configs[4] shard: under the 32 GB default cap
 
 
 def test_full_size_long_gallery_256bit_uncached_scan(xr, monkeypatch):
