@@ -1549,9 +1549,12 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
     const int nfull = (int)((hi - lo) >> 6);                         // whole batches of this chunk
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the counters are in place before the first asm atomic is counted
+    // the cache words are fetched TWO batches ahead: a batch is ~1.2 us of this wave's time at 5 waves per SIMD, an HBM miss under load
+    // takes longer than that (Q 5000 x R 117 218, 64 bit, pass 2 with the words one / two / three batches ahead: 0.187 / 0.178 / 0.181 ms)
     uint4 cw = crow[0];
+    uint4 nw = crow[(int64_t)(1 < nbatch ? 1 : 0) * 64];
     for (int bi = 0; bi < nfull; ++bi) {
-        const uint4 nw = crow[(int64_t)(bi + 1 < nbatch ? bi + 1 : bi) * 64];      // unconditional: counted vmcnt, no predication
+        const uint4 nw2 = crow[(int64_t)(bi + 2 < nbatch ? bi + 2 : nbatch - 1) * 64];      // unconditional: counted vmcnt, no predication
         if (EB == 8) {
             group(cw.x, cw.y, 0u, 0u);
             group(cw.z, cw.w, 0u, 0u);
@@ -1559,6 +1562,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
             group(cw.x, cw.y, cw.z, cw.w);
         }
         cw = nw;
+        nw = nw2;
     }
     if (prev) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
