@@ -9,6 +9,10 @@
 //   tables                  exclusive prefixes over chunks and over buckets (k_scan_below, k_scan_dpre);
 //   pass 2 (k_scan_ap_s)    counters start at the global base of (bucket, chunk); one returning ds_add per pair yields
 //                           (rank, ordinal) of the item, relevant items add ordinal/rank to the query's AP sum.
+// Binary codes of at most 256 bits take the MFMA-evaluated pass 1 further down (k_scan_hist_m2 up to 64 bits, k_scan_hist_m beyond),
+// which also leaves (distance << 1 | relevant) of every pair in the workspace; pass 2 then reads that pair cache instead of the
+// gallery (k_scan_ap_c up to 64 bits, the CACHE variant of k_scan_ap_s beyond).  What follows describes the VALU kernels, which
+// remain for ternary codes, long codes (512..2048 bits) and as the checked alternative (XMH_SCAN_MFMA=0).
 // Why slots: with one query per lane (S = 1) the counters of a wave cost nb*64*{4,8} bytes -- 33 KB at K = 64 with
 // 64-bit counters (one wave per SIMD), 131 KB at K = 256 (one wave per CU).  S lanes per query shrink the footprint by
 // S: 3-4 waves per SIMD for every supported K, which is what hides the LDS round trips of this loop (measured at
