@@ -6,8 +6,15 @@
 //                                         with L = (labels_i . labels_j > 0), m = sqrt(2 K vartheta);
 //                              cosine:    s = clip(cos(a_i, b_j), t, 1 - t); both outputs mean(-L log s - (1 - L) log(1 - s))
 //   xmh_quant_loss             soft_argmax_hash_loss (:100-105): 1 - mean((2 c - 1)^2)
-// Bound: B = 128 rows, D <= 4096: a few hundred KB of L2-resident reads -- launch-latency, not bandwidth.  Sums are kept in fp64.
-// Forward only: the backward pass of the training step is outside this path (the trainers' train_epoch raises).
+//   xmh_pair_similarity_loss_grad   d(positive + negative)/da of the same term (what autograd returns for the reference's expression):
+//                              euclidean: grad a_i = sum_j r_ij (a_i - b_j),  r_ij = 2/B^2 (L - (m/s - 1)(1 - L)[s <= m]), 0 where s = 0
+//                                         (torch.cdist's backward masks zero distances the same way);
+//                              cosine:    grad a_i = sum_j h_ij (b^_j - c_ij a^_i) / |a_i|,  h_ij = 2/B^2 (-L/s + (1 - L)/(1 - s))[t <= c_ij <= 1 - t]
+//                              The gradient with respect to b is the same call with a and b swapped (s, c and L are symmetric), and
+//                              for a term with a == b the caller passes scale = 2.
+//   xmh_quant_loss_grad        d/dcode = -4 (2 c - 1) / n
+// Bound: B = 128 rows, D <= 4096: a few hundred KB of L2-resident reads -- launch-latency, not bandwidth.  Sums are kept in fp64
+// (forward) / fp32 (gradient rows).  The backward of the encoders and the optimiser step stay outside this path.
 #include "xmh_common.h"
 
 namespace {
@@ -86,6 +93,81 @@ __global__ __launch_bounds__(256) void k_quant_loss(const float* __restrict__ co
     if (threadIdx.x == 0) atomicAdd(out, -s / (double)n);
 }
 
+// gradient of (positive + negative) with respect to row i of a: one block per row.  Phase 1 (threads over j): the coefficient of
+// every pair into LDS; phase 2 (threads over columns, coalesced rows of b): the weighted sum.  `up` (device, may be null) is the
+// upstream gradient of the loss, multiplied in so that backward() needs no host synchronisation.
+__global__ __launch_bounds__(256) void k_pair_similarity_grad(const float* __restrict__ a, const float* __restrict__ b, int B, int D,
+                                                              const uint32_t* __restrict__ lab, int Lw, int cosine, float max_value,
+                                                              float threshold, float scale, const float* __restrict__ up,
+                                                              float* __restrict__ grad, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float row[];  // a_i [D], then coef [B]
+    __shared__ double sh[8];
+    float* coef = row + D;
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) row[c] = a[(int64_t)i * D + c];
+    __syncthreads();
+    const float w = 2.0f / ((float)B * (float)B);
+    float na = 0.0f;
+    if (cosine)
+        for (int c = 0; c < D; ++c) na = fmaf(row[c], row[c], na);
+    const float inv_na = cosine ? 1.0f / sqrtf(na) : 0.0f;
+    double hc = 0.0;                                             // cosine: sum_j h_ij c_ij
+    for (int j = threadIdx.x; j < B; j += blockDim.x) {
+        const float* bj = b + (int64_t)j * D;
+        bool rel = false;
+        for (int x = 0; x < Lw; ++x) rel |= (lab[(int64_t)i * Lw + x] & lab[(int64_t)j * Lw + x]) != 0u;
+        float cf = 0.0f;
+        if (cosine) {
+            float dot = 0.0f, nb = 0.0f;
+            for (int c = 0; c < D; ++c) {
+                dot = fmaf(row[c], bj[c], dot);
+                nb = fmaf(bj[c], bj[c], nb);
+            }
+            const float inv_nb = 1.0f / sqrtf(nb);
+            const float cs = dot * inv_na * inv_nb;
+            if (cs >= threshold && cs <= 1.0f - threshold) {     // clamp passes the gradient on the closed interval
+                const float h = w * (rel ? -1.0f / cs : 1.0f / (1.0f - cs));
+                cf = h * inv_na * inv_nb;
+                hc += (double)h * (double)cs;
+            }
+        } else {
+            float d2 = 0.0f;
+            for (int c = 0; c < D; ++c) {
+                const float d = row[c] - bj[c];
+                d2 = fmaf(d, d, d2);
+            }
+            const float s = sqrtf(d2);
+            if (s > 0.0f) cf = rel ? w : (s <= max_value ? -w * (max_value / s - 1.0f) : 0.0f);
+        }
+        coef[j] = cf;
+    }
+    const double hcs = block_sum(hc, sh);                        // also the barrier that publishes coef[]
+    if (threadIdx.x == 0) sh[0] = hcs;
+    __syncthreads();
+    const float self = cosine ? (float)(sh[0] * (double)inv_na * (double)inv_na) : 0.0f;
+    const float g = scale * (up ? up[0] : 1.0f);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.0f;
+        if (cosine) {
+            for (int j = 0; j < B; ++j) acc = fmaf(coef[j], b[(int64_t)j * D + c], acc);
+            acc -= row[c] * self;
+        } else {
+            for (int j = 0; j < B; ++j) acc = fmaf(coef[j], row[c] - b[(int64_t)j * D + c], acc);
+        }
+        float* o = grad + (int64_t)i * D + c;
+        *o = accumulate ? *o + g * acc : g * acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_quant_grad(const float* __restrict__ code, int64_t n, float scale, const float* __restrict__ up,
+                                                    float* __restrict__ grad, int accumulate) {
+    const float g = scale * (up ? up[0] : 1.0f) * (-4.0f / (float)n);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float v = g * (2.0f * code[e] - 1.0f);
+        grad[e] = accumulate ? grad[e] + v : v;
+    }
+}
+
 __global__ void k_set_double(double* p, double v0, double v1, int n) {
     if (threadIdx.x == 0) {
         p[0] = v0;
@@ -118,5 +200,32 @@ extern "C" int xmh_quant_loss(const float* code, int64_t n, double* out, xmh_str
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_quant_loss, dim3((unsigned)grid), dim3(256), 0, st, code, n, out);
     XMH_LAUNCH_CHECK("xmh_quant_loss");
+    return XMH_OK;
+}
+
+extern "C" int xmh_pair_similarity_loss_grad(const float* a, const float* b, int64_t B, int D, const uint32_t* lab, int C, int cosine,
+                                             float max_value, float threshold, float scale, const float* upstream, float* grad_a,
+                                             int accumulate, xmh_stream_t stream) {
+    if (B <= 0 || D <= 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss_grad: bad shape B=%lld D=%d C=%d", (long long)B, D, C);
+    if (!a || !b || !lab || !grad_a) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss_grad: null pointer");
+    if (B >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_pair_similarity_loss_grad: B too large");
+    const size_t lds = ((size_t)D + (size_t)B) * 4;
+    if (lds > 64 * 1024) return xmh::fail(XMH_ENOTSUP, "xmh_pair_similarity_loss_grad: (D + B) * 4 = %zu bytes > 64 KB of LDS", lds);
+    hipStream_t st = xmh::as_stream(stream);
+    hipLaunchKernelGGL(k_pair_similarity_grad, dim3((unsigned)B), dim3(256), lds, st, a, b, (int)B, D, lab, (C + 31) / 32, cosine, max_value,
+                       threshold, scale, upstream, grad_a, accumulate);
+    XMH_LAUNCH_CHECK("xmh_pair_similarity_loss_grad");
+    return XMH_OK;
+}
+
+extern "C" int xmh_quant_loss_grad(const float* code, int64_t n, float scale, const float* upstream, float* grad, int accumulate,
+                                   xmh_stream_t stream) {
+    if (n <= 0) return xmh::fail(XMH_EINVAL, "xmh_quant_loss_grad: empty input");
+    if (!code || !grad) return xmh::fail(XMH_EINVAL, "xmh_quant_loss_grad: null pointer");
+    hipStream_t st = xmh::as_stream(stream);
+    int64_t grid = xmh::ceil_div(n, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_quant_grad, dim3((unsigned)grid), dim3(256), 0, st, code, n, scale, upstream, grad, accumulate);
+    XMH_LAUNCH_CHECK("xmh_quant_loss_grad");
     return XMH_OK;
 }

@@ -119,6 +119,8 @@ PROTOTYPES = {
     "xmh_float_rank_ap": (i32, [vp, vp, vp, i64, i64, i32, i64, vp, vp, vp]),
     "xmh_pair_similarity_loss": (i32, [vp, vp, i64, i32, vp, i32, i32, C.c_float, C.c_float, vp, vp]),
     "xmh_quant_loss": (i32, [vp, i64, vp, vp]),
+    "xmh_pair_similarity_loss_grad": (i32, [vp, vp, i64, i32, vp, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp, i32, vp]),
+    "xmh_quant_loss_grad": (i32, [vp, i64, C.c_float, vp, vp, i32, vp]),
     "xmh_topk_ws_bytes": (sz, [i64, i64, i32, i32]),
     "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
     "xmh_topk_ws_init": (i32, [i64, i64, i32, i32, vp, sz, vp]),

@@ -185,6 +185,17 @@ class BaseTrainer:
     def compute_loss(self, *a, **k):
         raise NotImplementedError("training is outside the encode-and-retrieve path this package implements")
 
+    def print_loss_dict(self, loss_dict, bits=16, epoch=0, times=0):
+        """runners/base.py:359-377 -- the nested loss dictionary flattened depth-first into one display line"""
+        def flat(key, value):
+            if isinstance(value, dict):
+                return f"{key}: " + "".join(flat(k, v) for k, v in value.items())
+            return f"{key}: {value}, "
+
+        rates = "-".join("%.9f" % r for r in sorted(set(self.optimizer.get_lr())))
+        self.logger.info(f">>>>>> Display ({self.loss_type} loss-{bits}) >>>>>> [{epoch}/{self.epochs}], [{times}/{len(self.train_loader)}]: "
+                         + "".join(flat(k, v) for k, v in loss_dict.items()) + f"lr: {rates}")
+
     def change_state(self, mode):
         if mode == "train":
             self.model.train()

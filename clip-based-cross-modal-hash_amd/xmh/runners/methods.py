@@ -50,6 +50,7 @@ class DCMHTTrainer(_MethodTrainer):
         self.hash_func = cfg.model.get("hash_func", "softmax")
         assert self.hash_func == "softmax", "DCMHT must adopt the 'softmax' hash technique."
         self.hash_scale = 2
+        self.loss_type = k.get("loss_type", "l1")               # runners/DCMHT/runner.py:26-30: only named in the display line
         super().__init__(cfg, *a, **k)
 
     @classmethod
@@ -61,6 +62,15 @@ class DCMHTTrainer(_MethodTrainer):
     @classmethod
     def pack_hash_code(cls, code, out, row_index, flags):
         R.pack_pair_argmax(code.reshape(code.shape[0], -1), out=out, row_index=row_index)
+
+    def compute_loss(self, img_hash=None, txt_hash=None, label=None, index=None, epoch=0, times=0, global_step=0, **kwags):
+        """runners/DCMHT/runner.py:97-105: the objective of one batch.  The returned loss is differentiable with respect to
+        img_hash / txt_hash (xmh_loss.hip behind torch.autograd); the display line of :101-103 needs the training loop's
+        loader and optimiser, which this package does not build, and is skipped without them."""
+        all_loss, loss_dict = self.model.object_function(img_hash=img_hash, txt_hash=txt_hash, labels=label, indexs=index, **kwags)
+        if global_step % self.display_step == 0 and getattr(self, "train_loader", None) is not None and getattr(self, "optimizer", None) is not None:
+            self.print_loss_dict(loss_dict, bits=img_hash.shape[-1] // self.hash_scale, epoch=epoch, times=times)
+        return all_loss
 
 
 @registry.register_runner("DSPHTrainer")

@@ -406,7 +406,8 @@ int xmh_float_rank_ap(const float* dist, const uint32_t* qlab, const uint32_t* r
                       int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Loss forward of the DCMHT objective (forward only, the backward pass is out of scope).
+ * Loss of the DCMHT objective: forward, and its gradient with respect to the two code matrices (what
+ * loss.backward() of runners/DCMHT/runner.py:124 hands to the hash heads).  The backward of the encoders is out of scope.
  * ------------------------------------------------------------------------------------------- */
 /* similarity_loss (models/DCMHT/DCMHT.py:72-98) of one pair of code matrices a, b [B, D] with packed multi-hot labels lab
  * [B][ceil(C/32)] (label_sim = calc_label_sim(labels, labels), common/calc_utils.py:8-10).  cosine == 0: euclidean branch with
@@ -416,6 +417,16 @@ int xmh_pair_similarity_loss(const float* a, const float* b, int64_t B, int D, c
                              float max_value, float threshold, double* out2, xmh_stream_t stream);
 /* soft_argmax_hash_loss (models/DCMHT/DCMHT.py:100-105): out (device, 1 double) = 1 - mean((2 code - 1)^2) over n elements */
 int xmh_quant_loss(const float* code, int64_t n, double* out, xmh_stream_t stream);
+/* d(positive_loss + negative_loss)/da of xmh_pair_similarity_loss, as autograd derives it from models/DCMHT/DCMHT.py:72-98
+ * (torch.cdist's backward: zero distances contribute nothing; clip passes the gradient on the closed interval).  grad_a [B, D]
+ * (device) is written, or added to when accumulate != 0, with scale * upstream[0] (upstream: device float, NULL = 1) folded in.
+ * The gradient with respect to b is the same call with a and b exchanged; for a term with a == b pass scale = 2. */
+int xmh_pair_similarity_loss_grad(const float* a, const float* b, int64_t B, int D, const uint32_t* lab, int C, int cosine,
+                                  float max_value, float threshold, float scale, const float* upstream, float* grad_a,
+                                  int accumulate, xmh_stream_t stream);
+/* d xmh_quant_loss / d code = -4 (2 code - 1) / n, times scale * upstream[0], written or accumulated like above */
+int xmh_quant_loss_grad(const float* code, int64_t n, float scale, const float* upstream, float* grad, int accumulate,
+                        xmh_stream_t stream);
 
 #ifdef __cplusplus
 }

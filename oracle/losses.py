@@ -1,6 +1,7 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the DCMHT loss forward (reference models/DCMHT/DCMHT.py:72-155) in float64
-torch; pinned against the reference's own `our_loss` by tests/golden/loss_dcmht.npz (oracle/make_golden_loss.py).
-Only tests/ may import this module."""
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the DCMHT loss (reference models/DCMHT/DCMHT.py:72-155) in float64 torch,
+and its gradient with respect to the two code matrices by autograd over that restatement (what loss.backward() of
+runners/DCMHT/runner.py:124 produces); pinned against the reference's own `our_loss` / its backward by
+tests/golden/loss_dcmht.npz (oracle/make_golden_loss.py).  Only tests/ may import this module."""
 import torch
 
 
@@ -43,3 +44,11 @@ def our_loss(image, text, labels, output_dim, vartheta=0.75, threshold=0.1, quan
     loss = (pt + pi + ni + nt) + (ip + in_) + quan_alpha * (qi + qt) / 2
     return {"loss": loss, "intra_pos": ip, "intra_neg": in_, "inter_pos_i": pi, "inter_neg_i": ni, "inter_pos_t": pt, "inter_neg_t": nt,
             "quan_i": qi, "quan_t": qt}
+
+
+def our_loss_grad(image, text, labels, output_dim, **kw):
+    """(d loss / d image, d loss / d text) in float64: autograd over our_loss above (runners/DCMHT/runner.py:124 loss.backward())"""
+    img = image.double().clone().requires_grad_(True)
+    txt = text.double().clone().requires_grad_(True)
+    our_loss(img, txt, labels, output_dim, **kw)["loss"].backward()
+    return img.grad, txt.grad

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Golden vectors of the DCMHT loss forward, produced by the UNMODIFIED reference (models/DCMHT/DCMHT.py our_loss) in this
-container: python oracle/make_golden_loss.py -> tests/golden/loss_dcmht.npz.  Build-container only (/root/reference)."""
+"""Golden vectors of the DCMHT loss and of its gradient with respect to the codes (loss.backward()), produced by the
+UNMODIFIED reference (models/DCMHT/DCMHT.py our_loss) in this container: python oracle/make_golden_loss.py -> tests/golden/loss_dcmht.npz.  Build-container only (/root/reference)."""
 import os
 import sys
 
@@ -34,7 +34,12 @@ for name, B, K, C, sim, has_labels in cases:
         labels = (torch.rand(B, C, generator=g) < 0.1).float()
         labels[torch.arange(B), torch.randint(0, C, (B,), generator=g)] = 1.0
     m = ref_model(K, sim)
+    img.requires_grad_(True)
+    txt.requires_grad_(True)
     loss, d = m.object_function(img, txt, labels=labels)
+    loss.backward()                                 # runners/DCMHT/runner.py:124
+    out[name + "_gimg"], out[name + "_gtxt"] = img.grad.numpy().copy(), txt.grad.numpy().copy()
+    img, txt = img.detach(), txt.detach()
     out[name + "_img"], out[name + "_txt"] = img.numpy(), txt.numpy()
     if has_labels:
         out[name + "_labels"] = labels.numpy()

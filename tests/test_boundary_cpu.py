@@ -103,3 +103,29 @@ def test_tower_helper_runs_back_to_back_without_a_gpu(monkeypatch):
     monkeypatch.setenv("XMH_TOWER_STREAMS", "0")
     out = towers.run_both(lambda: order.append("image") or "I", lambda: order.append("text") or "T")
     assert out == ("I", "T") and order == ["image", "text"]
+
+
+def test_loss_display_line_is_the_reference_format():
+    """runners/base.py:359-377 print_loss_dict on the dictionary our_loss returns (models/DCMHT/DCMHT.py:126-146)"""
+    import logging
+
+    from xmh.runners.methods import DCMHTTrainer
+
+    class Opt:
+        def get_lr(self):
+            return [1e-3, 1e-5, 1e-3]
+
+    lines = []
+    handler = logging.Handler()
+    handler.emit = lambda rec: lines.append(rec.getMessage())
+    t = DCMHTTrainer.__new__(DCMHTTrainer)
+    t.logger = logging.getLogger("xmh-test-display")
+    t.logger.setLevel(logging.INFO)
+    t.logger.addHandler(handler)
+    t.loss_type, t.epochs, t.train_loader, t.optimizer = "l1", 100, [0] * 79, Opt()
+    t.print_loss_dict({"All loss": 1.5, "Intra": {"Positive": 0.25, "Negative": 0.5},
+                       "Inter": {"Positive": {"i2t": 1, "t2i": 2}, "Negative": {"i2t": 3, "t2i": 4}}, "Quan": {"Image": 0.4, "Text": 0.3}},
+                      bits=16, epoch=3, times=40)
+    assert lines == [">>>>>> Display (l1 loss-16) >>>>>> [3/100], [40/79]: All loss: 1.5, Intra: Positive: 0.25, Negative: 0.5, "
+                     "Inter: Positive: i2t: 1, t2i: 2, Negative: i2t: 3, t2i: 4, Quan: Image: 0.4, Text: 0.3, "
+                     "lr: 0.000010000-0.001000000"]

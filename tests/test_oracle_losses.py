@@ -1,5 +1,5 @@
-"""CPU: the oracle's restatement of the DCMHT loss forward against goldens produced by the reference's own our_loss
-(oracle/make_golden_loss.py)."""
+"""CPU: the oracle's restatement of the DCMHT loss, and of its gradient with respect to the codes, against goldens produced by
+the reference's own our_loss and loss.backward() (oracle/make_golden_loss.py)."""
 import os
 
 import numpy as np
@@ -29,3 +29,23 @@ def test_oracle_loss_matches_the_reference():
         vec = np.array([float(got[k]) for k in ORDER])
         # fp32 reference (and its cdist may take the matmul route) against a float64 restatement
         assert np.allclose(vec, ref, rtol=2e-5, atol=1e-6), (name, vec, ref)
+
+
+def load_grads(name):
+    g = np.load(os.path.join(GOLDEN, "loss_dcmht.npz"))
+    return g[name + "_gimg"], g[name + "_gtxt"]
+
+
+def grads_close(got, ref):
+    """the reference differentiates in fp32 through cdist's matmul route: compare relative to the largest entry of the matrix"""
+    return float(np.abs(np.asarray(got, dtype=np.float64) - ref).max()) <= 2e-5 * float(np.abs(ref).max()) + 1e-9
+
+
+def test_oracle_gradient_matches_the_reference_backward():
+    for name in CASES:
+        img, txt, labels, K, sim, vartheta, threshold, alpha, _ = load(name)
+        if labels is None:
+            labels = torch.eye(img.shape[0])
+        gi, gt = OL.our_loss_grad(img, txt, labels, K, vartheta=vartheta, threshold=threshold, quan_alpha=alpha, similarity_function=sim)
+        ri, rt = load_grads(name)
+        assert grads_close(gi.numpy(), ri) and grads_close(gt.numpy(), rt), (name, np.abs(gi.numpy() - ri).max(), np.abs(ri).max())
