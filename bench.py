@@ -181,6 +181,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the fixed-gallery legs (configs[2], configs[4])")
     ap.add_argument("--no-extra-configs", action="store_true", help="N=1: skip the configs[3] (K=128) and MITH encode legs")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU exchange path even with one rank (RCCL smoke test)")
+    ap.add_argument("--force-strong", action="store_true", help="with --force-sharded: also run the N>1 fixed-gallery legs on the one rank")
     ap.add_argument("--query-blocks", type=int, default=1,
                     help="sharded path: query blocks whose histogram gathers are pipelined (default 1: on one GPU every extra "
                          "block costs 0.18 ms per step, more than the gather it would hide)")
@@ -466,7 +467,7 @@ def main():
                          "slowest_rank_captions_per_s": float(lo[1]), "n_gpus": world,
                          "config": {"workload": "CLIP ViT-B/32 + DCMHT 64-bit head, batch 100 per GPU, parity mode; one replica per GPU, "
                                                 "rates summed over ranks (measured concurrently)"}}
-    if world > 1 and not args.no_strong:
+    if (world > 1 or (args.force_sharded and args.force_strong)) and not args.no_strong:
         del ops, scan, piped, sq
         torch.cuda.empty_cache()
         try:
