@@ -144,6 +144,88 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
     return 0;
 }
 
+// ---- the block stack with saved activations ----------------------------------------------------------------
+// What a backward pass of ResidualAttentionBlock (models/CLIP/model.py:167-197) needs from the forward, kept per layer instead
+// of living in the shared scratch: one record of 16 * M * D floats per layer, fields in this order (xmh.h, xmh_clip_saved):
+//   x_in [M,D] | ln1 [M,D] | qkv [M,3D] | attn [M,D] | x_mid [M,D] | ln2 [M,D] | fc_pre [M,4D] | fc_act [M,4D]
+// Same kernels, same order and the same numbers as run_blocks: the producers write their fp32 result next to the operand planes
+// (LayerNorm, attention), the GEMMs write straight into the record, the residual stream hops from record to record (x_in of
+// layer i+1 is the output of layer i; the last layer writes x), and QuickGELU runs as its own elementwise pass between c_fc and
+// c_proj (xmh::quickgelu_planes: the epilogue's function on the stored pre-activation) so that both sides of it are kept.
+struct SavedRecord {
+    float *x_in, *ln1, *qkv, *attn, *x_mid, *ln2, *fc_pre, *fc_act;
+};
+
+constexpr int kSavedFloatsPerElement = 16;           // per (token, channel): 1 + 1 + 3 + 1 + 1 + 1 + 4 + 4
+
+SavedRecord saved_record(float* base, int layer, int64_t M, int D) {
+    float* p = base + (size_t)layer * kSavedFloatsPerElement * (size_t)M * D;
+    const size_t md = (size_t)M * D;
+    SavedRecord r;
+    r.x_in = p; r.ln1 = p + md; r.qkv = p + 2 * md; r.attn = p + 5 * md; r.x_mid = p + 6 * md; r.ln2 = p + 7 * md;
+    r.fc_pre = p + 8 * md; r.fc_act = p + 12 * md;
+    return r;
+}
+
+int run_blocks_saved(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L, int causal,
+                     const uint8_t* kpm, int precision, const BlockScratch& s, float* saved, xmh_stream_t st) {
+    const int64_t M = B * L;
+    const int D = width;
+    hipStream_t hs = xmh::as_stream(st);
+    const xmh::Planes none{nullptr, nullptr, 0};
+    if (layers > 0) {
+        hipError_t e = hipMemcpyAsync(saved_record(saved, 0, M, D).x_in, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, hs);
+        if (e != hipSuccess) return xmh::fail(-5, "xmh_clip_blocks_forward_saved: copy of x failed: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < layers; ++i) {
+        const xmh_clip_block& b = blocks[i];
+        if (b.qkv.n != 3 * D || b.qkv.k != D || b.out.n != D || b.out.k != D || b.fc.k != D || b.fc.n != 4 * D || b.proj.n != D || b.proj.k != b.fc.n)
+            return xmh::fail(-22, "xmh forward: block %d has layer shapes that do not fit width %d", i, D);
+        const SavedRecord r = saved_record(saved, i, M, D);
+        float* x_out = i + 1 < layers ? saved_record(saved, i + 1, M, D).x_in : x;
+        int rc;
+        if (precision == kPrecExact) {
+            if (!b.qkv.w_f32 || !b.out.w_f32 || !b.fc.w_f32 || !b.proj.w_f32) return xmh::fail(-22, "xmh forward: block %d lacks fp32 weights (exact mode)", i);
+            rc = xmh_layernorm_f32(r.x_in, D, b.ln1_w, b.ln1_b, kLnEps, r.ln1, D, M, D, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(r.ln1, D, b.qkv.w_f32, D, b.qkv.bias, nullptr, 0, r.qkv, 3 * D, M, 3 * D, D, kActNone, 0, st);
+            if (rc) return rc;
+            rc = xmh_attention_f32(r.qkv, B, L, heads, D / heads, causal, kpm, r.attn, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(r.attn, D, b.out.w_f32, D, b.out.bias, r.x_in, D, r.x_mid, D, M, D, D, kActNone, 0, st);
+            if (rc) return rc;
+            rc = xmh_layernorm_f32(r.x_mid, D, b.ln2_w, b.ln2_b, kLnEps, r.ln2, D, M, D, st);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(r.ln2, D, b.fc.w_f32, D, b.fc.bias, nullptr, 0, r.fc_pre, 4 * D, M, 4 * D, D, kActNone, 0, st);
+            if (rc) return rc;
+            rc = xmh::quickgelu_planes(r.fc_pre, M, 4 * D, r.fc_act, none, hs);
+            if (rc) return rc;
+            rc = xmh_gemm_nt_f32(r.fc_act, 4 * D, b.proj.w_f32, 4 * D, b.proj.bias, r.x_mid, D, x_out, D, M, D, 4 * D, kActNone, 0, st);
+            if (rc) return rc;
+            continue;
+        }
+        if (!planes_layer(b.qkv) || !planes_layer(b.out) || !planes_layer(b.fc) || !planes_layer(b.proj))
+            return xmh::fail(-22, "xmh forward: block %d lacks fp16 weights (w_hi) for width %d", i, D);
+        rc = xmh::layernorm_planes(r.x_in, D, b.ln1_w, b.ln1_b, kLnEps, r.ln1, D, s.hP, M, D, hs);
+        if (rc) return rc;
+        rc = linear_p(b.qkv, s.hP, nullptr, 0, r.qkv, 3 * D, nullptr, M, kActNone, precision, st);
+        if (rc) return rc;
+        rc = xmh::attention_planes(r.qkv, B, L, heads, D / heads, causal, kpm, r.attn, s.aP, true, hs);
+        if (rc) return rc;
+        rc = linear_p(b.out, s.aP, r.x_in, D, r.x_mid, D, nullptr, M, kActNone, precision, st);
+        if (rc) return rc;
+        rc = xmh::layernorm_planes(r.x_mid, D, b.ln2_w, b.ln2_b, kLnEps, r.ln2, D, s.hP, M, D, hs);
+        if (rc) return rc;
+        rc = linear_p(b.fc, s.hP, nullptr, 0, r.fc_pre, 4 * D, nullptr, M, kActNone, precision, st);
+        if (rc) return rc;
+        rc = xmh::quickgelu_planes(r.fc_pre, M, 4 * D, r.fc_act, s.fP, hs);
+        if (rc) return rc;
+        rc = linear_p(b.proj, s.fP, r.x_mid, D, x_out, D, nullptr, M, kActNone, precision, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 struct TowerScratch {
     BlockScratch blk;
     float *x, *cols, *patches, *row_a, *row_b, *y;
@@ -206,6 +288,28 @@ extern "C" int xmh_clip_blocks_forward(const xmh_clip_block* blocks, int layers,
     if (ar.used > workspace_bytes)
         return xmh::fail(-12, "xmh_clip_blocks_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
     return run_blocks(blocks, layers, width, heads, x, B, L, causal, key_padding_mask, precision, s, stream);
+}
+
+extern "C" size_t xmh_clip_saved_bytes(int64_t B, int L, int width, int layers) {
+    if (B <= 0 || L <= 0 || width <= 0 || layers <= 0) return 0;
+    return (size_t)layers * kSavedFloatsPerElement * (size_t)B * L * width * sizeof(float);
+}
+
+extern "C" int xmh_clip_blocks_forward_saved(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
+                                             int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
+                                             size_t workspace_bytes, float* saved, size_t saved_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!blocks || !x || !workspace || !saved || layers < 0 || heads <= 0 || width % heads)
+        return xmh::fail(-22, "xmh_clip_blocks_forward_saved: bad arguments");
+    if (width % 4) return xmh::fail(-95, "xmh_clip_blocks_forward_saved: width %d is not a multiple of 4", width);
+    const size_t need = xmh_clip_saved_bytes(B, L, width, layers);
+    if (saved_bytes < need) return xmh::fail(-12, "xmh_clip_blocks_forward_saved: saved buffer of %zu bytes, %zu needed", saved_bytes, need);
+    Arena ar(workspace);
+    const BlockScratch s = carve_blocks(ar, B * L, width, precision);
+    if (ar.used > workspace_bytes)
+        return xmh::fail(-12, "xmh_clip_blocks_forward_saved: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    return run_blocks_saved(blocks, layers, width, heads, x, B, L, causal, key_padding_mask, precision, s, saved, stream);
 }
 
 extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image, int64_t B, int precision, float* out_cls,

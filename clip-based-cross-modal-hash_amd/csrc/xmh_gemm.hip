@@ -599,6 +599,20 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     }
 }
 
+// f = QuickGELU(u), four columns per thread: fp32 and / or operand planes out (the saved-activation forward keeps both sides of the
+// c_fc activation; same function as the fused epilogue's ACT_QUICKGELU on the same fp32 value)
+__global__ __launch_bounds__(256) void k_quickgelu_planes(const float* __restrict__ u, int64_t rows, int cols4, float* __restrict__ f, xmh::Planes p) {
+    const int64_t total = rows * cols4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / cols4;
+        const int c = (int)(e % cols4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(u + row * (int64_t)cols4 * 4 + c);
+        const float o0 = quick_gelu(v.x), o1 = quick_gelu(v.y), o2 = quick_gelu(v.z), o3 = quick_gelu(v.w);
+        if (f) *reinterpret_cast<float4*>(f + row * (int64_t)cols4 * 4 + c) = make_float4(o0, o1, o2, o3);
+        if (p.hi) xmh::store_planes4(p, row, c, o0, o1, o2, o3);
+    }
+}
+
 template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
 int launch_g16(const GArgsP& a, hipStream_t st) {
     constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
@@ -669,6 +683,18 @@ int split_planes(const float* x, int64_t ldx, int64_t rows, int64_t cols, const 
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k_split_planes, dim3((unsigned)grid), dim3(256), 0, st, x, ldx, rows, (int)(cols / 8), p);
     XMH_LAUNCH_CHECK("xmh split_planes");
+    return XMH_OK;
+}
+
+int quickgelu_planes(const float* u, int64_t rows, int64_t cols, float* f, const Planes& p, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return XMH_OK;
+    if (cols % 4 || reinterpret_cast<uintptr_t>(u) % 16 || reinterpret_cast<uintptr_t>(f) % 16 || (p.hi && p.ld % 4))
+        return fail(XMH_ENOTSUP, "xmh quickgelu_planes: needs cols %% 4 == 0 and 16-byte aligned rows (cols=%lld)", (long long)cols);
+    int64_t grid = ceil_div(rows * (cols / 4), 256);
+    const int64_t cap = (int64_t)device_cu_count() * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_quickgelu_planes, dim3((unsigned)grid), dim3(256), 0, st, u, rows, (int)(cols / 4), f, p);
+    XMH_LAUNCH_CHECK("xmh quickgelu_planes");
     return XMH_OK;
 }
 

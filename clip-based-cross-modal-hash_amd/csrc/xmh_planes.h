@@ -95,6 +95,9 @@ int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const floa
 // split16: the products on the fp16 MFMA with hi/lo split operands (parity / fast mode) instead of the fp32 MFMA (exact mode)
 int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
                      bool split16, hipStream_t st);
+// f = QuickGELU(u) elementwise on [rows, cols] (cols % 4 == 0), as fp32 and / or operand planes: the c_fc epilogue's activation as a
+// pass of its own, for the saved-activation forward (xmh_gemm.hip)
+int quickgelu_planes(const float* u, int64_t rows, int64_t cols, float* f, const Planes& p, hipStream_t st);
 int im2col_planes(const float* image, int64_t B, int channels, int resolution, int patch, float* cols, const Planes& p, hipStream_t st);
 
 }  // namespace xmh

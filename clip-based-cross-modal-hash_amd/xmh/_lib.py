@@ -106,6 +106,8 @@ PROTOTYPES = {
     "xmh_bitwise_hash": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "xmh_clip_workspace_bytes": (sz, [i64, i32, i32, i32, i32, i32]),
     "xmh_clip_blocks_forward": (i32, [C.POINTER(ClipBlock), i32, i32, i32, vp, i64, i32, i32, vp, i32, vp, sz, vp]),
+    "xmh_clip_saved_bytes": (sz, [i64, i32, i32, i32]),
+    "xmh_clip_blocks_forward_saved": (i32, [C.POINTER(ClipBlock), i32, i32, i32, vp, i64, i32, i32, vp, i32, vp, sz, vp, sz, vp]),
     "xmh_vit_b32_forward": (i32, [C.POINTER(VitWeights), vp, i64, i32, vp, vp, vp, sz, vp]),
     "xmh_text_forward": (i32, [C.POINTER(TextWeights), vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "xmh_head_workspace_bytes": (sz, [i64, i32, i32]),

@@ -142,6 +142,36 @@ class Transformer(nn.Module):
         return x
 
 
+    # per-layer record of xmh_clip_blocks_forward_saved (include/xmh.h): field -> width in units of D
+    SAVED_FIELDS = (("x_in", 1), ("ln1", 1), ("qkv", 3), ("attn", 1), ("x_mid", 1), ("ln2", 1), ("fc_pre", 4), ("fc_act", 4))
+
+    def run_saved(self, x: torch.Tensor, causal: bool = False, key_padding_mask=None):
+        """The forward of `run` with the activations a backward pass of the blocks (models/CLIP/model.py:167-197) reads kept per
+        layer: returns (x, saved) with x updated in place exactly as `run` leaves it and saved = one dict per layer
+        of [B, L, n*D] fp32 views into one device buffer (16 * B*L*D floats per layer).  Native executor only."""
+        if not x.is_cuda or not x.is_contiguous() or x.dtype != torch.float32 or x.dim() != 3:
+            raise ValueError("run_saved takes a contiguous fp32 [B, L, D] tensor on the GPU")
+        B, L, D = x.shape
+        layers = len(self.resblocks)
+        blocks, precision = _cached_desc(self, lambda prec, keep: _blocks_desc(list(self.resblocks), prec, keep))
+        kpm = None if key_padding_mask is None else key_padding_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+        nbytes = lib.xmh_clip_workspace_bytes(B, L, D, 0, 0, precision)
+        ws = _workspace(nbytes, x.device)
+        sbytes = lib.xmh_clip_saved_bytes(B, L, D, layers)
+        buf = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.xmh_clip_blocks_forward_saved(blocks, layers, D, self.resblocks[0].heads if layers else 1, ptr(x), B, L, int(causal),
+                                                ptr(kpm), precision, ptr(ws), nbytes, ptr(buf), sbytes, current_stream()),
+              "xmh_clip_blocks_forward_saved")
+        saved, per_layer, md = [], 16 * B * L * D, B * L * D
+        for i in range(layers):
+            rec, off = {}, i * per_layer
+            for name, n in self.SAVED_FIELDS:
+                rec[name] = buf[off:off + n * md].view(B, L, n * D)
+                off += n * md
+            saved.append(rec)
+        return x, saved
+
+
 class VisionTransformer(nn.Module):
     def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, return_patches=False):
         super().__init__()

@@ -331,6 +331,17 @@ size_t xmh_clip_workspace_bytes(int64_t B, int L, int width, int conv_k, int out
 int xmh_clip_blocks_forward(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
                             int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
                             size_t workspace_bytes, xmh_stream_t stream);
+/* The same forward with every activation a backward pass of ResidualAttentionBlock (models/CLIP/model.py:167-197) reads kept per
+ * layer instead of in the shared scratch ("forward kernels with saved activations"; no backward is built here).
+ * `saved` holds `layers` records of 16 * B*L*width floats (xmh_clip_saved_bytes), each record the row-major fp32 fields
+ *     x_in [M, D] | ln1 [M, D] | qkv [M, 3D] | attn [M, D] | x_mid [M, D] | ln2 [M, D] | fc_pre [M, 4D] | fc_act [M, 4D]      (M = B*L, D = width)
+ * x_in = the residual stream entering the block, ln1 = ln_1(x_in), qkv = in_proj(ln1), attn = the heads' outputs before out_proj,
+ * x_mid = x_in + out_proj(attn), ln2 = ln_2(x_mid), fc_pre = c_fc(ln2), fc_act = QuickGELU(fc_pre); the block's output is the
+ * next record's x_in, the last block's output is x (in place, bit-identical to xmh_clip_blocks_forward in every precision). */
+size_t xmh_clip_saved_bytes(int64_t B, int L, int width, int layers);
+int xmh_clip_blocks_forward_saved(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
+                                  int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
+                                  size_t workspace_bytes, float* saved, size_t saved_bytes, xmh_stream_t stream);
 /* VisionTransformer.forward: image [B, 3, r, r] f32 -> out_cls [B, out_dim]; out_tokens [B, L, out_dim] (L = patches + 1,
  * every token through ln_post and proj: the return_patches mode, row 0 of each item = the cls feature) or NULL.
  * Exactly one of out_cls / out_tokens may be NULL. */

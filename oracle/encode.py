@@ -63,19 +63,53 @@ def _blocks(x, sd, prefix, layers, heads, mask, probe=None):
     return x
 
 
+def blocks_saved(x, sd, prefix, layers, heads, mask):
+    """ResidualAttentionBlock stack (models/CLIP/model.py:167-211) on x [L, N, E], every intermediate a backward pass reads kept:
+    -> (x_out, [per layer {x_in, ln1, qkv, attn (heads' outputs before out_proj), x_mid, ln2, fc_pre, fc_act}])"""
+    saved = []
+    for i in range(layers):
+        p = "%sresblocks.%d." % (prefix, i)
+        L, N, E = x.shape
+        dh = E // heads
+        rec = {"x_in": x}
+        rec["ln1"] = F.layer_norm(x, (E,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], 1e-5)
+        rec["qkv"] = F.linear(rec["ln1"], sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"])
+        q, k, v = rec["qkv"].chunk(3, dim=-1)
+
+        def split(t):
+            return t.contiguous().view(L, N * heads, dh).transpose(0, 1)
+        s = torch.bmm(split(q) * (1.0 / math.sqrt(dh)), split(k).transpose(1, 2))
+        if mask is not None:
+            s = s + mask.repeat_interleave(heads, dim=0)
+        rec["attn"] = torch.bmm(torch.softmax(s, dim=-1), split(v)).transpose(0, 1).contiguous().view(L, N, E)
+        rec["x_mid"] = x + F.linear(rec["attn"], sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"])
+        rec["ln2"] = F.layer_norm(rec["x_mid"], (E,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], 1e-5)
+        rec["fc_pre"] = F.linear(rec["ln2"], sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"])
+        rec["fc_act"] = rec["fc_pre"] * torch.sigmoid(1.702 * rec["fc_pre"])
+        x = rec["x_mid"] + F.linear(rec["fc_act"], sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
+        saved.append(rec)
+    return x, saved
+
+
 def _count_layers(sd, prefix):
     return len({k.split("resblocks.")[1].split(".")[0] for k in sd if k.startswith(prefix + "resblocks.")})
 
 
-def clip_image(sd, image, return_patches=False, probe=None):
-    """-> cls [B, out] (and tokens [n_patches, B, out] when return_patches)."""
+def vit_front(sd, image):
+    """conv1 + class / positional embedding + ln_pre (models/CLIP/model.py:232-244) -> x [B, L, width] entering the block stack"""
     w = sd["visual.conv1.weight"]
     width, patch = w.shape[0], w.shape[-1]
     x = F.conv2d(image.float(), w, stride=patch)
     x = x.reshape(x.shape[0], width, -1).permute(0, 2, 1)
     cls = sd["visual.class_embedding"] + torch.zeros(x.shape[0], 1, width)
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
-    x = F.layer_norm(x, (width,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+    return F.layer_norm(x, (width,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+
+
+def clip_image(sd, image, return_patches=False, probe=None):
+    """-> cls [B, out] (and tokens [n_patches, B, out] when return_patches)."""
+    x = vit_front(sd, image)
+    width = x.shape[-1]
     x = _blocks(x.permute(1, 0, 2), sd, "visual.transformer.", _count_layers(sd, "visual.transformer."), width // 64, None, probe)
     x = F.layer_norm(x.permute(1, 0, 2), (width,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
     x = x @ sd["visual.proj"]

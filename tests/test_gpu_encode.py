@@ -287,6 +287,90 @@ def test_whole_tower_entry_points_equal_the_primitive_chain(ops, clip_models):
         ops.set_precision(before)
 
 
+def _vit_front(m, image):
+    """the image tower up to the block stack, through the primitives (VisionTransformer.run's chain)"""
+    from xmh import ops as o
+    v = m.visual
+    width, n_patches = v.conv1.weight.shape[0], v.positional_embedding.shape[0] - 1
+    patches = o.gemm_nt(o.im2col_patch(image, v.patch_size), v.conv1.weight.reshape(width, -1))
+    return o.vit_assemble(patches, v.class_embedding, v.positional_embedding, v.ln_pre.weight, v.ln_pre.bias, image.shape[0], n_patches)
+
+
+def test_saved_activation_forward_matches_reference_hooks_oracle_and_the_plain_forward(ops, clip_models):
+    """xmh_clip_blocks_forward_saved: the per-layer records against (1) forward hooks inside the reference's own
+    ResidualAttentionBlocks (tests/golden/encode_saved_b2.npz), (2) the oracle's restatement for every field of every layer,
+    qkv and the pre-out_proj attention output included, (3) the plain forward, whose output it must reproduce bit for bit in
+    every precision."""
+    from oracle import encode as enc
+    from test_oracle_encode import saved_subset
+    g, W, m, _ = clip_models
+    gs = np.load(os.path.join(GOLDEN, "encode_saved_b2.npz"))
+    seed = int(gs["seed"])
+    image = W.synth_images(seed, 2)
+    T = m.visual.transformer
+    before = ops.get_precision()
+    try:
+        for prec, tol in (("f32", 1e-4), ("f32x", 1e-4), ("f16", None)):
+            ops.set_precision(prec)
+            x0 = _vit_front(m, image.cuda())
+            plain = T.run(x0.clone())
+            y, saved = T.run_saved(x0.clone())
+            assert torch.equal(y, plain), prec
+            assert len(saved) == 12 and saved[0]["qkv"].shape == (2, 50, 2304) and saved[0]["fc_act"].shape == (2, 50, 3072)
+            assert torch.equal(saved[0]["x_in"], x0)
+            for i in range(11):                                    # the residual stream hops from record to record
+                assert saved[i + 1]["x_in"].data_ptr() == saved[i]["fc_act"].data_ptr() + saved[i]["fc_act"].numel() * 4
+            if tol is None:
+                continue
+            lnd = [{k: v.permute(1, 0, 2).cpu() for k, v in rec.items()} for rec in saved]            # reference layout [L, B, n]
+            got = saved_subset(lnd, lambda li: lnd[li + 1]["x_in"] if li + 1 < 12 else y.permute(1, 0, 2).cpu(), gs)
+            for name, v in got.items():
+                assert rel(torch.from_numpy(v), torch.from_numpy(gs[name])) < tol, (prec, name)
+            sd = enc.fp16_round_like_reference(W.synth_clip_state_dict(seed))
+            with torch.no_grad():
+                _, want = enc.blocks_saved(enc.vit_front(sd, image).permute(1, 0, 2), sd, "visual.transformer.", 12, 12, None)
+            for li in (0, 6, 11):
+                for name in want[li]:
+                    assert rel(lnd[li][name], want[li][name]) < tol, (prec, li, name)
+    finally:
+        ops.set_precision(before)
+
+
+def test_saved_activation_forward_text_tower_masks_and_bad_arguments(ops, clip_models):
+    import xmh.models.clip as C
+    from oracle import encode as enc
+    from xmh._lib import XmhError, lib
+    g, W, m, _ = clip_models
+    seed = int(g["seed"])
+    ids, pad = W.synth_text(seed, 3)
+    sd = enc.fp16_round_like_reference(W.synth_clip_state_dict(seed))
+    x0 = (sd["token_embedding.weight"][ids] + sd["positional_embedding"][:ids.shape[1]]).float()
+    T = m.transformer
+    plain = T.run(x0.cuda().clone(), causal=True, key_padding_mask=pad.cuda())
+    y, saved = T.run_saved(x0.cuda().clone(), causal=True, key_padding_mask=pad.cuda())
+    assert torch.equal(y, plain)
+    L = ids.shape[1]
+    mask = torch.full((L, L), float("-inf")).triu_(1)[None].repeat(3, 1, 1).masked_fill(pad[:, None, :].bool(), float("-inf"))
+    with torch.no_grad():
+        _, want = enc.blocks_saved(x0.permute(1, 0, 2), sd, "transformer.", 12, 8, mask)
+    keep = ~pad                                                    # padded query rows are unspecified (SURVEY: masked rows)
+    for li in (0, 11):
+        for name in want[li]:
+            assert rel(saved[li][name].cpu()[keep], want[li][name].permute(1, 0, 2)[keep]) < 1e-4, (li, name)
+    assert lib.xmh_clip_saved_bytes(2, 50, 768, 12) == 12 * 16 * 2 * 50 * 768 * 4 and lib.xmh_clip_saved_bytes(0, 50, 768, 12) == 0
+    x = torch.zeros(1, 4, 64, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    blk = (C._lib.ClipBlock * 1)()
+    with pytest.raises(XmhError):                                  # saved buffer too small
+        C.check(lib.xmh_clip_blocks_forward_saved(blk, 1, 64, 1, C.ptr(x), 1, 4, 0, None, 0, C.ptr(ws), ws.numel(), C.ptr(x), 16,
+                                                  C.current_stream()), "saved")
+    with pytest.raises(XmhError):                                  # no saved buffer
+        C.check(lib.xmh_clip_blocks_forward_saved(blk, 1, 64, 1, C.ptr(x), 1, 4, 0, None, 0, C.ptr(ws), ws.numel(), None, 1 << 30,
+                                                  C.current_stream()), "saved")
+    with pytest.raises(ValueError):
+        T.run_saved(torch.zeros(2, 4, 512))
+
+
 def test_whole_tower_entry_points_follow_weight_updates_and_reject_bad_input(ops, clip_models):
     import copy
     import xmh.models.clip as C

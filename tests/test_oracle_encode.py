@@ -41,6 +41,37 @@ def test_clip_towers_match_reference_goldens():
         assert _rel(ttok.numpy()[keep], g["txt_tokens_rp"][keep]) < 2e-5
 
 
+def saved_subset(saved, x_out_of, g):
+    """the rows the golden file keeps: [layer, token, n] per field, from per-layer records of [L, B, n] tensors"""
+    b = int(g["sample"])
+    out = {}
+    for name in ("x_in", "ln1", "x_mid", "ln2", "fc_pre", "fc_act"):
+        out[name] = np.stack([np.stack([np.asarray(saved[li][name][t, b]) for t in g["tokens"]]) for li in g["layers"]])
+    out["x_out"] = np.stack([np.stack([np.asarray(x_out_of(li)[t, b]) for t in g["tokens"]]) for li in g["layers"]])
+    return out
+
+
+def test_saved_activations_of_the_oracle_match_the_reference_hooks():
+    """oracle.blocks_saved against forward hooks inside the reference's own ResidualAttentionBlocks (oracle/make_golden_saved.py)"""
+    g = np.load(os.path.join(GOLDEN, "encode_saved_b2.npz"))
+    W = _weights()
+    seed = int(g["seed"])
+    sd = enc.fp16_round_like_reference(W.synth_clip_state_dict(seed))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        x = enc.vit_front(sd, W.synth_images(seed, 2)).permute(1, 0, 2)
+        y, saved = enc.blocks_saved(x, sd, "visual.transformer.", 12, 12, None)
+        assert _rel(y, enc._blocks(x, sd, "visual.transformer.", 12, 12, None)) < 1e-6
+    got = saved_subset(saved, lambda li: saved[li + 1]["x_in"] if li + 1 < 12 else y, g)
+    for name, v in got.items():
+        assert _rel(v, g[name]) < 2e-5, name
+    # the two fields no module output exposes: qkv is in_proj of ln1, attn is what out_proj maps to x_mid - x_in
+    r = saved[5]
+    p = "visual.transformer.resblocks.5."
+    assert _rel(torch.nn.functional.linear(r["attn"], sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"]), r["x_mid"] - r["x_in"]) < 1e-5
+    assert r["qkv"].shape == (50, 2, 2304)
+
+
 def head_params(W, seed, prefix, shapes):
     return {k: v for k, v in shapes.items()}
 
