@@ -687,6 +687,160 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
     }
 }
 
+// ---- the filter for MANY queries on the matrix cores -------------------------------------------------------------------------
+// Above ~16 queries the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery stream.
+// v_mfma_i32_16x16x64_i8 takes that work: the Hamming distance of query q and item x is popcount(q) + sum_i s_i x_i with
+// s_i = 1 - 2 q_i.  The item's bits become bytes WITHOUT being moved: word & (0x01010101 << p) leaves bits p, p + 8, p + 16, p + 24 of
+// a 32-bit word each alone in its byte, worth 2^p there (p = 7 goes through (word >> 1) & 0x40404040: +128 is not an int8) -- 9
+// operations for 32 bits, independent of the number of queries.  The query side (B operand, built once per wave and kept in
+// registers) carries the matching weight: its byte for that bit is s_i * 64 / 2^p, so every product is 64 s_i x_i, and with the
+// accumulator started at 64 (popcount(q) - threshold(q) - 1) one chain of K/64 MFMAs leaves 64 (distance - threshold - 1) for 16
+// items x 16 queries: lane l holds query l & 15 and the items 4 * (l >> 4) + r, r = 0..3.  A candidate is a NEGATIVE result, so ONE
+// vote on the OR of a lane's 4 * QT results covers all of them.  Lane (row = l & 15, quarter = l >> 4) supplies the quarter
+// `quarter` of item `row`; which of its bits sits in which k slot of which MFMA is the same on both operands and otherwise free (a
+// sum over k does not care).
+// Candidates go to the same per-query lists as in k_topk_filter, through a wave-private staging list (below).  W % 4 == 0
+// (128-bit steps of the code length); QT = query tiles of 16 per pass over the gallery.
+typedef int topk_v4i __attribute__((ext_vector_type(4)));
+
+template <int W, int QT>
+__global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                               int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                               uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    static_assert(W % 4 == 0, "a lane owns a quarter of an item: whole words");
+    constexpr int KT = W / 2;                               // MFMAs per distance (64 bits each)
+    constexpr int LW = W / 4;                               // words per lane
+    constexpr int U = 4;                                    // groups of 16 items per wave and step
+    const int lane = lane_id(), row = lane & 15, quarter = lane >> 4;
+    const int q0 = blockIdx.y * (16 * QT);
+    topk_v4i bq[QT][KT];
+    int bias[QT], thr[QT];                                  // accumulator start 64 (popcount(q) - threshold - 1)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0 + 16 * t + row;                    // B operand: column = lane & 15
+        const int qq = q < Q ? q : Q - 1;
+        int pc = 0;
+        for (int x = 0; x < W; ++x) pc += __popc(qbits[(int64_t)qq * W + x]);
+        thr[t] = q < Q ? (int)t_est[qq] : -1;               // surplus columns: start at 64 * popcount >= 0, never negative
+        bias[t] = 64 * (pc - thr[t] - 1);
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+            const uint32_t w = qbits[(int64_t)qq * W + quarter * LW + (m >> 1)];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int p = 4 * (m & 1) + x;              // the item side's mask number: bits p, p + 8, p + 16, p + 24 of the word
+                const int mag = p < 7 ? (64 >> p) : 1;
+                uint32_t b = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b |= (uint32_t)(uint8_t)(((w >> (p + 8 * j)) & 1u) ? -mag : mag) << (8 * j);
+                bq[t][m][x] = (int)b;
+            }
+        }
+    }
+    const int64_t nstep = (R + 16 * U - 1) / (16 * U);
+    const int64_t wstride = (int64_t)gridDim.x * (kThreads / 64);
+    int64_t step = (int64_t)blockIdx.x * (kThreads / 64) + wave_id();
+    uint32_t cur[U][LW], nxt[U][LW];
+    auto load = [&](uint32_t (&dst)[U][LW], int64_t st) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // the 64 lanes read the 16 items of a group as ONE contiguous run (lane j: quarter j & 3 of item j >> 2); the operand
+            // layout wants quarter l >> 4 of item l & 15 in lane l: exchanged through ds_bpermute when the words are used
+            int64_t it = (st * U + u) * 16 + (lane >> 2);
+            if (it >= R) it = R - 1;                        // clamped rows repeat the last item: dropped where candidates are staged
+            const uint32_t* p = rbits + it * W + (lane & 3) * LW;
+            if constexpr (LW == 1) dst[u][0] = p[0];
+            else if constexpr (LW == 2) {
+                const uint2 v = *reinterpret_cast<const uint2*>(p);
+                dst[u][0] = v.x; dst[u][1] = v.y;
+            } else {
+#pragma unroll
+                for (int x = 0; x < LW / 4; ++x) {
+                    const uint4 v = reinterpret_cast<const uint4*>(p)[x];
+                    dst[u][4 * x] = v.x; dst[u][4 * x + 1] = v.y; dst[u][4 * x + 2] = v.z; dst[u][4 * x + 3] = v.w;
+                }
+            }
+        }
+    };
+    // Candidates are staged in a wave-private LDS list (positions from wave votes, no atomics) and go out 64 at a time: one global
+    // atomic round trip per flush instead of one per candidate -- each used to hold its wave for the atomic's return AND for the
+    // prefetched tile, because the two share vmcnt (Q = 64: 0.23 ms per pass with the direct append, 0.16 staged).
+    constexpr int kStage = 192;
+    __shared__ uint2 stage_all[kThreads / 64][kStage];
+    uint2* mine_stage = stage_all[wave_id()];
+    int staged = 0;                                         // wave-uniform
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < staged; b += 64) {
+            if (b + lane < staged) {
+                const uint2 e = mine_stage[b + lane];
+                const int q = q0 + (int)(e.y >> 16);
+                const uint32_t pos = atomicAdd(cnt + q, 1u);
+                if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)(e.y & 0xffffu) << 32) | e.x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        staged = 0;
+    };
+    const int src4 = 4 * (4 * row + quarter);               // ds_bpermute address: the lane that loaded this lane's quarter of its item
+    if (step < nstep) load(cur, step);
+    for (; step < nstep; step += wstride) {
+        const bool more = step + wstride < nstep;
+        if (more) load(nxt, step + wstride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            topk_v4i a[KT];
+#pragma unroll
+            for (int v = 0; v < LW; ++v) {                  // one word = two k tiles: 9 operations for 32 bits
+                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)cur[u][v]);
+#pragma unroll
+                for (int p = 0; p < 7; ++p) a[2 * v + (p >> 2)][p & 3] = (int)(w & (0x01010101u << p));
+                a[2 * v + 1][3] = (int)((w >> 1) & 0x40404040u);
+            }
+            topk_v4i acc[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) acc[t] = topk_v4i{bias[t], bias[t], bias[t], bias[t]};
+#pragma unroll
+            for (int m = 0; m < KT; ++m)                    // k tile outermost: consecutive MFMAs belong to different chains
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], bq[t][m], acc[t], 0, 0, 0);
+            int tsign[QT], sign = 0;                        // sign bit set <=> a candidate among the 4 results of the tile / of the lane
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                tsign[t] = acc[t][0] | acc[t][1] | acc[t][2] | acc[t][3];
+                sign |= tsign[t];
+            }
+            if (__ballot(sign < 0)) {                       // a candidate somewhere in these 16 items x 16 QT queries (about one group in five at Q = 64)
+                const int64_t it0 = (step * U + u) * 16 + 4 * quarter;       // C rows of this lane: it0 + r
+                const bool tail = (step * U + u + 1) * 16 > R;               // only the last group holds clamped rows
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    if (!__ballot(tsign[t] < 0)) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool hit = acc[t][r] < 0 && (!tail || it0 + r < R);
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {
+                            if (hit)
+                                mine_stage[staged + __popcll(m & ((1ull << lane) - 1ull))] =
+                                    make_uint2((uint32_t)(it0 + r), (uint32_t)((acc[t][r] >> 6) + thr[t] + 1) | ((uint32_t)(16 * t + row) << 16));
+                            staged += __popcll(m);
+                            if (staged > kStage - 64) flush();
+                        }
+                    }
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int x = 0; x < LW; ++x) cur[u][x] = nxt[u][x];
+        }
+    }
+    flush();
+}
+
 // block-wide search: first bin b of hist[0..n) whose cumulative count reaches `need` (1 <= need <= total) -> out[0] = b,
 // out[1] = count below b.  Every thread sums a contiguous segment, wave scan, cross-wave offsets through LDS, the owning
 // thread walks its segment (one wave stepping through 64 bins at a time was 16 dependent rounds for the 1024 index bins).
@@ -938,6 +1092,24 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 int a_ = 0, b_ = 0;                                                                                        \
                 if (sscanf(e_, "%dx%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4 || a_ == 8) && a_ <= qmax && (b_ == 1 || b_ == 2 || b_ == 4) && (a_ > 1 || b_ == 1) && WW < 16) { qn = a_; qg = b_; } \
             }                                                                                                              \
+            /* many queries, code lengths in steps of 128 bits: the distances on the matrix cores (k_topk_filter_mfma) */         \
+            static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : 16; }();            \
+            bool on_mfma = false;                                                                                          \
+            if constexpr (WW == 4 || WW == 8 || WW == 16) {                                                                 \
+                if (mfma_min_q > 0 && Q >= mfma_min_q) {                                                                   \
+                    constexpr int QT_ = WW == 16 ? 2 : 4;                                                                   \
+                    const unsigned gy_ = (unsigned)xmh::ceil_div(Q, 16 * QT_);                                             \
+                    int64_t fb_ = (int64_t)xmh::device_cu_count() * 8 / gy_;                                               \
+                    if (fb_ < xmh::device_cu_count()) fb_ = xmh::device_cu_count();                                        \
+                    const int64_t steps_ = xmh::ceil_div(R, (int64_t)64 * (kThreads / 64));                                 \
+                    if (fb_ > steps_) fb_ = steps_;                                                                        \
+                    xmh::ProfScope prof("topk_filter", st);                                                                \
+                    hipLaunchKernelGGL((k_topk_filter_mfma<WW, QT_>), dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                                       (const uint32_t*)f.t_est, f.cnt, f.cand);                                           \
+                    on_mfma = true;                                                                                        \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (!on_mfma) {                                                                                                \
             const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
             const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
             int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;     /* 2..32 blocks per CU measured within 5 % */        \
@@ -962,6 +1134,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 if (qn == 2 && qg == 1) go_(k_topk_filter<WW, II, 2, 1>);                                                   \
             }                                                                                                              \
             if (qn == 1) go_(k_topk_filter<WW, II, 1, 1>);                                                                 \
+            }                                                                                                              \
         }
         switch (p.W) {
             case 1: XMH_FAST(1, 8) break;

@@ -14,7 +14,7 @@ print(bench_topk.measure(R=10_000_000, K=$K, Q=$Q, iters=5, warmup=2))
 PY
 CMD="python /tmp/topk_once.py"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE SQ_INSTS_SMEM -d $OUT/pmc1 -o t -- $CMD > $OUT/pmc1.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_DEP_WAIT -d $OUT/pmc2 -o t -- $CMD > $OUT/pmc2.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $OUT/pmc2 -o t -- $CMD > $OUT/pmc2.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_VALU_DEP_STALL SQ_INST_LEVEL_VMEM SQ_WAIT_INST_VMEM TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc3 -o t -- $CMD > $OUT/pmc3.log 2>&1
 python - <<'PY'
 import csv, glob, collections
