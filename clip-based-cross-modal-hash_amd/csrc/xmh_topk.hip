@@ -447,6 +447,9 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
 // Exactness is verified, not assumed: if a list overflowed or holds fewer than k items the select kernel
 // raises `fail`, and the robust streaming kernels above (gated on that flag) recompute the call.
 // ===================================================================================================
+// candidate counters live kCntStride words apart: the appends of ALL blocks are device-scope atomics on these few words, and
+// counters that share a cache line share one memory channel (64 queries on two lines: 45 us of a 160 us pass at Q = 64)
+constexpr int kCntStride = 64;
 constexpr int kCandCap = 8192;        // candidates kept per query (keys of 8 B)
 constexpr int kSampleBlocks = 256;
 constexpr int kSamplePerBlock = 1024;
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
         const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane);
         if (lane == 0) {
             t_est[q] = (uint32_t)t;
-            cnt[q] = 0u;
+            cnt[(int64_t)q * kCntStride] = 0u;
         }
     }
     if (threadIdx.x == 0) {
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, i
     const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane);
     if (lane == 0) {
         t_est[q] = (uint32_t)t;
-        cnt[q] = 0u;
+        cnt[(int64_t)q * kCntStride] = 0u;
         if (q == 0) *fail = 0;
     }
 }
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
                     // vote per (query, item slot) here: the out-of-line call (argument moves, swappc, return) is paid only by the
                     // slots that hold a candidate, not by all QN x IPT slots of a tile that holds one somewhere (2-4 % at Q = 8)
                     const bool hit = item_of(tile, j) < R && dd[q][j] <= thr[q];
-                    if (__ballot(hit)) append_candidates(item_of(tile, j), dd[q][j], hit, cnt + q0 + q, cand + (int64_t)(q0 + q) * kCandCap);
+                    if (__ballot(hit)) append_candidates(item_of(tile, j), dd[q][j], hit, cnt + (int64_t)(q0 + q) * kCntStride, cand + (int64_t)(q0 + q) * kCandCap);
                 }
             }
         }
@@ -702,6 +705,29 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
 // Candidates go to the same per-query lists as in k_topk_filter, through a wave-private staging list (below).  W % 4 == 0
 // (128-bit steps of the code length); QT = query tiles of 16 per pass over the gallery.
 typedef int topk_v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void append_one(int q, uint32_t d, uint32_t it, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    const uint32_t pos = atomicAdd(cnt + (int64_t)q * kCntStride, 1u);
+    if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)d << 32) | it;
+}
+
+// the wave's staged candidates -> the per-query lists, 64 per round trip; *count (the wave's own LDS word) goes back to zero
+__device__ __noinline__ void flush_staged(const uint2* stage, uint32_t* count, int cap, int q0, uint32_t* __restrict__ cnt,
+                                          unsigned long long* __restrict__ cand) {
+    __builtin_amdgcn_wave_barrier();
+    const int lane = lane_id();
+    int n = (int)*count;
+    n = __builtin_amdgcn_readfirstlane(n < cap ? n : cap);      // entries past the capacity went out directly
+    for (int b = 0; b < n; b += 64) {
+        if (b + lane < n) {
+            const uint2 e = stage[b + lane];
+            append_one(q0 + (int)(e.y >> 16), e.y & 0xffffu, e.x, cnt, cand);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *count = 0;
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int W, int QT>
 __global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
@@ -762,26 +788,17 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* _
             }
         }
     };
-    // Candidates are staged in a wave-private LDS list (positions from wave votes, no atomics) and go out 64 at a time: one global
+    // Candidates are staged in a wave-private LDS list (a lane with a candidate takes its slot with an LDS atomic on the wave's own
+    // counter: only the lanes that hold one run that code) and go out 64 at a time: one global
     // atomic round trip per flush instead of one per candidate -- each used to hold its wave for the atomic's return AND for the
     // prefetched tile, because the two share vmcnt (Q = 64: 0.23 ms per pass with the direct append, 0.16 staged).
     constexpr int kStage = 192;
     __shared__ uint2 stage_all[kThreads / 64][kStage];
+    __shared__ uint32_t stage_n[kThreads / 64];
     uint2* mine_stage = stage_all[wave_id()];
-    int staged = 0;                                         // wave-uniform
-    auto flush = [&]() {
-        __builtin_amdgcn_wave_barrier();
-        for (int b = 0; b < staged; b += 64) {
-            if (b + lane < staged) {
-                const uint2 e = mine_stage[b + lane];
-                const int q = q0 + (int)(e.y >> 16);
-                const uint32_t pos = atomicAdd(cnt + q, 1u);
-                if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)(e.y & 0xffffu) << 32) | e.x;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        staged = 0;
-    };
+    uint32_t* mine_n = stage_n + wave_id();
+    if (lane == 0) *mine_n = 0;
+    bool dirty = false;                                     // wave-uniform: something was staged since the last look at the count
     const int src4 = 4 * (4 * row + quarter);               // ds_bpermute address: the lane that loaded this lane's quarter of its item
     if (step < nstep) load(cur, step);
     for (; step < nstep; step += wstride) {
@@ -810,26 +827,30 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* _
                 tsign[t] = acc[t][0] | acc[t][1] | acc[t][2] | acc[t][3];
                 sign |= tsign[t];
             }
-            if (__ballot(sign < 0)) {                       // a candidate somewhere in these 16 items x 16 QT queries (about one group in five at Q = 64)
-                const int64_t it0 = (step * U + u) * 16 + 4 * quarter;       // C rows of this lane: it0 + r
-                const bool tail = (step * U + u + 1) * 16 > R;               // only the last group holds clamped rows
+            if (__ballot(sign < 0)) {                       // a candidate somewhere in these 16 items x 16 QT queries (about one group in six at Q = 64)
+                dirty = true;
+                if (sign < 0) {                             // divergent from here: usually one lane
+                    const int64_t it0 = (step * U + u) * 16 + 4 * quarter;   // C rows of this lane: it0 + r
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    if (!__ballot(tsign[t] < 0)) continue;
+                    for (int t = 0; t < QT; ++t) {
+                        if (tsign[t] >= 0) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool hit = acc[t][r] < 0 && (!tail || it0 + r < R);
-                        const unsigned long long m = __ballot(hit);
-                        if (m) {
-                            if (hit)
-                                mine_stage[staged + __popcll(m & ((1ull << lane) - 1ull))] =
-                                    make_uint2((uint32_t)(it0 + r), (uint32_t)((acc[t][r] >> 6) + thr[t] + 1) | ((uint32_t)(16 * t + row) << 16));
-                            staged += __popcll(m);
-                            if (staged > kStage - 64) flush();
+                        for (int r = 0; r < 4; ++r) {
+                            if (acc[t][r] < 0 && it0 + r < R) {         // clamped rows of the last group repeat item R - 1: dropped here
+                                const uint32_t d = (uint32_t)((acc[t][r] >> 6) + thr[t] + 1);
+                                const uint32_t pos = atomicAdd(mine_n, 1u);
+                                if (pos < (uint32_t)kStage) mine_stage[pos] = make_uint2((uint32_t)(it0 + r), d | ((uint32_t)(16 * t + row) << 16));
+                                else append_one(q0 + 16 * t + row, d, (uint32_t)(it0 + r), cnt, cand);
+                            }
                         }
                     }
                 }
             }
+        }
+        if (dirty) {                                        // once per step at most: is the list worth a round trip?
+            dirty = false;
+            __builtin_amdgcn_wave_barrier();
+            if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStage, q0, cnt, cand);
         }
         if (more) {
 #pragma unroll
@@ -838,7 +859,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* _
                 for (int x = 0; x < LW; ++x) cur[u][x] = nxt[u][x];
         }
     }
-    flush();
+    flush_staged(mine_stage, mine_n, kStage, q0, cnt, cand);
 }
 
 // block-wide search: first bin b of hist[0..n) whose cumulative count reaches `need` (1 <= need <= total) -> out[0] = b,
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     // the first 512 keys are requested together with the count (lists are a few hundred keys: one miss latency instead of two)
     const unsigned long long* cq = cand + (int64_t)q * kCandCap;
     const unsigned long long k0 = cq[threadIdx.x], k1 = cq[threadIdx.x + kThreads];
-    const uint32_t n = cnt[q];
+    const uint32_t n = cnt[(int64_t)q * kCntStride];
     const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
     if (n > (uint32_t)kCandCap || n < want) {
         if (threadIdx.x == 0) atomicOr(fail, 1);
@@ -1007,7 +1028,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->off_ctl = take(256);                           // ctl, hist, t_est, cnt, fail are contiguous: one memset clears them
     p->off_hist = take((size_t)Q * (K + 1) * 4);
     p->off_test = take((size_t)Q * 4);
-    p->off_cnt = take((size_t)Q * 4);
+    p->off_cnt = take((size_t)Q * kCntStride * 4);
     p->off_fail = take(256);
     p->off_cand = take((size_t)Q * kCandCap * 8);
     p->ws_bytes = o;
