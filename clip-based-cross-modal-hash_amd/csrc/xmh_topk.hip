@@ -691,7 +691,8 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __rest
 }
 
 // ---- the filter for MANY queries on the matrix cores -------------------------------------------------------------------------
-// Above ~16 queries the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery stream.
+// From a handful of queries on the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery
+// stream.
 // v_mfma_i32_16x16x64_i8 takes that work: the Hamming distance of query q and item x is popcount(q) + sum_i s_i x_i with
 // s_i = 1 - 2 q_i.  The item's bits become bytes WITHOUT being moved: word & (0x01010101 << p) leaves bits p, p + 8, p + 16, p + 24 of
 // a 32-bit word each alone in its byte, worth 2^p there (p = 7 goes through (word >> 1) & 0x40404040: +128 is not an int8) -- 9
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_mfma(const uint32_t* _
     static_assert(W % 4 == 0, "a lane owns a quarter of an item: whole words");
     constexpr int KT = W / 2;                               // MFMAs per distance (64 bits each)
     constexpr int LW = W / 4;                               // words per lane
-    constexpr int U = 4;                                    // groups of 16 items per wave and step
+    constexpr int U = 4;                                    // groups of 16 items per wave and step (2 and 8 measured the same)
     const int lane = lane_id(), row = lane & 15, quarter = lane >> 4;
     const int q0 = blockIdx.y * (16 * QT);
     topk_v4i bq[QT][KT];
@@ -1114,19 +1115,25 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 if (sscanf(e_, "%dx%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4 || a_ == 8) && a_ <= qmax && (b_ == 1 || b_ == 2 || b_ == 4) && (a_ > 1 || b_ == 1) && WW < 16) { qn = a_; qg = b_; } \
             }                                                                                                              \
             /* many queries, code lengths in steps of 128 bits: the distances on the matrix cores (k_topk_filter_mfma) */         \
-            static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : 16; }();            \
+            /* measured (10 M x 256 bit): one pass over 16 queries 63 us whatever their number, against 54 / 58 / 95 / 61 / 79 / 80 us \
+               for 1 / 2 / 3 / 4 / 6 / 8 queries on the VALU; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never */    \
+            static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();            \
             bool on_mfma = false;                                                                                          \
             if constexpr (WW == 4 || WW == 8 || WW == 16) {                                                                 \
-                if (mfma_min_q > 0 && Q >= mfma_min_q) {                                                                   \
-                    constexpr int QT_ = WW == 16 ? 2 : 4;                                                                   \
-                    const unsigned gy_ = (unsigned)xmh::ceil_div(Q, 16 * QT_);                                             \
+                if (mfma_min_q < 0 ? (Q >= 5 || Q == 3) : (mfma_min_q > 0 && Q >= mfma_min_q)) {                            \
+                    constexpr int QTMAX_ = WW == 16 ? 2 : 4;          /* B operands: 16 * QT * W / 8 registers */                  \
+                    const int qt_ = Q <= 16 ? 1 : (Q <= 32 || QTMAX_ == 2 ? 2 : 4);                                          \
+                    const unsigned gy_ = (unsigned)xmh::ceil_div(Q, 16 * qt_);                                             \
                     int64_t fb_ = (int64_t)xmh::device_cu_count() * 8 / gy_;                                               \
                     if (fb_ < xmh::device_cu_count()) fb_ = xmh::device_cu_count();                                        \
                     const int64_t steps_ = xmh::ceil_div(R, (int64_t)64 * (kThreads / 64));                                 \
                     if (fb_ > steps_) fb_ = steps_;                                                                        \
                     xmh::ProfScope prof("topk_filter", st);                                                                \
-                    hipLaunchKernelGGL((k_topk_filter_mfma<WW, QT_>), dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
-                                       (const uint32_t*)f.t_est, f.cnt, f.cand);                                           \
+                    auto gom_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                                                                     (const uint32_t*)f.t_est, f.cnt, f.cand); };           \
+                    if (qt_ == 1) gom_(k_topk_filter_mfma<WW, 1>);                                                          \
+                    else if (qt_ == 2) gom_(k_topk_filter_mfma<WW, 2>);                                                     \
+                    else if constexpr (QTMAX_ == 4) gom_(k_topk_filter_mfma<WW, 4>);                                        \
                     on_mfma = true;                                                                                        \
                 }                                                                                                          \
             }                                                                                                              \

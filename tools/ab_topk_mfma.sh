@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the matrix-core top-k filter (XMH_TOPK_MFMA = smallest query count that takes it, 0 = never); run on the GPU box
 mkdir -p gpurun_out
-for v in ${1:-0 16}; do
+for v in ${1:--1 0}; do
   echo "== XMH_TOPK_MFMA=$v"
   XMH_TOPK_MFMA=$v timeout 600 python bench.py --steps 5 --no-cpu-baseline --no-encode --no-extra-configs 2>>gpurun_out/ab_topk.err | python -c "
 import sys,json
