@@ -21,6 +21,16 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
+def filter_on_matrix_cores(K, Q):
+    """the dispatch rule of xmh_topk.hip: 3 and >= 5 queries at code lengths of 128 / 256 / 512 bits run k_topk_filter_mfma"""
+    e = os.environ.get("XMH_TOPK_MFMA")
+    if (K + 31) // 32 not in (4, 8, 16):
+        return False
+    if e is None:
+        return Q >= 5 or Q == 3
+    return int(e) > 0 and Q >= int(e)
+
+
 def _traffic(K, Q):
     """PMC HBM bytes of exactly the filter instance this (K, Q) launches: k_topk_filter<words, items per thread, query group>"""
     try:
@@ -28,7 +38,11 @@ def _traffic(K, Q):
         W = (K + 31) // 32
         qn = 8 if Q >= 8 else (4 if Q >= 4 else (2 if Q >= 2 else 1))
         d, _ = bench_roofline._newest_summary()
-        names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter<%d, " % W) and n.endswith(", %d>" % qn)]
+        if filter_on_matrix_cores(K, Q):
+            qt = 1 if Q <= 16 else (2 if Q <= 32 or W == 16 else 4)
+            names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter_mfma<%d, %d>" % (W, qt))]
+        else:
+            names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter<%d, " % W) and n.endswith(", %d>" % qn)]
         if len(names) != 1:
             return None
         t = bench_roofline.pmc_traffic(names[0])
@@ -126,7 +140,8 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
 
 
 def _result(alg, t, t_call, launches, R, K, Q, k, kind):
-    return {"kernel": "k_topk_filter (streaming pass of xmh_hamming_topk), HIP events around the launch, %d launches" % launches,
+    name = "k_topk_filter_mfma (distances on v_mfma_i32_16x16x64_i8)" if filter_on_matrix_cores(K, Q) else "k_topk_filter"
+    return {"kernel": "%s, the streaming pass of xmh_hamming_topk; HIP events around the launch, %d launches" % (name, launches),
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
             "traffic": _traffic(K, Q), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
             "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9,

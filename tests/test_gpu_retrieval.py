@@ -934,6 +934,17 @@ def test_topk_full_size_sample_path(xr):
     _topk_check(xr, 4, 1_500_000, 256, 10, seed=22)
 
 
+@pytest.mark.parametrize("Q,R,K,k", [(3, 50001, 128, 10), (16, 33333, 128, 100), (17, 70001, 256, 100), (33, 40007, 256, 5), (70, 25013, 256, 100),
+                                     (20, 30011, 512, 50), (40, 9999, 512, 100), (5, 15, 256, 3), (64, 1_200_003, 256, 100), (12, 900_001, 128, 20)])
+def test_topk_matrix_core_filter(xr, Q, R, K, k):
+    """k_topk_filter_mfma (3 and >= 5 queries at 128 / 256 / 512 bits): one, two and four query tiles per pass, several passes,
+    ragged last groups, galleries below and above the sampling size; and a duplicate-heavy gallery whose candidates outgrow the
+    wave's staging list and the per-query lists (direct appends, then the robust path)."""
+    _topk_check(xr, Q, R, K, k, seed=3 * Q + R + K + k, base_index=77)
+    if R < 100000:
+        _topk_check(xr, Q, R, K, k, seed=Q + K, dup=True)
+
+
 def test_topk_prepared_workspace_stays_clean_over_calls(xr):
     """xmh_topk_ws_init once, then a query loop through xmh_hamming_topk_prepared: every call finds the control words and the sample
     histogram zero and leaves them zero -- few queries (thresholds picked by the last sample block), many queries (pick kernel),
