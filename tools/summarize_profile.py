@@ -59,7 +59,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
                 e["per_launch"][c] = val / n
 # HBM traffic per launch as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
 # the bytes of a wide (16 B/lane) coalesced streaming read -> doubled for the kernels whose reads are of that kind.
-WIDE = ("k_topk_filter<", "k_gemm_nt", "k_gemm_g16", "k_topk_stream", "k_im2col_patch", "k_scan_hist_m", "k_scan_ap_c")   # 16-byte loads: LDS-DMA of the operand images, the pair cache (k_topk_filter_mfma reads 8 bytes per lane: not in the list)
+WIDE = ("k_topk_filter", "k_gemm_nt", "k_gemm_g16", "k_topk_stream", "k_im2col_patch", "k_scan_hist_m", "k_scan_ap_c")   # coalesced streaming reads of 8-16 bytes per lane: LDS-DMA of the operand images, the pair cache, the gallery stream (k_topk_filter_mfma's 8-byte loads are halved by FETCH_SIZE too: 160 MB raw against TCC_MISS_sum x 128 B = 327 MB)
 for k, e in res["pmc"].items():
     pl = e["per_launch"]
     if "FETCH_SIZE" in pl or "WRITE_SIZE" in pl:
