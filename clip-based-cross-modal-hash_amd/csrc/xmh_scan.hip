@@ -35,6 +35,7 @@
 // wave at K=64, C=80.  The relevance test is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does
 // not form them).  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
+#include "xmh_scan_bits.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -1956,6 +1957,14 @@ inline M2Geom m2_geom(int K) {
     return g;
 }
 inline bool m2_shape(int K, bool ternary) { return m2_enabled() && mfma_shape(K, ternary) && K <= 64; }
+// k_scan_hist_b (xmh_scan_bits.hip, round 3): 65..256-bit binary codes with at most 128 classes build their MFMA operands from the
+// packed bits in registers -- no operand image, no LDS ring; counters in the (all << 16 | relevant) form of k_scan_hist_m2.
+// XMH_SCAN_BITS=0 brings back k_scan_hist_m (read per call: tests switch it); the MFMA pass 2 reads k_scan_hist_m's images.
+static_assert(xmh::kScanBitsWaves == kMfmaWaves, "k_scan_hist_b shares the plan's query tiles with k_scan_hist_m");
+inline bool bits_shape(int K, bool ternary, int LW) {
+    const char* e = getenv("XMH_SCAN_BITS");
+    return !(e && atoi(e) == 0) && !mfma_ap_on() && mfma_shape(K, ternary) && K > 64 && K <= 256 && LW <= 4;
+}
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
 inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
@@ -2212,6 +2221,12 @@ int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits
     if (K <= 64)
         return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    if (bits_shape(K, false, LW)) {
+        XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words k_scan_expand clears for the image kernels
+        const xmh::ScanBitsArgs a{rbits, rlab, qbits, qlab, (int)Q, (int)R, K, W, LW, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)),
+                                  (int)p.nbuckets, (int)p.qpad};
+        return xmh::launch_scan_hist_bits(a, K <= 128 ? 2 : 4, chunk_hist, cache, st);
+    }
     if (K <= 128)
         return LW <= 2 ? mfma_hist_t<2, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist_t<2, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
@@ -2258,7 +2273,8 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
         const M2Geom g = m2_geom(K);
         snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
     } else if (use_mfma) {
-        snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false");
+        if (bits_shape(K, tern, LW)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s>", K <= 128 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
+        else snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false");
     } else {
         const bool cached = cache && !tern && Wc <= 8;
         const int S = cached ? cache_slots(Wc) : S4;
@@ -2354,7 +2370,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) ? kRelHi16 : kRelScale) : 0u, below, tot,
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) || bits_shape(K, tern, LW) ? kRelHi16 : kRelScale) : 0u, below, tot,
                        reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
                        reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate), hist_all, hist_rel);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");

@@ -1,0 +1,21 @@
+// k_scan_hist_b (xmh_scan_bits.hip): pass 1 of the ranking scan for 128 / 256-bit codes, MFMA operands from the packed bits
+#pragma once
+#include "xmh_common.h"
+
+namespace xmh {
+
+constexpr int kScanBitsWaves = 4;                    // waves (16 queries each) per block; must equal kMfmaWaves of xmh_scan.hip
+
+struct ScanBitsArgs {
+    const uint32_t* rbits;
+    const uint32_t* rlab;
+    const uint32_t* qbits;
+    const uint32_t* qlab;
+    int Q, R, K, W, LW;
+    int chunk, nchunk, nqt, nb, qpad;
+};
+
+// nmc = code tiles of 64 bits (2: up to 128 bits, 4: up to 256); counters come out as (all << 16 | relevant) per (chunk, bucket, query)
+int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st);
+
+}  // namespace xmh

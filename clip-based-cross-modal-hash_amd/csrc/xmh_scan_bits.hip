@@ -1,0 +1,183 @@
+// Pass 1 of the fused ranking scan for 128- and 256-bit binary codes with the MFMA operands built IN REGISTERS from the packed
+// bits (round 3; the boundary, the tables and pass 2 are those of xmh_scan.hip -- this file only replaces k_scan_hist_m there).
+//
+// k_scan_hist_m stages a pre-expanded int8 image of the gallery (8 bytes per code bit and label bit, built by k_scan_expand, 1 KB
+// pieces through a two-deep LDS ring by LDS-DMA, two barriers per 64-item batch) and at 129 / 257 bucket rows per wave its LDS
+// footprint leaves one block per CU.  Here nothing is staged: as in k_topk_filter_mfma (xmh_topk.hip), `word & (0x01010101 << p)`
+// leaves bits p, p + 8, p + 16, p + 24 of a packed word each alone in its byte, worth 2^p there (p = 7 through
+// `(word >> 1) & 0x40404040`), 9 VALU operations for 32 bits; the query side (B operand, built once per wave, kept in registers)
+// carries the matching weight s_i * 64 / 2^p with s_i = 1 - 2 q_i, so every product is 64 s_i x_i and an accumulator started at
+// (LDS address of this lane's bucket-0 counter) + 64 * popcount(q) ends as the ADDRESS of counter [distance][query] -- counter rows
+// are 64 bytes (16 queries x u32), exactly the layout of k_scan_hist_m.  Lane (row = l & 15, quarter = l >> 4) loads the quarter
+// `quarter` of the code words of its item straight from the packed gallery (one or two words), and the label word `quarter` (labels:
+// up to 128 classes = 4 words = two label tiles; their B bytes are 64 / 2^p where the query has the label, so the label chain ends
+// as 0x10000 + 64 * (common labels) and min(., 0x10001) is the counter increment (all << 16 | relevant)).  No operand image, no
+// LDS ring, no barrier; LDS holds the counters only (K = 256: 66 KB per block of 4 waves, two blocks per CU).
+// The pair cache (16-bit entries, distance << 1 | relevant) is written in k_scan_hist_m's layout for the cached pass 2, and the
+// items of a 16-item group sit in the same C rows (row r <-> item 16 g + 4 (r & 3) + (r >> 2)), so pass 2 is unchanged.
+// Compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (Makefile): the MFMA results are LDS addresses and VALU inputs right away.
+#include "xmh_common.h"
+#include "xmh_scan_bits.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// word -> the 8 operand registers of its two k tiles (register p: bits p, p + 8, p + 16, p + 24, each worth 2^p; p = 7 worth 64)
+__device__ __forceinline__ void word_to_bytes(uint32_t w, v4i& lo, v4i& hi) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lo[p] = (int)(w & (0x01010101u << p));
+#pragma unroll
+    for (int p = 4; p < 7; ++p) hi[p - 4] = (int)(w & (0x01010101u << p));
+    hi[3] = (int)((w >> 1) & 0x40404040u);
+}
+
+// the matching B registers: byte j of register p <- bit p + 8 j of the word; on = value where the bit is set, off = where it is not,
+// both scaled by 64 / 2^p (p = 7: 1)
+__device__ __forceinline__ void word_to_weights(uint32_t w, int on, int off, v4i& lo, v4i& hi) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int mag = p < 7 ? (64 >> p) : 1;
+        uint32_t b = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b |= (uint32_t)(uint8_t)((((w >> (p + 8 * j)) & 1u) ? on : off) * mag) << (8 * j);
+        if (p < 4) lo[p] = (int)b;
+        else hi[p - 4] = (int)b;
+    }
+}
+
+template <int NMC, int NW, bool CACHE>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+    constexpr int LWC = NMC / 2;                                    // code words per lane (a quarter of the padded code)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters
+    const int b = blockIdx.x;
+    const int qtile = (b >> 3) % a.nqt, chunk_id = (b & 7) + 8 * ((b >> 3) / a.nqt);        // as mfma_map_block (xmh_scan.hip)
+    if (chunk_id >= a.nchunk) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int q0 = (qtile * NW + wave) * 16;
+    const int q = q0 + ql;
+    const int ncell = a.nb * 16;
+    uint32_t* cnt = lds + wave * ncell;
+    for (int e = lane; e < ncell; e += 64) cnt[e] = 0u;
+    const bool valid = q < a.Q;
+    // B operands: this lane is column ql (its query) and k quarter `slot`
+    v4i bq[NMC], bl[2];
+    int pc = 0;
+    if (valid)
+        for (int w = 0; w < a.W; ++w) pc += __popc(a.qbits[(int64_t)q * a.W + w]);
+#pragma unroll
+    for (int v = 0; v < LWC; ++v) {
+        const int wi = slot * LWC + v;
+        const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
+        word_to_weights(w, -1, valid ? 1 : 0, bq[2 * v], bq[2 * v + 1]);
+    }
+    word_to_weights(valid && slot < a.LW ? a.qlab[(int64_t)q * a.LW + slot] : 0u, 1, 0, bl[0], bl[1]);
+    const int lanebase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4;     // this lane's bucket-0 counter
+    const int cinit = lanebase + 64 * pc;
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    // A rows: row r of group g is item 16 g + 4 (r & 3) + (r >> 2) (k_scan_hist_m's image order: C register j of lane (slot, query)
+    // is item 16 g + 4 j + slot, which is what the pair-cache layout below and the cached pass 2 count on)
+    const int rowitem = 4 * (ql & 3) + (ql >> 2);
+    uint4* crow = nullptr;
+    if (CACHE) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
+    uint32_t cur[4][LWC + 1], nxt[4][LWC + 1];
+    auto load = [&](uint32_t (&dst)[4][LWC + 1], int i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t it = lo + (int64_t)i * 64 + 16 * g + rowitem;
+            const bool ok = it < hi;                                // beyond the chunk: all-zero code, no labels (corrected below)
+#pragma unroll
+            for (int v = 0; v < LWC; ++v) {
+                const int wi = slot * LWC + v;
+                dst[g][v] = ok && wi < a.W ? a.rbits[it * a.W + wi] : 0u;
+            }
+            dst[g][LWC] = ok && slot < a.LW ? a.rlab[it * a.LW + slot] : 0u;
+        }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the zeroed counters are in place (this wave's own cells)
+    if (nbat > 0) load(cur, 0);
+    for (int i = 0; i < nbat; ++i) {
+        if (i + 1 < nbat) load(nxt, i + 1);
+        uint32_t cw[4], cw2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4i am[NMC], al[2];
+#pragma unroll
+            for (int v = 0; v < LWC; ++v) word_to_bytes(cur[g][v], am[2 * v], am[2 * v + 1]);
+            word_to_bytes(cur[g][LWC], al[0], al[1]);
+            v4i acc = {cinit, cinit, cinit, cinit};
+#pragma unroll
+            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[m], bq[m], acc, 0, 0, 0);
+            v4i lab = {0x10000, 0x10000, 0x10000, 0x10000};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(al[m], bl[m], lab, 0, 0, 0);
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t inc = min((uint32_t)lab[j], 0x10001u);                       // all << 16 | relevant
+                asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
+                if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[j] - lanebase) >> 5);          // entry: distance << 1 | relevant (16 bits)
+            }
+            if (CACHE) {                                             // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
+                cw[g] = e[0] | (e[2] << 16);
+                cw2[g] = e[1] | (e[3] << 16);
+            }
+        }
+        if (CACHE) {
+            uint4* dst = crow + (int64_t)i * 64;
+            __builtin_nontemporal_store(cw[0], &dst->x);
+            __builtin_nontemporal_store(cw[1], &dst->y);
+            __builtin_nontemporal_store(cw[2], &dst->z);
+            __builtin_nontemporal_store(cw[3], &dst->w);
+            __builtin_nontemporal_store(cw2[0], &dst[32].x);
+            __builtin_nontemporal_store(cw2[1], &dst[32].y);
+            __builtin_nontemporal_store(cw2[2], &dst[32].z);
+            __builtin_nontemporal_store(cw2[3], &dst[32].w);
+        }
+        if (i + 1 < nbat) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int v = 0; v <= LWC; ++v) cur[g][v] = nxt[g][v];
+        }
+    }
+    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
+    const int npad = nbat * 64 - (int)(hi - lo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (npad > 0 && slot == 0 && valid) cnt[pc * 16 + ql] -= (uint32_t)npad << 16;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
+    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
+}
+
+template <int NMC, int NW>
+int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    const size_t lds = (size_t)NW * a.nb * 16 * 4;
+    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(a.nchunk, 8)));
+    xmh::ProfScope prof("scan_hist", st);
+    if (cache) {
+        auto kern = k_scan_hist_b<NMC, NW, true>;
+        if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    } else {
+        auto kern = k_scan_hist_b<NMC, NW, false>;
+        if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+    }
+    return XMH_OK;
+}
+
+}  // namespace
+
+namespace xmh {
+
+int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    if (nmc == 2) return launch_t<2, kScanBitsWaves>(a, chunk_hist, cache, st);
+    if (nmc == 4) return launch_t<4, kScanBitsWaves>(a, chunk_hist, cache, st);
+    return fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_b instance for %d code tiles", nmc);
+}
+
+}  // namespace xmh
