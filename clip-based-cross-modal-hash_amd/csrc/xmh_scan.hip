@@ -1959,11 +1959,15 @@ inline M2Geom m2_geom(int K) {
 inline bool m2_shape(int K, bool ternary) { return m2_enabled() && mfma_shape(K, ternary) && K <= 64; }
 // k_scan_hist_b (xmh_scan_bits.hip, round 3): 65..256-bit binary codes with at most 128 classes build their MFMA operands from the
 // packed bits in registers -- no operand image, no LDS ring; counters in the (all << 16 | relevant) form of k_scan_hist_m2.
-// XMH_SCAN_BITS=0 brings back k_scan_hist_m (read per call: tests switch it); the MFMA pass 2 reads k_scan_hist_m's images.
+// Measured (Q 5000, C 80): 256 bit x R 117 218 pass 1 0.561 -> 0.514 ms, x R 1.25 M (configs[4] shard) 5.84 -> 4.61 ms; at 128 bit the
+// expansion of the label words (as many VALU operations as for the code) makes it lose, 0.381 against 0.326 ms, so 65..128 bits stay
+// on k_scan_hist_m.  XMH_SCAN_BITS=0 brings k_scan_hist_m back for all lengths, =2 takes 65..128 bits as well (read per call: tests
+// switch it); the MFMA pass 2 reads k_scan_hist_m's images.
 static_assert(xmh::kScanBitsWaves == kMfmaWaves, "k_scan_hist_b shares the plan's query tiles with k_scan_hist_m");
 inline bool bits_shape(int K, bool ternary, int LW) {
     const char* e = getenv("XMH_SCAN_BITS");
-    return !(e && atoi(e) == 0) && !mfma_ap_on() && mfma_shape(K, ternary) && K > 64 && K <= 256 && LW <= 4;
+    const int mode = e ? atoi(e) : 1;
+    return mode != 0 && !mfma_ap_on() && mfma_shape(K, ternary) && K > (mode == 2 ? 64 : 128) && K <= 256 && LW <= 4;
 }
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group

@@ -434,6 +434,27 @@ def test_scan_mfma_pass1_for_65_to_256_bit_codes_matches_the_valu_pass1(xr, monk
         assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-6, atol=1e-9), (Q, R, K, C)
 
 
+def test_scan_pass1_with_operands_from_the_packed_bits_gives_identical_bits(xr, monkeypatch):
+    """k_scan_hist_b (xmh_scan_bits.hip; default for 129..256 bits, XMH_SCAN_BITS=2 also 65..128) against k_scan_hist_m
+    (XMH_SCAN_BITS=0): same plan, same chunks, same pair-cache layout -- histograms, caps AND credits bit for bit; ragged chunks,
+    surplus query columns, code lengths that do not fill their last word, 1..128 classes."""
+    for (Q, R, K, C, p, k) in ((150, 9001, 256, 80, 0.06, 9), (17, 130, 256, 5, 0.3, 3), (64, 8157, 200, 33, 0.2, 85), (33, 4096, 129, 128, 0.05, None),
+                               (70, 9100, 128, 80, 0.06, None), (20, 700, 160, 24, 0.2, 11), (5, 70000, 96, 1, 0.5, 100), (130, 20011, 224, 97, 0.03, None)):
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R, p=p)
+        outs = []
+        for flag in ("0", "2"):
+            monkeypatch.setenv("XMH_SCAN_BITS", flag)
+            q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+            scan = xr.RankingScan(q, xr.pack_labels(qL.cuda()), r, xr.pack_labels(rL.cuda()), C)
+            import bench_roofline
+            assert ("k_scan_hist_b" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (flag == "2")
+            ha, hr = scan.histograms(True)
+            ap, cap = scan.ap_sums(k)
+            outs.append((ha.clone(), hr.clone(), cap.clone(), ap.clone()))
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y), (Q, R, K, C)
+
+
 def test_scan_many_evaluations_after_one_histogram_pass(xr):
     """One xmh_hamming_hist, then several evaluations with different k on the same workspace: the offsets pass 1 left behind are
     reused, the finalize ticket puts itself back to zero (a stale ticket would leave map_out unwritten), and a sharded-style
