@@ -555,7 +555,7 @@ def test_sharded_fuzz_random_splits(xr):
     from the one-kernel form, partial AP sums added up == the unsharded scan (bit-exact caps, 1e-6 sums)."""
     rng = np.random.default_rng(31)
     for case in range(12):
-        K = int(rng.choice([16, 64, 128, 512]))
+        K = int(rng.choice([16, 64, 128, 256, 512]))              # 256: pass 1 with the operands built from the packed bits
         Q, R, C = int(rng.choice([5, 64, 97])), int(rng.choice([300, 2000, 5003])), int(rng.choice([3, 24, 80]))
         world = int(rng.integers(2, 6))
         cuts = np.sort(rng.choice(np.arange(1, R), size=world - 1, replace=False))
@@ -579,7 +579,7 @@ def test_sharded_fuzz_random_splits(xr):
         assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9), (case, Q, R, K, world, bounds)
 
 
-@pytest.mark.parametrize("Q,R,K,C,world,k", [(300, 9001, 64, 80, 4, None), (130, 5000, 16, 24, 2, 9), (200, 7000, 128, 40, 8, None),
+@pytest.mark.parametrize("Q,R,K,C,world,k", [(300, 9001, 64, 80, 4, None), (130, 5000, 16, 24, 2, 9), (200, 7000, 128, 40, 8, None), (150, 6001, 256, 80, 3, 50),
                                              (100, 3, 64, 10, 4, None)])
 def test_sharded_all_to_all_exchange_by_query_slice(xr, Q, R, K, C, world, k):
     """The all-to-all form of the sharded evaluation with the `world` ranks played by one process: every shard's totals table cut
