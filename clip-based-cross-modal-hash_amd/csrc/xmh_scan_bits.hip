@@ -15,7 +15,7 @@
 // LDS ring, no barrier; LDS holds the counters only (K = 256: 66 KB per block of 4 waves, two blocks per CU).
 // The pair cache (16-bit entries, distance << 1 | relevant) is written in k_scan_hist_m's layout for the cached pass 2, and the
 // items of a 16-item group sit in the same C rows (row r <-> item 16 g + 4 (r & 3) + (r >> 2)), so pass 2 is unchanged.
-// NOT compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (xmh_topk.hip is): with the results in VGPRs hipcc re-materialises the label
+// NOT compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (no file of the library is): with the results in VGPRs hipcc re-materialises the label
 // chain's start value (v_mov_b64 into the quad) three instructions behind the MFMA that still reads that quad as srcC, and the
 // hardware takes the new value -- wrong distances by a few units for K = 256 (found with tools/diag_bits.py).  In the default
 // AGPR form the start values go through v_accvgpr_write and the hazard table covers them.
