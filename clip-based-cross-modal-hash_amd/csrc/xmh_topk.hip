@@ -536,7 +536,8 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
     constexpr int QG = 16;
     const int64_t lo = (int64_t)blockIdx.x * stride;
     const int64_t hi = (lo + per_block < R) ? lo + per_block : R;
-    for (int q0 = 0; q0 < Q; q0 += QG) {
+    // many queries (no fold): the groups of 16 queries are spread over blockIdx.y -- 64 queries in one block were 52 us of a 200 us call
+    for (int q0 = blockIdx.y * QG; q0 < Q; q0 += QG * gridDim.y) {
         const int nq = (Q - q0 < QG) ? Q - q0 : QG;
         for (int e = threadIdx.x; e < nq * nb; e += kThreads) sh[e] = 0u;
         __syncthreads();
@@ -1117,7 +1118,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         const size_t slds = (size_t)16 * nb * 4;
 #define XMH_FAST(WW, II)                                                                                                   \
         {                                                                                                                  \
-            hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
+            hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096)), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
                                per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
