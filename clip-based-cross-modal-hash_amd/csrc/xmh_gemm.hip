@@ -6,7 +6,8 @@
 //   g16   k_gemm_g16: the fp16-MFMA GEMM of parity and fast mode.  Operands are fp16 "planes" in memory (xmh_planes.h), staged by
 //         LDS-DMA into a swizzled, double-buffered LDS tile; parity mode = two activation planes (x = hi + lo) x one or two
 //         weight planes, every fp16 x fp16 product exact in fp32, 2^-22 relative error per product, 2-3 MFMAs per product;
-//         fast mode = one plane per operand.  Peak 2.5 PFLOP/s (1.25 useful in parity mode).  See the comment at the kernel.
+//         fast mode = one plane per operand.  Peak 2.5 PFLOP/s (1.25 useful in parity mode); what the chip sustains on random
+//         operands with nothing but MFMAs issued is 1.64-1.85 PFLOP/s (power).  See the comment at the kernel.
 //   f32   k_gemm_nt_f32, v_mfma_f32_32x32x2_f32: exact fp32 products -- "exact mode" and unaligned shapes; peak 157 TFLOP/s;
 //         register-staged, LDS rows padded so that the ds_read_b128 of a 16-lane group lands on 16 distinct 16-byte slots.
 //   f16   k_gemm_nt_f16: fp32 operands rounded to fp16 while staged -- fast mode for shapes the planes kernel does not take (K % 32).
@@ -29,6 +30,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int kThreads = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum Act { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3, ACT_RELU = 4 };
@@ -352,12 +354,15 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(GemmArgs g) {
 // computed them, so the k-loop moves bytes and issues MFMAs and nothing else:
 //   * global_load_lds_dwordx4 (1 KB per wave instruction) straight into a double-buffered LDS tile, next tile in flight under the
 //     MFMAs of the current one, ONE barrier per k-step (s_waitcnt vmcnt(0); s_barrier; issue next; compute);
-//   * LDS tile = [rows][BK halves], 16-byte chunk c of row r stored at chunk c ^ ((r / RPB) & (CH-1)) (CH chunks per row, RPB
-//     rows per 256-byte bank row): the 16 lanes of every ds_read_b128 group -- 16 different rows, one k chunk -- cover all 16
-//     slots of the bank row.  LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address (same
-//     128-byte line, chunks swapped) and again on the read;
-//   * v_mfma_f32_32x32x16_f16, slabs of 16 in k order, per slab  acc += a_lo*w_hi; acc += a_hi*w_lo; acc += a_hi*w_hi  (the
-//     terms that exist): every tile shape and BK walks k in the same order, so results do not depend on the dispatch;
+//   * LDS tile = [rows][BK halves], 16-byte chunk c of row r stored at chunk c ^ g16_chunk_swz(r): the 16 lanes of every
+//     ds_read_b128 group cover all 16 slots of the 256-byte bank row (derivation at g16_chunk_swz).  LDS-DMA writes lane-linear, so
+//     the permutation is applied to the per-lane SOURCE address (same 128-byte line, chunks swapped) and again on the read;
+//   * v_mfma_f32_16x16x32_f16, slabs of 32 in k order, per slab  acc += a_lo*w_hi; acc += a_hi*w_lo; acc += a_hi*w_hi  (the
+//     terms that exist): every tile shape and BK walks k in the same order, so results do not depend on the dispatch.
+//     Round 4: 16x16x32 instead of 32x32x16.  The chip is POWER-bound on these kernels (tools/ubench_mfma_power.hip: a loop of
+//     nothing but independent MFMAs on uniform random fp16 data sustains 1.64 PFLOP/s with 32x32x16 -- the clock drops to 1.62 GHz
+//     -- and 1.85 PFLOP/s with 16x16x32, which touches each accumulator half as often per flop; zeros run 2.45 on both).  Same
+//     LDS reads, same registers, twice the MFMA instructions: +9-16 % on the ViT-B/32 shapes (tools/proto_gemm_pp.hip);
 //   * tiles are numbered for the XCD's L2: block -> XCD-contiguous id range, inside it groups of 8 tile rows x all tile columns;
 //   * epilogue through LDS: accumulators -> the wave's own fp32 region -> 16-byte row pieces; bias / activation / residual there,
 //     then fp32 C (dwordx4) and / or the operand planes of the result (8 bytes per plane and lane) for the next GEMM.
@@ -386,16 +391,23 @@ __device__ __forceinline__ float act_ct(float x) {
     return x;
 }
 
-// the wave's (32 MI) x (32 NJ) accumulators -> memory, 32 rows at a time through the wave's own [32][32 NJ] fp32 LDS region:
-// written in C layout (lane = column, 16 rows per lane), read back as 16-byte row pieces, so that bias / activation / residual
-// and the stores work on 4 consecutive columns: fp32 C as dwordx4, operand planes as 8 bytes per plane.
+// the wave's (32 MI) x (32 NJ) accumulators -> memory, 32 rows at a time through the wave's own [32][32 NJ + 4] fp32 LDS region:
+// written in the 16x16 C layout (lane = column l & 15, rows 4 (l >> 4) + e; the 4 floats of row padding put the four lane groups
+// of a ds_write_b32 on two bank halves: 2-way, which a store does not pay for), read back as 16-byte row pieces, so that bias /
+// activation / residual and the stores work on 4 consecutive columns: fp32 C as dwordx4, operand planes as 8 bytes per plane.
+template <int NJ>
+struct G16Epi {
+    static constexpr int TW = 32 * NJ, RS = TW + 4, LPR = TW / 4;   // region width in floats, row stride, 16-byte pieces per row
+    static constexpr int kWaveBytes = 32 * RS * 4;
+};
+
 template <int ACT, int MI, int NJ>
-__device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][NJ], char* lds, int wave, int lane, int row0, int col0) {
-    constexpr int TW = 32 * NJ, LPR = TW / 4;                      // region width in floats, 16-byte pieces per row
+__device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x4 (&acc)[2 * MI][2 * NJ], char* lds, int wave, int lane, int row0, int col0) {
+    typedef G16Epi<NJ> E;
+    constexpr int RS = E::RS, LPR = E::LPR;
     constexpr bool kFixedCol = 64 % LPR == 0;                      // every pass of the 64 lanes covers whole rows: a lane keeps its columns
-    float* reg = reinterpret_cast<float*>(lds) + wave * (32 * TW);
-    const float4* reg4 = reinterpret_cast<const float4*>(lds) + wave * (32 * LPR);
-    const int fr = lane & 31, fh = lane >> 5;
+    float* reg = reinterpret_cast<float*>(lds + wave * E::kWaveBytes);
+    const int c16 = lane & 15, g4 = lane >> 4;
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.ldr % 4 == 0) && (g.ldo % 4 == 0);
     const xmh::Planes op{g.O_hi, g.O_lo, g.ldo};
     // C and residual are the same buffer in the blocks' x += ... GEMMs.  Every lane reads exactly the addresses it then writes and
@@ -420,14 +432,16 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * TW + j * 32 + fr] = acc[i][j][e];
+            for (int j = 0; j < 2 * NJ; ++j)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {                         // the region is contiguous: piece f of the slab = float4 f
+                for (int e = 0; e < 4; ++e) reg[(i2 * 16 + 4 * g4 + e) * RS + j * 16 + c16] = acc[2 * i + i2][j][e];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int f = it * 64 + lane;
             const int r = f / LPR, col = col0 + (f % LPR) * 4;
-            const float4 v4 = reg4[f];
+            const float4 v4 = *reinterpret_cast<const float4*>(reg + r * RS + (f % LPR) * 4);
             const int64_t row = row0 + i * 32 + r;
             if (row >= g.M || col >= g.N) continue;
             if (!kFixedCol) bv = bias_at(col);
@@ -455,20 +469,31 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x16 (&acc)[MI][
     }
 }
 
+// Swizzle of the 16-byte chunks of an LDS row for v_mfma_f32_16x16x32_f16 fragments (lane l = row l & 15, k chunk l >> 4 of a slab
+// of 32).  The lane groups of a ds_read_b128 are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35, 44-47, 52-59}, {36-43, 48-51,
+// 60-63}: each is the 16 rows of the fragment with rows 4-11 one chunk further than rows 0-3 and 12-15.  With BK = 64 (two rows
+// per 256-byte bank row) chunk ^ ((r / 2) & 7) puts the 8 rows of either parity on 8 distinct chunks; with BK = 32 (four rows per
+// bank row) the rows r, r + 4, r + 8, r + 12 share their 64 bytes of the bank row and chunk ^ (-(r / 4) & 3) separates them
+// (chunk ^ ((r / 4) & 3), right for the 32-row fragments this kernel used before, is 2-way here).
+template <int BK>
+__device__ __forceinline__ int g16_chunk_swz(int r) {
+    constexpr int CH = BK / 8, RPB = 16 / CH;
+    return (BK == 32 ? -(r / RPB) : r / RPB) & (CH - 1);
+}
+
 template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
     constexpr int NWAVE = WM * WN;
     constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
-    constexpr int CH = BK / 8, RPB = 16 / CH, RPP = 64 / CH;        // chunks per row, rows per bank row, rows per 1 KB piece
+    constexpr int CH = BK / 8, RPP = 64 / CH;                       // chunks per row, rows per 1 KB piece
     constexpr int ROWB = BK * 2;
     constexpr int PA = TBM / RPP, PW = TBN / RPP;                   // 1 KB pieces per operand plane
     constexpr int NPIECE = NA * PA + NW * PW;
     static_assert(NPIECE % NWAVE == 0, "pieces per wave");
     constexpr int PPW = NPIECE / NWAVE;
     constexpr int BUFB = NPIECE * 1024;
-    constexpr int TW = 32 * NJ;                                     // epilogue: the wave's region is [32][TW] fp32
-    static_assert(2 * BUFB >= NWAVE * 32 * TW * 4, "the epilogue regions fit the staging buffers");
-    static_assert((32 * TW / 4) % 64 == 0, "epilogue: whole passes of 64 lanes");
+    constexpr int MF = 2 * MI, NF = 2 * NJ;                         // 16 x 16 fragments per wave
+    static_assert((32 * 32 * NJ / 4) % 64 == 0, "epilogue: whole passes of 64 lanes");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
     int tm, tn;
@@ -487,7 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
     const int m0 = tm * TBM, n0 = tn * TBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
-    const int fr = lane & 31, fh = lane >> 5;
+    const int r16 = lane & 15, kc = lane >> 4;
 
     // staging: piece p = j * NWAVE + wave; pieces [0, NA*PA) the A planes, then the W planes
     const _Float16* src[PPW];
@@ -507,7 +532,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
             const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
             base = (q / PW == 0 ? g.W0 : g.W1) + (int64_t)rg * g.ldw;
         }
-        src[j] = base + ((lane % CH) ^ ((r / RPB) & (CH - 1))) * 8;
+        src[j] = base + ((lane % CH) ^ g16_chunk_swz<BK>(r)) * 8;
     }
     auto stage = [&](int buf, int k0) {
 #pragma unroll
@@ -518,15 +543,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
         }
     };
 
-    f32x16 acc[MI][NJ];
+    f32x4 acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
 
-    const int swz = (fr / RPB) & (CH - 1);      // wm, wn, i*32 are multiples of 32: the swizzle depends on fr only
+    const int swz = g16_chunk_swz<BK>(r16);     // wm, wn, i*16 are multiples of 16: the swizzle depends on r16 only
     const int nk = g.K / BK;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -537,38 +562,38 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgsP g) {
         const char* bA = lds + buf * BUFB;
         const char* bW = bA + NA * PA * 1024;
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {                        // k slabs of 16: lane half fh takes chunk 2s + fh
-            const int coff = ((2 * s + fh) ^ swz) * 16;
-            f16x8 b[NJ], bl[NW == 2 ? NJ : 1], a[MI], ah[NA == 2 ? MI : 1];
+        for (int s = 0; s < BK / 32; ++s) {                        // k slabs of 32: lane group kc takes chunk 4s + kc
+            const int coff = ((4 * s + kc) ^ swz) * 16;
+            f16x8 b[NF], bl[NW == 2 ? NF : 1], a[MF], ah[NA == 2 ? MF : 1];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+            for (int j = 0; j < NF; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 16 + r16) * ROWB + coff);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + (wm + i * 32 + fr) * ROWB + coff);
+            for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + (wm + i * 16 + r16) * ROWB + coff);
             // low parts first: the small terms meet the accumulator before the large ones of this slab
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
             if (NA == 2) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) ah[i] = *reinterpret_cast<const f16x8*>(bA + PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+                for (int i = 0; i < MF; ++i) ah[i] = *reinterpret_cast<const f16x8*>(bA + PA * 1024 + (wm + i * 16 + r16) * ROWB + coff);
                 if (NW == 2) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) bl[j] = *reinterpret_cast<const f16x8*>(bW + PW * 1024 + (wn + j * 32 + fr) * ROWB + coff);
+                    for (int j = 0; j < NF; ++j) bl[j] = *reinterpret_cast<const f16x8*>(bW + PW * 1024 + (wn + j * 16 + r16) * ROWB + coff);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MF; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
     }
 
-    // epilogue, 32 accumulator rows at a time: C layout (lane = column, 16 rows) -> LDS -> row pieces of 4 consecutive columns
+    // epilogue, 32 accumulator rows at a time: C layout (lane = column, 4 rows) -> LDS -> row pieces of 4 consecutive columns
     __builtin_amdgcn_s_barrier();                                  // every wave is done with the staging buffers
     const int row0 = m0 + wm, col0 = n0 + wn;
     switch (g.act) {                                               // one straight-line epilogue per activation
@@ -616,7 +641,8 @@ __global__ __launch_bounds__(256) void k_quickgelu_planes(const float* __restric
 template <int WM, int WN, int MI, int NJ, int NA, int NW, int BK, int MINB>
 int launch_g16(const GArgsP& a, hipStream_t st) {
     constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
-    constexpr size_t lds = (size_t)2 * (NA * TBM + NW * TBN) * BK * 2;
+    constexpr size_t stage_b = (size_t)2 * (NA * TBM + NW * TBN) * BK * 2, epi_b = (size_t)WM * WN * G16Epi<NJ>::kWaveBytes;
+    constexpr size_t lds = stage_b > epi_b ? stage_b : epi_b;     // the epilogue regions reuse the staging buffers
     auto kern = k_gemm_g16<WM, WN, MI, NJ, NA, NW, BK, MINB>;
     if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh gemm")) return rl;
     const int64_t nblk = xmh::ceil_div(a.M, TBM) * xmh::ceil_div(a.N, TBN);

@@ -1,0 +1,585 @@
+// Prototype bench of the ping-pong fp16 GEMM (k_gemm_pp) before it moves into xmh_gemm.hip, A/B against the round-2/3 kernel
+// (k_gemm_g16, one barrier per k-step, vmcnt(0) each step) in one process on the same random operands.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/proto_gemm_pp.hip -o /tmp/pp && /tmp/pp
+// C[M,N] = sum over NA planes of A_p[M,K] . W[N,K]^T  (NT, fp16 operands, fp32 accumulate / output).
+//
+// k_gemm_pp: 8 waves = two groups of four (waves w and w+4 share a SIMD).  Every wave alternates a MEM segment (ds_read the
+// fragments of k-tile p, issue the LDS-DMA of k-tile p+NBUF-1, counted s_waitcnt) and an MFMA segment (2 slabs of 16), each ended
+// by s_barrier; group 1 runs one barrier behind group 0, so on every SIMD one wave's MFMAs run beside the other wave's memory
+// segment.  LDS is a ring of NBUF tiles of BK = 32; loads stay in flight across barriers (vmcnt never 0 in the loop).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct GArgs {
+    const _Float16* A;      // plane 0 (lo when NA == 2)
+    const _Float16* A2;     // plane 1 (hi)
+    const _Float16* W;
+    float* C;
+    int64_t lda, ldw, ldc;
+    int M, N, K;
+    unsigned long long* tim;
+};
+
+__device__ __forceinline__ void tile_of_block(int nbm, int nbn, int b, int& tm, int& tn) {
+    const int nwg = nbm * nbn;
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tn = id / nbm;
+    tm = id % nbm;
+}
+
+template <int GM>
+__device__ __forceinline__ void regroup(int nbm, int nbn, int& tm, int& tn) {
+    if (GM > 0) {
+        const int id = tn * nbm + tm;
+        const int per = GM * nbn;
+        const int grp = id / per, rem = id % per;
+        const int gm0 = grp * GM;
+        const int gsz = nbm - gm0 < GM ? nbm - gm0 : GM;
+        tm = gm0 + rem % gsz;
+        tn = rem / gsz;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// baseline: the shipped structure (xmh_gemm.hip k_gemm_g16), trimmed
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// swizzle of the 16-byte chunks of an LDS row.  32x32x16 fragments (lane = row l&31, chunk 2s + (l>>5)): chunk ^ ((r / RPB) & (CH-1)).
+// 16x16x32 fragments (lane = row l&15, chunk 4s + (l>>4)): the ds_read_b128 lane groups are {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... =
+// 16 distinct rows with rows 4-11 one chunk further: BK = 64 (two rows per 256-byte bank row) is conflict-free with the same
+// function, BK = 32 (four rows per bank row) needs chunk ^ (-(r/4) & 3).
+template <int BK, bool M16>
+__device__ __forceinline__ int chunk_swz(int r) {
+    constexpr int CH = BK / 8, RPB = 16 / CH;
+    if (M16 && BK == 32) return (-(r / RPB)) & (CH - 1);
+    return (r / RPB) & (CH - 1);
+}
+
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int MINB, int GM, bool M16 = false>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
+    constexpr int NWAVE = WM * WN;
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr int CH = BK / 8, RPB = 16 / CH, RPP = 64 / CH;
+    constexpr int ROWB = BK * 2;
+    constexpr int PA = TBM / RPP, PW = TBN / RPP;
+    constexpr int NPIECE = NA * PA + PW;
+    static_assert(NPIECE % NWAVE == 0, "pieces per wave");
+    constexpr int PPW = NPIECE / NWAVE;
+    constexpr int BUFB = NPIECE * 1024;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    int tm, tn;
+    tile_of_block(nbm, nbn, blockIdx.x, tm, tn);
+    regroup<GM>(nbm, nbn, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
+    const int fr = lane & 31, fh = lane >> 5;
+    const _Float16* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = j * NWAVE + wave;
+        const int prow = lane / CH;
+        int r;
+        const _Float16* base;
+        if (p < NA * PA) {
+            const int pl = p / PA;
+            r = (p % PA) * RPP + prow;
+            const int rg = m0 + r < g.M ? m0 + r : g.M - 1;
+            base = (pl == 0 ? g.A : g.A2) + (int64_t)rg * g.lda;
+        } else {
+            r = (p - NA * PA) * RPP + prow;
+            const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
+            base = g.W + (int64_t)rg * g.ldw;
+        }
+        src[j] = base + ((lane % CH) ^ chunk_swz<BK, M16>(r)) * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = j * NWAVE + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BUFB + p * 1024), 16, 0, 0);
+        }
+    };
+    if (M16) {
+        // v_mfma_f32_16x16x32_f16: lane l supplies row l&15, k chunk l>>4 of a slab of 32; holds C rows 4*(l>>4)+e, column l&15
+        f32x4 c16[2 * MI][2 * NJ];
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c16[i][j][e] = 0.0f;
+        const int r16 = lane & 15, kc = lane >> 4;
+        const int swz16 = chunk_swz<BK, true>(r16);
+        const int nk = g.K / BK;
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+            const char* bA = lds + buf * BUFB;
+            const char* bW = bA + NA * PA * 1024;
+#pragma unroll
+            for (int s = 0; s < BK / 32; ++s) {
+                const int coff = ((4 * s + kc) ^ swz16) * 16;
+                f16x8 b[2 * NJ];
+#pragma unroll
+                for (int j = 0; j < 2 * NJ; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 16 + r16) * ROWB + coff);
+#pragma unroll
+                for (int pl = 0; pl < NA; ++pl) {
+                    f16x8 a[2 * MI];
+#pragma unroll
+                    for (int i = 0; i < 2 * MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 16 + r16) * ROWB + coff);
+#pragma unroll
+                    for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2 * NJ; ++j) c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], c16[i][j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * NJ; ++j) {
+                const int col = n0 + wn + j * 16 + r16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + wm + i * 16 + 4 * kc + e;
+                    if (row < g.M && col < g.N) g.C[(int64_t)row * g.ldc + col] = c16[i][j][e];
+                }
+            }
+        return;
+    }
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int swz = (fr / RPB) & (CH - 1);
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+        const char* bA = lds + buf * BUFB;
+        const char* bW = bA + NA * PA * 1024;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int coff = ((2 * s + fh) ^ swz) * 16;
+            f16x8 b[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+#pragma unroll
+            for (int pl = 0; pl < NA; ++pl) {
+                f16x8 a[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn + j * 32 + fr;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < g.M) g.C[(int64_t)row * g.ldc + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ping-pong kernel.  ABL: 0 plain; 1 no setprio; 2 persistent loop over tiles (grid = min(tiles, CUs)); 3 = 2 without setprio
+// EPI: 0 direct dword stores from the C layout; 1 through LDS as 16-byte row pieces
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int MI, int NJ, int NA, int NBUF, int ABL, int EPI, int GM>
+__global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
+    constexpr int WN = 4, NWAVE = 8;
+    constexpr int TBM = 64 * MI, TBN = 128 * NJ;
+    constexpr int CH = 4, RPB = 4, RPP = 16, ROWB = 64, BK = 32;
+    constexpr int PA = TBM / RPP, PW = TBN / RPP;
+    constexpr int NPIECE = NA * PA + PW;
+    constexpr int PPW = (NPIECE + NWAVE - 1) / NWAVE;               // a wave without a piece of its own in the last round repeats piece NPIECE-1
+    constexpr int BUFB = NPIECE * 1024;
+    constexpr bool kPersist = ABL == 2 || ABL == 3;
+    constexpr bool kPrio = ABL == 0 || ABL == 2 || ABL >= 4;
+    constexpr bool kNoStage = ABL == 4 || ABL == 8;
+    static_assert(NBUF >= 3, "ring: one tile being read, one being waited for, one being written");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    const int ntile = nbm * nbn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int swz = (fr / RPB) & (CH - 1);
+    const int nk = g.K / BK;
+
+    // this block's tiles: b, b + gridDim, ...; the k-tiles of consecutive output tiles form ONE stream through the ring
+    const int ntb = kPersist ? (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int nq = ntb * nk;                                        // k-tiles this block walks
+
+    const _Float16* src[PPW];
+    auto set_tile = [&](int t, int& m0, int& n0) {
+        int tm, tn;
+        tile_of_block(nbm, nbn, t, tm, tn);
+        regroup<GM>(nbm, nbn, tm, tn);
+        m0 = tm * TBM;
+        n0 = tn * TBN;
+    };
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            int p = j * NWAVE + wave;
+            if (p > NPIECE - 1) p = NPIECE - 1;
+            const int prow = lane / CH;
+            int r;
+            const _Float16* base;
+            if (p < NA * PA) {
+                const int pl = p / PA;
+                r = (p % PA) * RPP + prow;
+                const int rg = m0 + r < g.M ? m0 + r : g.M - 1;
+                base = (pl == 0 ? g.A : g.A2) + (int64_t)rg * g.lda;
+            } else {
+                r = (p - NA * PA) * RPP + prow;
+                const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
+                base = g.W + (int64_t)rg * g.ldw;
+            }
+            src[j] = base + ((lane % CH) ^ ((r / RPB) & (CH - 1))) * 8;
+            if (ABL == 5) src[j] = g.W + (int64_t)(((n0 + (p % PW) * 8 + lane / 8) % g.N)) * g.ldw + (lane % 8) * 8;   // timing only: 8 rows x 128 B per piece
+        }
+    };
+    auto stage = [&](int buf, int k0) {
+        if (kNoStage) return;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            int p = j * NWAVE + wave;
+            if (p > NPIECE - 1) p = NPIECE - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BUFB + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staging cursor: (tile index in this block's list, k-tile) of the next k-tile to issue
+    int st_t = 0, st_k = 0, st_buf = 0;
+    int sm0, sn0;
+    set_tile(blockIdx.x, sm0, sn0);
+    set_src(sm0, sn0);
+    auto stage_next = [&]() {                                       // issue the next k-tile of the stream (caller checks there is one)
+        stage(st_buf, st_k * BK);
+        st_buf = st_buf + 1 == NBUF ? 0 : st_buf + 1;
+        if (++st_k == nk) {
+            st_k = 0;
+            ++st_t;
+            if (kPersist && st_t < ntb) {
+                set_tile(blockIdx.x + st_t * gridDim.x, sm0, sn0);
+                set_src(sm0, sn0);
+            }
+        }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (issued < nq) { stage_next(); ++issued; }
+    // k-tile 0 landed (own pieces): at most the younger NBUF-2 tiles may be outstanding
+    if (nq >= NBUF - 1) wait_vm<(NBUF - 2) * PPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one barrier behind
+
+    int cm0, cn0;                                                   // output tile being accumulated
+    set_tile(blockIdx.x, cm0, cn0);
+    int ct = 0, ck = 0, rbuf = 0;
+    unsigned long long t_mem = 0, t_b1 = 0, t_mfma = 0, t_b2 = 0, t_all = 0, w_all = 0;
+    if (ABL == 7 || ABL == 8) { t_all = __builtin_readcyclecounter(); w_all = wall_clock64(); }
+    for (int q = 0; q < nq; ++q) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        if (ABL == 7 || ABL == 8) s0 = __builtin_readcyclecounter();
+        // ---------------- MEM segment: fragments of k-tile q, LDS-DMA of k-tile q + NBUF - 1 into the buffer k-tile q-1 left
+        const char* bA = lds + rbuf * BUFB;
+        const char* bW = bA + NA * PA * 1024;
+        f16x8 fb[2][NJ], fa[2][NA][MI];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int coff = ((2 * s + fh) ^ swz) * 16;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[s][j] = (ABL == 6 && (s || j)) ? fb[0][0] : *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+#pragma unroll
+            for (int pl = 0; pl < NA; ++pl)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[s][pl][i] = (ABL == 6) ? fb[0][0] : *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
+        }
+        if (issued < nq) { stage_next(); ++issued; }
+        // k-tile q+1 must have landed before anyone reads it (the other group reads one barrier later than this wait, this group two):
+        // tiles q+2 .. issued-1 may stay in flight; also retire this wave's ds_reads so the buffer can be refilled after the barrier
+        {
+            const int inflight = issued - (q + 2);                  // younger tiles than q+1
+            if (inflight >= NBUF - 2) wait_vm_lgkm0<(NBUF - 2) * PPW>();
+            else if (NBUF > 3 && inflight == 1) wait_vm_lgkm0<1 * PPW>();
+            else if (NBUF > 4 && inflight == 2) wait_vm_lgkm0<2 * PPW>();
+            else wait_vm_lgkm0<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL == 7 || ABL == 8) s1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        if (ABL == 7 || ABL == 8) s2 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA segment
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < NA; ++pl)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][pl][i], fb[s][j], acc[i][j], 0, 0, 0);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+        if (++ck == nk) {
+            // ---------------- output tile done: store, zero, next
+            ck = 0;
+            if (EPI == 0) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int col = cn0 + wn + j * 32 + fr;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = cm0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                            if (row < g.M && col < g.N) g.C[(int64_t)row * g.ldc + col] = acc[i][j][e];
+                        }
+                    }
+            } else {
+                // the wave's own 4 KB region behind the ring: one 32 x 32 accumulator at a time, C layout in, 16-byte row pieces out
+                float* reg = reinterpret_cast<float*>(lds + NBUF * BUFB) + wave * 1024;
+                const float4* reg4 = reinterpret_cast<const float4*>(reg);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = acc[i][j][e];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int f = it * 64 + lane;
+                            const int r = f >> 3, c = (f & 7) * 4;
+                            const float4 v = reg4[f];
+                            const int row = cm0 + wm + i * 32 + r, col = cn0 + wn + j * 32 + c;
+                            if (row < g.M && col < g.N) *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = v;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            ++ct;
+            if (kPersist && ct < ntb) set_tile(blockIdx.x + ct * gridDim.x, cm0, cn0);
+        }
+        if (ABL == 7 || ABL == 8) s3 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL == 7 || ABL == 8) { s4 = __builtin_readcyclecounter(); t_mem += s1 - s0; t_b1 += s2 - s1; t_mfma += s3 - s2; t_b2 += s4 - s3; }
+    }
+    if ((ABL == 7 || ABL == 8) && lane == 0 && blockIdx.x < 64) {
+        unsigned long long* o = g.tim + (blockIdx.x * 8 + wave) * 8;
+        o[0] = __builtin_readcyclecounter() - t_all; o[1] = wall_clock64() - w_all; o[2] = t_mem; o[3] = t_b1; o[4] = t_mfma; o[5] = t_b2; o[6] = nq;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+__global__ void k_ref(GArgs g, int na, float* out, int rows) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * g.N) return;
+    const int m = (int)((int64_t)(idx / g.N) * g.M / rows), n = (int)(idx % g.N);
+    double s = 0.0;
+    for (int k = 0; k < g.K; ++k) {
+        double a = (double)(float)g.A[(int64_t)m * g.lda + k];
+        if (na == 2) a += (double)(float)g.A2[(int64_t)m * g.lda + k];
+        s += a * (double)(float)g.W[(int64_t)n * g.ldw + k];
+    }
+    out[idx] = (float)s;
+}
+
+__global__ void k_fill(_Float16* p, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (_Float16)(((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale);
+    }
+}
+
+static int g_refrows = 64;
+static float* g_ref = nullptr;
+static float* g_keep = nullptr;      // the baseline's full C, for the bit-identity check
+
+struct Res { float ms; double relerr; long long diff; };
+
+template <typename K>
+Res time_kernel(K kern, const GArgs& g, int nblk, int nthr, size_t ldsb, int iters, int na, const char* name, bool keep) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(g.C, 0xff, (size_t)g.M * g.ldc * 4));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), ldsb, 0, g);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), ldsb, 0, g);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    std::vector<float> hc((size_t)g.M * g.N), hr((size_t)g_refrows * g.N);
+    CK(hipMemcpy(hc.data(), g.C, hc.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hr.data(), g_ref, hr.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0;
+    for (int r = 0; r < g_refrows; ++r) {
+        const int m = (int)((int64_t)r * g.M / g_refrows);
+        for (int n = 0; n < g.N; ++n) {
+            const double d = fabs((double)hc[(size_t)m * g.N + n] - hr[(size_t)r * g.N + n]);
+            maxerr = std::max(maxerr, d != d ? 1e30 : d);
+            maxref = std::max(maxref, (double)fabsf(hr[(size_t)r * g.N + n]));
+        }
+    }
+    long long diff = -1;
+    if (keep) CK(hipMemcpy(g_keep, g.C, hc.size() * 4, hipMemcpyDeviceToDevice));
+    else {
+        std::vector<float> hk(hc.size());
+        CK(hipMemcpy(hk.data(), g_keep, hk.size() * 4, hipMemcpyDeviceToHost));
+        diff = 0;
+        for (size_t i = 0; i < hc.size(); ++i) diff += memcmp(&hc[i], &hk[i], 4) != 0;
+    }
+    if (strstr(name, "abl7") || strstr(name, "abl8")) {
+        std::vector<unsigned long long> ht(64 * 8 * 8);
+        CK(hipMemcpy(ht.data(), g.tim, ht.size() * 8, hipMemcpyDeviceToHost));
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < 8; w += 4) {
+                const unsigned long long* o = &ht[(b * 8 + w) * 8];
+                const double n = (double)o[6];
+                printf("      block %d wave %d: %llu cycles, %llu wall ticks (100 MHz) -> %.0f MHz; per k-tile: MEM %.0f  barrier %.0f  MFMA %.0f  barrier %.0f  (sum %.0f)\n", b, w,
+                       o[0], o[1], o[0] / (o[1] / 100.0), o[2] / n, o[3] / n, o[4] / n, o[5] / n, (o[2] + o[3] + o[4] + o[5]) / n);
+            }
+    }
+    const double tf = 2.0 * g.M * g.N * g.K * na / ms / 1e9;
+    printf("  %-44s %4d blocks  %8.4f ms  %8.1f TF MFMA (useful %7.1f)  rel err %.2e  bits differing from baseline %lld\n", name, nblk, ms, tf,
+           tf / na, maxerr / maxref, diff);
+    fflush(stdout);
+    return Res{ms, maxerr / maxref, diff};
+}
+
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int MINB, int GM, bool M16 = false>
+Res run_base(const GArgs& g, int iters, bool keep) {
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr size_t ldsb = (size_t)2 * (NA * TBM + TBN) * BK * 2;
+    char name[128];
+    snprintf(name, sizeof name, "base %dx%d w%dx%d(%dx%d) NA%d BK%d mb%d%s", TBM, TBN, WM, WN, MI, NJ, NA, BK, MINB, M16 ? " 16x16x32" : "");
+    const int nblk = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    return time_kernel(k_gemm_g16<WM, WN, MI, NJ, NA, BK, MINB, GM, M16>, g, nblk, 64 * WM * WN, ldsb, iters, NA, name, keep);
+}
+
+template <int MI, int NJ, int NA, int NBUF, int ABL, int EPI, int GM>
+Res run_pp(const GArgs& g, int iters) {
+    constexpr int TBM = 64 * MI, TBN = 128 * NJ;
+    constexpr size_t ldsb = (size_t)NBUF * (NA * TBM + TBN) * 64 + (EPI ? 32768 : 0);
+    static_assert(ldsb <= 163840, "LDS");
+    char name[128];
+    snprintf(name, sizeof name, "pp   %dx%d (%dx%d) NA%d ring%d abl%d epi%d gm%d", TBM, TBN, MI, NJ, NA, NBUF, ABL, EPI, GM);
+    int nblk = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    if ((ABL == 2 || ABL == 3) && nblk > 256) nblk = 256;
+    return time_kernel(k_gemm_pp<MI, NJ, NA, NBUF, ABL, EPI, GM>, g, nblk, 512, ldsb, iters, NA, name, false);
+}
+
+int main(int argc, char** argv) {
+    const int shapes[][3] = {{4096, 4096, 4096}, {5000, 2304, 768}, {5000, 768, 768}, {5000, 3072, 768}, {5000, 768, 3072}, {20000, 2304, 768},
+                             {20000, 768, 768}, {20000, 3072, 768}, {20000, 768, 3072}, {3200, 1536, 512}, {3200, 512, 2048}, {8192, 8192, 8192}};
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    int si = 0;
+    for (auto& s : shapes) {
+        if (only >= 0 && si++ != only) continue;
+        const int M = s[0], N = s[1], K = s[2];
+        _Float16 *A, *A2, *W;
+        float* C;
+        CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&A2, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
+        CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&g_keep, (size_t)M * N * 4));
+        CK(hipMalloc(&g_ref, (size_t)g_refrows * N * 4));
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, A, (int64_t)M * K, 1u, 1.0f);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, A2, (int64_t)M * K, 2u, 0.001f);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, W, (int64_t)N * K, 3u, 1.0f);
+        unsigned long long* tim;
+        CK(hipMalloc(&tim, 64 * 8 * 8 * 8));
+        GArgs g{A, A2, W, C, K, K, N, M, N, K, tim};
+        printf("M=%d N=%d K=%d\n", M, N, K);
+        const int iters = 20;
+        // ---- fast mode (one plane per operand)
+        hipLaunchKernelGGL(k_ref, dim3((g_refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, g_ref, g_refrows);
+        run_base<4, 2, 1, 2, 1, 64, 2, 8>(g, iters, true);
+        run_base<4, 2, 1, 2, 1, 64, 2, 8, true>(g, iters, false);
+        run_base<2, 4, 4, 2, 1, 64, 1, 8>(g, iters, false);
+        run_base<2, 4, 4, 2, 1, 64, 1, 8, true>(g, iters, false);
+        hipLaunchKernelGGL(k_ref, dim3((g_refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, g_ref, g_refrows);
+        run_base<2, 4, 2, 2, 2, 32, 1, 8>(g, iters, true);
+        run_base<2, 4, 2, 2, 2, 32, 1, 8, true>(g, iters, false);
+        run_base<2, 2, 2, 3, 2, 32, 2, 8>(g, iters, false);
+        run_base<2, 2, 2, 3, 2, 32, 2, 8, true>(g, iters, false);
+        run_base<2, 4, 1, 1, 2, 64, 2, 8>(g, iters, false);
+        run_base<2, 4, 1, 1, 2, 64, 2, 8, true>(g, iters, false);
+        run_base<2, 2, 2, 2, 2, 32, 3, 8>(g, iters, false);
+        run_base<2, 2, 2, 2, 2, 32, 3, 8, true>(g, iters, false);
+        CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(g_ref)); CK(hipFree(g_keep));
+    }
+    return 0;
+}
