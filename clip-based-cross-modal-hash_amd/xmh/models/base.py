@@ -14,8 +14,6 @@ from .weights import synth_clip_state_dict
 
 class BaseModel(nn.Module):
 
-    DEFAULT_CONFIG_FILE = {"base": "confing/base.yaml"}
-
     def __init__(self, cfg=None):
         super().__init__()
         self.cfg = cfg
@@ -56,11 +54,9 @@ class BaseModel(nn.Module):
         raise NotImplementedError()
 
     def forward(self, image, text, labels=None, indexs=None, return_loss=False):
-        image_embed = self.encode_image(image)
-        text_embed = self.encode_text(text)
-        if return_loss:
-            return self.object_function(image_embed, text_embed, labels=labels, indexs=indexs)
-        return image_embed, text_embed
+        """both towers; with ``return_loss`` the method's objective instead of the pair (reference models/base.py:52-60)"""
+        embeds = (self.encode_image(image), self.encode_text(text))
+        return self.object_function(*embeds, labels=labels, indexs=indexs) if return_loss else embeds
 
     @classmethod
     def from_config(cls, cfg, output_dim=None, train_num=None):
@@ -73,8 +69,3 @@ class BaseModel(nn.Module):
     def unfreezen(self):
         for p in self.parameters():
             p.requires_grad = True
-
-    @classmethod
-    def default_config_path(cls, model_type):
-        assert model_type in cls.DEFAULT_CONFIG_FILE, "Unknown model type {}".format(model_type)
-        return os.path.join(cls.DEFAULT_CONFIG_FILE[model_type])

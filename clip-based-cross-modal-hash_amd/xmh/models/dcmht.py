@@ -124,6 +124,7 @@ class _Objective(torch.autograd.Function):
         return (loss,) + parts
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # the gradient kernels are not themselves differentiable: fail loudly on double backward
     def backward(ctx, g, *_):
         a, b, lab = ctx.saved_tensors
         m, C = ctx.model, ctx.C

@@ -11,6 +11,8 @@ Reference counterparts (file:line under the reference repo):
 from __future__ import annotations
 
 import ctypes as C
+import os
+import warnings
 from dataclasses import dataclass
 from typing import Optional
 
@@ -198,6 +200,28 @@ def scan_plan(Q: int, R: int, K: int, ternary: bool) -> _lib.ScanPlan:
     return p
 
 
+def _plan_and_workspace(Q: int, R: int, K: int, ternary: bool, device):
+    """Plan the scan and allocate its workspace.  The plan includes the pair cache (one or two bytes per (query, item) pair, up to
+    XMH_SCAN_CACHE_MB, default 32 GB) whenever the shape has one -- sized for an empty 288 GB device, not for what is free next to
+    a resident encoder.  When the workspace does not fit, the cache cap is lowered for this process (the library reads
+    XMH_SCAN_CACHE_MB per call, so plan, pass 1 and pass 2 all see the same value) and the scan runs uncached: slower, never an
+    out-of-memory error for a shape that ran before the cache existed."""
+    plan = scan_plan(Q, R, K, ternary)
+    free, _ = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the caching allocator's idle blocks count
+    if plan.ws_bytes <= 0.9 * free:
+        try:
+            return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
+        except torch.cuda.OutOfMemoryError:
+            pass
+    before = plan.ws_bytes
+    os.environ["XMH_SCAN_CACHE_MB"] = "0"
+    plan = scan_plan(Q, R, K, ternary)
+    warnings.warn("xmh: scan workspace of %.1f GB does not fit in %.1f GB of free device memory; pair cache switched off for this process "
+                  "(workspace now %.1f GB)" % (before / 2**30, free / 2**30, plan.ws_bytes / 2**30))
+    return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
+
+
 class RankingScan:
     """The two-pass fused scan for one (query set, gallery shard): owns the workspace and exposes the
     pieces the sharded driver needs (histogram totals, AP partial sums)."""
@@ -209,8 +233,7 @@ class RankingScan:
         q, r = widened(q), widened(r)
         self.q, self.r, self.qlab, self.rlab, self.C = q, r, qlab.contiguous(), rlab.contiguous(), Cn
         self.qz, self.rz = _both_planes(q, r)
-        self.plan = scan_plan(q.n, r.n, q.K, self.qz is not None)
-        self.ws = torch.empty(self.plan.ws_bytes, dtype=torch.uint8, device=q.bits.device)
+        self.plan, self.ws = _plan_and_workspace(q.n, r.n, q.K, self.qz is not None, q.bits.device)
 
     def _common(self):
         return (ptr(self.q.bits), ptr(self.qz), ptr(self.qlab), ptr(self.r.bits), ptr(self.rz), ptr(self.rlab),

@@ -177,6 +177,8 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
     shares; no [Q] all-reduce, no finalize launch.  ``exchange`` (map_only): "alltoall" = two all-to-alls by query slice (see
     below), "gather" = the all-gather of whole tables it replaces (kept as the checked reference), "auto" = all-to-all whenever
     the padded query count divides by the world size.  ``map_only`` is ignored for QueryBlocks (they pipeline the [Q] form)."""
+    if exchange not in ("auto", "alltoall", "gather"):
+        raise ValueError("map_k_sharded: exchange must be 'auto', 'alltoall' or 'gather', not %r" % (exchange,))
     rank = dist.get_rank(group)
     if isinstance(ops, QueryBlocks):
         m, ap, cap = _map_k_blocks(ops.blocks, k, rank, group)
@@ -185,6 +187,10 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
         t = ops.totals()                                         # pass 1; the shard's totals table where pass 1 left it
         world = dist.get_world_size(group)
         nb, qpad = t.shape[0], t.shape[1]
+        # which collective follows is decided from the table shape, and the padded query count depends on per-process
+        # environment switches (XMH_SCAN_M2, XMH_SCAN_M2_GEOM, XMH_SCAN_MFMA_AP): ranks that disagree would enter different
+        # collectives and hang until the group's timeout.  One 16-byte MIN/MAX all-reduce turns that into an error.
+        _require_same_shape(nb, qpad, hasattr(ops, "slice_offsets"), t.device, group)
         if exchange != "gather" and hasattr(ops, "slice_offsets") and qpad % world == 0:
             # all-to-all by query slice: rank j resolves the offsets of qpad / world queries for every shard.  Per rank 2 x the table
             # travels (2 x 2.6 MB at Q 5000, K 64) instead of world x (21 MB at 8 ranks), and the offsets are computed once, not
@@ -222,6 +228,25 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
     else:
         m = (ap / cap.to(torch.float64)).mean().reshape(1)       # cap == 0 -> NaN like the reference
     return m, ap, cap
+
+
+_shape_seen = {}      # process group -> the table shape the ranks last agreed on
+
+
+def _require_same_shape(nb: int, qpad: int, has_slices: bool, device, group) -> None:
+    """checked when a group is first used and whenever the local shape changes (in a consistent job every rank changes at the same
+    call), so the steady state pays nothing for it"""
+    key, shape = id(group), (nb, qpad, has_slices)
+    if _shape_seen.get(key) == shape:
+        return
+    v = torch.tensor([nb, qpad, int(has_slices)], dtype=torch.int64, device=device)
+    both = torch.stack([v, -v])                                  # MAX of (v, -v) = (max, -min)
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = both[0], -both[1]
+    if not torch.equal(hi, lo):
+        raise RuntimeError("map_k_sharded: ranks disagree on the totals table (nbuckets, padded queries, slice kernel): min %s max %s "
+                           "-- the XMH_SCAN_* environment must be the same on every rank" % (lo.tolist(), hi.tolist()))
+    _shape_seen[key] = shape
 
 
 def _offsets(ops, g, rank):

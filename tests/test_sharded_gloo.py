@@ -124,6 +124,16 @@ def _worker(rank, world, port, tmp):
             assert float(m3) == float(m2)
             with pytest.raises(ValueError):
                 sharded.map_k_sharded(ops, k, map_only=True, exchange="alltoall")             # 37 queries do not split over 2 ranks
+            with pytest.raises(ValueError):
+                sharded.map_k_sharded(ops, k, map_only=True, exchange="all-to-all")           # unknown spellings are not "auto"
+        # ranks whose tables differ in shape (a per-process XMH_SCAN_* switch changes the query padding) would enter different
+        # collectives: the shape agreement check turns the hang into an error on every rank
+        class Mispadded(PaddedOracleShardOps):
+            def totals(self):
+                t = super().totals()
+                return t if rank == 0 else torch.cat([t, torch.zeros(t.shape[0], 4, 2, dtype=t.dtype)], dim=1)
+        with pytest.raises(RuntimeError, match="ranks disagree"):
+            sharded.map_k_sharded(Mispadded(qb, ql, rb[lo:hi], rl[lo:hi], K + 1), None, map_only=True)
         # the same over query blocks (asynchronous gathers, one per block): identical results
         for nblk in (2, 3):
             qbl = sharded.shard_bounds(Q, nblk)

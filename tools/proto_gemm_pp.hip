@@ -227,21 +227,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm_g16(GArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// ping-pong kernel.  ABL: 0 plain; 1 no setprio; 2 persistent loop over tiles (grid = min(tiles, CUs)); 3 = 2 without setprio
-// EPI: 0 direct dword stores from the C layout; 1 through LDS as 16-byte row pieces
+// ping-pong kernel, v_mfma_f32_16x16x32_f16.  8 waves as WM x WN, wave tile (16 MF) x (16 NF).
+// ABL: 0 plain; 1 no setprio; 2 persistent loop over tiles (grid = min(tiles, CUs)); 4 no staging (timing only)
+// PP: 1 = group 1 one barrier behind (MFMA beside the partner's memory segment); 0 = all waves in step (two barriers per k-tile, no stagger)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int MI, int NJ, int NA, int NBUF, int ABL, int EPI, int GM>
+template <int WM, int WN, int MF, int NF, int NA, int NBUF, int ABL, int PP, int GM>
 __global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
-    constexpr int WN = 4, NWAVE = 8;
-    constexpr int TBM = 64 * MI, TBN = 128 * NJ;
-    constexpr int CH = 4, RPB = 4, RPP = 16, ROWB = 64, BK = 32;
+    constexpr int NWAVE = 8;
+    static_assert(WM * WN == NWAVE, "8 waves");
+    constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
+    constexpr int CH = 4, RPP = 16, ROWB = 64, BK = 32;
     constexpr int PA = TBM / RPP, PW = TBN / RPP;
     constexpr int NPIECE = NA * PA + PW;
     constexpr int PPW = (NPIECE + NWAVE - 1) / NWAVE;               // a wave without a piece of its own in the last round repeats piece NPIECE-1
     constexpr int BUFB = NPIECE * 1024;
-    constexpr bool kPersist = ABL == 2 || ABL == 3;
-    constexpr bool kPrio = ABL == 0 || ABL == 2 || ABL >= 4;
-    constexpr bool kNoStage = ABL == 4 || ABL == 8;
+    constexpr bool kPersist = ABL == 2;
+    constexpr bool kPrio = ABL != 1;
+    constexpr bool kNoStage = ABL == 4;
     static_assert(NBUF >= 3, "ring: one tile being read, one being waited for, one being written");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
@@ -249,14 +251,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
-    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int swz = (fr / RPB) & (CH - 1);
+    // waves w and w+4 share a SIMD: give them the same wave row so the pair reads the same A fragments
+    const int wm = (wave % WM) * 16 * MF, wn = (wave / WM) * 16 * NF;
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int swz = chunk_swz<32, true>(r16);
     const int nk = g.K / BK;
-
-    // this block's tiles: b, b + gridDim, ...; the k-tiles of consecutive output tiles form ONE stream through the ring
     const int ntb = kPersist ? (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
-    const int nq = ntb * nk;                                        // k-tiles this block walks
+    const int nq = ntb * nk;
 
     const _Float16* src[PPW];
     auto set_tile = [&](int t, int& m0, int& n0) {
@@ -284,8 +285,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
                 const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
                 base = g.W + (int64_t)rg * g.ldw;
             }
-            src[j] = base + ((lane % CH) ^ ((r / RPB) & (CH - 1))) * 8;
-            if (ABL == 5) src[j] = g.W + (int64_t)(((n0 + (p % PW) * 8 + lane / 8) % g.N)) * g.ldw + (lane % 8) * 8;   // timing only: 8 rows x 128 B per piece
+            src[j] = base + ((lane % CH) ^ chunk_swz<32, true>(r)) * 8;
         }
     };
     auto stage = [&](int buf, int k0) {
@@ -299,20 +299,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
         }
     };
 
-    f32x16 acc[MI][NJ];
+    f32x4 acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
 
-    // staging cursor: (tile index in this block's list, k-tile) of the next k-tile to issue
     int st_t = 0, st_k = 0, st_buf = 0;
     int sm0, sn0;
     set_tile(blockIdx.x, sm0, sn0);
     set_src(sm0, sn0);
-    auto stage_next = [&]() {                                       // issue the next k-tile of the stream (caller checks there is one)
+    auto stage_next = [&]() {
         stage(st_buf, st_k * BK);
         st_buf = st_buf + 1 == NBUF ? 0 : st_buf + 1;
         if (++st_k == nk) {
@@ -328,116 +327,86 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pp(GArgs g) {
 #pragma unroll
     for (int d = 0; d < NBUF - 1; ++d)
         if (issued < nq) { stage_next(); ++issued; }
-    // k-tile 0 landed (own pieces): at most the younger NBUF-2 tiles may be outstanding
     if (nq >= NBUF - 1) wait_vm<(NBUF - 2) * PPW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one barrier behind
+    if (PP && grp == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
 
-    int cm0, cn0;                                                   // output tile being accumulated
+    int cm0, cn0;
     set_tile(blockIdx.x, cm0, cn0);
     int ct = 0, ck = 0, rbuf = 0;
-    unsigned long long t_mem = 0, t_b1 = 0, t_mfma = 0, t_b2 = 0, t_all = 0, w_all = 0;
-    if (ABL == 7 || ABL == 8) { t_all = __builtin_readcyclecounter(); w_all = wall_clock64(); }
     for (int q = 0; q < nq; ++q) {
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-        if (ABL == 7 || ABL == 8) s0 = __builtin_readcyclecounter();
-        // ---------------- MEM segment: fragments of k-tile q, LDS-DMA of k-tile q + NBUF - 1 into the buffer k-tile q-1 left
+        // ---------------- MEM segment
         const char* bA = lds + rbuf * BUFB;
         const char* bW = bA + NA * PA * 1024;
-        f16x8 fb[2][NJ], fa[2][NA][MI];
+        f16x8 fb[NF], fa[NA][MF];
+        const int coff = (kc ^ swz) * 16;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int coff = ((2 * s + fh) ^ swz) * 16;
+        for (int j = 0; j < NF; ++j) fb[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 16 + r16) * ROWB + coff);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[s][j] = (ABL == 6 && (s || j)) ? fb[0][0] : *reinterpret_cast<const f16x8*>(bW + (wn + j * 32 + fr) * ROWB + coff);
+        for (int pl = 0; pl < NA; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < NA; ++pl)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[s][pl][i] = (ABL == 6) ? fb[0][0] : *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 32 + fr) * ROWB + coff);
-        }
+            for (int i = 0; i < MF; ++i) fa[pl][i] = *reinterpret_cast<const f16x8*>(bA + pl * PA * 1024 + (wm + i * 16 + r16) * ROWB + coff);
         if (issued < nq) { stage_next(); ++issued; }
-        // k-tile q+1 must have landed before anyone reads it (the other group reads one barrier later than this wait, this group two):
-        // tiles q+2 .. issued-1 may stay in flight; also retire this wave's ds_reads so the buffer can be refilled after the barrier
         {
-            const int inflight = issued - (q + 2);                  // younger tiles than q+1
+            const int inflight = issued - (q + 2);
             if (inflight >= NBUF - 2) wait_vm_lgkm0<(NBUF - 2) * PPW>();
             else if (NBUF > 3 && inflight == 1) wait_vm_lgkm0<1 * PPW>();
             else if (NBUF > 4 && inflight == 2) wait_vm_lgkm0<2 * PPW>();
             else wait_vm_lgkm0<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL == 7 || ABL == 8) s1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
-        if (ABL == 7 || ABL == 8) s2 = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA segment
         if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int pl = 0; pl < NA; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < NA; ++pl)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][pl][i], fb[s][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[pl][i], fb[j], acc[i][j], 0, 0, 0);
         if (kPrio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         rbuf = rbuf + 1 == NBUF ? 0 : rbuf + 1;
         if (++ck == nk) {
-            // ---------------- output tile done: store, zero, next
             ck = 0;
-            if (EPI == 0) {
+            // the wave's own 4 KB region behind the ring: a 32 x 32 block of four fragments at a time, C layout in, 16-byte row pieces out
+            constexpr bool kAlias = (size_t)NBUF * BUFB + 8 * 1152 * 4 > 163840;      // no room behind the ring: reuse it (every read of the last k-tile retired before the last barrier; nothing in flight)
+            static_assert(!(kAlias && kPersist), "persistent needs its own epilogue region");
+            float* reg = reinterpret_cast<float*>(lds + (kAlias ? 0 : NBUF * BUFB)) + wave * 1152;
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MF; i += 2)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int col = cn0 + wn + j * 32 + fr;
+                for (int j = 0; j < NF; j += 2) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int row = cm0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                            if (row < g.M && col < g.N) g.C[(int64_t)row * g.ldc + col] = acc[i][j][e];
-                        }
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) reg[(i2 * 16 + 4 * kc + e) * 36 + j2 * 16 + r16] = acc[i + i2][j + j2][e];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int f = it * 64 + lane;
+                        const int r = f >> 3, c = (f & 7) * 4;
+                        const float4 v = *reinterpret_cast<const float4*>(reg + r * 36 + c);
+                        const int row = cm0 + wm + i * 16 + r, col = cn0 + wn + j * 16 + c;
+                        if (row < g.M && col < g.N) *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = v;
                     }
-            } else {
-                // the wave's own 4 KB region behind the ring: one 32 x 32 accumulator at a time, C layout in, 16-byte row pieces out
-                float* reg = reinterpret_cast<float*>(lds + NBUF * BUFB) + wave * 1024;
-                const float4* reg4 = reinterpret_cast<const float4*>(reg);
+                }
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
+                for (int j = 0; j < NF; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = acc[i][j][e];
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int f = it * 64 + lane;
-                            const int r = f >> 3, c = (f & 7) * 4;
-                            const float4 v = reg4[f];
-                            const int row = cm0 + wm + i * 32 + r, col = cn0 + wn + j * 32 + c;
-                            if (row < g.M && col < g.N) *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = v;
-                        }
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
             ++ct;
             if (kPersist && ct < ntb) set_tile(blockIdx.x + ct * gridDim.x, cm0, cn0);
         }
-        if (ABL == 7 || ABL == 8) s3 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL == 7 || ABL == 8) { s4 = __builtin_readcyclecounter(); t_mem += s1 - s0; t_b1 += s2 - s1; t_mfma += s3 - s2; t_b2 += s4 - s3; }
     }
-    if ((ABL == 7 || ABL == 8) && lane == 0 && blockIdx.x < 64) {
-        unsigned long long* o = g.tim + (blockIdx.x * 8 + wave) * 8;
-        o[0] = __builtin_readcyclecounter() - t_all; o[1] = wall_clock64() - w_all; o[2] = t_mem; o[3] = t_b1; o[4] = t_mfma; o[5] = t_b2; o[6] = nq;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (PP && grp == 0) __builtin_amdgcn_s_barrier();
 }
 
 __global__ void k_ref(GArgs g, int na, float* out, int rows) {
@@ -531,16 +500,17 @@ Res run_base(const GArgs& g, int iters, bool keep) {
     return time_kernel(k_gemm_g16<WM, WN, MI, NJ, NA, BK, MINB, GM, M16>, g, nblk, 64 * WM * WN, ldsb, iters, NA, name, keep);
 }
 
-template <int MI, int NJ, int NA, int NBUF, int ABL, int EPI, int GM>
+template <int WM, int WN, int MF, int NF, int NA, int NBUF, int ABL, int PP, int GM>
 Res run_pp(const GArgs& g, int iters) {
-    constexpr int TBM = 64 * MI, TBN = 128 * NJ;
-    constexpr size_t ldsb = (size_t)NBUF * (NA * TBM + TBN) * 64 + (EPI ? 32768 : 0);
+    constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
+    constexpr size_t ring = (size_t)NBUF * (NA * TBM + TBN) * 64;
+    constexpr size_t ldsb = ring + 8 * 1152 * 4 > 163840 ? ring : ring + 8 * 1152 * 4;
     static_assert(ldsb <= 163840, "LDS");
     char name[128];
-    snprintf(name, sizeof name, "pp   %dx%d (%dx%d) NA%d ring%d abl%d epi%d gm%d", TBM, TBN, MI, NJ, NA, NBUF, ABL, EPI, GM);
+    snprintf(name, sizeof name, "pp%d  %dx%d w%dx%d(%dx%d) NA%d ring%d abl%d", PP, TBM, TBN, WM, WN, 16 * MF, 16 * NF, NA, NBUF, ABL);
     int nblk = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
-    if ((ABL == 2 || ABL == 3) && nblk > 256) nblk = 256;
-    return time_kernel(k_gemm_pp<MI, NJ, NA, NBUF, ABL, EPI, GM>, g, nblk, 512, ldsb, iters, NA, name, false);
+    if (ABL == 2 && nblk > 256) nblk = 256;
+    return time_kernel(k_gemm_pp<WM, WN, MF, NF, NA, NBUF, ABL, PP, GM>, g, nblk, 512, ldsb, iters, NA, name, false);
 }
 
 int main(int argc, char** argv) {
@@ -566,19 +536,26 @@ int main(int argc, char** argv) {
         const int iters = 20;
         // ---- fast mode (one plane per operand)
         hipLaunchKernelGGL(k_ref, dim3((g_refrows * N + 255) / 256), dim3(256), 0, 0, g, 1, g_ref, g_refrows);
-        run_base<4, 2, 1, 2, 1, 64, 2, 8>(g, iters, true);
-        run_base<4, 2, 1, 2, 1, 64, 2, 8, true>(g, iters, false);
-        run_base<2, 4, 4, 2, 1, 64, 1, 8>(g, iters, false);
-        run_base<2, 4, 4, 2, 1, 64, 1, 8, true>(g, iters, false);
+        run_base<2, 4, 4, 2, 1, 64, 1, 8, true>(g, iters, true);
+        run_pp<2, 4, 8, 4, 1, 3, 0, 1, 8>(g, iters);
+        run_pp<2, 4, 8, 4, 1, 3, 0, 0, 8>(g, iters);
+        run_pp<2, 4, 8, 4, 1, 3, 2, 1, 8>(g, iters);
+        run_pp<2, 4, 8, 4, 1, 3, 4, 1, 8>(g, iters);
         hipLaunchKernelGGL(k_ref, dim3((g_refrows * N + 255) / 256), dim3(256), 0, 0, g, 2, g_ref, g_refrows);
-        run_base<2, 4, 2, 2, 2, 32, 1, 8>(g, iters, true);
-        run_base<2, 4, 2, 2, 2, 32, 1, 8, true>(g, iters, false);
-        run_base<2, 2, 2, 3, 2, 32, 2, 8>(g, iters, false);
+        run_base<2, 4, 2, 2, 2, 32, 1, 8, true>(g, iters, true);
         run_base<2, 2, 2, 3, 2, 32, 2, 8, true>(g, iters, false);
-        run_base<2, 4, 1, 1, 2, 64, 2, 8>(g, iters, false);
         run_base<2, 4, 1, 1, 2, 64, 2, 8, true>(g, iters, false);
-        run_base<2, 2, 2, 2, 2, 32, 3, 8>(g, iters, false);
-        run_base<2, 2, 2, 2, 2, 32, 3, 8, true>(g, iters, false);
+        run_base<4, 2, 2, 4, 2, 32, 1, 8, true>(g, iters, false);      // 256 x 256, waves of 64 x 128
+        run_pp<2, 4, 4, 4, 2, 3, 0, 1, 8>(g, iters);                   // 128 x 256, waves 64 x 64
+        run_pp<2, 4, 4, 4, 2, 3, 0, 0, 8>(g, iters);
+        run_pp<2, 4, 4, 4, 2, 3, 2, 1, 8>(g, iters);
+        run_pp<4, 2, 4, 8, 2, 3, 0, 1, 8>(g, iters);                   // 256 x 256, waves 64 x 128
+        run_pp<4, 2, 4, 8, 2, 3, 0, 0, 8>(g, iters);
+        run_pp<4, 2, 4, 8, 2, 3, 4, 1, 8>(g, iters);
+        run_pp<2, 4, 8, 4, 2, 3, 0, 1, 8>(g, iters);                   // 256 x 256, waves 128 x 64
+        run_pp<2, 4, 2, 4, 2, 4, 2, 1, 8>(g, iters);                   // 64 x 256, waves 32 x 64
+        run_pp<4, 2, 2, 4, 2, 4, 2, 1, 8>(g, iters);                   // 128 x 128, waves 32 x 64
+        run_pp<2, 4, 4, 3, 2, 4, 2, 1, 8>(g, iters);                   // 128 x 192
         CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(g_ref)); CK(hipFree(g_keep));
     }
     return 0;
