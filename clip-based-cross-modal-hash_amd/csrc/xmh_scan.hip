@@ -35,6 +35,9 @@
 // wave at K=64, C=80.  The relevance test is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does
 // not form them).  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
+#include <mutex>
+#include <string.h>
+#include <vector>
 #include "xmh_scan_bits.h"
 
 #include <stdlib.h>
@@ -1919,9 +1922,19 @@ struct WsLayout {
 inline bool mfma_ap_on();
 // k_scan_hist_m2 (round 3) also takes codes of at most 32 bits, the pair cache with it: XMH_SCAN_M2=0 brings back k_scan_hist_m for
 // 33..64 bits and the VALU kernels below that
+// k_scan_hist_m2 keeps five hazards the compiler cannot see apart by hand (s_nop counts, early-clobber operands, statement order: see
+// the kernel), each of which was a wrong result on hardware before it was a comment.  A hipcc or ROCm change could break one of them
+// silently, so the kernel has to EARN its place once per device and process: m2_selfcheck_ok runs a small scan (several chunks, ties,
+// both geometries) with and without it and compares histograms and divisors bit for bit, AP sums to float rounding; a mismatch prints one line to stderr
+// and every later plan of this process uses the round-2 kernels (k_scan_hist_m / the VALU kernels), as XMH_SCAN_M2=0 does.
+// XMH_SCAN_M2_SELFCHECK=0 skips it, =2 runs it and pretends it failed (the test of the fallback); g_m2_force pins the answer while the
+// check itself runs.
+static thread_local int g_m2_force = -1;
+bool m2_selfcheck_ok();
 inline bool m2_enabled() {
+    if (g_m2_force >= 0) return g_m2_force != 0 && !mfma_ap_on();
     const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
-    return !(e && atoi(e) == 0) && !mfma_ap_on();
+    return !(e && atoi(e) == 0) && !mfma_ap_on() && m2_selfcheck_ok();
 }
 inline bool mfma_shape(int K, bool ternary) {
     static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
@@ -2098,6 +2111,100 @@ int lane_order_ok(hipStream_t st) {
     cached[dev] = ok;
     have[dev] = true;
     return ok;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc(&p, n) == hipSuccess; }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+// one (K, forced kernel choice) evaluation of the self-check scan into host vectors; false on any HIP / library error
+bool selfcheck_eval(int K, int force, const std::vector<uint32_t>& qb, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rb,
+                    const std::vector<uint32_t>& rl, int64_t Q, int64_t R, int C, std::vector<uint32_t>& hist, std::vector<double>& ap,
+                    std::vector<int32_t>& cap) {
+    g_m2_force = force;
+    bool ok = false;
+    do {
+        xmh_scan_plan p;
+        if (xmh_scan_plan_make(Q, R, K, 0, &p) != XMH_OK) break;
+        const size_t nb = (size_t)p.nbuckets;
+        DevBuf dq, dql, dr, drl, ws, dh, dap, dcap;
+        if (!dq.alloc(qb.size() * 4) || !dql.alloc(ql.size() * 4) || !dr.alloc(rb.size() * 4) || !drl.alloc(rl.size() * 4) || !ws.alloc(p.ws_bytes) ||
+            !dh.alloc(2 * Q * nb * 4) || !dap.alloc(Q * 8) || !dcap.alloc(Q * 4))
+            break;
+        if (hipMemcpy(dq.p, qb.data(), qb.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dql.p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dr.p, rb.data(), rb.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(drl.p, rl.data(), rl.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            break;
+        uint32_t* h = dh.as<uint32_t>();
+        if (xmh_hamming_hist(dq.as<uint32_t>(), nullptr, dql.as<uint32_t>(), dr.as<uint32_t>(), nullptr, drl.as<uint32_t>(), Q, R, K, C, ws.p, p.ws_bytes, h, h + Q * nb,
+                             nullptr) != XMH_OK)
+            break;
+        if (xmh_hamming_ap(dq.as<uint32_t>(), nullptr, dql.as<uint32_t>(), dr.as<uint32_t>(), nullptr, drl.as<uint32_t>(), Q, R, K, C, ws.p, p.ws_bytes, nullptr, nullptr,
+                           nullptr, 0, dap.as<double>(), dcap.as<int32_t>(), nullptr) != XMH_OK)
+            break;
+        hist.resize(2 * Q * nb); ap.resize(Q); cap.resize(Q);
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (hipMemcpy(hist.data(), dh.p, hist.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ap.data(), dap.p, Q * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cap.data(), dcap.p, Q * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            break;
+        ok = true;
+    } while (false);
+    g_m2_force = -1;
+    return ok;
+}
+}  // namespace
+
+bool m2_selfcheck_ok() {
+    static int state[64];                                 // 0 unknown, 1 passed, 2 failed
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;     // no device: nothing can run, nothing to guard
+    const char* e = getenv("XMH_SCAN_M2_SELFCHECK");
+    if (e && atoi(e) == 0) return true;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev]) return state[dev] == 1;
+    state[dev] = 1;                                       // the evaluations below re-enter through g_m2_force only
+    const int64_t Q = 200, R = 9000;
+    const int C = 80, LW = 3;
+    bool same = true, ran = true;
+    for (int K : {64, 40, 16}) {                          // 4 waves x 2 query groups (two code words), one code word, 4 x 4 groups (<= 32 bits)
+        const int W = (K + 31) / 32;
+        std::vector<uint32_t> qb(Q * W), ql(Q * LW), rb(R * W), rl(R * LW);
+        uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)K;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 16); };
+        const uint32_t last = K % 32 ? (1u << (K % 32)) - 1 : 0xffffffffu;
+        for (auto& v : qb) v = rnd();
+        for (int64_t i = 0; i < R; ++i)                   // a quarter of the gallery repeats earlier codes: ties inside and across chunks
+            for (int w = 0; w < W; ++w) rb[i * W + w] = (i > 64 && (rnd() & 3) == 0) ? rb[(rnd() % 64) * W + w] : rnd();
+        for (int64_t i = 0; i < Q; ++i) qb[i * W + W - 1] &= last;
+        for (int64_t i = 0; i < R; ++i) rb[i * W + W - 1] &= last;
+        for (int64_t i = 0; i < Q * LW; ++i) ql[i] = rnd() & rnd() & rnd() & (i % LW == LW - 1 ? 0xffffu : 0xffffffffu);
+        for (int64_t i = 0; i < R * LW; ++i) rl[i] = rnd() & rnd() & rnd() & (i % LW == LW - 1 ? 0xffffu : 0xffffffffu);
+        for (int64_t i = 0; i < Q; ++i) ql[i * LW] |= 1u;                            // every query has a relevant item
+        for (int64_t i = 0; i < R; i += 7) rl[i * LW] |= 1u;
+        std::vector<uint32_t> h1, h0;
+        std::vector<double> a1, a0;
+        std::vector<int32_t> c1, c0;
+        if (!selfcheck_eval(K, 1, qb, ql, rb, rl, Q, R, C, h1, a1, c1) || !selfcheck_eval(K, 0, qb, ql, rb, rl, Q, R, C, h0, a0, c0)) { ran = false; break; }
+        // histograms and divisors bit for bit; the two kernels chunk the gallery differently, so pass 2's per-chunk float partial sums
+        // add in another order: the AP sums to float rounding (a wrong pair moves one by >= 1 / R relative, far above it)
+        bool ap_close = true;
+        for (int64_t i = 0; i < Q; ++i) ap_close = ap_close && fabs(a1[i] - a0[i]) <= 4e-6 * fabs(a0[i]) + 1e-9;
+        if (h1 != h0 || c1 != c0 || !ap_close) { same = false; break; }
+    }
+    if (e && atoi(e) == 2) same = false;
+    if (!ran) {                                           // out of memory or a launch failure: no verdict, do not cache one
+        state[dev] = 0;
+        return true;
+    }
+    if (!same) {
+        state[dev] = 2;
+        fprintf(stderr, "xmh: k_scan_hist_m2 self-check FAILED on device %d (results differ from the reference kernels): falling back to k_scan_hist_m / the VALU "
+                        "pass 1 for this process.  Please report the hipcc / ROCm versions.\n", dev);
+    }
+    return state[dev] == 1;
 }
 
 template <bool TERN, typename F>

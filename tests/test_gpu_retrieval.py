@@ -329,13 +329,16 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
         assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("Q,R,K,C", [(130, 6000, 64, 80), (70, 9100, 64, 33), (300, 20011, 48, 80), (17, 63, 64, 5), (129, 6463, 128, 80), (200, 7000, 16, 24), (90, 5001, 32, 80),
-                                     (65, 3000, 256, 24)])
-def test_pair_cache_entries_match_oracle(xr, Q, R, K, C):
+@pytest.mark.parametrize("Q,R,K,C,m2", [(130, 6000, 64, 80, "1"), (70, 9100, 64, 33, "1"), (300, 20011, 48, 80, "1"), (17, 63, 64, 5, "1"), (129, 6463, 128, 80, "1"),
+                                        (200, 7000, 16, 24, "1"), (90, 5001, 32, 80, "1"), (65, 3000, 256, 24, "1"),
+                                        (130, 6000, 64, 80, "0"), (300, 20011, 48, 80, "0"), (17, 63, 64, 5, "0")])
+def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     """Every entry pass 1 leaves in the pair cache (distance << 1 | relevant; xmh_scan_pair_cache_offset documents the layout)
     against the oracle's distance and relevance of that (query, item) pair -- the MFMA-evaluated pass 1 writes the entry from a
-    second accumulator chain, so this checks that chain directly and not only through the mAP it leads to."""
+    second accumulator chain, so this checks that chain directly and not only through the mAP it leads to.  m2 = "0": the kernel
+    k_scan_hist_m2 replaced (k_scan_hist_m with the cache, what a failed self-check or XMH_SCAN_M2=0 selects) writes the same entries."""
     from xmh._lib import lib
+    monkeypatch.setenv("XMH_SCAN_M2", m2)
     orc = _orc()
     qB, rB, qL, rL = _synth(Q, R, K, C, seed=3 * K + R)
     q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
@@ -373,6 +376,62 @@ def test_pair_cache_entries_match_oracle(xr, Q, R, K, C):
             assert not bad.any(), (c, tile, np.argwhere(bad)[:5], got[c, tile][bad][:5], w[bad][:5])
             checked += int(m.sum())
     assert checked == Q * R
+
+
+@pytest.mark.parametrize("K", [16, 32, 48, 64])
+def test_scan_m2_against_the_kernels_it_replaced(xr, monkeypatch, K):
+    """XMH_SCAN_M2=0 (k_scan_hist_m for 33..64 bits, the VALU pass 1 below; also what the per-device self-check falls back to) against
+    the default k_scan_hist_m2: the shard histograms and the divisors are equal bit for bit; the chunking differs, so the per-chunk
+    float sums of pass 2 add in another order and the AP sums agree to float rounding; mAP@all and mAP@k to 1e-9."""
+    for (Q, Rn, C, p, k) in ((150, 9001, 80, 0.06, 9), (64, 8157, 32, 0.5, 85), (127, 62, 1, 0.01, None), (300, 20011, 24, 0.1, 50)):
+        qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=5 * K + Q, p=p)
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("XMH_SCAN_M2", flag)
+            scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+            ha, hr = scan.histograms(True)
+            ap, cap = scan.ap_sums(None)
+            apk, capk = scan.ap_sums(k)
+            outs.append((ha.clone(), hr.clone(), cap.clone(), capk.clone(), ap.clone(), apk.clone()))
+        for x, y in zip(outs[0][:4], outs[1][:4]):
+            assert torch.equal(x, y), (Q, Rn, K, C)
+        for x, y, c in ((outs[0][4], outs[1][4], outs[0][2]), (outs[0][5], outs[1][5], outs[0][3])):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (Q, Rn, K, C)
+            assert abs(float((x / c).mean()) - float((y / c).mean())) < 1e-9
+
+
+def test_scan_m2_self_check_failure_falls_back_with_one_warning():
+    """XMH_SCAN_M2_SELFCHECK=2 runs the per-device self-check of k_scan_hist_m2 and pretends it failed: one line on stderr, and the
+    process goes on with the kernels it replaced -- same mAP as a process that passed the check."""
+    import subprocess, sys
+    code = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "from xmh import retrieval as R\n"
+        "from xmh._lib import lib\n"
+        "import ctypes\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "for K in (64, 16):\n"
+        "    qB, rB = torch.randn(90, K, generator=g).sign(), torch.randn(7000, K, generator=g).sign()\n"
+        "    qL, rL = (torch.rand(90, 24, generator=g) < .1).long(), (torch.rand(7000, 24, generator=g) < .1).long()\n"
+        "    qL[:, 0] = 1; rL[::3, 0] = 1\n"
+        "    scan = R.RankingScan(R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda()), 24)\n"
+        "    scan.histograms(False)\n"
+        "    a, c = scan.ap_sums(None)\n"
+        "    buf = ctypes.create_string_buffer(512)\n"
+        "    lib.xmh_scan_describe(90, 7000, K, 24, 0, buf, 512)\n"
+        "    print('ROW', K, '%%.12f' %% float((a / c).mean()), buf.value.decode())\n"
+    ) % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"))
+    runs = {}
+    for mode in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMH_SCAN_M2_SELFCHECK=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[mode] = ([l.split() for l in r.stdout.splitlines() if l.startswith("ROW ")], r.stderr)
+    ok, failed = runs["1"], runs["2"]
+    assert "self-check FAILED" not in ok[1] and failed[1].count("self-check FAILED") == 1
+    assert len(ok[0]) == 2 and len(failed[0]) == 2
+    for a, b in zip(ok[0], failed[0]):
+        assert abs(float(a[2]) - float(b[2])) < 1e-9
+        assert "k_scan_hist_m2" in a[3] and "k_scan_hist_m2" not in b[3]
 
 
 def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):

@@ -1,0 +1,77 @@
+"""The hand-placed MFMA hazards of the scan kernels ("each item was a wrong result on hardware
+first") as a regression gate that needs no GPU: disassemble the gfx950 code objects inside the libxmh.so the build just produced
+and check wait states, operand overwrites and SDWA spacing instruction by instruction (tools/isa_hazards.py).  A compiler upgrade,
+or an edit that drops one `s_nop` from xmh_scan.hip, fails here instead of changing mAP on a GPU box."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_hazards as H  # noqa: E402
+
+# the compiler the pinned counts below were read from; the hazard rules hold for any compiler, the counts are only asserted for this one
+PINNED_COMPILER = "AMD clang version 22.0.0git"
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(H.LIB) and os.path.exists(os.path.join(H.LLVM_BIN, "llvm-objdump"))),
+                                reason="needs the built libxmh.so and ROCm's llvm-objdump")
+
+
+@pytest.fixture(scope="module")
+def report():
+    return H.analyse()
+
+
+def _template_ints(name, kernel):
+    m = re.search(kernel + r"I((?:L[ib]\d+E)+)E", name)
+    return [int(x) for x in re.findall(r"L[ib](\d+)E", m.group(1))]
+
+
+def test_every_hand_scheduled_kernel_is_in_the_library(report):
+    names = "\n".join(report)
+    for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
+        assert k in names, k
+    assert sum(st["n_mfma"] for _, st in report.values()) > 1000
+
+
+def test_no_mfma_hazard_in_the_shipped_isa(report):
+    """R1: MFMA result -> VALU / DS read at least 8 wait states later; R2 (k_scan_hist_m2): no VALU write onto an MFMA's operands within
+    3 slots behind it; R3: VALU write -> srcC read at least 2 wait states; R4: SDWA byte inserts into one register never back to back."""
+    bad = [v for vs, _ in report.values() for v in vs]
+    assert not bad, "\n".join("%s %s[%d] %s -- %s" % (v.rule, v.kernel[:60], v.index, v.text[:80], v.detail) for v in bad[:20])
+
+
+def test_hand_scheduled_statements_keep_their_margins(report):
+    """k_scan_hist_m2: the consumers of an MFMA result sit a full statement behind it (>= 12 wait states, 8 are required); the pair-cache
+    variants carry 12 preserving SDWA inserts per (item group x query group) pair of a batch body; every asm statement opens with
+    `s_nop 3` (8 NQ + 2 of them per instance: deleting one from xmh_scan.hip changes the count)."""
+    seen = 0
+    for name, (_, st) in report.items():
+        if "k_scan_hist_m2" not in name:
+            continue
+        nml, nw, nq, cache, stamp = _template_ints(name, "k_scan_hist_m2")
+        assert st["R1"] is not None and st["R1"] >= 12, (name, st)
+        assert st["n_sdwa_preserve"] == (24 * nq if cache else 0), (name, st)
+        if H.hipcc_version().startswith(PINNED_COMPILER):
+            assert st["n_snop3"] == 8 * nq + 2, (name, st)
+        seen += 1
+    assert seen >= 20
+
+
+def test_the_checker_sees_a_planted_hazard():
+    """the rules fire on a three-instruction stream with each hazard planted (the checker itself is not vacuous)"""
+    def stream(*lines):
+        return H.parse("0000 <k_scan_hist_m2_probe>:\n" + "".join("\t%s // 0: 0\n" % l for l in lines))["k_scan_hist_m2_probe"]
+    mf = "v_mfma_i32_16x16x64_i8 v[0:3], v[4:7], v[8:11], v[12:15]"
+    rules = lambda ins: sorted({v.rule for v in H.check(ins, "k_scan_hist_m2_probe")[0]})      # noqa: E731
+    assert rules(stream(mf, "s_nop 5", "v_min_u32_e32 v20, 0x10001, v1")) == ["R1"]                      # 6 wait states < 8
+    assert rules(stream(mf, "s_nop 7", "v_min_u32_e32 v20, 0x10001, v1")) == []
+    assert rules(stream(mf, "s_nop 6", "ds_add_u32 v2, v21")) == ["R1"]                                     # DS address from the result
+    assert rules(stream(mf, "v_mov_b32_e32 v5, v30")) == ["R2"]                                            # lands on the A operand
+    assert rules(stream("v_mov_b32_e32 v12, v30", mf)) == ["R3"]                                           # srcC written in the slot before
+    assert rules(stream("v_mov_b32_e32 v12, v30", "s_nop 3", mf)) == []
+    sd = "v_or_b32_sdwa v40, v41, v42 dst_sel:BYTE_%d dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0"
+    assert rules(stream(sd % 1, sd % 2)) == ["R4"]
+    assert rules(stream(sd % 1, "ds_add_u32 v50, v51", sd % 2)) == []
