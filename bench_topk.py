@@ -170,6 +170,72 @@ def measure_structured(R=10_000_000, K=256, k=100):
     return out
 
 
+def measure_many_queries(R=10_000_000, K=256, Q=5000, k=100, iters=2):
+    """SURVEY 8d shape (5), the Q = 5000 end: exact top-k of a whole query set over the unsharded 10 M x 256-bit gallery (the reference
+    would need a 5000 x 10 M fp32 distance matrix = 200 GB for this, common/calc_utils.py:51-56).  Whole call only: with this many
+    queries per gallery pass the filter is matrix-core bound, not HBM bound."""
+    from xmh import retrieval as X
+    q, r = _codes("iid", R, K, Q)
+    d, i = X.hamming_topk(q, r, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        d, i = X.hamming_topk(q, r, k)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    # size-independent checks on the full result: lists ascending in (distance, index), indices in range and distinct per query
+    dd = d.to(torch.int32) & 0xFFFF
+    key = (dd.to(torch.int64) << 32) | i.to(torch.int64)
+    ok = bool((key[:, 1:] > key[:, :-1]).all()) and bool((i >= 0).all()) and bool((i < R).all())
+    return {"workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU, iid codes" % (k, Q, R, K), "whole_call_ms": t * 1e3,
+            "pairs_per_s_whole_call": Q * R / t, "lists_sorted_distinct_in_range": ok, "mean_kth_distance": float(dd[:, -1].float().mean())}
+
+
+def measure_cache_defeat(R=10_000_000, K=256, k=100, galleries=4, iters=20):
+    """Is the HBM-regime number HBM?  One 10 M x 256-bit gallery is 320 MB against 256 MiB of Infinity Cache, and a loop over it re-reads
+    the same bytes; FETCH_SIZE counts cache hits.  Here the calls rotate over `galleries` different 10 M galleries (1.28 GB in all), so
+    every byte a call streams was evicted since it was last read.  Same workspace, same queries; filter time from the library's own
+    HIP events, whole call from events around the loop."""
+    from xmh import _lib
+    from xmh import retrieval as X
+    W = (K + 31) // 32
+    out = {}
+    gs = [_codes("iid", R, K, 8, seed=1814 + 7 * j)[1] for j in range(galleries)]
+    for Q in (1, 8):
+        q = _codes("iid", 16, K, Q)[0]
+        ws = X.TopkWorkspace(Q, R, K, k, "cuda")
+        alg = R * W * 4 + Q * W * 4 + Q * 4
+        res = {}
+        for name, pool in (("one_gallery", gs[:1]), ("rotating_%d_galleries" % galleries, gs)):
+            for n in range(2 * len(pool)):
+                X.hamming_topk(q, pool[n % len(pool)], k, workspace=ws)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for n in range(iters):
+                X.hamming_topk(q, pool[n % len(pool)], k, workspace=ws)
+            e1.record()
+            torch.cuda.synchronize()
+            t_call = e0.elapsed_time(e1) / iters * 1e-3
+            _lib.prof_enable(True)
+            for n in range(iters):
+                X.hamming_topk(q, pool[n % len(pool)], k, workspace=ws)
+            torch.cuda.synchronize()
+            t, launches = _lib.prof_read("topk_filter")
+            _lib.prof_enable(False)
+            t *= 1e-3
+            res[name] = {"filter_GBps": alg / t / 1e9, "filter_frac_of_8TBps": alg / t / 1e9 / HBM_PEAK_GBS, "filter_ms": t * 1e3,
+                         "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9}
+        a, b = res["one_gallery"], res["rotating_%d_galleries" % galleries]
+        res["filter_rate_rotating_over_one"] = b["filter_GBps"] / a["filter_GBps"]
+        out["Q%d" % Q] = res
+    out["workload"] = "top-%d over 10 M x %d bit: the same gallery every call (320 MB, 1.2 x the Infinity Cache) against %d galleries in rotation (%.2f GB)" % (
+        k, K, galleries, galleries * R * W * 4 / 1e9)
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--R", type=int, default=10_000_000)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""End-to-end `BaseTrainer.valid()` at BASELINE configs[1] scale -- the thing the reference runs (runners/base.py:307-339:
+2 x get_code over the query and retrieval loaders, 4 x calc_map_k, .mat / .pth writers, the log line) -- with the encode /
+retrieve split, so the one line shows what the headline retrieval number is a part of.
+
+The loaders yield DEVICE-RESIDENT batches (a pool of distinct synthetic 100-item batches, cycled): the loader side of the
+reference (PIL decode, resize, tokenise on DataLoader workers) is outside SURVEY 8a and would otherwise be what is timed.  Codes
+therefore repeat with the pool's period; encode time does not depend on the data, and the mAP scan is timed on what the encoder
+produced (heavily tied codes -- the tie path of the ranking -- so the retrieve share is, if anything, pessimistic).
+
+    python bench_valid.py [--Q 5000 --R 117218 --K 64]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+class DeviceLoader:
+    """iterable of (image, text, key_padding_mask, label, index) batches that already live on the GPU"""
+
+    def __init__(self, n, batch, pool_images, pool_ids):
+        self.n, self.batch, self.images, self.ids = n, batch, pool_images, pool_ids
+        self.masks = [t == 0 for t in pool_ids]
+        self.index = torch.arange(n, dtype=torch.int64, device=pool_ids[0].device)
+
+    def __len__(self):
+        return (self.n + self.batch - 1) // self.batch
+
+    def __iter__(self):
+        for b, lo in enumerate(range(0, self.n, self.batch)):
+            m = min(self.batch, self.n - lo)
+            j = b % len(self.images)
+            yield self.images[j][:m], self.ids[j][:m], self.masks[j][:m], None, self.index[lo:lo + m]
+
+
+def _labels(n, C, seed, p=0.04):
+    g = torch.Generator().manual_seed(seed)
+    L = torch.rand(n, C, generator=g) < p
+    L[torch.arange(n), torch.randint(0, C, (n,), generator=g)] = True
+    return L.to(torch.int64)
+
+
+def measure(Q=5000, Rn=117218, K=64, C=80, batch=100, pool=4, arch=("DCMHT", "DCMHTTrainer")):
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from xmh.common.register import registry
+    from xmh.models import weights as W
+    from xmh.utils.config import Config
+    tmp = tempfile.mkdtemp(prefix="xmh_valid_")
+    cfg = Config({
+        "model": {"arch": arch[0], "clip_path": "synthetic:1814"},
+        "dataset": {"arch": "synthetic", "name": "synth", "num_classes": C, "retrieval_num": 8, "max_word": 32, "image_resolution": 224},
+        "run": {"arch": arch[1], "output_dim": K, "device": 0, "batch_size": batch, "num_workers": 0, "is_train": False, "query_num": 4,
+                "train_num": 4, "save_dir": tmp, "log_dir": tmp, "seed": 1814},
+    })
+    t = registry.get_runner_class(arch[1]).from_config(cfg=cfg, autorun=False)
+    dev = torch.device("cuda", 0)
+    images = [W.synth_images(11 + j, batch).to(dev) for j in range(pool)]
+    ids = [W.synth_text(11 + j, batch)[0].to(dev) for j in range(pool)]
+    # the configs[1] shape on the trainer the config built (its own loaders held 4 + 8 items)
+    t.query_num, t.retrieval_num = Q, Rn
+    t.query_labels, t.retrieval_labels = _labels(Q, C, 1), _labels(Rn, C, 2)
+    t.query_loader, t.retrieval_loader = DeviceLoader(Q, batch, images, ids), DeviceLoader(Rn, batch, images, ids)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    # warm-up: allocator, LDS opt-ins, clocks (one pass over the query loader)
+    t.encode_shard(t.query_loader, Q)
+    sync()
+    # ---- split: encode (2 x get_code worth of forwards), then the four scans on the codes it produced
+    t0 = time.perf_counter()
+    t._qlab = t._rlab = None
+    q_img, q_txt = t.encode_shard(t.query_loader, Q)
+    r_img, r_txt = t.encode_shard(t.retrieval_loader, Rn)
+    sync()
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    maps = (t._map(q_img, r_txt, None), t._map(q_txt, r_img, None), t._map(q_img, r_img, None), t._map(q_txt, r_txt, None))
+    sync()
+    t_ret_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(5):
+        maps2 = (t._map(q_img, r_txt, None), t._map(q_txt, r_img, None), t._map(q_img, r_img, None), t._map(q_txt, r_txt, None))
+    sync()
+    t_ret = (time.perf_counter() - t0) / 5
+    assert maps == maps2
+    # ---- the call itself, writers included
+    t0 = time.perf_counter()
+    got = t.valid(0, k=None)
+    sync()
+    t_valid = time.perf_counter() - t0
+    files = sorted(os.listdir(os.path.join(tmp, "mat_files")))
+    mat_bytes = sum(os.path.getsize(os.path.join(tmp, "mat_files", f)) for f in files)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    n_items = Q + Rn
+    return {
+        "workload": "BaseTrainer.valid(): %s %d-bit, Q=%d + R=%d image/caption pairs encoded (parity mode, %d loader batches of %d fused per "
+                    "forward), 4 x mAP@all, .mat / .pth writers; device-resident loader batches (pool of %d, cycled)" % (arch[0], K, Q, Rn, t.encode_fuse, batch, pool),
+        "valid_seconds": t_valid,
+        "encode_seconds": t_enc, "retrieve_seconds": t_ret, "retrieve_seconds_first_call": t_ret_first,
+        "writers_and_rest_seconds": max(0.0, t_valid - t_enc - t_ret),
+        "encode_share": t_enc / (t_enc + t_ret),
+        "pairs_encoded_per_s": n_items / t_enc,
+        "retrieve_pairs_per_s": 4 * Q * Rn / t_ret,
+        "mAP_i2t_t2i_i2i_t2t": [float(x) for x in got],
+        "artefacts": files, "artefact_bytes": mat_bytes,
+        "reference": "runners/base.py:307-339 (valid), :242-266 (get_code), common/calc_utils.py:58-92 (calc_map_k, on the CPU in the reference)",
+    }
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--Q", type=int, default=5000)
+    ap.add_argument("--R", type=int, default=117218)
+    ap.add_argument("--K", type=int, default=64)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.Q, a.R, a.K)))

@@ -14,6 +14,8 @@
 // Bound: HBM for few queries.  Algorithmic bytes per launch = R*W*4 (gallery read once)
 // + Q*W*4 + nblocks*Q*k*6 (partial lists) ; per pair 2W lane-ops.
 #include "xmh_common.h"
+#include <algorithm>
+#include <vector>
 
 #include <stdlib.h>
 
@@ -1245,4 +1247,43 @@ extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, in
 extern "C" int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index,
                                          void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
     return topk_call(qbits, rbits, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, true);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host merge of per-shard lists (sharded retrieval): plain host code, a k-way merge with one cursor per shard
+// -- world <= 8 comparisons per output slot instead of an argsort of [Q][world * k] 64-bit keys
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t xmh_topk_record_bytes(int64_t Q, int k) {
+    if (Q < 0 || k <= 0) return 0;
+    return ((size_t)Q * (size_t)k * 6 + 3) & ~(size_t)3;
+}
+
+extern "C" int xmh_topk_merge_host(const void* gathered_host, int world, int64_t Q, int k, int32_t* dist_out, int32_t* idx_out) {
+    if (world <= 0 || world > 4096 || Q < 0 || k <= 0) return xmh::fail(XMH_EINVAL, "xmh_topk_merge_host: bad shape world=%d Q=%lld k=%d", world, (long long)Q, k);
+    if (Q == 0) return XMH_OK;
+    if (!gathered_host || !dist_out || !idx_out) return xmh::fail(XMH_EINVAL, "xmh_topk_merge_host: null pointer");
+    const size_t rec = xmh_topk_record_bytes(Q, k);
+    const char* base = static_cast<const char*>(gathered_host);
+    std::vector<int> cur((size_t)world);
+    for (int64_t q = 0; q < Q; ++q) {
+        std::fill(cur.begin(), cur.end(), 0);
+        for (int o = 0; o < k; ++o) {
+            int best = -1;
+            uint64_t best_key = ~0ull;
+            for (int w = 0; w < world; ++w) {
+                if (cur[w] >= k) continue;
+                const int32_t* idx = reinterpret_cast<const int32_t*>(base + (size_t)w * rec) + q * k;
+                const int32_t id = idx[cur[w]];
+                if (id < 0) { cur[w] = k; continue; }                                  // unused slots end a list
+                const uint16_t* dist = reinterpret_cast<const uint16_t*>(base + (size_t)w * rec + (size_t)Q * k * 4) + q * k;
+                const uint64_t key = ((uint64_t)dist[cur[w]] << 32) | (uint32_t)id;
+                if (key < best_key) { best_key = key; best = w; }
+            }
+            if (best < 0) { dist_out[q * k + o] = 0xFFFF; idx_out[q * k + o] = -1; continue; }
+            dist_out[q * k + o] = (int32_t)(best_key >> 32);
+            idx_out[q * k + o] = (int32_t)(uint32_t)best_key;
+            ++cur[best];
+        }
+    }
+    return XMH_OK;
 }

@@ -383,11 +383,23 @@ class TopkWorkspace:
         check(lib.xmh_topk_ws_init(*self.shape, ptr(self.buf), self.bytes, current_stream()), "xmh_topk_ws_init")
 
 
-def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, workspace: Optional[TopkWorkspace] = None):
+def _topk_out(out, Q: int, k: int, dev):
+    if out is None:
+        return torch.empty(Q, k, dtype=torch.int16, device=dev), torch.empty(Q, k, dtype=torch.int32, device=dev)
+    dist, idx = out
+    if (tuple(dist.shape) != (Q, k) or tuple(idx.shape) != (Q, k) or dist.dtype != torch.int16 or idx.dtype != torch.int32
+            or dist.device != dev or idx.device != dev or not dist.is_contiguous() or not idx.is_contiguous()):
+        raise ValueError("hamming_topk: out must be contiguous (int16 [%d, %d], int32 [%d, %d]) tensors on %s" % (Q, k, Q, k, dev))
+    return dist, idx
+
+
+def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, workspace: Optional[TopkWorkspace] = None, out=None):
     """Exact top-k of every query over this gallery shard under (distance, index) order.
     Returns (dist int16-storage [Q,k] (uint16 bit pattern, 0xFFFF = unused slot), idx int32 [Q,k] global
     indices = base_index + row, -1 = unused slot when the shard has fewer than k rows).
-    ``workspace``: a TopkWorkspace of this shape (see there); without one a scratch workspace is allocated and cleared per call."""
+    ``workspace``: a TopkWorkspace of this shape (see there); without one a scratch workspace is allocated and cleared per call.
+    ``out``: (dist, idx) contiguous device tensors of those shapes and dtypes to write into (the sharded driver passes views of the
+    record it all-gathers)."""
     _require_cuda(q.bits, r.bits)
     if q.K != r.K:
         raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
@@ -400,8 +412,7 @@ def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, wo
         if workspace.shape != (Q, R, q.K, int(k)) or workspace.buf.device != dev:
             raise ValueError("top-k workspace was prepared for %r on %s, call is %r on %s"
                              % (workspace.shape, workspace.buf.device, (Q, R, q.K, int(k)), dev))
-        dist = torch.empty(Q, k, dtype=torch.int16, device=dev)
-        idx = torch.empty(Q, k, dtype=torch.int32, device=dev)
+        dist, idx = _topk_out(out, Q, k, dev)
         check(lib.xmh_hamming_topk_prepared(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(workspace.buf), workspace.bytes,
                                             ptr(dist), ptr(idx), current_stream()), "xmh_hamming_topk_prepared")
         return dist, idx
@@ -409,8 +420,7 @@ def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, wo
     if need == 0:
         check(lib.xmh_hamming_topk(None, None, Q, R, q.K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    dist = torch.empty(Q, k, dtype=torch.int16, device=dev)
-    idx = torch.empty(Q, k, dtype=torch.int32, device=dev)
+    dist, idx = _topk_out(out, Q, k, dev)
     check(lib.xmh_hamming_topk(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(ws), need, ptr(dist), ptr(idx),
                                current_stream()), "xmh_hamming_topk")
     return dist, idx

@@ -320,30 +320,59 @@ def gather_rows_to(t: torch.Tensor, counts: Sequence[int], dst: int = 0, group=N
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
+_pinned = {}          # record bytes -> pinned host staging buffer for the gathered lists (reused over calls)
+
+
+def merge_topk_records(gathered: torch.Tensor, world: int, nq: int, k: int):
+    """xmh_topk_merge_host over `world` gathered records ([Q][k] i32 indices then [Q][k] u16 distances each, uint8 tensor on any
+    device): ONE device-to-host copy into pinned memory, then a k-way merge in C.  Returns (dist, idx) int32 [Q, k] CPU tensors."""
+    from ._lib import check, lib, ptr
+    rec = int(lib.xmh_topk_record_bytes(nq, k))
+    if gathered.dtype != torch.uint8 or gathered.numel() != world * rec:
+        raise ValueError("merge_topk_records: expected %d x %d bytes of records" % (world, rec))
+    if gathered.is_cuda:
+        host = _pinned.get(world * rec)
+        if host is None:
+            host = _pinned[world * rec] = torch.empty(world * rec, dtype=torch.uint8).pin_memory()
+        host.copy_(gathered.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(gathered.device).synchronize()
+    else:
+        host = gathered.reshape(-1).contiguous()
+    d = torch.empty(nq, k, dtype=torch.int32)
+    i = torch.empty(nq, k, dtype=torch.int32)
+    check(lib.xmh_topk_merge_host(ptr(host), world, nq, k, ptr(d), ptr(i)), "xmh_topk_merge_host")
+    return d, i
+
+
 def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
     """north_star retrieval mode over a sharded gallery: exact top-k of every query on this rank's shard (global indices
-    = base_index + row), ONE all-gather of the [Q, k] (distance, index) lists, k-way merge on the host.  Returns
+    = base_index + row) written straight into this rank's record, ONE all-gather of the records ([Q, k] indices + distances,
+    6 bytes per entry), one pinned device-to-host copy, k-way merge on the host (xmh_topk_merge_host).  Returns
     (dist int32 [Q,k], idx int32 [Q,k]) CPU tensors, identical on every rank; unused slots (fewer than k rows in all)
-    carry idx -1.  ``topk_fn(q, r_shard, k, base_index) -> (dist, idx)`` defaults to the HIP op; a rank without gallery
-    rows contributes empty lists."""
+    carry distance 0xFFFF and idx -1.  ``topk_fn(q, r_shard, k, base_index) -> (dist, idx)`` defaults to the HIP op; a rank
+    without gallery rows contributes empty lists."""
+    from ._lib import lib
     world = dist.get_world_size(group)
     n_rows = r_shard.n if hasattr(r_shard, "n") else len(r_shard)
     nq = q.n if hasattr(q, "n") else len(q)
-    if topk_fn is None:
-        from . import retrieval as R
-        topk_fn = R.hamming_topk
-        dev = q.bits.device
-    else:
-        dev = torch.device("cpu")
+    hip = topk_fn is None
+    dev = q.bits.device if hip else torch.device("cpu")
+    rec = int(lib.xmh_topk_record_bytes(nq, k))
+    out = torch.empty(world, rec, dtype=torch.uint8, device=dev)            # the all-gather lands here; this rank's record is written in place
+    mine = out[dist.get_rank(group)]
+    i_view = mine[: nq * k * 4].view(torch.int32).view(nq, k)
+    d_view = mine[nq * k * 4: nq * k * 6].view(torch.int16).view(nq, k)
     if n_rows == 0:
-        d = torch.full((nq, k), -1, dtype=torch.int16, device=dev)          # 0xFFFF = unused slot
-        i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+        mine.fill_(0xFF)                                                     # distance 0xFFFF, index -1 = unused slots
+    elif hip:
+        from . import retrieval as R
+        R.hamming_topk(q, r_shard, k, base_index, out=(d_view, i_view))
     else:
         d, i = topk_fn(q, r_shard, k, base_index)
-    both = torch.stack([(d.to(torch.int32) & 0xFFFF) if d.dtype == torch.int16 else d.to(torch.int32), i.to(torch.int32)]).contiguous()
-    out = torch.empty((world,) + tuple(both.shape), dtype=torch.int32, device=both.device)
-    if hasattr(dist, "all_gather_into_tensor") and both.is_cuda:
-        dist.all_gather_into_tensor(out, both, group=group)
+        d_view.copy_(d.to(torch.int16) if d.dtype != torch.int16 else d)
+        i_view.copy_(i.to(torch.int32))
+    if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
+        dist.all_gather_into_tensor(out, mine, group=group)                 # in place: rank r's record is already at out[r]
     else:
-        dist.all_gather(list(out.unbind(0)), both, group=group)
-    return merge_topk(out[:, 0], out[:, 1], k)
+        dist.all_gather(list(out.unbind(0)), mine.clone(), group=group)
+    return merge_topk_records(out, world, nq, k)

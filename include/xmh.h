@@ -201,6 +201,14 @@ int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_byt
 int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
                               int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
                               xmh_stream_t stream);
+/* Host-side k-way merge of the shards' exact top-k lists (north_star: "partial top-k lists are merged on the host"; replaces the
+ * reference's gather of the whole code matrix, runners/base.py:259-264, on the retrieval side).  HOST pointers, no GPU work:
+ * gathered_host = `world` records as the ranks all-gathered them, each [Q][k] i32 global indices followed by [Q][k] u16
+ * distances (xmh_topk_record_bytes(Q, k) bytes per record, 4-byte aligned); every list ascending in (distance, index) with unused
+ * slots (index -1) at its end, which is what xmh_hamming_topk writes.  dist_out / idx_out [Q][k] i32: the k smallest (distance,
+ * index) pairs over all shards; slots past the total number of rows carry distance 0xFFFF and index -1. */
+size_t xmh_topk_record_bytes(int64_t Q, int k);
+int xmh_topk_merge_host(const void* gathered_host, int world, int64_t Q, int k, int32_t* dist_out_host, int32_t* idx_out_host);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder primitives (a-9 .. a-12).  fp32 activations, token-major [B, L, D].  The Python model classes

@@ -382,7 +382,7 @@ def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
 def test_scan_m2_against_the_kernels_it_replaced(xr, monkeypatch, K):
     """XMH_SCAN_M2=0 (k_scan_hist_m for 33..64 bits, the VALU pass 1 below; also what the per-device self-check falls back to) against
     the default k_scan_hist_m2: the shard histograms and the divisors are equal bit for bit; the chunking differs, so the per-chunk
-    float sums of pass 2 add in another order and the AP sums agree to float rounding; mAP@all and mAP@k to 1e-9."""
+    float sums of pass 2 add in another order and the AP sums agree to float rounding; mAP@all and mAP@k to 1e-7."""
     for (Q, Rn, C, p, k) in ((150, 9001, 80, 0.06, 9), (64, 8157, 32, 0.5, 85), (127, 62, 1, 0.01, None), (300, 20011, 24, 0.1, 50)):
         qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=5 * K + Q, p=p)
         outs = []
@@ -397,7 +397,7 @@ def test_scan_m2_against_the_kernels_it_replaced(xr, monkeypatch, K):
             assert torch.equal(x, y), (Q, Rn, K, C)
         for x, y, c in ((outs[0][4], outs[1][4], outs[0][2]), (outs[0][5], outs[1][5], outs[0][3])):
             assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (Q, Rn, K, C)
-            assert abs(float((x / c).mean()) - float((y / c).mean())) < 1e-9
+            assert abs(float((x / c).mean()) - float((y / c).mean())) < 1e-7
 
 
 def test_scan_m2_self_check_failure_falls_back_with_one_warning():
@@ -430,7 +430,7 @@ def test_scan_m2_self_check_failure_falls_back_with_one_warning():
     assert "self-check FAILED" not in ok[1] and failed[1].count("self-check FAILED") == 1
     assert len(ok[0]) == 2 and len(failed[0]) == 2
     for a, b in zip(ok[0], failed[0]):
-        assert abs(float(a[2]) - float(b[2])) < 1e-9
+        assert abs(float(a[2]) - float(b[2])) < 1e-7                  # another chunking: float partial sums add in another order
         assert "k_scan_hist_m2" in a[3] and "k_scan_hist_m2" not in b[3]
 
 
@@ -860,7 +860,8 @@ def test_full_size_nuswide_shape_sharded_eight_ways(xr):
     assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)                          # fp32 credits, summed per chunk: order differs
 
 
-@pytest.mark.parametrize("leg", ["configs0_dcmht_16bit_mirflickr", "k16_coco_shape", "configs3_dsph_128bit", "configs4_shard_scan_256bit"])
+@pytest.mark.parametrize("leg", ["configs0_dcmht_16bit_mirflickr", "k16_coco_shape", "configs3_dsph_128bit", "configs4_shard_scan_256bit",
+                                 "configs4_unsharded_scan_256bit"])
 def test_bench_legs_full_shapes_match_the_oracle(xr, leg):
     """The extra scan legs of bench.py at their FULL shapes (BASELINE configs[0], 16 bit at the COCO shape, configs[3] through the
     MFMA pass 1 + 16-bit-entry cache, one GPU's shard of configs[4] with a 12.7 GB cache), through the very function the bench
@@ -875,13 +876,16 @@ def test_bench_legs_full_shapes_match_the_oracle(xr, leg):
     ap, cap = scan.ap_sums(None)
     assert torch.equal(hr.to(torch.int64).sum(1).to(torch.int32), cap)
     assert abs(out["mAP"] - float((ap / cap.double()).mean())) < 1e-9
-    nsub = 8 if R > 500000 else 32
+    nsub = 4 if R > 5000000 else (8 if R > 500000 else 32)
     sub = np.arange(0, Q, Q // nsub)[:nsub]
     dist = orc.hamming_packed(_u32(scan.q.bits)[sub], _u32(scan.r.bits))
     rel = orc.relevance_packed(_u32(scan.qlab)[sub], _u32(scan.rlab))
     assert np.array_equal(cap.cpu().numpy()[sub], rel.sum(-1))
     assert np.allclose(ap.cpu().numpy()[sub], orc.ap_from_ranking(dist, rel), rtol=3e-6)
-    assert out["pair_cache_bytes"] > 0                                                # 12.7 GB for the configs[4] shard: under the 32 GB default cap
+    if R <= 1250000:
+        assert out["pair_cache_bytes"] > 0                                            # 12.7 GB for the configs[4] shard: under the 32 GB default cap
+    else:
+        assert out["pair_cache_bytes"] == 0                                           # the unsharded 10 M gallery: 100 GB, over it -- uncached pass 2
 
 
 def test_full_size_long_gallery_256bit_uncached_scan(xr, monkeypatch):
@@ -1012,6 +1016,25 @@ def test_topk_full_size_sample_path(xr):
     """a gallery large enough that the threshold comes from a 2.6 % sample (fast path proper)."""
     _topk_check(xr, 8, 2_000_000, 64, 100, seed=21)
     _topk_check(xr, 4, 1_500_000, 256, 10, seed=22)
+
+
+def test_topk_whole_query_set_over_the_unsharded_10m_gallery(xr):
+    """SURVEY 8d shape (5), the Q = 5000 end (bench leg `topk_q5000_10M_256bit` calls the same function): every list of the full result
+    is ascending in (distance, index) with distinct in-range indices, and a subsample of the queries equals the C oracle's exact
+    top-100 over all 10 M items bit for bit."""
+    import bench_topk
+    from oracle import c_oracle as co
+    Q, R, K, k = 5000, 10_000_000, 256, 100
+    out = bench_topk.measure_many_queries(R, K, Q, k, iters=1)
+    assert out["lists_sorted_distinct_in_range"]
+    q, r = bench_topk._codes("iid", R, K, Q)
+    d, i = xr.hamming_topk(q, r, k)
+    sub = [0, 1777, 4999]
+    qb = q.bits[sub].cpu().numpy().view(np.uint32)
+    rb = r.bits.cpu().numpy().view(np.uint32)
+    wd, wi = co.topk(qb, rb, K + 1, k)
+    assert np.array_equal(i[sub].cpu().numpy(), wi)
+    assert np.array_equal(d[sub].cpu().numpy().view(np.uint16), wd)
 
 
 @pytest.mark.parametrize("Q,R,K,k", [(3, 50001, 128, 10), (16, 33333, 128, 100), (17, 70001, 256, 100), (33, 40007, 256, 5), (70, 25013, 256, 100),

@@ -236,3 +236,41 @@ def test_bench_self_launches_n_ranks_dry_run():
     # N=1 takes no launcher
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["ranks_in_group"] == 1
+
+
+def test_topk_merge_host_equals_the_torch_merge():
+    """xmh_topk_merge_host (k-way merge in C on the gathered records) against sharded.merge_topk (argsort of 64-bit keys), bit for
+    bit: ties across shards, lists shorter than k (index -1 padding), shards without rows, fewer rows than k in all."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "clip-based-cross-modal-hash_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from xmh import sharded
+    from xmh._lib import lib
+    rng = np.random.default_rng(3)
+    for world, Q, k, rows in ((8, 5, 100, 300), (3, 17, 7, 4), (2, 1, 1, 1), (4, 9, 20, 0), (5, 3, 16, 2)):
+        rec = int(lib.xmh_topk_record_bytes(Q, k))
+        assert rec >= Q * k * 6 and rec % 4 == 0
+        gathered = torch.zeros(world, rec, dtype=torch.uint8)
+        ds, is_ = [], []
+        base = 0
+        for w in range(world):
+            n = 0 if (w == 1 and world > 2) else rows + w                    # one shard owns no rows at all
+            d = np.full((Q, k), 0xFFFF, dtype=np.uint16)
+            i = np.full((Q, k), -1, dtype=np.int32)
+            for q in range(Q):
+                m = min(n, k)
+                dd = np.sort(rng.integers(0, 6, size=n))[:m]                 # few distinct distances: many ties
+                ii = np.concatenate([np.sort(rng.choice(n, size=int((dd == v).sum()), replace=False)) for v in np.unique(dd)]) if m else np.zeros(0, np.int64)
+                d[q, :m], i[q, :m] = dd, base + ii
+            base += n
+            gathered[w, : Q * k * 4] = torch.from_numpy(i.view(np.uint8).reshape(-1).copy())
+            gathered[w, Q * k * 4: Q * k * 6] = torch.from_numpy(d.view(np.uint8).reshape(-1).copy())
+            ds.append(torch.from_numpy(d.view(np.int16).copy()))
+            is_.append(torch.from_numpy(i))
+        got_d, got_i = sharded.merge_topk_records(gathered, world, Q, k)
+        want_d, want_i = sharded.merge_topk(torch.stack(ds), torch.stack(is_), k)
+        assert torch.equal(got_i, want_i), (world, Q, k)
+        live = want_i >= 0
+        assert torch.equal(got_d[live], want_d[live]) and bool((got_d[~live] == 0xFFFF).all())
