@@ -377,10 +377,19 @@ class BaseTrainer:
         return R.PackedCodes(bits, zero, p.K, p.flags) if bits is not None else None
 
     def _save_codes(self, codes, save_file):
-        q_img, q_txt, r_img, r_txt = codes
-        r_img, r_txt = self._gather_packed_to_writer(r_img, self.retrieval_num), self._gather_packed_to_writer(r_txt, self.retrieval_num)
+        """one .mat of the reference's layout (:386-405).  valid() may write the same codes up to three times (i2t-best, t2i-best,
+        last): the gather to the writer, the unpack to fp32 [N, K] and the device-to-host copies are done once per code set."""
+        memo = self.__dict__.get("_mat_memo")
+        if memo is None or memo[0] is not codes:
+            q_img, q_txt, r_img, r_txt = codes
+            r_img, r_txt = self._gather_packed_to_writer(r_img, self.retrieval_num), self._gather_packed_to_writer(r_txt, self.retrieval_num)
+            arrays = None
+            if self._is_writer():
+                arrays = tuple(t.unpack().cpu().numpy() for t in (q_img, q_txt, r_img, r_txt))
+            memo = self._mat_memo = (codes, arrays)
         if self._is_writer():
-            self.save_mat(q_img.unpack(), q_txt.unpack(), self.query_labels, r_img.unpack(), r_txt.unpack(), self.retrieval_labels, save_file=save_file)
+            a = memo[1]
+            self.save_mat(a[0], a[1], self.query_labels, a[2], a[3], self.retrieval_labels, save_file=save_file)
 
     def valid(self, epoch, k=None):
         assert self.query_loader is not None and self.retrieval_loader is not None
@@ -388,19 +397,22 @@ class BaseTrainer:
         os.makedirs(save_dir, exist_ok=True)
         self.logger.info("Valid.")
         (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(k)
+        saved = False                                        # both bests in one epoch name the same model-<epoch>.pth: written once
         if self.max_mapi2t < mAPi2t:
             self.best_epoch_i = epoch
             self._save_codes(codes, os.path.join(save_dir, "i2t-best.mat"))
             if self._is_writer():
                 self.save_model(save_dir=self.save_dir, epoch=epoch)
+                saved = True
         self.max_mapi2t = max(self.max_mapi2t, mAPi2t)
         if self.max_mapt2i < mAPt2i:
             self.best_epoch_t = epoch
             self._save_codes(codes, os.path.join(save_dir, "t2i-best.mat"))
-            if self._is_writer():
+            if self._is_writer() and not saved:
                 self.save_model(save_dir=self.save_dir, epoch=epoch)
         self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
         self._save_codes(codes, os.path.join(save_dir, "last.mat"))
+        self._mat_memo = None
         self.logger.info(f">>>>>> [{epoch}/{self.epochs}], MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}, "
                          f"MAX MAP(i->t): {self.max_mapi2t}, epoch: {self.best_epoch_i}, MAX MAP(t->i): {self.max_mapt2i}, epoch: {self.best_epoch_t}")
         return mAPi2t, mAPt2i, mAPi2i, mAPt2t
@@ -412,6 +424,7 @@ class BaseTrainer:
         os.makedirs(save_dir, exist_ok=True)
         (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(self.top_k)
         self._save_codes(codes, os.path.join(save_dir, "test.mat"))
+        self._mat_memo = None
         self.logger.info(f">>>>>> TEST, MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}")
         return mAPi2t, mAPt2i, mAPi2i, mAPt2t
 
