@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")]
 import torch
 from xmh import ops
-for B, L, H, causal in ((100, 50, 12, False), (100, 32, 8, True), (100, 64, 12, False)):
+SHAPES = ((100, 50, 12, False), (100, 32, 8, True), (100, 64, 12, False))
+for B, L, H, causal in (SHAPES[:1] if os.environ.get("XMH_ATT_ONE") else SHAPES):
     qkv = torch.randn(B, L, 3 * 64 * H, device="cuda")
     for _ in range(3):
         ops.attention(qkv, H, causal=causal)
