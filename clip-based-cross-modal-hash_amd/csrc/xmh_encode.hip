@@ -241,15 +241,20 @@ __device__ __forceinline__ attn_f32x16 attn_mm_f32(const float (&a)[32], const f
 // per ViT layer (the V operand is 32 strided loads per block and lane).
 template <bool S16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
-                                                         const uint8_t* __restrict__ kpm, float* __restrict__ out, xmh::Planes pl) {
+void k_attention_mfma64(const float* __restrict__ qkv, int Lmax, int H, int causal,
+                                                         const uint8_t* __restrict__ kpm, float* __restrict__ out, xmh::Planes pl,
+                                                         const int32_t* __restrict__ offs) {
     constexpr int DH = 64, SP = 68;                                  // score row stride: 16-byte aligned, rows on distinct 16-B slots
     __shared__ __attribute__((aligned(16))) float sS[32 * SP];
-    const int nblk = (L + 31) / 32;                                  // 32-row blocks of queries / keys (1 or 2)
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // packed sequences (the text tower without its padding, xmh_text_forward_packed): this one's rows start at offs[b], and it is
+    // offs[b + 1] - offs[b] tokens long; otherwise B sequences of Lmax rows
+    const int64_t row0 = offs ? (int64_t)offs[b] : (int64_t)b * Lmax;
+    const int L = offs ? offs[b + 1] - offs[b] : Lmax;
+    const int nblk = (L + 31) / 32;                                  // 32-row blocks of queries / keys (1 or 2)
     const int D = H * DH;
     const int lane = threadIdx.x, r = lane & 31, kk = lane >> 5;
-    const float* base = qkv + (int64_t)b * L * 3 * D + h * DH;
+    const float* base = qkv + row0 * 3 * D + h * DH;
     const float scale = rsqrtf((float)DH);
 
     // K rows (columns of S) and V columns.  All loads are unconditional on a clamped row and zeroed by a select afterwards: a
@@ -375,7 +380,7 @@ void k_attention_mfma64(const float* __restrict__ qkv, int L, int H, int causal,
             const int row = ib * 32 + rr;
             const float4 v = *reinterpret_cast<const float4*>(&sS[rr * SP + cc]);
             if (row < L) {
-                const int64_t orow = (int64_t)b * L + row;
+                const int64_t orow = row0 + row;
                 if (out) *reinterpret_cast<float4*>(out + orow * D + h * DH + cc) = v;
                 if (pl.hi) xmh::store_planes4(pl, orow, h * DH + cc, v.x, v.y, v.z, v.w);
             }
@@ -463,6 +468,33 @@ __global__ __launch_bounds__(256) void k_text_embed(const int64_t* __restrict__ 
             }
         }
         eos[b] = best;
+    }
+}
+
+// the same rows without the padding: caption b keeps its first offs[b + 1] - offs[b] tokens (up to and including EOS), stored from
+// row offs[b] on.  Same arithmetic per element as k_text_embed.
+__global__ __launch_bounds__(256) void k_text_embed_packed(const int64_t* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                                           float* __restrict__ x, const int32_t* __restrict__ offs, int64_t B, int L, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int64_t b = row / L;
+    const int l = (int)(row % L);
+    const int o0 = offs[b];
+    if (l >= offs[b + 1] - o0) return;
+    int64_t id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    float* dst = x + (int64_t)(o0 + l) * D;
+    for (int c = lane; c < D; c += 64) dst[c] = tok[id * D + c] + pos[(int64_t)l * D + c];
+}
+
+__global__ __launch_bounds__(256) void k_gather_last_rows(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ offs, float* __restrict__ out,
+                                                          int64_t rows, int D) {
+    const int64_t total = rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D;
+        out[e] = x[(int64_t)(offs[r + 1] - 1) * ldx + (int)(e % D)];
     }
 }
 
@@ -623,16 +655,17 @@ int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const floa
 }
 
 int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
-                     bool split16, hipStream_t st) {
+                     bool split16, hipStream_t st, const int32_t* row_offsets) {
     if (B < 0 || L <= 0 || H <= 0) return fail(XMH_EINVAL, "xmh_attention_f32: bad shape");
     if (B == 0) return XMH_OK;
     if (dh != 64) return fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
     if (L > 128) return fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
     if (!qkv || (!out && !p.hi)) return fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
     static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
-    if (L <= 64 && !valu_only) {                                     // fp32-MFMA kernel: one wave per head
-        if (split16) hipLaunchKernelGGL(k_attention_mfma64<true>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
-        else hipLaunchKernelGGL(k_attention_mfma64<false>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p);
+    if (row_offsets && (L > 64 || key_padding_mask)) return fail(XMH_ENOTSUP, "xmh attention: packed sequences need L <= 64 and no key padding mask (L=%d)", L);
+    if (L <= 64 && (!valu_only || row_offsets)) {                    // fp32-MFMA kernel: one wave per head
+        if (split16) hipLaunchKernelGGL(k_attention_mfma64<true>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p, row_offsets);
+        else hipLaunchKernelGGL(k_attention_mfma64<false>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p, row_offsets);
         XMH_LAUNCH_CHECK("xmh_attention_f32");
         return XMH_OK;
     }
@@ -642,6 +675,25 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
     if (const int rl = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_attention_f32")) return rl;
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(threads), lds, st, qkv, L, H, causal, key_padding_mask, out, p);
     XMH_LAUNCH_CHECK("xmh_attention_f32");
+    return XMH_OK;
+}
+
+int text_embed_packed(const int64_t* ids, const float* tok_emb, const float* pos, float* x, const int32_t* row_offsets, int64_t B, int L, int D,
+                      int vocab, hipStream_t st) {
+    if (B < 0 || L <= 0 || D <= 0 || vocab <= 0) return fail(XMH_EINVAL, "xmh text_embed_packed: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!ids || !tok_emb || !pos || !x || !row_offsets) return fail(XMH_EINVAL, "xmh text_embed_packed: null pointer");
+    hipLaunchKernelGGL(k_text_embed_packed, dim3((unsigned)ceil_div(B * L, 4)), dim3(256), 0, st, ids, tok_emb, pos, x, row_offsets, B, L, D, vocab);
+    XMH_LAUNCH_CHECK("xmh text_embed_packed");
+    return XMH_OK;
+}
+
+int gather_last_rows(const float* x, int64_t ldx, const int32_t* row_offsets, float* out, int64_t B, int D, hipStream_t st) {
+    if (B < 0 || D <= 0) return fail(XMH_EINVAL, "xmh gather_last_rows: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!x || !out || !row_offsets) return fail(XMH_EINVAL, "xmh gather_last_rows: null pointer");
+    hipLaunchKernelGGL(k_gather_last_rows, dim3(grid1d(B * D)), dim3(256), 0, st, x, ldx, row_offsets, out, B, D);
+    XMH_LAUNCH_CHECK("xmh gather_last_rows");
     return XMH_OK;
 }
 

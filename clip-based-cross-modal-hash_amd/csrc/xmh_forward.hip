@@ -94,9 +94,11 @@ int linear_any(const xmh_linear& l, const float* A, int64_t lda, const float* re
     return xmh_gemm_nt_f32(A, lda, l.w_f32, K, l.bias, residual, ldr, C, ldc, M, N, K, act, precision == kPrecFast ? 1 : 0, st);
 }
 
+// offs / M_packed: packed sequences (xmh_text_forward_packed) -- the row-wise kernels see M_packed rows, attention finds sequence b at
+// rows [offs[b], offs[b + 1])
 int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L, int causal,
-               const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st) {
-    const int64_t M = B * L;
+               const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st, const int32_t* offs = nullptr, int64_t M_packed = 0) {
+    const int64_t M = offs ? M_packed : B * L;
     const int D = width;
     hipStream_t hs = xmh::as_stream(st);
     const xmh::Planes none{nullptr, nullptr, 0};
@@ -111,7 +113,8 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
             if (rc) return rc;
             rc = xmh_gemm_nt_f32(s.h, D, b.qkv.w_f32, D, b.qkv.bias, nullptr, 0, s.qkv, 3 * D, M, 3 * D, D, kActNone, 0, st);
             if (rc) return rc;
-            rc = xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
+            rc = offs ? xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, none, false, hs, offs)
+                      : xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
             if (rc) return rc;
             rc = xmh_gemm_nt_f32(s.a, D, b.out.w_f32, D, b.out.bias, x, D, x, D, M, D, D, kActNone, 0, st);
             if (rc) return rc;
@@ -129,7 +132,7 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
         if (rc) return rc;
         rc = linear_p(b.qkv, s.hP, nullptr, 0, s.qkv, 3 * D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
-        rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, true, hs);
+        rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, true, hs, offs);
         if (rc) return rc;
         rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
@@ -378,6 +381,33 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
         return rc;
     }
     rc = xmh_gather_rows(t.x, D, eos, 0, L, t.row_a, B, D, stream);
+    if (rc) return rc;
+    return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
+}
+
+// CLIP.encode_text (models/CLIP/model.py:373-396) when only the EOS embedding is wanted, WITHOUT the padding: under the causal mask
+// (build_attention_mask, :358-364) no token behind a caption's EOS can reach the row x[b, argmax(ids[b])] that :392 selects, so only
+// the rows up to and including EOS are embedded, normalised, multiplied and attended -- sum_b (eos_b + 1) rows instead of B * L.
+// Every kept row goes through the same kernels with the same per-element arithmetic as in xmh_text_forward (GEMM and LayerNorm are
+// row-wise; in the attention kernel the keys behind a row are masked either way), so out_eos is bit-identical to the padded call.
+extern "C" int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t* ids, const int32_t* row_offsets, int64_t total_rows, int64_t B,
+                                       int L, int precision, float* out_eos, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (B == 0) return 0;
+    if (!w || !ids || !row_offsets || !workspace || !out_eos) return xmh::fail(-22, "xmh_text_forward_packed: bad arguments");
+    if (L <= 0 || L > w->context || L > 64) return xmh::fail(-22, "xmh_text_forward_packed: %d tokens (positional embedding %d, packed attention 64)", L, w->context);
+    if (total_rows < B || total_rows > B * L) return xmh::fail(-22, "xmh_text_forward_packed: %lld rows for %lld captions of at most %d tokens", (long long)total_rows, (long long)B, L);
+    const int D = w->width;
+    if (w->heads <= 0 || D % w->heads || w->proj.n != w->out_dim || w->proj.k != D) return xmh::fail(-22, "xmh_text_forward_packed: shapes do not fit the tower");
+    Arena ar(workspace);
+    const TowerScratch t = carve_tower(ar, B, L, D, 0, 0, precision);      // sized for B * L rows: total_rows <= that
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_text_forward_packed: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    hipStream_t hs = xmh::as_stream(stream);
+    int rc = xmh::text_embed_packed(ids, w->tok_emb, w->pos, t.x, row_offsets, B, L, D, w->vocab, hs);
+    if (rc) return rc;
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, nullptr, precision, t.blk, stream, row_offsets, total_rows);
+    if (rc) return rc;
+    rc = xmh::gather_last_rows(t.x, D, row_offsets, t.row_a, B, D, hs);
     if (rc) return rc;
     return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
 }

@@ -93,8 +93,16 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st);
 int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y, int64_t ldy, const Planes& p,
                      int64_t rows, int D, hipStream_t st);
 // split16: the products on the fp16 MFMA with hi/lo split operands (parity / fast mode) instead of the fp32 MFMA (exact mode)
+// row_offsets (device, [B + 1] i32, may be null): PACKED sequences -- sequence b owns rows [row_offsets[b], row_offsets[b + 1]) of qkv
+// and of the outputs and is that many (1 .. L) tokens long; null: B sequences of exactly L rows each.  Packed form: L <= 64, no key
+// padding mask.
 int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int causal, const uint8_t* key_padding_mask, float* out, const Planes& p,
-                     bool split16, hipStream_t st);
+                     bool split16, hipStream_t st, const int32_t* row_offsets = nullptr);
+// the packed text tower's first and last step (xmh_text_forward_packed): x[row_offsets[b] + l] = tok[ids[b][l]] + pos[l] for l below the
+// caption's length; out[b] = x[row_offsets[b + 1] - 1] (the EOS row)
+int text_embed_packed(const int64_t* ids, const float* tok_emb, const float* pos, float* x, const int32_t* row_offsets, int64_t B, int L, int D,
+                      int vocab, hipStream_t st);
+int gather_last_rows(const float* x, int64_t ldx, const int32_t* row_offsets, float* out, int64_t B, int D, hipStream_t st);
 // f = QuickGELU(u) elementwise on [rows, cols] (cols % 4 == 0), as fp32 and / or operand planes: the c_fc epilogue's activation as a
 // pass of its own, for the saved-activation forward (xmh_gemm.hip)
 int quickgelu_planes(const float* u, int64_t rows, int64_t cols, float* f, const Planes& p, hipStream_t st);

@@ -30,6 +30,7 @@ from .._lib import check, current_stream, lib, ptr
 # The towers run through the whole-tower entry points of libxmh.so (xmh_vit_b32_forward / xmh_text_forward /
 # xmh_clip_blocks_forward: one C call enqueues the ~150 launches).  XMH_FORWARD=ops keeps the per-primitive chain below
 # (the same kernels in the same order, enqueued from Python) -- the tests run both and compare them bit for bit.
+TEXT_PACKING = os.environ.get("XMH_TEXT_PACKING", "1") != "0"     # module switch (tests flip it): run the text tower without its padding rows
 NATIVE_FORWARD = os.environ.get("XMH_FORWARD", "native") != "ops"
 
 
@@ -283,6 +284,18 @@ class CLIP(nn.Module):
         nbytes = lib.xmh_clip_workspace_bytes(B, L, desc.width, 0, out_dim if self.return_patches else 0, precision)
         ws = _workspace(nbytes, ids.device)
         eos_tok = torch.empty(B, out_dim, dtype=torch.float32, device=ids.device)
+        if not self.return_patches and kpm is None and L <= 64 and TEXT_PACKING:
+            # only the EOS embedding is wanted and the attention is causal: the tokens behind a caption's EOS cannot reach it, so the
+            # tower runs on the rows up to EOS only (xmh_text_forward_packed: bit-identical output, sum(lengths) / (B L) of the work).
+            # The launches are sized by the row count, hence one small device-to-host copy (the stream this forward is enqueued on has
+            # at most the previous text forward in flight).
+            offs = torch.zeros(B + 1, dtype=torch.int32, device=ids.device)
+            offs[1:] = torch.cumsum(ids.argmax(dim=1) + 1, 0)
+            total = int(offs[B].item())
+            if total < 0.9 * B * L:
+                check(lib.xmh_text_forward_packed(ctypes.byref(desc), ptr(ids), ptr(offs), total, B, L, precision, ptr(eos_tok), ptr(ws), nbytes,
+                                                  current_stream()), "xmh_text_forward_packed")
+                return eos_tok
         if not self.return_patches:
             check(lib.xmh_text_forward(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), None, None, ptr(ws), nbytes,
                                        current_stream()), "xmh_text_forward")

@@ -16,6 +16,7 @@ keys and dtypes :397-404, ``model-<epoch>.pth`` :379-384).  What changes underne
 from __future__ import annotations
 
 import os
+import shutil
 
 import numpy as np
 import torch
@@ -378,7 +379,9 @@ class BaseTrainer:
 
     def _save_codes(self, codes, save_file):
         """one .mat of the reference's layout (:386-405).  valid() may write the same codes up to three times (i2t-best, t2i-best,
-        last): the gather to the writer, the unpack to fp32 [N, K] and the device-to-host copies are done once per code set."""
+        last): the gather to the writer, the unpack to fp32 [N, K] and the device-to-host copies are done once per code set, and
+        the second and third file are byte copies of the first (same arrays, same keys: scipy would serialise the 75 MB of int64
+        labels again each time)."""
         memo = self.__dict__.get("_mat_memo")
         if memo is None or memo[0] is not codes:
             q_img, q_txt, r_img, r_txt = codes
@@ -386,10 +389,14 @@ class BaseTrainer:
             arrays = None
             if self._is_writer():
                 arrays = tuple(t.unpack().cpu().numpy() for t in (q_img, q_txt, r_img, r_txt))
-            memo = self._mat_memo = (codes, arrays)
+            memo = self._mat_memo = [codes, arrays, None]
         if self._is_writer():
+            if memo[2] is not None and os.path.exists(memo[2]) and type(self).save_mat.__func__ is BaseTrainer.save_mat.__func__:
+                shutil.copyfile(memo[2], save_file)
+                return
             a = memo[1]
             self.save_mat(a[0], a[1], self.query_labels, a[2], a[3], self.retrieval_labels, save_file=save_file)
+            memo[2] = save_file
 
     def valid(self, epoch, k=None):
         assert self.query_loader is not None and self.retrieval_loader is not None

@@ -23,10 +23,10 @@ def run_both(fn_image, fn_text):
     side = _side.get(cur.device)
     if side is None:
         side = _side[cur.device] = torch.cuda.Stream(device=cur.device)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
+    side.wait_stream(cur)                # the side stream starts behind what is on the caller's stream NOW: the inputs, not this image forward
+    img = fn_image()                     # enqueued first: the packed text tower reads its row count back (one small device-to-host
+    with torch.cuda.stream(side):        # copy behind the wait above), and while the host waits for it the GPU has this to run
         txt = fn_text()
-    img = fn_image()
     cur.wait_stream(side)
     _record(txt, cur)
     return img, txt

@@ -360,6 +360,14 @@ int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image, int64_t B,
 int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
                      int precision, float* out_eos, float* out_tokens, int32_t* eos_index, void* workspace,
                      size_t workspace_bytes, xmh_stream_t stream);
+/* The same tower when only out_eos is wanted, on PACKED rows: caption b takes part with its tokens up to and including EOS only
+ * (row_offsets [B + 1] i32 on the device, row_offsets[b + 1] - row_offsets[b] = argmax(ids[b]) + 1; total_rows = row_offsets[B], a
+ * HOST value that sizes the launches).  Under the causal mask of CLIP.encode_text (models/CLIP/model.py:358-364, :373-396) nothing
+ * behind a caption's EOS token can reach the row :392 selects, so out_eos is bit-identical to xmh_text_forward's -- at
+ * sum(lengths) / (B L) of the work.  No key padding mask, no token outputs (callers that need those use xmh_text_forward); L <= 64;
+ * workspace as for xmh_text_forward (xmh_clip_workspace_bytes(B, L, width, 0, 0, precision)). */
+int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t* ids, const int32_t* row_offsets, int64_t total_rows, int64_t B,
+                            int L, int precision, float* out_eos, void* workspace, size_t workspace_bytes, xmh_stream_t stream);
 
 /* One modality of the DCMHT head in eval mode (models/DCMHT/hash/hash.py:15-82): MultiheadAttention over a length-1
  * sequence == out_proj(v_proj(x)) (softmax over one key is 1), BatchNorm1d with running statistics (image) or LayerNorm

@@ -287,6 +287,45 @@ def test_whole_tower_entry_points_equal_the_primitive_chain(ops, clip_models):
         ops.set_precision(before)
 
 
+def test_text_tower_without_its_padding_rows_is_bit_identical(ops, clip_models):
+    """xmh_text_forward_packed (round 4): the text tower on the rows up to each caption's EOS only.  Under the causal mask nothing behind
+    EOS reaches the EOS row, and every kept row runs through the same kernels, so the embeddings equal the padded call's bit for bit --
+    in all three precisions, for captions of every length from 1 token (a degenerate all-padding row: argmax = 0) to the full 32, and
+    for a batch large enough that the packed GEMMs pick other tiles than the padded ones."""
+    import xmh.models.clip as C
+    g, W, m, _ = clip_models
+    gen = torch.Generator().manual_seed(77)
+    B, L = 203, 32
+    ids = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = [0, 1, 30, 29][b] if b < 4 else int(torch.randint(2, 30, (1,), generator=gen))       # tokens between SOS and EOS
+        if b == 0:
+            continue                                                                             # all zeros: length 1
+        ids[b, 0] = 49406
+        ids[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=gen)
+        ids[b, 1 + n] = 49407
+    ids = ids.cuda()
+    before = ops.get_precision()
+    assert C.TEXT_PACKING
+    try:
+        for prec in ("f32", "f32x", "f16"):
+            ops.set_precision(prec)
+            packed = m.encode_text(ids).clone()
+            C.TEXT_PACKING = False
+            try:
+                padded = m.encode_text(ids)
+            finally:
+                C.TEXT_PACKING = True
+            assert torch.equal(packed, padded), prec
+            small = m.encode_text(ids[:5].contiguous())                                          # another batch size, other tiles: same rows
+            assert torch.equal(small, padded[:5]), prec
+    finally:
+        ops.set_precision(before)
+    # the entry point's argument checks
+    from xmh._lib import lib
+    assert lib.xmh_text_forward_packed(None, None, None, 0, 4, 32, 0, None, None, 0, None) != 0
+
+
 def _vit_front(m, image):
     """the image tower up to the block stack, through the primitives (VisionTransformer.run's chain)"""
     from xmh import ops as o
