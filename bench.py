@@ -329,7 +329,7 @@ def front_loaded(out):
     if "valid_e2e" in out:
         summ["valid_e2e"] = pick(out["valid_e2e"], "valid_seconds", "encode_seconds", "retrieve_seconds", "encode_share", "cpu_estimate_seconds", "error")
     if "encode" in out:
-        summ["encode"] = pick(out["encode"], "images_per_s_f32", "captions_per_s_f32", "images_per_s_f16", "error")
+        summ["encode"] = pick(out["encode"], "images_per_s_f32", "captions_per_s_f32", "captions_per_s_f32_padded_tower", "captions_rows_run_fraction", "images_per_s_f16", "error")
         fb = out["encode"].get("fused_batches") if isinstance(out["encode"], dict) else None
         if fb:
             summ["encode_batch400"] = pick(fb, "images_per_s_f32", "images_per_s_f16")

@@ -38,6 +38,13 @@ def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), e
     ids, _ = W.synth_text(5, batch)
     ids = ids.cuda()
     out = {}
+    # round 4: with only the EOS embedding wanted the text tower runs on the rows up to each caption's EOS (xmh_text_forward_packed,
+    # bit-identical output); the synthetic captions of SURVEY 8d are 4-30 tokens + SOS + EOS of 32.  Rates are per caption either way;
+    # the GEMM TFLOP/s count the rows that really ran, and the padded tower's rate is reported beside it.
+    import xmh.models.clip as CM
+    frac = float((ids.argmax(1) + 1).sum()) / ids.numel()
+    packed = CM.TEXT_PACKING and frac < 0.9
+    out["captions_rows_run_fraction"] = frac if packed else 1.0
     for mode in modes:
         ops.set_precision(mode)
         try:
@@ -69,10 +76,24 @@ def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), e
                 _lib.prof_enable(False)
                 out["%s_per_s_%s" % (what, mode)] = batch / dt
                 out["%s_ms_per_batch_%s" % (what, mode)] = dt * 1e3
-                out["%s_gemm_tflops_%s" % (what, mode)] = flop * batch / gemm_total / 1e12
+                out["%s_gemm_tflops_%s" % (what, mode)] = flop * (frac if (what == "captions" and packed) else 1.0) * batch / gemm_total / 1e12
                 out["%s_gemm_share_%s" % (what, mode)] = gemm_total / dt
         finally:
             ops.set_precision("f32")
+    if packed and "f32" in modes:                              # the padded text tower (what rounds 1-3 measured), parity mode
+        CM.TEXT_PACKING = False
+        try:
+            fn = lambda: R.pack_pair_argmax(model.encode_text(ids))     # noqa: E731
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            out["captions_per_s_f32_padded_tower"] = batch * steps / (time.perf_counter() - t0)
+        finally:
+            CM.TEXT_PACKING = True
     if not extras:                                             # multi-GPU leg of bench.py: throughput of the chosen modes only
         return out
     # the eval transform on raw photo bytes (COCO-like 375 x 500 RGB uint8, device-resident)
