@@ -19,8 +19,23 @@ for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
 
 import torch  # noqa: E402
 
-FLOP_IMAGE = 8.86e9        # patch-embed 0.23 + 12 x 0.716 + proj 0.04 GFLOP (cls-only projection is ~0.04 less)
-FLOP_TEXT = 2.46e9         # 12 x 0.203 + 0.017 GFLOP at L=32
+# Flops the GEMM launches really execute per item (the TFLOP/s figures divide these by the GEMM kernel time).  SURVEY 2.2 counts
+# 8.86 GFLOP per image and 2.46 per caption for the reference, which runs every token through every layer; since round 4 the last
+# block's row-wise half (out_proj, c_fc, c_proj) runs on the one row per sequence the tower returns (cls / EOS):
+#   image: 8.86 - 49/50 * 2 * 50 * (768^2 + 2 * 768 * 3072) = 8.86 - 0.52;   caption (per kept row fraction f of 32 rows):
+#   12 blocks of 2 * 32 f * (512 * 1536 + 512^2 + 2 * 512 * 2048) minus the same tail, + the projection.
+FLOP_IMAGE = 8.86e9 - 49 * 2 * (768 * 768 + 2 * 768 * 3072)
+FLOP_IMAGE_REFERENCE = 8.86e9
+
+
+def _flop_text(frac):
+    per_row_block = 2.0 * (512 * 1536 + 512 * 512 + 2 * 512 * 2048)
+    tail = 2.0 * (512 * 512 + 2 * 512 * 2048)
+    rows = 32.0 * frac
+    return 12 * rows * per_row_block - (rows - 1) * tail + 2.0 * 512 * 512
+
+
+FLOP_TEXT = _flop_text(1.0)
 # TFLOP/s dense MFMA peaks, MI355X_MICROARCH.md.  The split kernel spends two fp16 MFMAs per product: its ceiling in
 # useful flops is half the fp16 peak.
 PEAK = {"f32": 2500.0 / 2, "f32x": 157.3, "f16": 2500.0}
@@ -76,7 +91,7 @@ def measure(batch=100, steps=10, warmup=5, K=64, modes=("f32", "f32x", "f16"), e
                 _lib.prof_enable(False)
                 out["%s_per_s_%s" % (what, mode)] = batch / dt
                 out["%s_ms_per_batch_%s" % (what, mode)] = dt * 1e3
-                out["%s_gemm_tflops_%s" % (what, mode)] = flop * (frac if (what == "captions" and packed) else 1.0) * batch / gemm_total / 1e12
+                out["%s_gemm_tflops_%s" % (what, mode)] = (_flop_text(frac if packed else 1.0) if what == "captions" else flop) * batch / gemm_total / 1e12
                 out["%s_gemm_share_%s" % (what, mode)] = gemm_total / dt
         finally:
             ops.set_precision("f32")

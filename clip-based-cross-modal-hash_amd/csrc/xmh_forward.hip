@@ -94,10 +94,29 @@ int linear_any(const xmh_linear& l, const float* A, int64_t lda, const float* re
     return xmh_gemm_nt_f32(A, lda, l.w_f32, K, l.bias, residual, ldr, C, ldc, M, N, K, act, precision == kPrecFast ? 1 : 0, st);
 }
 
+// Which rows of the stack's output the caller keeps.  A tower that returns one embedding per sequence (cls / EOS, return_patches =
+// False: models/CLIP/model.py:262-265, :392) needs ONE row of the last block's output per sequence; behind the last attention every
+// operation is row-wise (out_proj + residual, ln_2, c_fc, QuickGELU, c_proj + residual), so the last block runs them on those B rows
+// only -- the reference computes all B * L and discards them.  Same kernels, same per-element arithmetic: bit-identical rows.
+struct TailRows {
+    int mode = 0;                  // 0: every row; 1: row 0 of every group of L (cls); 2: row idx[b] of group b (EOS); 3: last row of every packed sequence
+    const int32_t* idx = nullptr;
+    float* x_tail = nullptr;       // [B, width] fp32: the kept rows of the stack's output (x itself is then stale in the last block)
+};
+
 // offs / M_packed: packed sequences (xmh_text_forward_packed) -- the row-wise kernels see M_packed rows, attention finds sequence b at
 // rows [offs[b], offs[b + 1])
 int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L, int causal,
-               const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st, const int32_t* offs = nullptr, int64_t M_packed = 0) {
+               const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st, const int32_t* offs = nullptr, int64_t M_packed = 0,
+               TailRows tail = TailRows{}) {
+    static const bool tail_off = getenv("XMH_TAIL_ROWS") && atoi(getenv("XMH_TAIL_ROWS")) == 0;      // A/B switch: 0 = the full last block + a gather
+    const bool want_tail = tail.mode != 0;
+    const bool tail_fused = want_tail && !tail_off && width % 2 == 0;
+    // rows of a float-typed [*, cols] view (fp16 planes: two halves per float) -> the B kept rows
+    auto keep_rows = [&](const void* src, int64_t ld_f, void* dst, int cols_f) -> int {
+        if (tail.mode == 3) return xmh::gather_last_rows(static_cast<const float*>(src), ld_f, offs, static_cast<float*>(dst), B, cols_f, xmh::as_stream(st));
+        return xmh_gather_rows(static_cast<const float*>(src), ld_f, tail.mode == 2 ? tail.idx : nullptr, 0, L, static_cast<float*>(dst), B, cols_f, st);
+    };
     const int64_t M = offs ? M_packed : B * L;
     const int D = width;
     hipStream_t hs = xmh::as_stream(st);
@@ -116,6 +135,16 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
             rc = offs ? xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, none, false, hs, offs)
                       : xmh_attention_f32(s.qkv, B, L, heads, D / heads, causal, kpm, s.a, st);
             if (rc) return rc;
+            if (tail_fused && i == layers - 1) {             // the last block's row-wise half on the kept rows only
+                float* xt = tail.x_tail;
+                if ((rc = keep_rows(s.a, D, s.h, D))) return rc;
+                if ((rc = keep_rows(x, D, xt, D))) return rc;
+                if ((rc = xmh_gemm_nt_f32(s.h, D, b.out.w_f32, D, b.out.bias, xt, D, xt, D, B, D, D, kActNone, 0, st))) return rc;
+                if ((rc = xmh_layernorm_f32(xt, D, b.ln2_w, b.ln2_b, kLnEps, s.a, D, B, D, st))) return rc;
+                if ((rc = xmh_gemm_nt_f32(s.a, D, b.fc.w_f32, D, b.fc.bias, nullptr, 0, s.f, 4 * D, B, 4 * D, D, kActQuickGelu, 0, st))) return rc;
+                if ((rc = xmh_gemm_nt_f32(s.f, 4 * D, b.proj.w_f32, 4 * D, b.proj.bias, xt, D, xt, D, B, D, 4 * D, kActNone, 0, st))) return rc;
+                return 0;
+            }
             rc = xmh_gemm_nt_f32(s.a, D, b.out.w_f32, D, b.out.bias, x, D, x, D, M, D, D, kActNone, 0, st);
             if (rc) return rc;
             rc = xmh_layernorm_f32(x, D, b.ln2_w, b.ln2_b, kLnEps, s.h, D, M, D, st);
@@ -134,6 +163,18 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
         if (rc) return rc;
         rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, true, hs, offs);
         if (rc) return rc;
+        if (tail_fused && i == layers - 1) {                 // the last block's row-wise half on the kept rows only
+            float* xt = tail.x_tail;
+            const xmh::Planes hc{s.hP.hi, s.hP.lo, D}, ac{s.aP.hi, s.aP.lo, D}, fc{s.fP.hi, s.fP.lo, 4 * (int64_t)D};
+            if ((rc = keep_rows(s.aP.hi, s.aP.ld / 2, hc.hi, D / 2))) return rc;       // attention output planes -> the kept rows (hP is free)
+            if (s.aP.lo && (rc = keep_rows(s.aP.lo, s.aP.ld / 2, hc.lo, D / 2))) return rc;
+            if ((rc = keep_rows(x, D, xt, D))) return rc;
+            if ((rc = linear_p(b.out, hc, xt, D, xt, D, nullptr, B, kActNone, precision, st))) return rc;
+            if ((rc = xmh::layernorm_planes(xt, D, b.ln2_w, b.ln2_b, kLnEps, nullptr, 0, ac, B, D, hs))) return rc;
+            if ((rc = linear_p(b.fc, ac, nullptr, 0, nullptr, 0, &fc, B, kActQuickGelu, precision, st))) return rc;
+            if ((rc = linear_p(b.proj, fc, xt, D, xt, D, nullptr, B, kActNone, precision, st))) return rc;
+            return 0;
+        }
         rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st);
         if (rc) return rc;
         rc = xmh::layernorm_planes(x, D, b.ln2_w, b.ln2_b, kLnEps, nullptr, 0, s.hP, M, D, hs);
@@ -144,6 +185,7 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
         if (rc) return rc;
     }
     (void)none;
+    if (want_tail) return keep_rows(x, D, tail.x_tail, D);    // no block ran its tail on the kept rows (switched off, or no layers): gather them
     return 0;
 }
 
@@ -343,7 +385,9 @@ extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image,
     if (rc) return rc;
     rc = xmh_vit_assemble(t.patches, w->cls, w->pos, w->ln_pre_w, w->ln_pre_b, kLnEps, t.x, B, P, D, stream);
     if (rc) return rc;
-    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 0, nullptr, precision, t.blk, stream);
+    TailRows tail;
+    if (!out_tokens) { tail.mode = 1; tail.x_tail = t.row_a; }      // the cls row is all the caller keeps
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 0, nullptr, precision, t.blk, stream, nullptr, 0, tail);
     if (rc) return rc;
     if (out_tokens) {                                 // return_patches: ln_post + proj on every token (model.py:257-265)
         rc = ln_linear(t.x, M, D, w->ln_post_w, w->ln_post_b, w->proj, t.y, out_tokens, precision, t.blk, stream);
@@ -351,8 +395,6 @@ extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image,
         if (out_cls) rc = xmh_gather_rows(out_tokens, w->out_dim, nullptr, 0, L, out_cls, B, w->out_dim, stream);
         return rc;
     }
-    rc = xmh_gather_rows(t.x, D, nullptr, 0, L, t.row_a, B, D, stream);       // the cls row is all the caller keeps
-    if (rc) return rc;
     return ln_linear(t.row_a, B, D, w->ln_post_w, w->ln_post_b, w->proj, t.row_b, out_cls, precision, t.blk, stream);
 }
 
@@ -372,7 +414,9 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
     int32_t* eos = eos_index ? eos_index : t.eos;
     int rc = xmh_text_embed(ids, w->tok_emb, w->pos, t.x, eos, B, L, D, w->vocab, stream);
     if (rc) return rc;
-    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream);
+    TailRows tail;
+    if (!out_tokens) { tail.mode = 2; tail.idx = eos; tail.x_tail = t.row_a; }      // only the EOS row of every caption is kept
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream, nullptr, 0, tail);
     if (rc) return rc;
     if (out_tokens) {
         rc = ln_linear(t.x, M, D, w->ln_final_w, w->ln_final_b, w->proj, t.y, out_tokens, precision, t.blk, stream);
@@ -380,8 +424,6 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
         if (out_eos) rc = xmh_gather_rows(out_tokens, w->out_dim, eos, 0, L, out_eos, B, w->out_dim, stream);
         return rc;
     }
-    rc = xmh_gather_rows(t.x, D, eos, 0, L, t.row_a, B, D, stream);
-    if (rc) return rc;
     return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
 }
 
@@ -405,9 +447,10 @@ extern "C" int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t*
     hipStream_t hs = xmh::as_stream(stream);
     int rc = xmh::text_embed_packed(ids, w->tok_emb, w->pos, t.x, row_offsets, B, L, D, w->vocab, hs);
     if (rc) return rc;
-    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, nullptr, precision, t.blk, stream, row_offsets, total_rows);
-    if (rc) return rc;
-    rc = xmh::gather_last_rows(t.x, D, row_offsets, t.row_a, B, D, hs);
+    TailRows tail;
+    tail.mode = 3;
+    tail.x_tail = t.row_a;
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, nullptr, precision, t.blk, stream, row_offsets, total_rows, tail);
     if (rc) return rc;
     return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
 }
