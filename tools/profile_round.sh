@@ -11,6 +11,9 @@ CMD="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 # the counter passes leave the extra scan legs out: they launch some of the headline's kernel instances at OTHER shapes (k_scan_ap_c<false>
 # serves 16- and 64-bit codes alike), and a per-launch average over mixed shapes is nobody's number
 PMC_CMD="$CMD --no-extra-configs"
+# the per-device self-check of k_scan_hist_m2 launches the headline's kernel instances once at a 200 x 9000 shape: keep it out of the
+# per-launch counter averages
+export XMH_SCAN_M2_SELFCHECK=0
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o b -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o b -- $PMC_CMD > $OUT/pmc_write.log 2>&1
