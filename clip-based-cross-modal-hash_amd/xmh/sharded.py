@@ -321,6 +321,7 @@ def gather_rows_to(t: torch.Tensor, counts: Sequence[int], dst: int = 0, group=N
 
 
 _pinned = {}          # record bytes -> pinned host staging buffer for the gathered lists (reused over calls)
+_topk_ws = {}         # the prepared top-k workspace of the last (Q, R, K, k, device) topk_sharded ran
 
 
 def merge_topk_records(gathered: torch.Tensor, world: int, nq: int, k: int):
@@ -366,7 +367,12 @@ def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
         mine.fill_(0xFF)                                                     # distance 0xFFFF, index -1 = unused slots
     elif hip:
         from . import retrieval as R
-        R.hamming_topk(q, r_shard, k, base_index, out=(d_view, i_view))
+        # a query loop over one gallery shard calls with the same shape every time: keep the prepared workspace of the last shape
+        # (cleared once, left clean by every call) instead of allocating and clearing a scratch one per call
+        shape = (nq, n_rows, q.K, int(k), dev)
+        if _topk_ws.get("shape") != shape:
+            _topk_ws["shape"], _topk_ws["ws"] = shape, R.TopkWorkspace(nq, n_rows, q.K, int(k), dev)
+        R.hamming_topk(q, r_shard, k, base_index, workspace=_topk_ws["ws"], out=(d_view, i_view))
     else:
         d, i = topk_fn(q, r_shard, k, base_index)
         d_view.copy_(d.to(torch.int16) if d.dtype != torch.int16 else d)
