@@ -21,31 +21,25 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
+def filter_instance(K, Q, R=10_000_000, k=100):
+    """the streaming kernel instance this call launches, as the library reports it (xmh_topk_describe: one decision function for the
+    launch and for this name)"""
+    import ctypes
+    from xmh._lib import check, lib
+    buf = ctypes.create_string_buffer(256)
+    check(lib.xmh_topk_describe(Q, R, K, k, buf, 256), "xmh_topk_describe")
+    return buf.value.decode().split("=", 1)[1]
+
+
 def filter_on_matrix_cores(K, Q):
-    """the dispatch rule of xmh_topk.hip: 3 and >= 5 queries at code lengths of 128 / 256 / 512 bits run k_topk_filter_mfma"""
-    e = os.environ.get("XMH_TOPK_MFMA")
-    if (K + 31) // 32 not in (4, 8, 16):
-        return False
-    if e is None:
-        return Q >= 5 or Q == 3
-    return int(e) > 0 and Q >= int(e)
+    return filter_instance(K, Q).startswith("k_topk_filter_mfma")
 
 
 def _traffic(K, Q):
-    """PMC HBM bytes of exactly the filter instance this (K, Q) launches: k_topk_filter<words, items per thread, query group>"""
+    """PMC HBM bytes of exactly the filter instance this (K, Q) launches"""
     try:
         import bench_roofline
-        W = (K + 31) // 32
-        qn = 8 if Q >= 8 else (4 if Q >= 4 else (2 if Q >= 2 else 1))
-        d, _ = bench_roofline._newest_summary()
-        if filter_on_matrix_cores(K, Q):
-            qt = 1 if Q <= 16 else (2 if Q <= 32 or W == 16 else 4)
-            names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter_mfma<%d, %d>" % (W, qt))]
-        else:
-            names = [n for n in (d or {}).get("pmc", {}) if n.startswith("k_topk_filter<%d, " % W) and n.endswith(", %d>" % qn)]
-        if len(names) != 1:
-            return None
-        t = bench_roofline.pmc_traffic(names[0])
+        t = bench_roofline.pmc_traffic(filter_instance(K, Q))
         return None if t is None else t["bytes"]
     except Exception:
         return None

@@ -2367,6 +2367,19 @@ extern "C" size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int te
 // Which kernel instances an UNSHARDED mAP@all evaluation of this shape launches for the two passes (as rocprofv3 prints them, minus
 // the namespace): bench_roofline.py picks the PMC rows of exactly these -- a prefix match once took the 128-bit kernel's row for
 // the 64-bit headline.  Mirrors the dispatch of xmh_hamming_hist / hamming_ap_impl (lane order assumed to hold).
+// Width of the rank field of the packed 32-bit pass-2 counters for an UNSHARDED evaluation of this shape, 0 = only the 64-bit kernels
+// are launched.  One function for the launch path (hamming_ap_impl) and for xmh_scan_describe, so that the kernel name the bench looks
+// up in a profile is the kernel that ran (the two had drifted apart on XMH_SCAN_NO_PACK32).
+int packed_rank_bits(int K, int64_t R, bool mfma_plan) {
+    if (!(K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) || getenv("XMH_SCAN_NO_PACK32") != nullptr) return 0;
+    // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
+    // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
+    const int64_t rank_max = (mfma_plan && K <= 64 && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
+    int rank_bits = 0;
+    while ((1ll << rank_bits) < rank_max) ++rank_bits;
+    return rank_bits > 24 ? 0 : rank_bits;
+}
+
 extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary, char* out, size_t out_bytes) {
     if (!out || out_bytes < 64) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
     xmh_scan_plan p;
@@ -2393,7 +2406,7 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
                  cached ? "true" : "false");
     }
     const char* apc_env = getenv("XMH_SCAN_AP_C");
-    const bool packable = K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr;
+    const bool packable = packed_rank_bits(K, R, use_mfma) > 0;       // exactly what hamming_ap_impl launches for an unsharded evaluation
     const int apc_mode = apc_env ? atoi(apc_env) : 1;
     if (cache && !tern && (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256) && R <= kFloatBitsMaxItems) {
         snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", K <= 64 ? 8 : 16);
@@ -2520,15 +2533,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // K=32 0.278 / 0.253, K=64 0.199 / 0.195, K=128 0.274 / 0.286, K=256 0.347 / 0.412 -- packed counters pay from 65 bits on;
     // below that only the 64-bit kernel is launched (and no gated launch returns at once); XMH_SCAN_PACK32_ALL=1 brings the packed
     // kernels back for every length (tests).
-    int rank_bits = 0;
     const bool sharded = base_all != nullptr || hist_g != nullptr;
-    if (!sharded && (K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) && getenv("XMH_SCAN_NO_PACK32") == nullptr) {
-        // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
-        // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
-        const int64_t rank_max = (mfma_plan && K <= 64 && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
-        while ((1ll << rank_bits) < rank_max) ++rank_bits;
-        if (rank_bits > 24) rank_bits = 0;
-    }
+    const int rank_bits = sharded ? 0 : packed_rank_bits(K, R, mfma_plan);
     // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
     if (hist_g && rank < 0) {                                        // the all-to-all form: this shard's offset rows, by slice owner
         const int S = (int)(p.qpad / world);

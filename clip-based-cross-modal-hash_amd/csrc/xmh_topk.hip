@@ -1079,6 +1079,31 @@ extern "C" int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, si
 }
 
 namespace {
+// Which instance of the streaming filter a (code words, queries) call launches: k_topk_filter_mfma<W, qt> (distances on the matrix
+// cores: 3 and >= 5 queries at 128 / 256 / 512 bits; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never) or
+// k_topk_filter<W, items per thread, qn, qg> (qn queries per group in VGPRs, qg groups per block sharing each tile through L1: Q = 8 runs
+// as 2 x 4, 16 and more queries as up to 4 x 8; XMH_TOPK_QG = "<qn>x<qg>" overrides).  Measured (10 M x 256 bit): one matrix-core pass
+// over 16 queries 63 us whatever their number, against 54 / 58 / 95 / 61 / 79 / 80 us for 1 / 2 / 3 / 4 / 6 / 8 queries on the VALU.
+struct FilterChoice { bool mfma; int qt, qn, qg; };
+FilterChoice topk_filter_choice(int W, int64_t Q) {
+    FilterChoice c{false, 0, 1, 1};
+    const int qmax = W >= 64 ? 1 : (W >= 32 ? 2 : (W >= 16 ? 4 : 8));      // query words live in VGPRs
+    c.qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));
+    if (W < 16 && Q >= 5 && Q <= 8) { c.qn = 4; c.qg = 2; }
+    else if (W < 16 && Q >= 16) c.qg = Q >= 32 ? 4 : 2;
+    if (const char* e = getenv("XMH_TOPK_QG")) {                           // tuning: "<queries per group>x<groups per block>"
+        int a = 0, b = 0;
+        if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4 || a == 8) && a <= qmax && (b == 1 || b == 2 || b == 4) && (a > 1 || b == 1) && W < 16) { c.qn = a; c.qg = b; }
+    }
+    static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
+    if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? (Q >= 5 || Q == 3) : (mfma_min_q > 0 && Q >= mfma_min_q))) {
+        const int qtmax = W == 16 ? 2 : 4;
+        c.mfma = true;
+        c.qt = Q <= 16 ? 1 : (Q <= 32 || qtmax == 2 ? 2 : 4);
+    }
+    return c;
+}
+
 int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes,
               uint16_t* dist, int32_t* idx, xmh_stream_t stream, bool prepared) {
     TopkPlan p;
@@ -1124,25 +1149,13 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                                per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
-            const int qmax = WW >= 64 ? 1 : (WW >= 32 ? 2 : (WW >= 16 ? 4 : 8));      /* query words live in VGPRs */     \
-            int qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));             \
-            /* query groups per block (they share each tile through L1): Q = 8 runs as 2 x 4, 16 and more queries as up to 4 x 8 */ \
-            int qg = 1;                                                                                                    \
-            if (WW < 16 && Q >= 5 && Q <= 8) { qn = 4; qg = 2; }                                                           \
-            else if (WW < 16 && Q >= 16) qg = Q >= 32 ? 4 : 2;                                                             \
-            if (const char* e_ = getenv("XMH_TOPK_QG")) {                 /* tuning: "<queries per group>x<groups per block>" */ \
-                int a_ = 0, b_ = 0;                                                                                        \
-                if (sscanf(e_, "%dx%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2 || a_ == 4 || a_ == 8) && a_ <= qmax && (b_ == 1 || b_ == 2 || b_ == 4) && (a_ > 1 || b_ == 1) && WW < 16) { qn = a_; qg = b_; } \
-            }                                                                                                              \
-            /* many queries, code lengths in steps of 128 bits: the distances on the matrix cores (k_topk_filter_mfma) */         \
-            /* measured (10 M x 256 bit): one pass over 16 queries 63 us whatever their number, against 54 / 58 / 95 / 61 / 79 / 80 us \
-               for 1 / 2 / 3 / 4 / 6 / 8 queries on the VALU; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never */    \
-            static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();            \
+            const FilterChoice fc_ = topk_filter_choice(WW, Q);      /* one decision for the launch and for xmh_topk_describe */        \
+            const int qn = fc_.qn, qg = fc_.qg;                                                                            \
             bool on_mfma = false;                                                                                          \
             if constexpr (WW == 4 || WW == 8 || WW == 16) {                                                                 \
-                if (mfma_min_q < 0 ? (Q >= 5 || Q == 3) : (mfma_min_q > 0 && Q >= mfma_min_q)) {                            \
+                if (fc_.mfma) {                                                                                            \
                     constexpr int QTMAX_ = WW == 16 ? 2 : 4;          /* B operands: 16 * QT * W / 8 registers */                  \
-                    const int qt_ = Q <= 16 ? 1 : (Q <= 32 || QTMAX_ == 2 ? 2 : 4);                                          \
+                    const int qt_ = fc_.qt;                                                                                \
                     const unsigned gy_ = (unsigned)xmh::ceil_div(Q, 16 * qt_);                                             \
                     int64_t fb_ = (int64_t)xmh::device_cu_count() * 8 / gy_;                                               \
                     if (fb_ < xmh::device_cu_count()) fb_ = xmh::device_cu_count();                                        \
@@ -1253,6 +1266,19 @@ extern "C" int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* 
 // host merge of per-shard lists (sharded retrieval): plain host code, a k-way merge with one cursor per shard
 // -- world <= 8 comparisons per output slot instead of an argsort of [Q][world * k] 64-bit keys
 // ---------------------------------------------------------------------------------------------------
+// Diagnostics for the measurement harness, like xmh_scan_describe: "filter=<kernel instance>" of the fast path's streaming pass for
+// this shape, spelled as rocprofv3 prints it, so that a profile row is matched by its exact name.
+extern "C" int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, size_t out_bytes) {
+    TopkPlan p;
+    if (const int rc = plan_topk(Q, R, K, k, &p)) return rc;
+    if (!out || out_bytes < 64) return xmh::fail(XMH_EINVAL, "xmh_topk_describe: buffer too small");
+    const FilterChoice c = topk_filter_choice(p.W, Q);
+    const int ipt = p.W <= 2 ? 8 : (p.W == 4 ? 4 : (p.W == 8 ? 2 : 1));      // items per thread of the VALU filter (XMH_FAST table)
+    if (c.mfma) snprintf(out, out_bytes, "filter=k_topk_filter_mfma<%d, %d>", p.W, c.qt);
+    else snprintf(out, out_bytes, "filter=k_topk_filter<%d, %d, %d, %d>", p.W, ipt, c.qn, c.qg);
+    return XMH_OK;
+}
+
 extern "C" size_t xmh_topk_record_bytes(int64_t Q, int k) {
     if (Q < 0 || k <= 0) return 0;
     return ((size_t)Q * (size_t)k * 6 + 3) & ~(size_t)3;

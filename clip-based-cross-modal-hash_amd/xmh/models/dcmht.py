@@ -109,6 +109,10 @@ class _Objective(torch.autograd.Function):
         a, b = model._codes(image), model._codes(text)
         if a.shape != b.shape:
             raise ValueError("our_loss: image codes %s, text codes %s" % (tuple(a.shape), tuple(b.shape)))
+        if (image.requires_grad or text.requires_grad) and (a.shape[0] + a.shape[1]) * 4 > 64 * 1024:
+            # the gradient kernel keeps one code row and one row of pair weights in LDS: say so now, not at backward() time
+            raise ValueError("our_loss: batch %d x code width %d exceeds the gradient kernel's (B + D) * 4 <= 65536 bytes of LDS"
+                             % (a.shape[0], a.shape[1]))
         C = labels.shape[1]
         lab = R.pack_labels(labels.to(a.device))
         intra_p, intra_n = model._pair(a, b, lab, C)

@@ -201,6 +201,9 @@ int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_byt
 int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
                               int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
                               xmh_stream_t stream);
+/* Diagnostics for the measurement harness: writes "filter=<kernel instance>" -- the streaming kernel the fast path of
+ * xmh_hamming_topk launches for this shape, spelled as rocprofv3 prints it (the counterpart of xmh_scan_describe).  out_bytes >= 64. */
+int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, size_t out_bytes);
 /* Host-side k-way merge of the shards' exact top-k lists (north_star: "partial top-k lists are merged on the host"; replaces the
  * reference's gather of the whole code matrix, runners/base.py:259-264, on the retrieval side).  HOST pointers, no GPU work:
  * gathered_host = `world` records as the ranks all-gathered them, each [Q][k] i32 global indices followed by [Q][k] u16
