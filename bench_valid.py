@@ -50,7 +50,7 @@ def _labels(n, C, seed, p=0.04):
     return L.to(torch.int64)
 
 
-def measure(Q=5000, Rn=117218, K=64, C=80, batch=100, pool=4, arch=("DCMHT", "DCMHTTrainer")):
+def measure(Q=5000, Rn=117218, K=64, C=80, batch=100, pool=4, arch=("DCMHT", "DCMHTTrainer"), encode_fuse=None):
     import xmh.models  # noqa: F401
     import xmh.runners  # noqa: F401
     from xmh.common.register import registry
@@ -64,6 +64,8 @@ def measure(Q=5000, Rn=117218, K=64, C=80, batch=100, pool=4, arch=("DCMHT", "DC
                 "train_num": 4, "save_dir": tmp, "log_dir": tmp, "seed": 1814},
     })
     t = registry.get_runner_class(arch[1]).from_config(cfg=cfg, autorun=False)
+    if encode_fuse:
+        t.encode_fuse = int(encode_fuse)
     dev = torch.device("cuda", 0)
     images = [W.synth_images(11 + j, batch).to(dev) for j in range(pool)]
     ids = [W.synth_text(11 + j, batch)[0].to(dev) for j in range(pool)]
@@ -125,5 +127,6 @@ if __name__ == "__main__":
     ap.add_argument("--Q", type=int, default=5000)
     ap.add_argument("--R", type=int, default=117218)
     ap.add_argument("--K", type=int, default=64)
+    ap.add_argument("--fuse", type=int, default=0, help="loader batches per forward (default: the runner's run.encode_fuse)")
     a = ap.parse_args()
-    print(json.dumps(measure(a.Q, a.R, a.K)))
+    print(json.dumps(measure(a.Q, a.R, a.K, encode_fuse=a.fuse or None)))
