@@ -131,6 +131,9 @@ __device__ __forceinline__ void rec_eval01(const QueryRegs<W, LW, TERN>& qr, con
 // rel_scale = 0: pass-1 counters are (all | relevant << 16); kRelHi16: (all << 16 | relevant) (k_scan_hist_m2); else all + relevant * rel_scale
 // (k_scan_hist_m)
 constexpr uint32_t kRelHi16 = 0xffffffffu;
+// words of the gate block of the workspace (cleared at the start of every xmh_hamming_hist): 0 = nrel_max, 1 = finalize ticket,
+// 2 = gallery items over all shards, 3 = "a distance wrapped in the one-byte pair cache of 65..128-bit codes"
+constexpr int kGateWrapped = 3;
 // The block that finishes a 64-query tile LAST (ticket per tile, zeroed ahead of the launch) also writes what the unsharded pass 2
 // needs from the totals -- dpre[d][q] = exclusive prefix of tot over d, nrel[q], the nrel_max gate word -- which used to be a
 // launch of its own between the passes (k_scan_dpre: 9 us + a launch gap; kept for the sharded call and the histogram export).
@@ -238,7 +241,10 @@ __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot
                                                    const uint32_t* __restrict__ nrel_total, int64_t kcap,
                                                    uint2* __restrict__ dpre, uint32_t* __restrict__ cap_ws,
                                                    int32_t* __restrict__ cap_out, uint32_t* __restrict__ hist_all,
-                                                   uint32_t* __restrict__ hist_rel, uint32_t* __restrict__ nrel_max) {
+                                                   uint32_t* __restrict__ hist_rel, uint32_t* __restrict__ nrel_max,
+                                                   uint32_t* __restrict__ rank_max = nullptr) {
+    // rank_max (explicit-offsets form): the largest rank this shard can hand out, max over (q, d) of base_all + tot -- the word the
+    // float-bit pass 2 is gated on, as the gallery size is for the totals-table form.
     // 64 queries per block, the bucket axis split over the 4 waves: each wave sums its quarter, the quarter sums are
     // prefixed through LDS, then each wave walks its quarter again (L2 hits) writing the exclusive prefixes.  One wave per
     // 64 queries walking all buckets was a 13 us latency chain of dependent-free but serialised load groups.
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot
     }
     part[wq][lane] = make_uint2(sa, sr);
     __syncthreads();
-    uint32_t ra = 0, rr = 0, ta = 0, tr = 0;
+    uint32_t ra = 0, rr = 0, ta = 0, tr = 0, rmax = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const uint2 p = part[w][lane];
@@ -273,7 +279,10 @@ __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot
         for (int j = 0; j < 8; ++j) {
             if (d + j < d1) {
                 uint2 o = make_uint2(ra, rr);
-                if (base_all && qok) o = make_uint2(base_all[(int64_t)q * nb + d + j], base_rel[(int64_t)q * nb + d + j]);
+                if (base_all && qok) {
+                    o = make_uint2(base_all[(int64_t)q * nb + d + j], base_rel[(int64_t)q * nb + d + j]);
+                    rmax = max(rmax, o.x + t[j].x);
+                }
                 if (dpre) dpre[(int64_t)(d + j) * qpad + q] = o;
                 if (qok && hist_all) hist_all[(int64_t)q * nb + d + j] = t[j].x;
                 if (qok && hist_rel) hist_rel[(int64_t)q * nb + d + j] = t[j].y;
@@ -288,6 +297,10 @@ __global__ __launch_bounds__(256) void k_scan_dpre(const uint2* __restrict__ tot
         cap_ws[q] = nrel;
         if (qok && cap_out) cap_out[q] = (int32_t)cap;
         if (qok && nrel_max) atomicMax(nrel_max, nrel);
+    }
+    if (rank_max) {
+        for (int o = 32; o; o >>= 1) rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, o));
+        if (lane == 0 && rmax) atomicMax(rank_max, rmax);
     }
     (void)ta;
 }
@@ -500,11 +513,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
 // and start at the global base of (bucket, chunk).  MASKED: see the header (lane-order fallback).
 // CACHE: the pairs come from the byte cache of pass 1 (see k_scan_hist_s) instead of the gallery.
 // items_total (sharded calls that also launch k_scan_ap_c): that kernel takes the call when the gallery over all shards is small enough for it
+// run_if (65..128-bit codes with one-byte cache entries, k_scan_hist_m<.., BYTE>): this launch is the stand-in for k_scan_ap_c and runs
+// only when pass 1 raised the word (a distance of 128 wrapped in the cache) -- or when items_total says the gallery is too large for it
 template <int W, int LW, bool TERN, bool CAPPED, int S, bool P32, bool MASKED, int NW, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap,
-                                                  const uint32_t* __restrict__ items_total) {
+                                                  const uint32_t* __restrict__ items_total, const uint32_t* __restrict__ run_if = nullptr) {
     using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using SG = SlotGeom<S>;
@@ -515,7 +530,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
         if (P32 != fits32) return;                                   // the other variant takes this call
     }
-    if (items_total && (int64_t)*items_total <= kFloatBitsMaxItems) return;      // k_scan_ap_c takes this call
+    if (run_if) {
+        const bool too_large = items_total && (int64_t)*items_total > kFloatBitsMaxItems;
+        if (!too_large && *run_if == 0u) return;                     // k_scan_ap_c takes this call
+    } else if (items_total && (int64_t)*items_total <= kFloatBitsMaxItems) return;      // k_scan_ap_c takes this call
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;    // NW waves share the ring, see k_scan_hist_s
     const int ql = lane & (QW - 1), slot = lane >> SG::LOG_QW;
     const int q0 = (qtile * NW + wave) * QW;
@@ -843,8 +861,17 @@ __device__ __forceinline__ bool mfma_map_block(const MfmaArgs& a, int& chunk_id,
 
 // CACHE: also leaves the pair cache of k_scan_hist_s (one byte per pair, distance << 1 | relevant, 16 bytes per lane and batch in
 // the same lane geometry) so that the cached k_scan_ap_s runs as pass 2.
-template <int NMC, int NML, int NW, bool CACHE>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+// BYTE (round 4, NMC = 2: codes of 65..128 bits): ONE-byte entries in the layout of the codes of at most 64 bits, so that pass 2 is
+// k_scan_ap_c on half the bytes (the two-byte cache made this length traffic-bound: 1.19 GB written and read back per evaluation at
+// the COCO shape).  A byte holds distance << 1 | relevant for distances up to 127; the one distance it cannot hold, 128 = every
+// bit of a 128-bit code differs, wraps to 0 and raises *ovf (a control word cleared with the others at the start of the call): pass 2
+// then runs the kernel that evaluates the pairs from the codes instead of k_scan_ap_c (both are launched, the word lets one run).
+// The bucket counters are not affected: bucket 128 is counted where it belongs.
+template <int NMC, int NML, int NW, bool CACHE, bool BYTE = false>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
+                                                         uint32_t* __restrict__ ovf = nullptr) {
+    static_assert(!BYTE || (NMC == 2 && CACHE), "byte entries beyond 64 bits: 65..128-bit codes with the pair cache");
+    constexpr bool B8 = NMC == 1 || BYTE;                            // one-byte entries, 4 slots x 16 queries per cache tile
     constexpr int NM = NMC + NML;
     using ST = MfmaStage<NM, NW>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters, then the 2-deep ring
@@ -874,8 +901,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     // exactly the 8 steps of lane (slot4, query) there, its odd j those of lane (slot4 + 4, query) -- no exchange between lanes,
     // two 16-byte records per batch, 32 uint4 apart in the row of the query's 8-query tile.
     uint4* crow = nullptr;
-    if (CACHE && NMC == 1) crow = pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane;
-    if (CACHE && NMC >= 2) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
+    if (CACHE && B8) crow = pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane;
+    if (CACHE && !B8) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
+    uint32_t amax = 0u;
     ST::issue(a.gimg, ring, 0, bat0, lane, wave);
     for (int i = 0; i < nbat; ++i) {
         if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
@@ -904,20 +932,26 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
                 asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
                 if (CACHE) e[j] = ((inc >> 7) & 1u) | ((uint32_t)(acc[j] - lanebase) >> 5);     // entry: distance << 1 | relevant (8 or 16 bits)
             }
-            if (CACHE && NMC == 1) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
-            if (CACHE && NMC >= 2) {                                 // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
+            if (BYTE) {
+                // distance 128 does not fit the byte: it wraps to 0 (the byte selects below drop bit 8) and pass 2 is told.  Seen through the
+                // largest counter address of the lane (address = lanebase + 64 * distance; lanes of absent queries stay at distance 0).
+                amax = max(max((uint32_t)acc[0], (uint32_t)acc[1]), amax);
+                amax = max(max((uint32_t)acc[2], (uint32_t)acc[3]), amax);
+                cw[g] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0400u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0400u), 0x05040100u);
+            } else if (CACHE && B8) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+            if (CACHE && !B8) {                                      // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
                 cw[g] = e[0] | (e[2] << 16);
                 cw2[g] = e[1] | (e[3] << 16);
             }
         }
-        if (CACHE && NMC == 1) {                                     // streamed once each way: non-temporal (see k_scan_hist_s)
+        if (CACHE && B8) {                                           // streamed once each way: non-temporal (see k_scan_hist_s)
             uint4* dst = crow + (int64_t)i * 64;
             __builtin_nontemporal_store(cw[0], &dst->x);
             __builtin_nontemporal_store(cw[1], &dst->y);
             __builtin_nontemporal_store(cw[2], &dst->z);
             __builtin_nontemporal_store(cw[3], &dst->w);
         }
-        if (CACHE && NMC >= 2) {
+        if (CACHE && !B8) {
             uint4* dst = crow + (int64_t)i * 64;
             __builtin_nontemporal_store(cw[0], &dst->x);
             __builtin_nontemporal_store(cw[1], &dst->y);
@@ -940,6 +974,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* _
     }
     uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
     for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
+    if (BYTE && amax >= (uint32_t)lanebase + 64u * 128u) *ovf = 1u;   // every writer stores the same 1; read by the next launch
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1478,12 +1513,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
 template <bool CAPPED, int EB>
 __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                  const uint32_t* __restrict__ items_total, uint32_t kcap) {
+                                                  const uint32_t* __restrict__ items_total, uint32_t kcap, const uint32_t* __restrict__ skip_if = nullptr) {
     constexpr int QW = 128 / EB, LOG_QW = EB == 8 ? 4 : 3, S = 64 / QW, EPW = 32 / EB;      // queries per tile, slots, entries per cache word
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] 64-bit counters
     int chunk_id, qtile;
     if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
     if (items_total && (int64_t)*items_total > kFloatBitsMaxItems) return;      // sharded call: the integer-counter kernel takes it
+    if (skip_if && *skip_if != 0u) return;                           // a distance wrapped in the one-byte cache of 65..128-bit codes: see k_scan_hist_m
     const int lane = threadIdx.x & 63;
     const int ql = lane & (QW - 1), slot = lane >> LOG_QW;
     const int q0 = qtile * QW, q = q0 + ql;
@@ -1982,6 +2018,12 @@ inline bool bits_shape(int K, bool ternary, int LW) {
     const int mode = e ? atoi(e) : 1;
     return mode != 0 && !mfma_ap_on() && mfma_shape(K, ternary) && K > (mode == 2 ? 64 : 128) && K <= 256 && LW <= 4;
 }
+// One-byte pair-cache entries for 65..128-bit codes (k_scan_hist_m<2, .., BYTE> + k_scan_ap_c<., 8>, round 4): whenever those codes take
+// k_scan_hist_m at all.  XMH_SCAN_BYTE128=0 keeps the two-byte entries and the cached k_scan_ap_s (read per call: tests compare the two).
+inline bool byte128_shape(int K, bool ternary, int LW) {
+    const char* e = getenv("XMH_SCAN_BYTE128");
+    return !(e && atoi(e) == 0) && !ternary && K > 64 && K <= 128 && LW <= 4 && mfma_shape(K, ternary) && !bits_shape(K, ternary, LW) && !mfma_ap_on();
+}
 // operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
 inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
 inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
@@ -2271,15 +2313,24 @@ int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbi
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
     xmh::ProfScope prof("scan_hist", st);
     if (cache) {
-        auto kern = k_scan_hist_m<NMC, NML, NW, true>;
+        if constexpr (NMC == 2) {
+            if (byte128_shape(K, false, LW)) {
+                auto kern = k_scan_hist_m<NMC, NML, NW, true, true>;
+                const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+                if (r2) return r2;
+                hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, reinterpret_cast<uint32_t*>(base + L.gate) + kGateWrapped);
+                return XMH_OK;
+            }
+        }
+        auto kern = k_scan_hist_m<NMC, NML, NW, true, false>;
         const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
         if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (uint32_t*)nullptr);
     } else {
-        auto kern = k_scan_hist_m<NMC, NML, NW, false>;
+        auto kern = k_scan_hist_m<NMC, NML, NW, false, false>;
         const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
         if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (uint32_t*)nullptr);
     }
     return XMH_OK;
 }
@@ -2364,9 +2415,6 @@ extern "C" size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int te
     return ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0)).pair_cache;
 }
 
-// Which kernel instances an UNSHARDED mAP@all evaluation of this shape launches for the two passes (as rocprofv3 prints them, minus
-// the namespace): bench_roofline.py picks the PMC rows of exactly these -- a prefix match once took the 128-bit kernel's row for
-// the 64-bit headline.  Mirrors the dispatch of xmh_hamming_hist / hamming_ap_impl (lane order assumed to hold).
 // Width of the rank field of the packed 32-bit pass-2 counters for an UNSHARDED evaluation of this shape, 0 = only the 64-bit kernels
 // are launched.  One function for the launch path (hamming_ap_impl) and for xmh_scan_describe, so that the kernel name the bench looks
 // up in a profile is the kernel that ran (the two had drifted apart on XMH_SCAN_NO_PACK32).
@@ -2380,6 +2428,9 @@ int packed_rank_bits(int K, int64_t R, bool mfma_plan) {
     return rank_bits > 24 ? 0 : rank_bits;
 }
 
+// Which kernel instances an UNSHARDED mAP@all evaluation of this shape launches for the two passes (as rocprofv3 prints them, minus
+// the namespace): bench_roofline.py picks the PMC rows of exactly these -- a prefix match once took the 128-bit kernel's row for
+// the 64-bit headline.  Mirrors the dispatch of xmh_hamming_hist / hamming_ap_impl (lane order assumed to hold).
 extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary, char* out, size_t out_bytes) {
     if (!out || out_bytes < 64) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
     xmh_scan_plan p;
@@ -2398,7 +2449,8 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
         snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
     } else if (use_mfma) {
         if (bits_shape(K, tern, LW)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s>", K <= 128 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
-        else snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false");
+        else snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false",
+                      cache && byte128_shape(K, tern, LW) ? "true" : "false");
     } else {
         const bool cached = cache && !tern && Wc <= 8;
         const int S = cached ? cache_slots(Wc) : S4;
@@ -2408,8 +2460,9 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const char* apc_env = getenv("XMH_SCAN_AP_C");
     const bool packable = packed_rank_bits(K, R, use_mfma) > 0;       // exactly what hamming_ap_impl launches for an unsharded evaluation
     const int apc_mode = apc_env ? atoi(apc_env) : 1;
-    if (cache && !tern && (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256) && R <= kFloatBitsMaxItems) {
-        snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", K <= 64 ? 8 : 16);
+    const bool byte128 = cache && use_mfma && byte128_shape(K, tern, LW);
+    if (cache && !tern && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256)) && R <= kFloatBitsMaxItems) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", K <= 64 || byte128 ? 8 : 16);
     } else if (use_mfma && K <= 64 && mfma_ap_on()) {
         snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
@@ -2547,7 +2600,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         XMH_LAUNCH_CHECK("xmh_hamming_map_sharded offsets");
     } else if (base_all) {
         hipLaunchKernelGGL(k_scan_dpre, dim3((unsigned)p.nqtile), dim3(256), 0, st, tot, (int)Q, (int)p.qpad, (int)p.nbuckets, base_all,
-                           base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                           base_rel, nrel_total, k, dpre, cap_ws, cap, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, nrel_max + 2);
         XMH_LAUNCH_CHECK("xmh_hamming_ap dpre");
     }
     const uint32_t kcap = k > 0 && k < (int64_t)0xffffffffll ? (uint32_t)k : 0xffffffffu;
@@ -2558,17 +2611,27 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // k_scan_ap_c (float-bit counters): one-byte pair cache present, 64-bit counters, lane order holds, and the gallery over ALL
     // shards small enough -- known here for an unsharded call; for the totals-table form of the sharded call the offsets kernel leaves
     // the size in a device word and both kernels are launched, each returning at once when it is the other's turn (as for the counter
-    // widths); the explicit-offsets form stays on k_scan_ap_s.  XMH_SCAN_AP_C=0 turns it off.
+    // widths); the explicit-offsets form stays on k_scan_ap_s, except on one-byte entries
+    // of 65..128-bit codes (which that kernel cannot read), where k_scan_dpre leaves the largest rank of the shard in the word instead.
+    // XMH_SCAN_AP_C=0 turns it off.
     const char* apc_env = getenv("XMH_SCAN_AP_C");
     // Beyond 64 bits (two-byte entries, 8 x 8 queries) the same kernel measured no better than k_scan_ap_s (Q 5000 x R 117 218, K=128:
     // 0.286 against 0.288 ms; K=256, R 60 000: 0.233 against the packed 32-bit counters' 0.204), so it is used there only on request
     // (XMH_SCAN_AP_C=2; the tests hold it to bit identity with the default).
     const int apc_mode = apc_env ? atoi(apc_env) : 1;
-    const bool apc = cache_bytes && (K <= 64 ? apc_mode != 0 && rank_bits == 0 : apc_mode == 2 && K <= 256) && !tern && !masked && !base_all &&
-                     (hist_g != nullptr || R <= kFloatBitsMaxItems);
-    const uint32_t* fb_gate = apc && hist_g ? (const uint32_t*)(nrel_max + 2) : nullptr;
+    // 65..128-bit codes whose pass 1 left ONE-byte entries (k_scan_hist_m<2, .., BYTE>; the same predicate as in xmh_hamming_hist: the MFMA
+    // pass 1 ran iff the lane order holds and the labels fit): k_scan_ap_c reads them like those of shorter codes.  A distance of 128
+    // does not fit a byte and wrapped; pass 1 raised a control word then, k_scan_ap_c returns at once and the kernel that evaluates the
+    // pairs from the codes (launched behind it, gated the other way) takes the call.  The cached k_scan_ap_s cannot read these entries.
+    const bool byte128 = cache_bytes && mfma_plan && LW <= 4 && !masked && byte128_shape(K, tern, LW);
+    const uint32_t* wrapped = byte128 ? (const uint32_t*)(nrel_max + kGateWrapped) : nullptr;
+    const size_t cache_s = byte128 ? 0 : cache_bytes;                 // what the k_scan_ap_s launches below may read
+    const bool apc = cache_bytes && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && rank_bits == 0 : apc_mode == 2 && K <= 256)) && !tern && !masked &&
+                     (!base_all || byte128) && (sharded || R <= kFloatBitsMaxItems);
+    const uint32_t* fb_gate = apc && sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;
     if (apc) {
-        const int SC = K <= 64 ? 4 : 8;                                  // slots of the cache geometry: 64 / SC queries per wave
+        const bool b8 = K <= 64 || byte128;
+        const int SC = b8 ? 4 : 8;                                       // slots of the cache geometry: 64 / SC queries per wave
         ScanArgs as = a;
         as.nqt = a.nqt * SC;
         as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
@@ -2578,13 +2641,15 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         auto go = [&](auto kc) {
             const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
             if (r3) return r3;
-            hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
+            hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap, wrapped);
             return (int)XMH_OK;
         };
-        rc = K <= 64 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
+        rc = b8 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
     }
+    // behind k_scan_ap_c on one-byte entries of 65..128-bit codes only the 64-bit stand-in is launched (always valid; it runs once in a blue moon)
+    const int rb = (byte128 && apc) ? 0 : rank_bits;
     // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run
     auto launch = [&](auto tern_c, auto cap_c, auto p32_c, auto masked_c) {
         constexpr bool T = decltype(tern_c)::value;
@@ -2601,7 +2666,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             as.nqt = a.nqt * S / NW;
             xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
             if constexpr (kPairCacheShape<WW, T> && !MK) {
-                if (cache_bytes) {                                    // pass 1 of this call pair left the pairs in the workspace
+                if (cache_s) {                                        // pass 1 of this call pair left the pairs in the workspace
                     constexpr int SC = cache_slots(WW);
                     auto kc = k_scan_ap_s<WW, LL, T, CP, SC, P32, MK, 1, true>;
                     const size_t cellsc = (size_t)p.nbuckets * (64 / SC);
@@ -2611,19 +2676,21 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
                     as.nqt = a.nqt * SC;
                     as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
                     hipLaunchKernelGGL(kc, dim3(scan_grid(p) * SC), dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws,
-                                       ap_part, (const uint32_t*)nrel_max, rank_bits, kcap, fb_gate);
+                                       ap_part, (const uint32_t*)nrel_max, rb, kcap, fb_gate, (const uint32_t*)nullptr);
                     return (int)XMH_OK;
                 }
             }
             auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, false>;
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
+            // behind a launched k_scan_ap_c (one-byte entries of 65..128-bit codes): the stand-in, gated by the wrap word / the size word
+            const bool stand_in = byte128 && apc;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rank_bits, kcap, (const uint32_t*)nullptr);
+                               (const uint32_t*)nrel_max, rb, kcap, stand_in ? fb_gate : (const uint32_t*)nullptr, stand_in ? wrapped : (const uint32_t*)nullptr);
             return (int)XMH_OK;
         });
     };
-    if (apc && !fb_gate) {
+    if (apc && !fb_gate && !byte128) {
         // k_scan_ap_c alone takes the call
     } else if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
         MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
@@ -2660,7 +2727,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         if (tern) return capped ? by_mask(T1{}, T1{}) : by_mask(T1{}, T0{});
         return capped ? by_mask(T0{}, T1{}) : by_mask(T0{}, T0{});
     };
-    if (rank_bits) {
+    if (rb) {
         rc = launch_width(T1{});
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap packed");

@@ -106,14 +106,16 @@ typedef struct xmh_scan_plan {
 
 int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* plan_host);
 /* Bytes of the workspace (included in plan.ws_bytes) that hold the PAIR CACHE: xmh_hamming_hist leaves one byte per (query,
- * gallery item) pair -- distance << 1 | relevant; two bytes for codes of 65..256 bits -- and xmh_hamming_ap reads it instead of
- * evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 32768 MB;
+ * gallery item) pair -- distance << 1 | relevant; two bytes for codes of 129..256 bits (and the region is sized for two bytes from
+ * 65 bits on: codes of 65..128 bits use its first half with one-byte entries, where a distance of 128 wraps to 0 and a control word
+ * tells pass 2 to evaluate the pairs itself; XMH_SCAN_BYTE128=0 brings their two-byte entries back) -- and xmh_hamming_ap reads it
+ * instead of evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 32768 MB;
  * 0 = off); returns 0 when it is not used. */
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 /* Byte offset of that pair cache inside the workspace ((size_t)-1 on a bad shape) -- for tests and diagnostics, which decode it
  * and compare every entry with the oracle's distance and relevance.  Layout for codes of at most 64 bits:
  * [chunk][16-query tile][64-item batch of the chunk][lane 0..63][16 bytes]; lane = slot * 16 + query-in-tile, byte t of a lane
- * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant.  65..256 bits:
+ * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant (mod 256).  Two-byte form:
  * [chunk][8-query tile][batch][lane][8 x u16], lane = slot * 8 + query-in-tile, entry t = item 64 * batch + 8 * t + slot. */
 size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary);
 /* Diagnostics for the measurement harness: writes "pass1=<kernel instance>;pass2=<kernel instance>[|<second width>]" -- the kernels

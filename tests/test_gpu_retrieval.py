@@ -316,7 +316,13 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
     on, off = rows
     assert len(on) == 7 and len(off) == 7
     assert all(x[0] == "True" for x in on) and all(x[0] == "False" for x in off)
-    assert [x[1:] for x in on] == [x[1:] for x in off]
+    for n, (x, y) in enumerate(zip(on, off)):
+        if n in (2, 4):                                        # 65..128 bits (round 4): the one-byte entries are read 4 slots x 16 queries wide, the
+            assert x[2] == y[2]                                # uncached kernel runs 8 x 8: another order of the float partial sums inside a chunk
+            a, b = np.frombuffer(bytes.fromhex(x[1]), dtype=np.float64), np.frombuffer(bytes.fromhex(y[1]), dtype=np.float64)
+            assert np.allclose(a, b, rtol=2e-6, atol=1e-9)
+        else:
+            assert x[1:] == y[1:]
     # the MFMA-evaluated pass 1 (codes of at most 64 bits) against the VALU one: another chunking, so the per-chunk float sums
     # add in another order -- the caps are equal, the AP sums agree to float rounding
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, XMH_SCAN_MFMA="0"), capture_output=True, text=True, timeout=600)
@@ -355,8 +361,12 @@ def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     want = (dist << 1) | rel                                           # [Q, R]
     pl = scan.plan
     nbatch = (pl.chunk + 63) // 64
-    S, QW = (4, 16) if K <= 64 else (8, 8)                             # slots x queries of a cache tile; QW entries per lane and batch
-    got = raw.view(np.uint8 if K <= 64 else np.uint16).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
+    b8 = K <= 128                                                      # one-byte entries up to 128 bits (65..128: round 4; a distance of 128 wraps)
+    S, QW = (4, 16) if b8 else (8, 8)                                  # slots x queries of a cache tile; QW entries per lane and batch
+    if b8:
+        want = want & 0xFF
+        raw = raw[: pl.nchunk * (pl.qpad // QW) * nbatch * 64 * QW]    # 65..128 bits: the region is sized for two-byte entries, the first half is used
+    got = raw.view(np.uint8 if b8 else np.uint16).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
     lane = np.arange(64)
     slot, qin = lane // QW, lane % QW
     t = np.arange(QW)
@@ -434,6 +444,51 @@ def test_scan_m2_self_check_failure_falls_back_with_one_warning():
         assert "k_scan_hist_m2" in a[3] and "k_scan_hist_m2" not in b[3]
 
 
+def test_scan_one_byte_entries_for_65_to_128_bit_codes(xr, cu, monkeypatch):
+    """Round 4: 65..128-bit codes keep ONE byte per pair (k_scan_hist_m<2, .., BYTE> + k_scan_ap_c) instead of two.  (i) Against the
+    two-byte path (XMH_SCAN_BYTE128=0): histograms and divisors bit for bit, AP sums to float rounding (same chunking and credits; the
+    one-byte entries are read 4 slots x 16 queries wide, the two-byte ones 8 x 8, so a chunk's float partial sums add in another order).
+    (ii) The one distance a byte cannot hold -- 128, every bit of a 128-bit code differs -- wraps in the cache; pass 1 raises a control
+    word and the stand-in kernel evaluates the pairs from the codes: a gallery seeded with the complements of the queries must still give
+    the oracle's mAP, at mAP@all and mAP@k, and the float-bit kernel must not have been the one that ran (same sums as with the cache off)."""
+    orc = _orc()
+    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 96, 24, .1, 50), (33, 4097, 65, 40, .02, 7), (200, 20011, 128, 128, .02, None)):
+        qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=9 * K + Rn, p=p)
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("XMH_SCAN_BYTE128", flag)
+            scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+            ha, hr = scan.histograms(True)
+            ap, cap = scan.ap_sums(k)
+            outs.append((ha.clone(), hr.clone(), cap.clone(), ap.clone()))
+        monkeypatch.delenv("XMH_SCAN_BYTE128")
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(x, y), (Q, Rn, K, C)
+        assert torch.allclose(outs[0][3], outs[1][3], rtol=2e-6, atol=1e-9), (Q, Rn, K, C)      # 4 x 16 against 8 x 8 lanes: float sums in another order
+    # (ii) complements in the gallery: distance 128
+    Q, Rn, K, C = 90, 7000, 128, 24
+    qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=4242, p=0.1)
+    rB[5::97] = -qB[torch.arange(rB[5::97].shape[0]) % Q]                                  # exact complements of some queries, spread over the chunks
+    rL[5::97] = qL[torch.arange(rL[5::97].shape[0]) % Q]                                   # and relevant to them: their credit depends on bucket 128
+    for k in (None, 40):
+        got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), k))
+        want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))
+        assert abs(got - want) < 1e-6, (k, got, want)
+    scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+    ha, _ = scan.histograms(True)
+    assert int(ha[:, 128].sum()) >= 70                                                     # the complements sit in bucket 128
+    ap_wrapped, cap_w = scan.ap_sums(None)
+    monkeypatch.setenv("XMH_SCAN_CACHE_MB", "0")
+    plain = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+    plain.histograms(False)
+    ap_plain, cap_p = plain.ap_sums(None)
+    monkeypatch.delenv("XMH_SCAN_CACHE_MB")
+    assert torch.equal(cap_w, cap_p) and torch.allclose(ap_wrapped, ap_plain, rtol=2e-6, atol=1e-9)
+    dist = orc.hamming_packed(_u32(scan.q.bits), _u32(scan.r.bits))
+    rel = orc.relevance_packed(_u32(scan.qlab), _u32(scan.rlab))
+    assert np.allclose(ap_wrapped.cpu().numpy(), orc.ap_from_ranking(dist, rel), rtol=3e-6)
+
+
 def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):
     """k_scan_ap_c (pass 2 with float-bit counters; the default up to 64 bits, XMH_SCAN_AP_C=2 switches it on for the two-byte
     entries of longer codes) against k_scan_ap_s on the same pair cache: the same credits in the same order, so the per-query sums
@@ -445,6 +500,7 @@ def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):
         qL, rL = (torch.rand(Q, C, generator=g) < p).long(), (torch.rand(Rn, C, generator=g) < p).long()
         qL[:, 0] = 1
         rL[::3, 0] = 1
+        monkeypatch.setenv("XMH_SCAN_BYTE128", "0")            # 65..128 bits: the two-byte entries this kernel variant reads (the default is one byte now)
         scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
         scan.histograms(False)
         outs = []
@@ -496,7 +552,9 @@ def test_scan_mfma_pass1_for_65_to_256_bit_codes_matches_the_valu_pass1(xr, monk
 def test_scan_pass1_with_operands_from_the_packed_bits_gives_identical_bits(xr, monkeypatch):
     """k_scan_hist_b (xmh_scan_bits.hip; default for 129..256 bits, XMH_SCAN_BITS=2 also 65..128) against k_scan_hist_m
     (XMH_SCAN_BITS=0): same plan, same chunks, same pair-cache layout -- histograms, caps AND credits bit for bit; ragged chunks,
-    surplus query columns, code lengths that do not fill their last word, 1..128 classes."""
+    surplus query columns, code lengths that do not fill their last word, 1..128 classes.  (XMH_SCAN_BYTE128=0: the default for
+    65..128 bits is one-byte entries read by another pass 2, compared in test_scan_one_byte_entries_for_65_to_128_bit_codes.)"""
+    monkeypatch.setenv("XMH_SCAN_BYTE128", "0")
     for (Q, R, K, C, p, k) in ((150, 9001, 256, 80, 0.06, 9), (17, 130, 256, 5, 0.3, 3), (64, 8157, 200, 33, 0.2, 85), (33, 4096, 129, 128, 0.05, None),
                                (70, 9100, 128, 80, 0.06, None), (20, 700, 160, 24, 0.2, 11), (5, 70000, 96, 1, 0.5, 100), (130, 20011, 224, 97, 0.03, None)):
         qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R, p=p)
