@@ -1510,11 +1510,17 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
 // ---------------------------------------------------------------------------------------------------
 // EB = entry bits of the pair cache: 8 (codes of at most 64 bits: 4 slots x 16 queries, 16 steps per lane and batch) or 16 (65..256 bits:
 // 8 slots x 8 queries, 8 steps)
-template <bool CAPPED, int EB>
+// HALF (round 4, one-byte entries only): 8 slots x 8 queries on the cache pass 1 wrote for 4 slots x 16 queries -- half the counter rows per
+// wave (129 bucket rows of 65..128-bit codes: 16.5 -> 8.3 KB, twice the waves per CU).  Lane (slot8, query8) of half h reads the 16-byte
+// record of the writer's lane (slot8 & 3, 8 h + query8) and takes every other byte of it: the writer's step t holds items 4 t + slot4,
+// so step t' here = the writer's step 2 t' + (slot8 >> 2), items 8 t' + slot8 -- ascending with the lane, as the order of the returning
+// adds requires.  The byte offsets (8 (slot8 >> 2) and 16 more) go into v_bfe as register operands: no instruction more per pair.
+template <bool CAPPED, int EB, bool HALF = false>
 __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
                                                   const uint32_t* __restrict__ items_total, uint32_t kcap, const uint32_t* __restrict__ skip_if = nullptr) {
-    constexpr int QW = 128 / EB, LOG_QW = EB == 8 ? 4 : 3, S = 64 / QW, EPW = 32 / EB;      // queries per tile, slots, entries per cache word
+    static_assert(!HALF || EB == 8, "the 8 x 8 geometry on one-byte entries");
+    constexpr int QW = HALF ? 8 : 128 / EB, LOG_QW = QW == 16 ? 4 : 3, S = 64 / QW, EPW = HALF ? 2 : 32 / EB;      // queries per tile, slots, entries a lane takes from a cache word
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] 64-bit counters
     int chunk_id, qtile;
     if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
@@ -1560,11 +1566,19 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         if (CAPPED) m = ord <= capf ? m : 0u;
         acc = fmaf(ord, __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(rank)) & m), acc);
     };
+    const uint32_t hoff = HALF ? 8u * (uint32_t)(slot >> 2) : 0u;    // HALF: this lane's bytes of a word are hoff / 8 and hoff / 8 + 2
+    const uint32_t hb0 = hoff, hb1 = hoff + 16u, hd0 = hoff + 1u, hd1 = hoff + 17u;
     auto issue1 = [&](uint32_t w, int j, unsigned long long& old, uint32_t& m) {
-        m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * j, 1);                   // 0 / ~0
-        const uint32_t d = __builtin_amdgcn_ubfe(w, EB * j + 1, EB - 1);
+        uint32_t d;
+        if (HALF) {
+            m = (uint32_t)__builtin_amdgcn_sbfe((int)w, j ? hb1 : hb0, 1);
+            d = __builtin_amdgcn_ubfe(w, j ? hd1 : hd0, 7);
+        } else {
+            m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * j, 1);               // 0 / ~0
+            d = __builtin_amdgcn_ubfe(w, EB * j + 1, EB - 1);
+        }
         uint32_t addr;
-        if (EB == 8) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(d), "v"(cntbase));       // rows of 16 queries x 8 bytes
+        if (QW == 16) asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(addr) : "v"(d), "v"(cntbase));      // rows of 16 queries x 8 bytes
         else asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(addr) : "v"(d), "v"(cntbase));
         const unsigned long long inc = 1ull | ((unsigned long long)m << 32);
         asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(old) : "v"(addr), "v"(inc) : "memory");     // same-address lanes resolve in lane = item order
@@ -1590,7 +1604,8 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         prev = true;
     };
     const int nbatch = (a.chunk + 63) >> 6;
-    const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
+    const uint4* crow = HALF ? a.pair_cache + ((int64_t)chunk_id * (a.nqt >> 1) + (qtile >> 1)) * nbatch * 64 + (slot & 3) * 16 + (qtile & 1) * 8 + ql
+                             : a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
     const int nfull = (int)((hi - lo) >> 6);                         // whole batches of this chunk
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the counters are in place before the first asm atomic is counted
     // the cache words are fetched TWO batches ahead: a batch is ~1.2 us of this wave's time at 5 waves per SIMD, an HBM miss under load
@@ -1599,7 +1614,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     uint4 nw = crow[(int64_t)(1 < nbatch ? 1 : 0) * 64];
     for (int bi = 0; bi < nfull; ++bi) {
         const uint4 nw2 = crow[(int64_t)(bi + 2 < nbatch ? bi + 2 : nbatch - 1) * 64];      // unconditional: counted vmcnt, no predication
-        if (EB == 8) {
+        if (EB == 8 && !HALF) {
             group(cw.x, cw.y, 0u, 0u);
             group(cw.z, cw.w, 0u, 0u);
         } else {
@@ -1619,7 +1634,8 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     for (int t = 0; t < QW; ++t) {
         if (t * S + slot < cntb) {
             const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * (t % EPW), 1), d = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + 1, EB - 1);
+            const uint32_t bit = HALF ? hoff + 16u * (t % EPW) : (uint32_t)(EB * (t % EPW));
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, bit, 1), d = __builtin_amdgcn_ubfe(w, bit + 1u, HALF ? 7 : EB - 1);
             const unsigned long long o = atomicAdd(&cnt[d * QW + ql], 1ull | ((unsigned long long)m << 32));
             credit(o, m);
         }
@@ -2462,7 +2478,11 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const int apc_mode = apc_env ? atoi(apc_env) : 1;
     const bool byte128 = cache && use_mfma && byte128_shape(K, tern, LW);
     if (cache && !tern && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256)) && R <= kFloatBitsMaxItems) {
-        snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", K <= 64 || byte128 ? 8 : 16);
+        const bool b8 = K <= 64 || byte128;
+        const char* half_env = getenv("XMH_SCAN_AP_HALF");
+        const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
+        if (half) snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, true>");
+        else snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", b8 ? 8 : 16);
     } else if (use_mfma && K <= 64 && mfma_ap_on()) {
         snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
@@ -2631,7 +2651,11 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const uint32_t* fb_gate = apc && sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;
     if (apc) {
         const bool b8 = K <= 64 || byte128;
-        const int SC = b8 ? 4 : 8;                                       // slots of the cache geometry: 64 / SC queries per wave
+        // one-byte entries read 8 slots x 8 queries wide (k_scan_ap_c<., 8, HALF>): where the counter rows of 16 queries leave few waves per CU
+        // -- 65..128-bit codes (129 rows: 16.5 KB per wave).  XMH_SCAN_AP_HALF=0 / 1 forces it off / on for every one-byte shape (read per call).
+        const char* half_env = getenv("XMH_SCAN_AP_HALF");
+        const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
+        const int SC = b8 && !half ? 4 : 8;                              // slots of the geometry pass 2 runs: 64 / SC queries per wave
         ScanArgs as = a;
         as.nqt = a.nqt * SC;
         as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
@@ -2644,7 +2668,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap, wrapped);
             return (int)XMH_OK;
         };
-        rc = b8 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
+        rc = half ? (capped ? go(k_scan_ap_c<true, 8, true>) : go(k_scan_ap_c<false, 8, true>))
+             : b8 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
     }

@@ -489,6 +489,28 @@ def test_scan_one_byte_entries_for_65_to_128_bit_codes(xr, cu, monkeypatch):
     assert np.allclose(ap_wrapped.cpu().numpy(), orc.ap_from_ranking(dist, rel), rtol=3e-6)
 
 
+def test_scan_pass2_eight_queries_wide_on_one_byte_entries(xr, monkeypatch):
+    """k_scan_ap_c<., 8, HALF>: the one-byte pair cache read 8 slots x 8 queries wide (default for 65..128 bits, XMH_SCAN_AP_HALF=1 also for
+    shorter codes) against the 4 x 16 reading of the same cache: divisors bit for bit, AP sums to float rounding (another lane geometry, so a
+    chunk's partial sums add in another order) and equal to the oracle's ranking; ragged last batches, surplus query columns, capped and not."""
+    orc = _orc()
+    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 96, 24, .1, 50), (150, 9100, 64, 80, .06, None), (37, 2501, 40, 11, .2, 9),
+                                (200, 20011, 16, 24, .1, None), (9, 70, 128, 5, .3, 3)):
+        qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=3 * K + Rn, p=p)
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("XMH_SCAN_AP_HALF", flag)
+            scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+            scan.histograms(False)
+            m, ap, cap = scan.map_all(k)
+            outs.append((cap.clone(), ap.clone(), float(m)))
+        monkeypatch.delenv("XMH_SCAN_AP_HALF")
+        assert torch.equal(outs[0][0], outs[1][0]), (Q, Rn, K, C)
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=2e-6, atol=1e-9), (Q, Rn, K, C)
+        want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))
+        assert abs(outs[0][2] - want) < 1e-6 and abs(outs[1][2] - want) < 1e-6, (Q, Rn, K, C, outs[0][2], outs[1][2], want)
+
+
 def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):
     """k_scan_ap_c (pass 2 with float-bit counters; the default up to 64 bits, XMH_SCAN_AP_C=2 switches it on for the two-byte
     entries of longer codes) against k_scan_ap_s on the same pair cache: the same credits in the same order, so the per-query sums
