@@ -284,7 +284,7 @@ EXTRA_LEGS = {
     "configs3_dsph_128bit": dict(what="configs[3] DSPH COCO-shaped 128-bit", Q=5000, Rn=117218, K=128, C=80, p_label=0.04, seed=3814, steps=30),
     "configs4_shard_scan_256bit": dict(what="configs[4] one GPU's shard (10 M / 8) through the mAP scan (12.7 GB pair cache)", Q=5000, Rn=1250000, K=256, C=80,
                                        p_label=0.04, seed=4814, steps=4),
-    # SURVEY 8d shape (5): "plus the unsharded 10 M on one GPU" -- the pair cache would be 100 GB, over the cap: pass 2 re-evaluates the pairs
-    "configs4_unsharded_scan_256bit": dict(what="configs[4] UNSHARDED: the whole 10 M x 256-bit gallery through the mAP scan on one GPU (no pair cache: "
-                                                "it would be 100 GB)", Q=5000, Rn=10000000, K=256, C=80, p_label=0.04, seed=4815, steps=2),
+    # SURVEY 8d shape (5): "plus the unsharded 10 M on one GPU" -- a 100 GB pair cache, under the 128 GB cap since round 4 (uncached: 90 ms)
+    "configs4_unsharded_scan_256bit": dict(what="configs[4] UNSHARDED: the whole 10 M x 256-bit gallery through the mAP scan on one GPU (100 GB pair "
+                                                "cache in the 288 GB of HBM)", Q=5000, Rn=10000000, K=256, C=80, p_label=0.04, seed=4815, steps=2),
 }

@@ -2045,12 +2045,13 @@ inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) *
 inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
 
 // Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
-// pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 32768; 0 = off).
+// pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 131072; 0 = off).
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call, like XMH_SCAN_MFMA_AP
-    // default 32 GB: an MI355X has 288 GB of HBM, and up to there the cache still pays -- one GPU's shard of configs[4] (Q 5000 x
+    // default 128 GB: an MI355X has 288 GB of HBM, and up to there the cache still pays -- the UNSHARDED configs[4] gallery (Q 5000 x
+    // R 10 M x 256 bit: 100 GB of two-byte entries) runs 89.6 -> 67.3 ms per step with it (round 4; the cap was 32 GB), one GPU's shard of it (Q 5000 x
     // R 1 250 000 x 256 bit: 12.7 GB of two-byte entries) runs 13.3 -> 10.2 ms per step with it (round 2's cap was 4 GB)
-    const long long cap_mb = cap_env ? atoll(cap_env) : 32768;
+    const long long cap_mb = cap_env ? atoll(cap_env) : 131072;
     if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !m2_shape(K, ternary))) return 0;
     if (K <= 64 && mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave

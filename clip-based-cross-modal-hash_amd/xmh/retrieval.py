@@ -202,10 +202,10 @@ def scan_plan(Q: int, R: int, K: int, ternary: bool) -> _lib.ScanPlan:
 
 def _plan_and_workspace(Q: int, R: int, K: int, ternary: bool, device):
     """Plan the scan and allocate its workspace.  The plan includes the pair cache (one or two bytes per (query, item) pair, up to
-    XMH_SCAN_CACHE_MB, default 32 GB) whenever the shape has one -- sized for an empty 288 GB device, not for what is free next to
-    a resident encoder.  When the workspace does not fit, the cache cap is lowered for this process (the library reads
-    XMH_SCAN_CACHE_MB per call, so plan, pass 1 and pass 2 all see the same value) and the scan runs uncached: slower, never an
-    out-of-memory error for a shape that ran before the cache existed."""
+    XMH_SCAN_CACHE_MB, default 128 GB) whenever the shape has one -- sized for an empty 288 GB device, not for what is free next to
+    a resident encoder.  When the workspace does not fit, the cache cap is lowered for this process to just under this shape's cache
+    (the library reads XMH_SCAN_CACHE_MB per call, so plan, pass 1 and pass 2 all see the same value; smaller shapes keep their
+    caches) and the scan runs uncached: slower, never an out-of-memory error for a shape that ran before the cache existed."""
     plan = scan_plan(Q, R, K, ternary)
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the caching allocator's idle blocks count
@@ -215,10 +215,11 @@ def _plan_and_workspace(Q: int, R: int, K: int, ternary: bool, device):
         except torch.cuda.OutOfMemoryError:
             pass
     before = plan.ws_bytes
-    os.environ["XMH_SCAN_CACHE_MB"] = "0"
+    cache = int(lib.xmh_scan_pair_cache_bytes(Q, R, K, 1 if ternary else 0))
+    os.environ["XMH_SCAN_CACHE_MB"] = str(max(0, (cache - 1) >> 20))
     plan = scan_plan(Q, R, K, ternary)
-    warnings.warn("xmh: scan workspace of %.1f GB does not fit in %.1f GB of free device memory; pair cache switched off for this process "
-                  "(workspace now %.1f GB)" % (before / 2**30, free / 2**30, plan.ws_bytes / 2**30))
+    warnings.warn("xmh: scan workspace of %.1f GB does not fit in %.1f GB of free device memory; pair caches of %.1f GB and more switched "
+                  "off for this process (workspace now %.1f GB)" % (before / 2**30, free / 2**30, cache / 2**30, plan.ws_bytes / 2**30))
     return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
 
 

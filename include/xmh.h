@@ -109,7 +109,7 @@ int xmh_scan_plan_make(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* 
  * gallery item) pair -- distance << 1 | relevant; two bytes for codes of 129..256 bits (and the region is sized for two bytes from
  * 65 bits on: codes of 65..128 bits use its first half with one-byte entries, where a distance of 128 wraps to 0 and a control word
  * tells pass 2 to evaluate the pairs itself; XMH_SCAN_BYTE128=0 brings their two-byte entries back) -- and xmh_hamming_ap reads it
- * instead of evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 32768 MB;
+ * instead of evaluating the pair again.  Used for binary codes of 33..256 bits while it stays under XMH_SCAN_CACHE_MB (default 131072 MB;
  * 0 = off); returns 0 when it is not used. */
 size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 /* Byte offset of that pair cache inside the workspace ((size_t)-1 on a bad shape) -- for tests and diagnostics, which decode it
