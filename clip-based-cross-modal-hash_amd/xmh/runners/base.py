@@ -15,8 +15,9 @@ keys and dtypes :397-404, ``model-<epoch>.pth`` :379-384).  What changes underne
 """
 from __future__ import annotations
 
+import io
 import os
-import shutil
+import threading
 
 import numpy as np
 import torch
@@ -379,23 +380,37 @@ class BaseTrainer:
 
     def _save_codes(self, codes, save_file):
         """one .mat of the reference's layout (:386-405).  valid() may write the same codes up to three times (i2t-best, t2i-best,
-        last): the gather to the writer, the unpack to fp32 [N, K] and the device-to-host copies are done once per code set, and
-        the second and third file are byte copies of the first (same arrays, same keys: scipy would serialise the 75 MB of int64
-        labels again each time)."""
+        last): the gather to the writer and the unpack to fp32 [N, K] are done once per code set, the matrices go to the file writer as
+        device tensors (xmh/utils/matfile.py transposes them to the format's column-major order on the GPU), the label matrices -- the
+        same every epoch -- are kept in file form, and the second and third file are further names of the first (hard links; the writer
+        never rewrites a file in place)."""
+        from ..utils import matfile
         memo = self.__dict__.get("_mat_memo")
         if memo is None or memo[0] is not codes:
             q_img, q_txt, r_img, r_txt = codes
             r_img, r_txt = self._gather_packed_to_writer(r_img, self.retrieval_num), self._gather_packed_to_writer(r_txt, self.retrieval_num)
             arrays = None
             if self._is_writer():
-                arrays = tuple(t.unpack().cpu().numpy() for t in (q_img, q_txt, r_img, r_txt))
+                arrays = tuple(t.unpack() for t in (q_img, q_txt, r_img, r_txt))
             memo = self._mat_memo = [codes, arrays, None]
         if self._is_writer():
-            if memo[2] is not None and os.path.exists(memo[2]) and type(self).save_mat.__func__ is BaseTrainer.save_mat.__func__:
-                shutil.copyfile(memo[2], save_file)
+            plain = type(self).save_mat.__func__ is BaseTrainer.save_mat.__func__
+            if memo[2] is not None and os.path.exists(memo[2]) and plain:
+                matfile.link_or_copy(memo[2], save_file)
                 return
             a = memo[1]
-            self.save_mat(a[0], a[1], self.query_labels, a[2], a[3], self.retrieval_labels, save_file=save_file)
+            ql, rl = self.query_labels, self.retrieval_labels
+            if plain:                                        # the label matrices in file form, made once (keyed on the objects: a new dataset is a new key)
+                lab = self.__dict__.get("_mat_labels")
+                if lab is None or lab[0] is not self.query_labels or lab[1] is not self.retrieval_labels:
+                    try:
+                        dev = a[0].device
+                        on = [t.to(dev) if isinstance(t, torch.Tensor) else t for t in (self.query_labels, self.retrieval_labels)]
+                        lab = self._mat_labels = (self.query_labels, self.retrieval_labels, matfile.prepare(on[0]), matfile.prepare(on[1]))
+                    except matfile.UnsupportedMatValue:
+                        lab = self._mat_labels = (self.query_labels, self.retrieval_labels, self.query_labels, self.retrieval_labels)
+                ql, rl = lab[2], lab[3]
+            self.save_mat(a[0], a[1], ql, a[2], a[3], rl, save_file=save_file)
             memo[2] = save_file
 
     def valid(self, epoch, k=None):
@@ -403,6 +418,7 @@ class BaseTrainer:
         save_dir = os.path.join(self.save_dir, "mat_files")
         os.makedirs(save_dir, exist_ok=True)
         self.logger.info("Valid.")
+        self._start_model_bytes()                            # the .pth a new best would write is serialised under the encode loop
         (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(k)
         saved = False                                        # both bests in one epoch name the same model-<epoch>.pth: written once
         if self.max_mapi2t < mAPi2t:
@@ -420,6 +436,7 @@ class BaseTrainer:
         self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
         self._save_codes(codes, os.path.join(save_dir, "last.mat"))
         self._mat_memo = None
+        self._drop_model_bytes()
         self.logger.info(f">>>>>> [{epoch}/{self.epochs}], MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}, "
                          f"MAX MAP(i->t): {self.max_mapi2t}, epoch: {self.best_epoch_i}, MAX MAP(t->i): {self.max_mapt2i}, epoch: {self.best_epoch_t}")
         return mAPi2t, mAPt2i, mAPi2i, mAPt2t
@@ -438,18 +455,74 @@ class BaseTrainer:
     # ---- outputs -----------------------------------------------------------------------------------------
     def save_model(self, save_dir, epoch, other=""):
         path = os.path.join(save_dir, "model-" + other + str(epoch) + ".pth")
-        torch.save(self.model.state_dict(), path)
+        data = self._take_model_bytes()
+        if data is not None:                                 # torch.save(self.model.state_dict(), <memory>) done under the encode loop of this valid()
+            with open(path, "wb") as f:
+                f.write(data.getbuffer())
+        else:
+            torch.save(self.model.state_dict(), path)
         self.logger.info("save mode to {}".format(path))
+
+    # valid() saves the model when an epoch is a new best (reference :318-330): 0.6 GB of ViT-B/32 weights through pickle, 0.17 s at the
+    # end of an evaluation whose GPU work the host only enqueues.  The weights do not change inside valid(), so the same torch.save runs on
+    # a host thread while the encode loop keeps the GPU busy (device-to-host copies on a stream of its own) and save_model() only writes
+    # the bytes.  Not a new best: the bytes are dropped.
+    def _start_model_bytes(self):
+        self._model_bytes = None
+        if not self._is_writer() or type(self).save_model is not BaseTrainer.save_model:
+            return
+        box = {}
+        model = self.model
+        dev = next(model.parameters()).device
+
+        def work():
+            try:
+                buf = io.BytesIO()
+                if dev.type == "cuda":
+                    with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+                        torch.save(model.state_dict(), buf)
+                else:
+                    torch.save(model.state_dict(), buf)
+                box["bytes"] = buf
+            except Exception as e:                           # save_model() then serialises in line, and any real error shows there
+                box["error"] = e
+        th = threading.Thread(target=work, name="xmh-model-bytes", daemon=True)
+        th.start()
+        self._model_bytes = (th, box)
+
+    def _take_model_bytes(self):
+        pending = self.__dict__.get("_model_bytes")
+        if pending is None:
+            return None
+        pending[0].join()
+        return pending[1].get("bytes")                       # kept: a second best of the same epoch names the same file and is skipped by valid()
+
+    def _drop_model_bytes(self):
+        pending = self.__dict__.get("_model_bytes")
+        if pending is not None:
+            pending[0].join()
+        self._model_bytes = None
 
     @classmethod
     def save_mat(cls, query_img, query_txt, query_labels, retrieval_img, retrieval_txt, retrieval_labels, save_file="i2t"):
-        """reference :386-405 -- same keys; codes fp32 [N,K], labels as stored by the dataset (int64)."""
+        """reference :386-405 -- same keys; codes fp32 [N,K], labels as stored by the dataset (int64).  Level-5 MAT-file as
+        scipy.io.savemat writes it, through xmh/utils/matfile.py (tensors are put in the file's column-major order on their own
+        device); whatever that writer does not cover goes through scipy itself."""
+        from ..utils import matfile
+        names = ("q_img", "q_txt", "r_img", "r_txt", "q_l", "r_l")
+        values = (query_img, query_txt, retrieval_img, retrieval_txt, query_labels, retrieval_labels)
+        try:
+            matfile.write_mat5(os.path.join(save_file), dict(zip(names, values)))
+            return
+        except matfile.UnsupportedMatValue:
+            pass
         import scipy.io as scio
 
         def arr(t):
+            if isinstance(t, matfile.Prepared):
+                return np.ascontiguousarray(t.host.T)
             return t.cpu().detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-        scio.savemat(os.path.join(save_file), {"q_img": arr(query_img), "q_txt": arr(query_txt), "r_img": arr(retrieval_img),
-                                               "r_txt": arr(retrieval_txt), "q_l": arr(query_labels), "r_l": arr(retrieval_labels)})
+        scio.savemat(os.path.join(save_file), dict(zip(names, (arr(v) for v in values))))
 
     @classmethod
     def from_config(cls, cfg, logger=None):

@@ -55,6 +55,14 @@ def test_runner_valid_matches_oracle(tmp_path, arch, runner, K):
     sd = torch.load(pth, map_location="cpu")
     assert any(k.startswith("backbone.visual.transformer.resblocks.0.attn.in_proj_weight") for k in sd)
     assert any(k.startswith("hash.") for k in sd)
+    # the .pth was serialised on a host thread under the encode loop: the same file torch.save(model.state_dict(), path) writes
+    live = trainer.model.state_dict()
+    assert list(sd) == list(live) and all(torch.equal(sd[k], live[k].cpu()) for k in live)
+    assert next(iter(torch.load(pth).values())).device == next(iter(live.values())).device      # saved from the device, like the reference's
+    # i2t-best / t2i-best / last of one epoch are names of one file; each reads back complete
+    for other in ("i2t-best.mat", "t2i-best.mat"):
+        m2 = scio.loadmat(os.path.join(str(tmp_path), "mat_files", other))
+        assert all(np.array_equal(m2[k], mat[k]) for k in ("q_img", "q_txt", "r_img", "r_txt", "q_l", "r_l"))
     # mAP@k path and the calc_map_k injection seam
     m50 = trainer.valid(1, k=50)
     assert abs(m50[0] - float(orc.map_k(q_img.cpu(), r_txt.cpu(), qL, rL, 50, stable=True))) < 1e-6
