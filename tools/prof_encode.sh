@@ -13,8 +13,10 @@ from xmh.utils.config import Config
 from xmh.models import weights as W
 which = sys.argv[1]
 model = DCMHT.from_config(Config({"clip_path": "synthetic:1814"}), output_dim=64).cuda().eval()
-image = W.synth_images(5, 100).cuda()
-ids, _ = W.synth_text(5, 100); ids = ids.cuda()
+import os
+NB = int(os.environ.get("XMH_PROF_BATCH", "100"))
+image = W.synth_images(5, 100).cuda().repeat(NB // 100, 1, 1, 1)
+ids, _ = W.synth_text(5, 100); ids = ids.cuda().repeat(NB // 100, 1)
 fn = (lambda: R.pack_pair_argmax(model.encode_image(image))) if which == "image" else (lambda: R.pack_pair_argmax(model.encode_text(ids)))
 for _ in range(22): fn()
 torch.cuda.synchronize()
