@@ -751,6 +751,11 @@ struct MfmaArgs {
     const uint32_t* qbits;
     int Q, R, K, W;
     int chunk, nchunk, nqt, nb, qpad;
+    // k_scan_hist_r2 only (operands built in registers from the packed words)
+    const uint32_t* rbits = nullptr;
+    const uint32_t* rlab = nullptr;
+    const uint32_t* qlab = nullptr;
+    int LW = 0;
 };
 
 template <int NMC, int NML>
@@ -1089,14 +1094,16 @@ __global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict
 }
 
 // STAMP (tools/stamp_m2.hip only): s_memtime stamps around the phases of a batch, summed per wave into stamps[wave id][8]
-template <int NML, int NW, int NQ, bool CACHE, bool STAMP = false>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
-                                                          unsigned long long* __restrict__ stamps = nullptr) {
+// REGS (round 4, k_scan_hist_r2): the A operands are built in registers from the packed gallery words -- no operand image, no LDS-DMA, no
+// ring, no barrier; see k_scan_hist_r2 below.
+template <int NML, int NW, int NQ, bool CACHE, bool STAMP, bool REGS>
+__device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
+                                                  unsigned long long* __restrict__ stamps) {
     constexpr int NMI = 1 + NML, NMQ = 2 + NML;
     constexpr int PIECES = 4 * NMI;                                  // 1 KB pieces per 64-item batch
     constexpr int PPW = (PIECES + NW - 1) / NW;                      // LDS-DMA pieces a wave issues per batch
     constexpr int NST = CACHE ? NQ : 0;                              // cache stores a wave issues per batch (they share vmcnt)
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters, then the 3-deep ring
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters, then the 3-deep ring (none with REGS)
     int chunk_id, qtile;
     if (!mfma_map_block(a, chunk_id, qtile)) return;                 // a.nqt counts tiles of NW * NQ * 16 queries here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1111,24 +1118,60 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
     for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
     char* ring = reinterpret_cast<char*>(lds + NW * NQ * ncell);
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
-    v4i bq[NQ][NMQ], cq[NQ];
+    v4i bq[NQ][NMQ], cq[NQ], kqv[REGS ? NQ : 1];                    // the image kernels start every 2 * distance chain at K: one quad
     bool valid[NQ];
+    // REGS: byte b of operand register j of lane (row, slot) stands for bit 4 (slot & 1) + j + 8 b of word slot >> 1 (of the code, or of the
+    // 64 label bits of a tile): (word >> (4 (slot & 1) + j)) & 0x01010101 leaves those four bits each alone in its byte, worth 1.  Item bytes
+    // are therefore 0 / 1 (not -+1): distance = popcount(q) + sum x_i (1 - 2 q_i), so the query bytes are +-64 (counter rows of 64 bytes) for
+    // the address chain, +-2 for the 2 * distance chain, and the chains start at 64 popcount(q) / 2 popcount(q) more.
+    const int rsh = 4 * (slot & 1), rwi = slot >> 1;
 #pragma unroll
     for (int h = 0; h < NQ; ++h) {
-#pragma unroll
-        for (int m = 0; m < NMQ; ++m) bq[h][m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(t16 + h) * NMQ + m) * 64 + lane);
         valid[h] = (t16 + h) * 16 + ql < a.Q;
+        int pcq = 0;
+        if (REGS) {
+            const int64_t q = (int64_t)(t16 + h) * 16 + ql;
+            uint32_t qw = 0u;
+            if (valid[h]) {
+                for (int w = 0; w < a.W; ++w) pcq += __popc(a.qbits[q * a.W + w]);
+                if (rwi < a.W) qw = a.qbits[q * a.W + rwi];
+            }
+            qw >>= rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = (qw >> j) & 0x01010101u;
+                bq[h][0][j] = valid[h] ? (int)(0x40404040u ^ (t << 7)) : 0;
+                bq[h][1][j] = valid[h] ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;
+            }
+#pragma unroll
+            for (int m = 0; m < NML; ++m) {
+                uint32_t lw = 0u;
+                if (valid[h] && 2 * m + rwi < a.LW) lw = a.qlab[q * a.LW + 2 * m + rwi];
+                lw >>= rsh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[h][2 + m][j] = (int)((lw >> j) & 0x01010101u);
+            }
+            const int k2 = 2 * pcq;
+            kqv[REGS ? h : 0] = v4i{k2, k2, k2, k2};
+        } else {
+#pragma unroll
+            for (int m = 0; m < NMQ; ++m) bq[h][m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(t16 + h) * NMQ + m) * 64 + lane);
+            kqv[0] = v4i{a.K, a.K, a.K, a.K};
+        }
 #ifdef XMH_ABL_SUB2
         const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (slot & 1) * 64 + (valid[h] ? 64 * a.K : 0);
 #else
-        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 32 * a.K : 0);
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 +
+                       (valid[h] ? (REGS ? 64 * pcq : 32 * a.K) : 0);
 #endif
         cq[h] = v4i{c0, c0, c0, c0};
     }
-    v4i kq = {a.K, a.K, a.K, a.K}, lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
-    asm volatile("" : "+v"(kq), "+v"(lab0));                        // opaque: kept in VGPRs, not re-materialised from SGPRs inside the loop
+    v4i lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
+    asm volatile("" : "+v"(lab0));                                  // opaque: kept in VGPRs, not re-materialised from SGPRs inside the loop
 #pragma unroll
     for (int h = 0; h < NQ; ++h) asm volatile("" : "+v"(cq[h]));
+#pragma unroll
+    for (int h = 0; h < (REGS ? NQ : 1); ++h) asm volatile("" : "+v"(kqv[h]));
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     const int nbat = (int)((hi - lo + 63) >> 6);
@@ -1154,11 +1197,52 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         t_prev = t;
     };
     if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    stage(0, bat0);
-    if (nbat > 1) stage(1, bat0 + 1);
+    // REGS: the packed words of this lane's four items of a batch (row r of group g is item 16 g + 4 (r & 3) + (r >> 2): accumulator register j
+    // of a lane is its step j, as in the image), fetched one batch ahead with unconditional loads (clamped item, word index clamped to
+    // the last one and masked: no predication, so hipcc waits with counted vmcnt only where the words are used; two batches ahead measured
+    // the same 0.185 ms)
+    uint32_t wcur[4][NMI], wnxt[4][NMI];
+    const int ritem = 4 * (lane & 3) + ((lane & 15) >> 2);
+    const uint32_t wmask_c = rwi < a.W ? 0xffffffffu : 0u;
+    const int wi_c = rwi < a.W ? rwi : a.W - 1;
+    uint32_t wmask_l[NML];
+    int wi_l[NML];
+#pragma unroll
+    for (int m = 0; m < NML; ++m) {
+        wmask_l[m] = 2 * m + rwi < a.LW ? 0xffffffffu : 0u;
+        wi_l[m] = 2 * m + rwi < a.LW ? 2 * m + rwi : (a.LW > 0 ? a.LW - 1 : 0);
+    }
+    auto load_words = [&](int64_t batch, uint32_t (&w)[4][NMI]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t item = batch * 64 + g * 16 + ritem;
+            const int64_t it = item < a.R ? item : (int64_t)a.R - 1;
+            const uint32_t ok = item < a.R ? 0xffffffffu : 0u;       // items past the end: all-zero codes, no labels (the epilogue takes them out again)
+            w[g][0] = a.rbits[it * a.W + wi_c] & (wmask_c & ok);
+#pragma unroll
+            for (int m = 0; m < NML; ++m) w[g][1 + m] = a.rlab[it * a.LW + wi_l[m]] & (wmask_l[m] & ok);
+        }
+    };
+    auto build = [&](v4i (&At)[NMI], const uint32_t (&w)[NMI]) {
+#pragma unroll
+        for (int m = 0; m < NMI; ++m) {
+            const uint32_t x = w[m] >> rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) At[m][j] = (int)((x >> j) & 0x01010101u);
+        }
+    };
+    if (REGS) load_words(bat0, wcur);
+    else {
+        stage(0, bat0);
+        if (nbat > 1) stage(1, bat0 + 1);
+    }
     int buf = 0;
     stamp(0);
     for (int i = 0; i < nbat; ++i) {
+        uint32_t abase = 0u;
+        if (REGS) {
+            load_words(bat0 + (i + 1 < nbat ? i + 1 : i), wnxt);
+        } else {
         // this wave's pieces of batch i have landed: newer in flight are the pieces of batch i + 1 and the cache stores of batch i - 1
         if (i + 1 >= nbat) wait_vmcnt<0>();
         else if (i == 0) wait_vmcnt<PPW>();
@@ -1168,12 +1252,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         stamp(2);
         if (i + 2 < nbat) stage(buf >= 1 ? buf - 1 : 2, bat0 + i + 2);      // (i + 2) % 3 == (i - 1) % 3
         stamp(3);
-        const uint32_t abase = ring_lds + buf * (PIECES * 1024) + lane * 16;      // LDS byte address of this lane's 16 bytes of piece 0
+        abase = ring_lds + buf * (PIECES * 1024) + lane * 16;      // LDS byte address of this lane's 16 bytes of piece 0
         buf = buf == 2 ? 0 : buf + 1;
+        }
         // A tiles of item group g live in set g & 1; read (asm: hipcc would wait for ALL outstanding reads at the first use) one group
         // ahead of the MFMAs that use them, waited for with counted lgkmcnt (LDS operations of a wave complete in order):
         //   R(0) R(1) | group 0 | R(2) | group 1 | R(3) | group 2 | group 3      with 4 adds per statement behind the first
-        v4i A[2][NMI];
+        v4i A[REGS ? 4 : 2][NMI];                                    // REGS: one set per group, each kept alive one statement past its last MFMA
         uint32_t cw[NQ][4];
         v4i addr_p, d2_p, lab_p;                                     // results of the previous (group, query group), consumed by the next statement
         // One asm statement = the MFMAs of (group g, query group h) with the consumer instructions of the PREVIOUS pair between them:
@@ -1215,7 +1300,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     XMH_MFMA("%2", "%13", "%16", "%17")
                     XMH_ADD("%24", "%6") "v_or_b32_sdwa %3, %21, %7 " XMH_SDWA(3) XMH_ADD("%25", "%7")
                     : "=&v"(lab), "=&v"(addr), "=&v"(d2), "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq),
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kqv[REGS ? h : 0]),
                       "v"(d2_p[0]), "v"(d2_p[1]), "v"(d2_p[2]), "v"(d2_p[3]), "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]),
                       "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
                     : "memory");
@@ -1242,7 +1327,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                     XMH_MFMA("%2", "%11", "%14", "%15")
                     XMH_ADD("%22", "%6") "v_or_b32_sdwa %3, %19, %7 " XMH_SDWA(3) XMH_ADD("%23", "%7")
                     : "=&v"(lab), "=&v"(addr), "=&v"(d2), "=&v"(w), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq),
+                    : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kqv[REGS ? h : 0]),
                       "v"(d2_p[0]), "v"(d2_p[1]), "v"(d2_p[2]), "v"(d2_p[3]), "v"(addr_p[0]), "v"(addr_p[1]), "v"(addr_p[2]), "v"(addr_p[3]),
                       "v"(lab_p[0]), "v"(lab_p[1]), "v"(lab_p[2]), "v"(lab_p[3])
                     : "memory");
@@ -1266,7 +1351,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                              XMH_MFMA("%1", "%8", "%9", "%10") XMH_MFMA("%2", "%8", "%11", "%12") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr), "=&v"(d2)
                              : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[NMI - 1]), "v"(bq[h][NMQ - 1]), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]),
-                               "v"(bq[h][1]), "v"(kq));
+                               "v"(bq[h][1]), "v"(kqv[REGS ? h : 0]));
             } else if (NML == 2) {
                 asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%0", "%5", "%6", "%0")
                              XMH_MFMA("%1", "%7", "%8", "%9") "s_nop 7"
@@ -1276,7 +1361,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
                 asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%3", "%4", "%5") XMH_MFMA("%1", "%6", "%7", "%8")
                              XMH_MFMA("%2", "%6", "%9", "%10") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr), "=&v"(d2)
-                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kq));
+                             : "v"(At[1]), "v"(bq[h][2]), "v"(lab0), "v"(At[0]), "v"(bq[h][0]), "v"(cq[h]), "v"(bq[h][1]), "v"(kqv[REGS ? h : 0]));
             } else {
                 asm volatile("s_nop 3\n\t" XMH_MFMA("%0", "%2", "%3", "%4") XMH_MFMA("%1", "%5", "%6", "%7") "s_nop 7"
                              : "=&v"(lab), "=&v"(addr)
@@ -1311,27 +1396,41 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
 #undef XMH_MFMA
         auto group = [&](auto gc) {
             constexpr int G = decltype(gc)::value;
-            // the reads of this group have returned: operations issued behind them (see the sequence above), at most 15 countable
-            constexpr int newer = G == 0 ? NMI : (G == 1 ? 4 * (NQ - 1) + NMI : (G == 2 ? 4 * NQ + NMI : 4 * NQ));
-            wait_lgkmcnt<(newer < 15 ? newer : 15)>();
+            constexpr int SET = REGS ? G : (G & 1);
+            if (!REGS) {
+                // the reads of this group have returned: operations issued behind them (see the sequence above), at most 15 countable
+                constexpr int newer = G == 0 ? NMI : (G == 1 ? 4 * (NQ - 1) + NMI : (G == 2 ? 4 * NQ + NMI : 4 * NQ));
+                wait_lgkmcnt<(newer < 15 ? newer : 15)>();
+            }
             if (STAMP && G == 0) stamp(4);
 #pragma unroll
             for (int h = 0; h < NQ; ++h) {
                 v4i addr, d2, lab;
-                if (G == 0 && h == 0) evaluate(A[G & 1], h, addr, d2, lab);
-                else fused(A[G & 1], h, addr, d2, lab, cw[(h + NQ - 1) % NQ][h == 0 ? G - 1 : G]);
+                if (G == 0 && h == 0) evaluate(A[SET], h, addr, d2, lab);
+                else fused(A[SET], h, addr, d2, lab, cw[(h + NQ - 1) % NQ][h == 0 ? G - 1 : G]);
                 addr_p = addr; d2_p = d2; lab_p = lab;
+                if (REGS && G > 0 && h == 0) {                         // the previous group's tiles may be reused from here on, not earlier
+                    if constexpr (NMI == 2) asm volatile("" ::"v"(A[REGS ? G - 1 : 0][0]), "v"(A[REGS ? G - 1 : 0][1]));
+                    else asm volatile("" ::"v"(A[REGS ? G - 1 : 0][0]), "v"(A[REGS ? G - 1 : 0][1]), "v"(A[REGS ? G - 1 : 0][NMI - 1]));
+                }
             }
-            if (G + 2 < 4) lds_read_group<G + 2, NMI>(A[G & 1], abase);          // this set's MFMAs have been issued (operands are read at issue)
+            if (!REGS && G + 2 < 4) lds_read_group<G + 2, NMI>(A[G & 1], abase);          // this set's MFMAs have been issued (operands are read at issue)
         };
-        lds_read_group<0, NMI>(A[0], abase);
-        lds_read_group<1, NMI>(A[1], abase);
+        if (REGS) {
+            build(A[0], wcur[0]);
+            build(A[1], wcur[1]);
+            build(A[REGS ? 2 : 0], wcur[2]);
+            build(A[REGS ? 3 : 1], wcur[3]);
+        } else {
+            lds_read_group<0, NMI>(A[0], abase);
+            lds_read_group<1, NMI>(A[1], abase);
+        }
         group(std::integral_constant<int, 0>{});
         group(std::integral_constant<int, 1>{});
         group(std::integral_constant<int, 2>{});
         group(std::integral_constant<int, 3>{});
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
-        consume(cw[NQ - 1][3], A[1]);
+        consume(cw[NQ - 1][3], A[REGS ? 3 : 1]);
         stamp(5);
         if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
 #pragma unroll
@@ -1344,6 +1443,12 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
             }
         }
         stamp(7);
+        if (REGS) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int m = 0; m < NMI; ++m) wcur[g][m] = wnxt[g][m];
+        }
     }
     // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
     const int npad = nbat * 64 - (int)(hi - lo);
@@ -1368,6 +1473,45 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* 
         uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + (t16 + h) * 16;
         for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[h * ncell + e];
     }
+}
+
+template <int NML, int NW, int NQ, bool CACHE, bool STAMP = false>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
+                                                          unsigned long long* __restrict__ stamps = nullptr) {
+    scan_hist_m2_body<NML, NW, NQ, CACHE, STAMP, false>(a, chunk_hist, pair_cache, stamps);
+}
+
+// What is left of k_scan_expand2 for k_scan_hist_r2: the control words of the call are cleared, and the packed words of every chunk are
+// read once by blocks that land on the XCD whose k_scan_hist_r2 blocks will read them (block b runs on XCD b & 7, chunk c is scanned on XCD
+// c & 7: mfma_map_block).  k_scan_hist_r2 fetches its words one batch ahead, which covers an L2 hit but not a miss to HBM behind the
+// 600 MB the previous evaluation's pass 2 streamed through: without this launch pass 1 measured 0.204 ms instead of 0.184 (the image
+// kernel it replaces had been warming the caches by accident).
+constexpr int kTouchPerChunk = 8;
+__global__ __launch_bounds__(256) void k_scan_touch(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int64_t chunk,
+                                                    int nchunk, uint32_t* __restrict__ ctl, int ctl_words) {
+    if (blockIdx.x == 0)
+        for (int e = threadIdx.x; e < ctl_words; e += 256) ctl[e] = 0u;
+    const int b = blockIdx.x;
+    const int c = (b & 7) + 8 * ((b >> 3) / kTouchPerChunk), sub = (b >> 3) % kTouchPerChunk;
+    if (c >= nchunk) return;
+    const int64_t lo = (int64_t)c * chunk, hi = lo + chunk < R ? lo + chunk : R;
+    uint32_t acc = 0u;
+    auto sweep = [&](const uint32_t* base, int64_t w0, int64_t w1) {      // one load per 128-byte line is enough
+        for (int64_t w = w0 + ((int64_t)sub * 256 + threadIdx.x) * 32; w < w1; w += (int64_t)kTouchPerChunk * 256 * 32) acc ^= base[w];
+    };
+    sweep(rbits, lo * W, hi * W);
+    sweep(rlab, lo * LW, hi * LW);
+    asm volatile("" ::"v"(acc));
+}
+
+// k_scan_hist_r2 (round 4): k_scan_hist_m2's statements fed from registers.  The skeleton around the MFMA statements of k_scan_hist_m2 --
+// LDS-DMA issue, waiting for pieces, the barrier, the A-tile reads: a third of a wave's cycles (tools/stamp_m2.hip) -- and the 36 KB ring
+// that holds a block to two per CU exist only to bring 16 bytes per lane and tile that are a function of ONE packed word: here each lane
+// loads that word (4 bytes per tile; a wave's 16 items x 24 bytes per group, L2-resident) one batch ahead and spreads it with 8 VALU
+// operations per tile.  Waves are independent (no barrier, no shared staging); LDS holds the counters only.
+template <int NML, int NW, int NQ, bool CACHE>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_r2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+    scan_hist_m2_body<NML, NW, NQ, CACHE, false, true>(a, chunk_hist, pair_cache, nullptr);
 }
 
 // Pass 2 on the same operand images: the MFMA emits the counter address and the label overlap, ONE returning ds_add per pair
@@ -2007,6 +2151,14 @@ constexpr int kMfmaWaves = 4;                          // waves (16 queries each
 // k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
 struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
+// k_scan_hist_r2 (operands from the packed words, no image / ring / barrier) instead of k_scan_hist_m2: codes of 33..64 bits.  Up to 32 bits
+// half of r2's lane groups would build operands of a code word that does not exist, and k_scan_hist_m2's counters are small enough there
+// for 4 query groups per wave beside its ring (Q 5000 x R 117 218, pass 1, m2 / r2: 16 bit 0.155 / 0.173 ms, 32 bit 0.161 / 0.174,
+// 64 bit 0.191 / 0.178-0.184).  XMH_SCAN_M2_REGS=0 / 1 forces it off / on for all of them (read per call: the tests compare the two).
+inline bool m2_regs(int K) {
+    const char* e = getenv("XMH_SCAN_M2_REGS");
+    return e ? atoi(e) != 0 : K > 32;
+}
 inline M2Geom m2_geom(int K) {
     // XMH_SCAN_M2_GEOM / _BPC pick one of the instantiated shapes / the blocks per CU the chunk count is sized for (tuning; read per call).
     // Default: 4 waves x 2 query groups, two blocks per CU (70 KB of LDS each at 65 buckets); codes of at most 32 bits have so few
@@ -2015,7 +2167,10 @@ inline M2Geom m2_geom(int K) {
     // K=16 0.416 / 0.350 / 0.367 / 0.352 / 0.368 ms per step, K=32 0.426 / 0.362 / 0.385 / 0.375 / 0.393).
     static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
     const char* e = getenv("XMH_SCAN_M2_GEOM");
-    M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : table[0];
+    // k_scan_hist_r2 has no ring: 4 query groups per wave fit at 65 bucket rows as well (66 KB of counters, two blocks per CU), and every A
+    // tile it builds (8 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
+    // (pass 1 0.207-0.231 ms against 0.190)
+    M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : (m2_regs(K) ? M2Geom{4, 4, 2} : table[0]);
     if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
     const char* b = getenv("XMH_SCAN_M2_BPC");
     if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
@@ -2121,8 +2276,10 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
         // 65..128 bits: 129 bucket rows, 2 blocks per CU; 129..256 bits: 257 rows, one block per CU
         nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
         if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
-            static const int m2r = getenv("XMH_SCAN_M2_ROUNDS") ? atoi(getenv("XMH_SCAN_M2_ROUNDS")) : 2;
-            nchunk = (int64_t)(m2r > 0 ? m2r : 2) * xmh::device_cu_count() * m2_geom(K).blocks_per_cu / (nqt * 64 / m2q);
+            const char* m2r_env = getenv("XMH_SCAN_M2_ROUNDS");                  // read per call, like the geometry
+            const int m2r_def = K > 32 && m2_regs(K) ? 1 : 2;                     // k_scan_hist_r2: one set of two 256-query blocks per CU (rounds 1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
+            const int m2r = m2r_env && atoi(m2r_env) > 0 ? atoi(m2r_env) : m2r_def;
+            nchunk = (int64_t)m2r * xmh::device_cu_count() * m2_geom(K).blocks_per_cu / (nqt * 64 / m2q);
         }
     }
     if (nchunk < 1) nchunk = 1;
@@ -2360,13 +2517,31 @@ int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rb
     uint4* qimg = reinterpret_cast<uint4*>(base + L.qimg32);
     const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NMI * 64, qpieces = (p.qpad / 16) * NMQ * 64;
     const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
-    hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
-                       qimg, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
-    XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
+    const bool regs = m2_regs(K);
+    if (regs) {                                                      // no operand images
+        hipLaunchKernelGGL(k_scan_touch, dim3((unsigned)(8 * kTouchPerChunk * xmh::ceil_div(p.nchunk, 8))), dim3(256), 0, st, rbits, rlab, R, W, LW, p.chunk,
+                           (int)p.nchunk, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
+        XMH_LAUNCH_CHECK("xmh_hamming_hist control words");
+    } else {
+        hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
+                           qimg, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
+        XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
+    }
     MfmaArgs a{gimg, qimg, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
-    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
     xmh::ProfScope prof("scan_hist", st);
+    if (regs) {
+        a.rbits = rbits; a.rlab = rlab; a.qlab = qlab; a.LW = LW;
+        const size_t lds_r = (size_t)NW * NQ * p.nbuckets * 16 * 4;
+        auto go = [&](auto kern) {
+            const int r2 = raise_lds(kern, lds_r, "xmh_hamming_hist");
+            if (r2) return r2;
+            hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds_r, st, a, chunk_hist, cache);
+            return (int)XMH_OK;
+        };
+        return cache ? go(k_scan_hist_r2<NML, NW, NQ, true>) : go(k_scan_hist_r2<NML, NW, NQ, false>);
+    }
+    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
     if (cache) {
         auto kern = k_scan_hist_m2<NML, NW, NQ, true>;
         const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
@@ -2463,7 +2638,8 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const int S4 = slots_for(Wc, tern, 4), S8 = slots_for(Wc, tern, 8);
     if (use_mfma && m2_shape(K, tern)) {
         const M2Geom g = m2_geom(K);
-        snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
+        if (m2_regs(K)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
+        else snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
     } else if (use_mfma) {
         if (bits_shape(K, tern, LW)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s>", K <= 128 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
         else snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false",

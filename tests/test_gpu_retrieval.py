@@ -337,14 +337,23 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
 
 @pytest.mark.parametrize("Q,R,K,C,m2", [(130, 6000, 64, 80, "1"), (70, 9100, 64, 33, "1"), (300, 20011, 48, 80, "1"), (17, 63, 64, 5, "1"), (129, 6463, 128, 80, "1"),
                                         (200, 7000, 16, 24, "1"), (90, 5001, 32, 80, "1"), (65, 3000, 256, 24, "1"),
-                                        (130, 6000, 64, 80, "0"), (300, 20011, 48, 80, "0"), (17, 63, 64, 5, "0")])
+                                        (130, 6000, 64, 80, "0"), (300, 20011, 48, 80, "0"), (17, 63, 64, 5, "0"),
+                                        (130, 6000, 64, 80, "m2"), (300, 20011, 48, 33, "m2"), (17, 63, 64, 5, "m2"), (200, 7000, 16, 24, "r2"), (90, 5001, 32, 80, "r2"),
+                                        (257, 9000, 33, 128, "r2")])
 def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     """Every entry pass 1 leaves in the pair cache (distance << 1 | relevant; xmh_scan_pair_cache_offset documents the layout)
     against the oracle's distance and relevance of that (query, item) pair -- the MFMA-evaluated pass 1 writes the entry from a
     second accumulator chain, so this checks that chain directly and not only through the mAP it leads to.  m2 = "0": the kernel
     k_scan_hist_m2 replaced (k_scan_hist_m with the cache, what a failed self-check or XMH_SCAN_M2=0 selects) writes the same entries."""
     from xmh._lib import lib
-    monkeypatch.setenv("XMH_SCAN_M2", m2)
+    # "1": the default (round 4: k_scan_hist_r2, operands built in registers, for 33..64 bits; k_scan_hist_m2 up to 32); "m2" / "r2": one family
+    # for every length it is instantiated for
+    monkeypatch.setenv("XMH_SCAN_M2", "0" if m2 == "0" else "1")
+    if m2 in ("m2", "r2"):
+        monkeypatch.setenv("XMH_SCAN_M2_REGS", "1" if m2 == "r2" else "0")
+    import bench_roofline
+    if m2 != "0" and K <= 64:
+        assert ("k_scan_hist_r2" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (m2 == "r2" or (m2 == "1" and K > 32))
     orc = _orc()
     qB, rB, qL, rL = _synth(Q, R, K, C, seed=3 * K + R)
     q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
@@ -396,18 +405,24 @@ def test_scan_m2_against_the_kernels_it_replaced(xr, monkeypatch, K):
     for (Q, Rn, C, p, k) in ((150, 9001, 80, 0.06, 9), (64, 8157, 32, 0.5, 85), (127, 62, 1, 0.01, None), (300, 20011, 24, 0.1, 50)):
         qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=5 * K + Q, p=p)
         outs = []
-        for flag in ("1", "0"):
+        for flag, regs in (("1", None), ("0", None), ("1", "0"), ("1", "1")):      # default; the replaced kernels; k_scan_hist_m2; k_scan_hist_r2 (round 4)
             monkeypatch.setenv("XMH_SCAN_M2", flag)
+            if regs is None:
+                monkeypatch.delenv("XMH_SCAN_M2_REGS", raising=False)
+            else:
+                monkeypatch.setenv("XMH_SCAN_M2_REGS", regs)
             scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
             ha, hr = scan.histograms(True)
             ap, cap = scan.ap_sums(None)
             apk, capk = scan.ap_sums(k)
             outs.append((ha.clone(), hr.clone(), cap.clone(), capk.clone(), ap.clone(), apk.clone()))
-        for x, y in zip(outs[0][:4], outs[1][:4]):
-            assert torch.equal(x, y), (Q, Rn, K, C)
-        for x, y, c in ((outs[0][4], outs[1][4], outs[0][2]), (outs[0][5], outs[1][5], outs[0][3])):
-            assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (Q, Rn, K, C)
-            assert abs(float((x / c).mean()) - float((y / c).mean())) < 1e-7
+        monkeypatch.delenv("XMH_SCAN_M2_REGS", raising=False)
+        for other in outs[1:]:
+            for x, y in zip(outs[0][:4], other[:4]):
+                assert torch.equal(x, y), (Q, Rn, K, C)
+            for x, y, c in ((outs[0][4], other[4], outs[0][2]), (outs[0][5], other[5], outs[0][3])):
+                assert torch.allclose(x, y, rtol=2e-6, atol=1e-9), (Q, Rn, K, C)
+                assert abs(float((x / c).mean()) - float((y / c).mean())) < 1e-7
 
 
 def test_scan_m2_self_check_failure_falls_back_with_one_warning():
@@ -441,7 +456,7 @@ def test_scan_m2_self_check_failure_falls_back_with_one_warning():
     assert len(ok[0]) == 2 and len(failed[0]) == 2
     for a, b in zip(ok[0], failed[0]):
         assert abs(float(a[2]) - float(b[2])) < 1e-7                  # another chunking: float partial sums add in another order
-        assert "k_scan_hist_m2" in a[3] and "k_scan_hist_m2" not in b[3]
+        assert ("k_scan_hist_m2" in a[3] or "k_scan_hist_r2" in a[3]) and "k_scan_hist_m2" not in b[3] and "k_scan_hist_r2" not in b[3]
 
 
 def test_scan_one_byte_entries_for_65_to_128_bit_codes(xr, cu, monkeypatch):

@@ -31,7 +31,8 @@ def _template_ints(name, kernel):
 
 def test_every_hand_scheduled_kernel_is_in_the_library(report):
     names = "\n".join(report)
-    for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
+    for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_r2ILi2ELi4ELi4ELb1E", "k_scan_hist_r2ILi1ELi4ELi4ELb0E",
+              "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
         assert k in names, k
     assert sum(st["n_mfma"] for _, st in report.values()) > 1000
 
@@ -60,6 +61,27 @@ def test_hand_scheduled_statements_keep_their_margins(report):
     assert seen >= 20
 
 
+def test_register_built_operands_keep_the_same_margins(report):
+    """k_scan_hist_r2 = the statements of k_scan_hist_m2 with A tiles that VALU instructions build from the packed words: on top of the
+    margins above, every MFMA operand a VALU instruction wrote is at least 2 wait states old (R3 on A / B, covered by the `s_nop 3`
+    that opens each statement) and a tile is not overwritten within 3 slots of the last MFMA that read it (R2: each group has its own
+    tile set, kept alive one statement longer by an empty asm)."""
+    seen = 0
+    for name, (bad, st) in report.items():
+        if "k_scan_hist_r2" not in name:
+            continue
+        nml, nw, nq, cache = _template_ints(name, "k_scan_hist_r2")
+        assert not bad, (name, bad[:3])
+        assert st["R1"] is not None and st["R1"] >= 12, (name, st)
+        assert st["R3"] is not None and st["R3"] >= H.SRCC_WAIT, (name, st)
+        assert st["R2"] is None or st["R2"] >= H.WAR_WAIT, (name, st)
+        assert st["n_sdwa_preserve"] == (12 * nq if cache else 0), (name, st)
+        if H.hipcc_version().startswith(PINNED_COMPILER):
+            assert st["n_snop3"] == 4 * nq + 1, (name, st)
+        seen += 1
+    assert seen >= 20
+
+
 def test_the_checker_sees_a_planted_hazard():
     """the rules fire on a three-instruction stream with each hazard planted (the checker itself is not vacuous)"""
     def stream(*lines):
@@ -72,6 +94,8 @@ def test_the_checker_sees_a_planted_hazard():
     assert rules(stream(mf, "v_mov_b32_e32 v5, v30")) == ["R2"]                                            # lands on the A operand
     assert rules(stream("v_mov_b32_e32 v12, v30", mf)) == ["R3"]                                           # srcC written in the slot before
     assert rules(stream("v_mov_b32_e32 v12, v30", "s_nop 3", mf)) == []
+    assert rules(stream("v_and_b32_e32 v5, 0x1010101, v30", mf)) == ["R3"]                                 # an A operand a VALU wrote in the slot before
+    assert rules(stream("v_and_b32_e32 v5, 0x1010101, v30", "s_nop 1", mf)) == []
     sd = "v_or_b32_sdwa v40, v41, v42 dst_sel:BYTE_%d dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0"
     assert rules(stream(sd % 1, sd % 2)) == ["R4"]
     assert rules(stream(sd % 1, "ds_add_u32 v50, v51", sd % 2)) == []

@@ -11,7 +11,7 @@ disassembles the gfx950 code objects inside libxmh.so (llvm-objdump, no GPU need
   R2  (hand-scheduled kernels only) VALU write of a register an MFMA read as srcC / A / B: not within `WAR_WAIT` wait states behind
       that MFMA -- hipcc itself overwrites A / B operands in the very next slot elsewhere, so this pins the distances the
       hand-placed statements were validated with on hardware rather than an architectural minimum;
-  R3  VALU write -> MFMA reading the register as srcC: at least `SRCC_WAIT` wait states (the `s_nop 3` that opens every statement);
+  R3  VALU write -> MFMA reading the register (srcC, A or B): at least `SRCC_WAIT` wait states (the `s_nop 3` that opens every statement);
   R4  two SDWA byte inserts (dst_unused:UNUSED_PRESERVE) into one register: never back to back (dst_sel forwarding).
 
 Straight-line analysis: state is dropped at branches (a taken branch costs more than any of these distances; the hand-placed
@@ -105,7 +105,7 @@ def check(insns, kernel="", war=None):
     """-> (violations, stats).  stats: smallest distance seen per rule (None when the pattern does not occur).
     war: apply R2 (default: only to k_scan_hist_m2, the kernel whose MFMAs are inline asm)."""
     if war is None:
-        war = "k_scan_hist_m2" in kernel
+        war = "k_scan_hist_m2" in kernel or "k_scan_hist_r2" in kernel
     out = []
     stats = {"R1": None, "R2": None, "R3": None, "n_mfma": 0, "n_snop3": 0, "n_sdwa_preserve": 0}
     writer = {}           # reg -> ("mfma" | "valu" | "other", wait-state clock at issue)
@@ -127,13 +127,13 @@ def check(insns, kernel="", war=None):
         if is_mfma:
             stats["n_mfma"] += 1
             srcc = _regs(ins.text.split(",")[-1].split()[0]) if ins.text.count(",") >= 3 else []
-            for r in srcc:                                            # R3
+            for r in set(srcc) | set(ins.src):                        # R3: srcC, and A / B alike (k_scan_hist_r2 builds its A tiles with VALU instructions)
                 w = writer.get(r)
                 if w and w[0] == "valu":
                     d = clock - w[1] - 1
                     stats["R3"] = d if stats["R3"] is None else min(stats["R3"], d)
                     if d < SRCC_WAIT:
-                        out.append(Violation("R3", kernel, idx, ins.text, "srcC %s%d written by a VALU %d wait states earlier" % (r[0], r[1], d)))
+                        out.append(Violation("R3", kernel, idx, ins.text, "operand %s%d written by a VALU %d wait states earlier" % (r[0], r[1], d)))
             mfma_reads.append((clock, set(ins.src), set(srcc)))
             mfma_reads = [x for x in mfma_reads if clock - x[0] <= 32]
         else:
@@ -181,7 +181,7 @@ def disassemble(path):
     return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", path], check=True, capture_output=True, text=True).stdout
 
 
-def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_b", "k_scan_hist_m", "k_topk_filter_mfma")):
+def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_r2", "k_scan_hist_b", "k_scan_hist_m", "k_topk_filter_mfma")):
     """-> {kernel: (violations, stats)} for every kernel whose mangled name contains one of name_filter"""
     work = tempfile.mkdtemp(prefix="xmh_isa_")
     try:
