@@ -1140,8 +1140,9 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t t = (qw >> j) & 0x01010101u;
-                bq[h][0][j] = valid[h] ? (int)(0x40404040u ^ (t << 7)) : 0;
-                bq[h][1][j] = valid[h] ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;
+                const bool on = valid[h] && rwi < a.W;                 // no such code word (codes of at most 32 bits): zero operand, whatever the item lane holds
+                bq[h][0][j] = on ? (int)(0x40404040u ^ (t << 7)) : 0;
+                bq[h][1][j] = on ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;
             }
 #pragma unroll
             for (int m = 0; m < NML; ++m) {
@@ -1203,32 +1204,47 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
     // the same 0.185 ms)
     uint32_t wcur[4][NMI], wnxt[4][NMI];
     const int ritem = 4 * (lane & 3) + ((lane & 15) >> 2);
-    const uint32_t wmask_c = rwi < a.W ? 0xffffffffu : 0u;
+    // a word index past the end of the record is clamped to the last word: the query operand of that lane group is zero (above), so the
+    // bits loaded in its place count for nothing
     const int wi_c = rwi < a.W ? rwi : a.W - 1;
-    uint32_t wmask_l[NML];
     int wi_l[NML];
 #pragma unroll
-    for (int m = 0; m < NML; ++m) {
-        wmask_l[m] = 2 * m + rwi < a.LW ? 0xffffffffu : 0u;
-        wi_l[m] = 2 * m + rwi < a.LW ? 2 * m + rwi : (a.LW > 0 ? a.LW - 1 : 0);
-    }
+    for (int m = 0; m < NML; ++m) wi_l[m] = 2 * m + rwi < a.LW ? 2 * m + rwi : (a.LW > 0 ? a.LW - 1 : 0);
     auto load_words = [&](int64_t batch, uint32_t (&w)[4][NMI]) {
+        const int64_t first = batch * 64;
+        if (first + 64 <= (int64_t)a.R) {                             // whole batch inside the gallery (wave-uniform): one address per array, constant strides
+            const uint32_t* __restrict__ pc = a.rbits + (first + ritem) * a.W + wi_c;
+            const uint32_t* __restrict__ pl = a.rlab + (first + ritem) * a.LW;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t item = batch * 64 + g * 16 + ritem;
-            const int64_t it = item < a.R ? item : (int64_t)a.R - 1;
-            const uint32_t ok = item < a.R ? 0xffffffffu : 0u;       // items past the end: all-zero codes, no labels (the epilogue takes them out again)
-            w[g][0] = a.rbits[it * a.W + wi_c] & (wmask_c & ok);
+            for (int g = 0; g < 4; ++g) {
+                w[g][0] = pc[g * 16 * a.W];
 #pragma unroll
-            for (int m = 0; m < NML; ++m) w[g][1 + m] = a.rlab[it * a.LW + wi_l[m]] & (wmask_l[m] & ok);
+                for (int m = 0; m < NML; ++m) w[g][1 + m] = pl[g * 16 * a.LW + wi_l[m]];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t item = first + g * 16 + ritem;
+                const int64_t it = item < a.R ? item : (int64_t)a.R - 1;
+                const uint32_t ok = item < a.R ? 0xffffffffu : 0u;   // items past the end: all-zero codes, no labels (the epilogue takes them out again)
+                w[g][0] = a.rbits[it * a.W + wi_c] & ok;
+#pragma unroll
+                for (int m = 0; m < NML; ++m) w[g][1 + m] = a.rlab[it * a.LW + wi_l[m]] & ok;
+            }
         }
     };
+    // 8 operations per code tile (one shift to the lane's nibble, then shift + mask per register).  The label tiles only have to tell an
+    // overlap from none, so their bits stay where they are: x & (0x01010101 << j) is worth 2^j (1, 2, 4, 8) in its byte, the sum over the
+    // common labels is positive exactly when there is one, and min(0x10000 + sum, 0x10001) is the add operand as before -- 5 operations.
     auto build = [&](v4i (&At)[NMI], const uint32_t (&w)[NMI]) {
+        const uint32_t x = w[0] >> rsh;
 #pragma unroll
-        for (int m = 0; m < NMI; ++m) {
-            const uint32_t x = w[m] >> rsh;
+        for (int j = 0; j < 4; ++j) At[0][j] = (int)((x >> j) & 0x01010101u);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) At[m][j] = (int)((x >> j) & 0x01010101u);
+        for (int m = 1; m < NMI; ++m) {
+            const uint32_t y = w[m] >> rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) At[m][j] = (int)(y & (0x01010101u << j));
         }
     };
     if (REGS) load_words(bat0, wcur);
