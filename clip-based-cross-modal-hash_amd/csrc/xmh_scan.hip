@@ -1141,8 +1141,14 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
             for (int j = 0; j < 4; ++j) {
                 const uint32_t t = (qw >> j) & 0x01010101u;
                 const bool on = valid[h] && rwi < a.W;                 // no such code word (codes of at most 32 bits): zero operand, whatever the item lane holds
-                bq[h][0][j] = on ? (int)(0x40404040u ^ (t << 7)) : 0;
-                bq[h][1][j] = on ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;
+                // registers 1 and 3 of an item tile hold their bits worth 2 (see build()): their query bytes are halved, the products stay +-64 / +-2
+                if (j & 1) {
+                    bq[h][0][j] = on ? (int)(0x20202020u ^ (t * 0xc0u)) : 0;     // +32 / -32 (0xe0)
+                    bq[h][1][j] = on ? (int)(0x01010101u ^ (t * 0xfeu)) : 0;     // +1 / -1
+                } else {
+                    bq[h][0][j] = on ? (int)(0x40404040u ^ (t << 7)) : 0;        // +64 / -64 (0xc0)
+                    bq[h][1][j] = on ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;     // +2 / -2 (0xfe)
+                }
             }
 #pragma unroll
             for (int m = 0; m < NML; ++m) {
@@ -1233,13 +1239,17 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
             }
         }
     };
-    // 8 operations per code tile (one shift to the lane's nibble, then shift + mask per register).  The label tiles only have to tell an
-    // overlap from none, so their bits stay where they are: x & (0x01010101 << j) is worth 2^j (1, 2, 4, 8) in its byte, the sum over the
-    // common labels is positive exactly when there is one, and min(0x10000 + sum, 0x10001) is the add operand as before -- 5 operations.
+    // 6 operations per code tile: two shifts bring bits 0, 1 and bits 2, 3 of the lane's nibble to the bottom of their bytes, four masks
+    // pick them -- the odd ones worth 2 where they stand, which the halved query bytes above make up for (the products of both chains have
+    // to be exact: they are an address and a cache byte).  The label tiles only have to tell an overlap from none, so their bits stay where
+    // one shift leaves them: y & (0x01010101 << j) is worth 2^j (1, 2, 4, 8) in its byte, the sum over the common labels is positive
+    // exactly when there is one, and min(0x10000 + sum, 0x10001) is the add operand as before -- 5 operations.
     auto build = [&](v4i (&At)[NMI], const uint32_t (&w)[NMI]) {
-        const uint32_t x = w[0] >> rsh;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) At[0][j] = (int)((x >> j) & 0x01010101u);
+        const uint32_t xa = w[0] >> rsh, xb = w[0] >> (rsh + 2);
+        At[0][0] = (int)(xa & 0x01010101u);
+        At[0][1] = (int)(xa & 0x02020202u);
+        At[0][2] = (int)(xb & 0x01010101u);
+        At[0][3] = (int)(xb & 0x02020202u);
 #pragma unroll
         for (int m = 1; m < NMI; ++m) {
             const uint32_t y = w[m] >> rsh;
@@ -2167,13 +2177,14 @@ constexpr int kMfmaWaves = 4;                          // waves (16 queries each
 // k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
 struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
-// k_scan_hist_r2 (operands from the packed words, no image / ring / barrier) instead of k_scan_hist_m2: codes of 33..64 bits.  Up to 32 bits
-// half of r2's lane groups would build operands of a code word that does not exist, and k_scan_hist_m2's counters are small enough there
-// for 4 query groups per wave beside its ring (Q 5000 x R 117 218, pass 1, m2 / r2: 16 bit 0.155 / 0.173 ms, 32 bit 0.161 / 0.174,
-// 64 bit 0.191 / 0.178-0.184).  XMH_SCAN_M2_REGS=0 / 1 forces it off / on for all of them (read per call: the tests compare the two).
+// k_scan_hist_r2 (operands from the packed words, no image / ring / barrier) instead of k_scan_hist_m2: the default for every length
+// k_scan_hist_m2 takes (Q 5000 x R 117 218, pass 1 + the launch in front of it, m2 / r2: 16 bit 0.158 + 0.009 / 0.154 + 0.005 ms,
+// 32 bit 0.162 + 0.010 / 0.157 + 0.005, 64 bit 0.194 + 0.010 / 0.160 + 0.005).  XMH_SCAN_M2_REGS=0 brings k_scan_hist_m2 back
+// (read per call: the tests compare the two).
 inline bool m2_regs(int K) {
     const char* e = getenv("XMH_SCAN_M2_REGS");
-    return e ? atoi(e) != 0 : K > 32;
+    (void)K;
+    return e ? atoi(e) != 0 : true;
 }
 inline M2Geom m2_geom(int K) {
     // XMH_SCAN_M2_GEOM / _BPC pick one of the instantiated shapes / the blocks per CU the chunk count is sized for (tuning; read per call).
@@ -2184,8 +2195,8 @@ inline M2Geom m2_geom(int K) {
     static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
     const char* e = getenv("XMH_SCAN_M2_GEOM");
     // k_scan_hist_r2 has no ring: 4 query groups per wave fit at 65 bucket rows as well (66 KB of counters, two blocks per CU), and every A
-    // tile it builds (8 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
-    // (pass 1 0.207-0.231 ms against 0.190)
+    // tile it builds (5-6 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
+    // (first version, 8 operations per tile: pass 1 0.207-0.231 ms against 0.190)
     M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : (m2_regs(K) ? M2Geom{4, 4, 2} : table[0]);
     if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
     const char* b = getenv("XMH_SCAN_M2_BPC");

@@ -346,14 +346,13 @@ def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     second accumulator chain, so this checks that chain directly and not only through the mAP it leads to.  m2 = "0": the kernel
     k_scan_hist_m2 replaced (k_scan_hist_m with the cache, what a failed self-check or XMH_SCAN_M2=0 selects) writes the same entries."""
     from xmh._lib import lib
-    # "1": the default (round 4: k_scan_hist_r2, operands built in registers, for 33..64 bits; k_scan_hist_m2 up to 32); "m2" / "r2": one family
-    # for every length it is instantiated for
+    # "1": the default (round 4: k_scan_hist_r2, operands built in registers); "m2" / "r2": that family by name (XMH_SCAN_M2_REGS=0 / 1)
     monkeypatch.setenv("XMH_SCAN_M2", "0" if m2 == "0" else "1")
     if m2 in ("m2", "r2"):
         monkeypatch.setenv("XMH_SCAN_M2_REGS", "1" if m2 == "r2" else "0")
     import bench_roofline
     if m2 != "0" and K <= 64:
-        assert ("k_scan_hist_r2" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (m2 == "r2" or (m2 == "1" and K > 32))
+        assert ("k_scan_hist_r2" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (m2 in ("r2", "1"))
     orc = _orc()
     qB, rB, qL, rL = _synth(Q, R, K, C, seed=3 * K + R)
     q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
