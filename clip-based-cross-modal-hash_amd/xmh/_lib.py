@@ -18,6 +18,12 @@ if not os.path.exists(LIB_PATH):
         "libxmh.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "
         "or make -C clip-based-cross-modal-hash_amd). There is no CPU fallback." % LIB_PATH)
 
+# PyTorch first: it ships its own HIP runtime, and the process must end up with ONE.  Loaded after torch, libxmh.so binds to the runtime
+# torch already brought in (same soname); loaded before it, the library initialises /opt/rocm's copy, torch then initialises its own, and
+# the first caller of the second one finds "no ROCm-capable device" (seen with build() and smoke() in one process).  Every caller of this
+# module hands it torch tensors anyway.
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t

@@ -41,3 +41,15 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert _lib.lib.xmh_scan_plan_make(10, 1000, 512, 1, ctypes.byref(plan)) == -95       # zero planes only up to 256 bits
     assert b"at most 2048" in _lib.lib.xmh_last_error()
     assert _lib.lib.xmh_topk_ws_bytes(8, 1000, 64, 0) == 0
+
+
+def test_the_binding_brings_torch_in_before_the_library():
+    """One HIP runtime per process: libxmh.so loaded before PyTorch initialises /opt/rocm's runtime beside the one torch ships, and the
+    second one to be used reports "no ROCm-capable device" (build() followed by smoke() in one process did).  xmh/_lib.py therefore
+    imports torch above its CDLL call -- checked in a fresh interpreter, where nothing else has imported torch yet."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import xmh._lib as L; "
+            "assert 'torch' in sys.modules and L.lib.xmh_version() >= 100; print('ok')") % os.path.join(ROOT, "clip-based-cross-modal-hash_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-500:]
