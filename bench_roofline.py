@@ -190,10 +190,10 @@ def scan_roofline(scan, Q, Rn, K, C, steps=20, step_s=None):
                     e["issue_utilisation"][c] = v[0]
         return e
     v1, v2 = pass_entry(k1, t_hist), pass_entry(k2, t_ap)
-    if k1.startswith("k_scan_hist_m"):
+    if k1.startswith(("k_scan_hist_m", "k_scan_hist_r2")):
         nml = 1 if Lw <= 2 else 2
         nmc = 1 if K <= 64 else (2 if K <= 128 else 4)
-        chains = (2 * nmc if (k1.startswith("k_scan_hist_m2") and cache_bytes) else nmc) + nml
+        chains = (2 * nmc if (k1.startswith(("k_scan_hist_m2", "k_scan_hist_r2")) and cache_bytes) else nmc) + nml
         v1["mfma"] = {"instruction": "v_mfma_i32_16x16x64_i8", "per_64_pairs": chains / 4.0, "cycles_each": 16,
                       "matrix_pipe_frac": pairs / 64.0 * (chains / 4.0) * 16 / (t_hist * CLOCK_HZ * SIMDS)}
     dom_is_hist = t_hist > t_ap
