@@ -1540,6 +1540,307 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_r2(MfmaArgs a, uint32_t* 
     scan_hist_m2_body<NML, NW, NQ, CACHE, false, true>(a, chunk_hist, pair_cache, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_scan_hist_r2w (round 4): k_scan_hist_r2 for codes of 65..128 bits -- TWO code tiles per chain (six MFMAs per (16 items x 16 queries):
+// label, label, address, address, 2 * distance, 2 * distance), 129 bucket rows, 2 query groups per wave (66 KB of counters per block of four
+// waves, two blocks per CU), one-byte pair-cache entries in the layout of the shorter codes.  Same operand construction, same pipeline of
+// statements one (item group, query group) behind their MFMAs, same hazards (see k_scan_hist_m2).  Two differences in form: the operands
+// are named (a statement has 28 of the 30 an asm may take), and the cache word is assembled by a second, small statement -- byte j of the
+// word = byte0(2 * distance) | byte0(increment), the even bytes into one register and the odd ones into another so that no two SDWA
+// inserts into one register follow each other (the dst_sel hazard), OR-ed at the end.  A distance of 128 makes 2 * distance = 256, whose
+// byte wraps to 0: the same statement keeps the largest 2 * distance seen, and the kernel raises *ovf as k_scan_hist_m<.., BYTE> does.
+// ---------------------------------------------------------------------------------------------------
+#define XMH_W_MFMA(D, A, B, C) "v_mfma_i32_16x16x64_i8 %[" D "], %[" A "], %[" B "], %[" C "]\n\t"
+#define XMH_W_MIN(I, L) "v_min_u32 %[" I "], 0x10001, %[" L "]\n\t"
+#define XMH_W_ADD(A, D) "ds_add_u32 %[" A "], %[" D "]\n\t"
+template <int NML, int NW, int NQ, bool CACHE>
+__global__ __launch_bounds__(64 * NW) void k_scan_hist_r2w(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
+                                                           uint32_t* __restrict__ ovf) {
+    constexpr int NMC = 2, NMI = NMC + NML;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters (all << 16 | relevant)
+    int chunk_id, qtile;
+    if (!mfma_map_block(a, chunk_id, qtile)) return;                 // a.nqt counts tiles of NW * NQ * 16 queries here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int t16 = (qtile * NW + wave) * NQ;
+    const int ncell = a.nb * 16;
+    uint32_t* cnt = lds + (wave * NQ) * ncell;
+    for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
+    const int rsh = 4 * (slot & 1), rwi = slot >> 1;                 // this lane's nibble of the 16 bits it owns; its word inside a 64-bit tile
+    v4i bA[NQ][NMC], bD[NQ][NMC], bL[NQ][NML], cq[NQ], kq[NQ];
+    bool valid[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        const int64_t q = (int64_t)(t16 + h) * 16 + ql;
+        valid[h] = q < a.Q;
+        int pcq = 0;
+        if (valid[h])
+            for (int w = 0; w < a.W; ++w) pcq += __popc(a.qbits[q * a.W + w]);
+#pragma unroll
+        for (int c = 0; c < NMC; ++c) {
+            const int wi = 2 * c + rwi;
+            const bool on = valid[h] && wi < a.W;                    // no such code word: zero operand, whatever the item lane holds
+            const uint32_t qw = (on ? a.qbits[q * a.W + wi] : 0u) >> rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = (qw >> j) & 0x01010101u;
+                if (j & 1) {                                         // registers 1 and 3 of an item tile hold their bits worth 2: halved query bytes
+                    bA[h][c][j] = on ? (int)(0x20202020u ^ (t * 0xc0u)) : 0;
+                    bD[h][c][j] = on ? (int)(0x01010101u ^ (t * 0xfeu)) : 0;
+                } else {
+                    bA[h][c][j] = on ? (int)(0x40404040u ^ (t << 7)) : 0;
+                    bD[h][c][j] = on ? (int)(0x02020202u ^ (t * 0xfcu)) : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NML; ++m) {
+            uint32_t lw = 0u;
+            if (valid[h] && 2 * m + rwi < a.LW) lw = a.qlab[q * a.LW + 2 * m + rwi];
+            lw >>= rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bL[h][m][j] = (int)((lw >> j) & 0x01010101u);
+        }
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 64 * pcq : 0);
+        const int k2 = valid[h] ? 2 * pcq : 0;
+        cq[h] = v4i{c0, c0, c0, c0};
+        kq[h] = v4i{k2, k2, k2, k2};
+    }
+    v4i lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
+    asm volatile("" : "+v"(lab0));                                  // opaque: kept in VGPRs, not re-materialised in front of an MFMA
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) asm volatile("" : "+v"(cq[h]), "+v"(kq[h]));
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
+    uint4* crow[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h)
+        crow[h] = CACHE ? pair_cache + ((int64_t)chunk_id * (a.qpad >> 4) + (t16 + h)) * ((a.chunk + 63) >> 6) * 64 + lane : nullptr;
+    uint32_t wcur[4][NMI], wnxt[4][NMI];
+    const int ritem = 4 * (lane & 3) + ((lane & 15) >> 2);           // row r of group g is item 16 g + 4 (r & 3) + (r >> 2)
+    int wi_c[NMC], wi_l[NML];
+#pragma unroll
+    for (int c = 0; c < NMC; ++c) wi_c[c] = 2 * c + rwi < a.W ? 2 * c + rwi : a.W - 1;
+#pragma unroll
+    for (int m = 0; m < NML; ++m) wi_l[m] = 2 * m + rwi < a.LW ? 2 * m + rwi : (a.LW > 0 ? a.LW - 1 : 0);
+    auto load_words = [&](int64_t batch, uint32_t (&w)[4][NMI]) {
+        const int64_t first = batch * 64;
+        if (first + 64 <= (int64_t)a.R) {                             // whole batch inside the gallery (wave-uniform)
+            const uint32_t* __restrict__ pc = a.rbits + (first + ritem) * a.W;
+            const uint32_t* __restrict__ pl = a.rlab + (first + ritem) * a.LW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int c = 0; c < NMC; ++c) w[g][c] = pc[g * 16 * a.W + wi_c[c]];
+#pragma unroll
+                for (int m = 0; m < NML; ++m) w[g][NMC + m] = pl[g * 16 * a.LW + wi_l[m]];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t item = first + g * 16 + ritem;
+                const int64_t it = item < a.R ? item : (int64_t)a.R - 1;
+                const uint32_t ok = item < a.R ? 0xffffffffu : 0u;   // items past the end: all-zero codes, no labels (taken out again below)
+#pragma unroll
+                for (int c = 0; c < NMC; ++c) w[g][c] = a.rbits[it * a.W + wi_c[c]] & ok;
+#pragma unroll
+                for (int m = 0; m < NML; ++m) w[g][NMC + m] = a.rlab[it * a.LW + wi_l[m]] & ok;
+            }
+        }
+    };
+    auto build = [&](v4i (&At)[NMI], const uint32_t (&w)[NMI]) {     // see k_scan_hist_r2: 6 operations per code tile, 5 per label tile
+#pragma unroll
+        for (int c = 0; c < NMC; ++c) {
+            const uint32_t xa = w[c] >> rsh, xb = w[c] >> (rsh + 2);
+            At[c][0] = (int)(xa & 0x01010101u);
+            At[c][1] = (int)(xa & 0x02020202u);
+            At[c][2] = (int)(xb & 0x01010101u);
+            At[c][3] = (int)(xb & 0x02020202u);
+        }
+#pragma unroll
+        for (int m = 0; m < NML; ++m) {
+            const uint32_t y = w[NMC + m] >> rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) At[NMC + m][j] = (int)(y & (0x01010101u << j));
+        }
+    };
+    uint32_t dmax = 0u;                                              // largest 2 * distance this lane packed
+    load_words(bat0, wcur);
+    for (int i = 0; i < nbat; ++i) {
+        load_words(bat0 + (i + 1 < nbat ? i + 1 : i), wnxt);
+        v4i A[4][NMI];
+        uint32_t cw[NQ][4];
+        v4i addr_p = {0, 0, 0, 0}, d2_p = {0, 0, 0, 0}, lab_p = {0, 0, 0, 0};
+        // the MFMAs of (group g, query group h) with the increments and adds of the PREVIOUS pair between them
+        auto fused = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab, uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& i3) {
+            if (NML == 2 && CACHE) {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2")
+                             XMH_W_MFMA("lab", "al1", "bl1", "lab") XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0") XMH_W_MFMA("addr", "a0", "ba0", "cq")
+                             XMH_W_ADD("ap1", "i1") XMH_W_MFMA("addr", "a1", "ba1", "addr") XMH_W_ADD("ap2", "i2") XMH_W_MFMA("d2", "a0", "bd0", "kq")
+                             XMH_W_ADD("ap3", "i3") XMH_W_MFMA("d2", "a1", "bd1", "d2")
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr), [d2] "=&v"(d2), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [al0] "v"(At[2]), [al1] "v"(At[NMI - 1]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]),
+                               [bd0] "v"(bD[h][0]), [bd1] "v"(bD[h][1]), [bl0] "v"(bL[h][0]), [bl1] "v"(bL[h][NML - 1]), [lab0] "v"(lab0), [cq] "v"(cq[h]),
+                               [kq] "v"(kq[h]), [lp0] "v"(lab_p[0]), [lp1] "v"(lab_p[1]), [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]),
+                               [ap1] "v"(addr_p[1]), [ap2] "v"(addr_p[2]), [ap3] "v"(addr_p[3])
+                             : "memory");
+            } else if (NML == 2) {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2")
+                             XMH_W_MFMA("lab", "al1", "bl1", "lab") XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0") XMH_W_ADD("ap1", "i1")
+                             XMH_W_MFMA("addr", "a0", "ba0", "cq") XMH_W_ADD("ap2", "i2") XMH_W_ADD("ap3", "i3") XMH_W_MFMA("addr", "a1", "ba1", "addr")
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [al0] "v"(At[2]), [al1] "v"(At[NMI - 1]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]),
+                               [bl0] "v"(bL[h][0]), [bl1] "v"(bL[h][NML - 1]), [lab0] "v"(lab0), [cq] "v"(cq[h]), [lp0] "v"(lab_p[0]), [lp1] "v"(lab_p[1]),
+                               [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]), [ap1] "v"(addr_p[1]), [ap2] "v"(addr_p[2]), [ap3] "v"(addr_p[3])
+                             : "memory");
+            } else if (CACHE) {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2")
+                             XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0") XMH_W_MFMA("addr", "a0", "ba0", "cq") XMH_W_ADD("ap1", "i1")
+                             XMH_W_MFMA("addr", "a1", "ba1", "addr") XMH_W_ADD("ap2", "i2") XMH_W_MFMA("d2", "a0", "bd0", "kq") XMH_W_ADD("ap3", "i3")
+                             XMH_W_MFMA("d2", "a1", "bd1", "d2")
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr), [d2] "=&v"(d2), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [al0] "v"(At[2]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]), [bd0] "v"(bD[h][0]),
+                               [bd1] "v"(bD[h][1]), [bl0] "v"(bL[h][0]), [lab0] "v"(lab0), [cq] "v"(cq[h]), [kq] "v"(kq[h]), [lp0] "v"(lab_p[0]),
+                               [lp1] "v"(lab_p[1]), [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]), [ap1] "v"(addr_p[1]), [ap2] "v"(addr_p[2]),
+                               [ap3] "v"(addr_p[3])
+                             : "memory");
+            } else {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2")
+                             XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0") XMH_W_ADD("ap1", "i1") XMH_W_MFMA("addr", "a0", "ba0", "cq") XMH_W_ADD("ap2", "i2")
+                             XMH_W_ADD("ap3", "i3") XMH_W_MFMA("addr", "a1", "ba1", "addr")
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr), [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [al0] "v"(At[2]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]), [bl0] "v"(bL[h][0]), [lab0] "v"(lab0),
+                               [cq] "v"(cq[h]), [lp0] "v"(lab_p[0]), [lp1] "v"(lab_p[1]), [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]),
+                               [ap1] "v"(addr_p[1]), [ap2] "v"(addr_p[2]), [ap3] "v"(addr_p[3])
+                             : "memory");
+            }
+        };
+        // the cache word of the pair whose increments the statement above just made (d: that pair's 2 * distance results, a statement old)
+        auto pack = [&](uint32_t& w, const v4i& d, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3) {
+            uint32_t wb;
+            asm volatile("v_or_b32_sdwa %[wa], %[d0], %[i0] dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                         "v_or_b32_sdwa %[wb], %[d1], %[i1] dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                         "v_max3_u32 %[mx], %[d0], %[d1], %[mx]\n\t"
+                         "v_or_b32_sdwa %[wa], %[d2], %[i2] dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                         "v_or_b32_sdwa %[wb], %[d3], %[i3] dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                         "v_max3_u32 %[mx], %[d2], %[d3], %[mx]\n\t"
+                         "v_or_b32 %[wa], %[wa], %[wb]"
+                         : [wa] "=&v"(w), [wb] "=&v"(wb), [mx] "+v"(dmax)
+                         : [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]), [d3] "v"(d[3]), [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3));
+        };
+        // the first statement of a batch: nothing to consume yet; closed by 8 wait states (the next statement's consumers read these results)
+        auto evaluate = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab) {
+            if (NML == 2) {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") XMH_W_MFMA("lab", "al1", "bl1", "lab")
+                             : [lab] "=&v"(lab)
+                             : [al0] "v"(At[2]), [al1] "v"(At[NMI - 1]), [bl0] "v"(bL[h][0]), [bl1] "v"(bL[h][NML - 1]), [lab0] "v"(lab0));
+            } else {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("lab", "al0", "bl0", "lab0") : [lab] "=&v"(lab) : [al0] "v"(At[2]), [bl0] "v"(bL[h][0]), [lab0] "v"(lab0));
+            }
+            if (CACHE) {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("addr", "a0", "ba0", "cq") XMH_W_MFMA("addr", "a1", "ba1", "addr") XMH_W_MFMA("d2", "a0", "bd0", "kq")
+                             XMH_W_MFMA("d2", "a1", "bd1", "d2") "s_nop 7"
+                             : [addr] "=&v"(addr), [d2] "=&v"(d2)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]), [bd0] "v"(bD[h][0]), [bd1] "v"(bD[h][1]), [cq] "v"(cq[h]),
+                               [kq] "v"(kq[h]));
+            } else {
+                asm volatile("s_nop 3\n\t" XMH_W_MFMA("addr", "a0", "ba0", "cq") XMH_W_MFMA("addr", "a1", "ba1", "addr") "s_nop 7"
+                             : [addr] "=&v"(addr)
+                             : [a0] "v"(At[0]), [a1] "v"(At[1]), [ba0] "v"(bA[h][0]), [ba1] "v"(bA[h][1]), [cq] "v"(cq[h]));
+            }
+        };
+        // the last pair of a batch: its increments and adds (live: the tiles of the last statements stay untouched until here)
+        auto consume = [&](uint32_t& i0, uint32_t& i1, uint32_t& i2, uint32_t& i3, const v4i (&live)[NMI]) {
+            if constexpr (NMI == 4) {
+                asm volatile(XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2") XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0")
+                             XMH_W_ADD("ap1", "i1") XMH_W_ADD("ap2", "i2") XMH_W_ADD("ap3", "i3")
+                             : [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [lp0] "v"(lab_p[0]), [lp1] "v"(lab_p[1]), [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]), [ap1] "v"(addr_p[1]),
+                               [ap2] "v"(addr_p[2]), [ap3] "v"(addr_p[3]), "v"(live[0]), "v"(live[1]), "v"(live[2]), "v"(live[3])
+                             : "memory");
+            } else {
+                asm volatile(XMH_W_MIN("i0", "lp0") XMH_W_MIN("i1", "lp1") XMH_W_MIN("i2", "lp2") XMH_W_MIN("i3", "lp3") XMH_W_ADD("ap0", "i0")
+                             XMH_W_ADD("ap1", "i1") XMH_W_ADD("ap2", "i2") XMH_W_ADD("ap3", "i3")
+                             : [i0] "=&v"(i0), [i1] "=&v"(i1), [i2] "=&v"(i2), [i3] "=&v"(i3)
+                             : [lp0] "v"(lab_p[0]), [lp1] "v"(lab_p[1]), [lp2] "v"(lab_p[2]), [lp3] "v"(lab_p[3]), [ap0] "v"(addr_p[0]), [ap1] "v"(addr_p[1]),
+                               [ap2] "v"(addr_p[2]), [ap3] "v"(addr_p[3]), "v"(live[0]), "v"(live[1]), "v"(live[2])
+                             : "memory");
+            }
+        };
+        auto group = [&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                v4i addr, d2 = d2_p, lab;
+                if (G == 0 && h == 0) {
+                    evaluate(A[G], h, addr, d2, lab);
+                } else {
+                    uint32_t i0, i1, i2, i3;
+                    fused(A[G], h, addr, d2, lab, i0, i1, i2, i3);
+                    if (CACHE) pack(cw[(h + NQ - 1) % NQ][h == 0 ? G - 1 : G], d2_p, i0, i1, i2, i3);
+                }
+                addr_p = addr; d2_p = d2; lab_p = lab;
+                if (G > 0 && h == 0) {                                 // the previous group's tiles may be reused from here on, not earlier
+                    if constexpr (NMI == 4) asm volatile("" ::"v"(A[G > 0 ? G - 1 : 0][0]), "v"(A[G > 0 ? G - 1 : 0][1]), "v"(A[G > 0 ? G - 1 : 0][2]), "v"(A[G > 0 ? G - 1 : 0][3]));
+                    else asm volatile("" ::"v"(A[G > 0 ? G - 1 : 0][0]), "v"(A[G > 0 ? G - 1 : 0][1]), "v"(A[G > 0 ? G - 1 : 0][2]));
+                }
+            }
+        };
+        build(A[0], wcur[0]);
+        build(A[1], wcur[1]);
+        build(A[2], wcur[2]);
+        build(A[3], wcur[3]);
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
+        {
+            uint32_t i0, i1, i2, i3;
+            consume(i0, i1, i2, i3, A[3]);
+            if (CACHE) pack(cw[NQ - 1][3], d2_p, i0, i1, i2, i3);
+        }
+        if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                uint4* dst = crow[h] + (int64_t)i * 64;
+                __builtin_nontemporal_store(cw[h][0], &dst->x);
+                __builtin_nontemporal_store(cw[h][1], &dst->y);
+                __builtin_nontemporal_store(cw[h][2], &dst->z);
+                __builtin_nontemporal_store(cw[h][3], &dst->w);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int m = 0; m < NMI; ++m) wcur[g][m] = wnxt[g][m];
+    }
+    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
+    const int npad = nbat * 64 - (int)(hi - lo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (npad > 0 && slot == 0) {
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            if (!valid[h]) continue;
+            const int64_t q = (int64_t)(t16 + h) * 16 + ql;
+            int dpad = 0;
+            for (int w = 0; w < a.W; ++w) dpad += __popc(a.qbits[q * a.W + w]);
+            cnt[h * ncell + dpad * 16 + ql] -= (uint32_t)npad << 16;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + (t16 + h) * 16;
+        for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[h * ncell + e];
+    }
+    if (CACHE && dmax >= 256u) *ovf = 1u;                            // every writer stores the same 1; read by the next launch
+}
+#undef XMH_W_MFMA
+#undef XMH_W_MIN
+#undef XMH_W_ADD
+
 // Pass 2 on the same operand images: the MFMA emits the counter address and the label overlap, ONE returning ds_add per pair
 // advances {rank, ordinal} of (bucket, query) and hands back the pair's own rank and ordinal (same-address lanes of one
 // instruction resolve in ascending lane = item order, lane_order_ok), relevant pairs are credited ordinal / rank one group of
@@ -2198,6 +2499,7 @@ inline M2Geom m2_geom(int K) {
     // tile it builds (5-6 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
     // (first version, 8 operations per tile: pass 1 0.207-0.231 ms against 0.190)
     M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : (m2_regs(K) ? M2Geom{4, 4, 2} : table[0]);
+    if (K > 64) g = M2Geom{4, 2, 2};                                 // k_scan_hist_r2w: 129 bucket rows, 66 KB of counters per block with two groups per wave
     if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
     const char* b = getenv("XMH_SCAN_M2_BPC");
     if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
@@ -2216,6 +2518,17 @@ inline bool bits_shape(int K, bool ternary, int LW) {
     const int mode = e ? atoi(e) : 1;
     return mode != 0 && !mfma_ap_on() && mfma_shape(K, ternary) && K > (mode == 2 ? 64 : 128) && K <= 256 && LW <= 4;
 }
+// k_scan_hist_r2w (round 4): pass 1 of 65..128-bit codes in the manner of k_scan_hist_r2 (operands from the packed words, one-byte entries).
+// The plan follows it (4 waves x 2 query groups, two blocks per CU, chunks of up to 32768 items); XMH_SCAN_R2W=0 keeps k_scan_hist_m.
+// Needs what it builds on: the self-checked statements (m2_enabled), the one-byte entries (XMH_SCAN_BYTE128), no k_scan_hist_b by request.
+inline bool r2w_plan_shape(int K, bool ternary) {
+    const char* e = getenv("XMH_SCAN_R2W");
+    const char* b = getenv("XMH_SCAN_BYTE128");
+    const char* bits = getenv("XMH_SCAN_BITS");
+    return !(e && atoi(e) == 0) && !(b && atoi(b) == 0) && !(bits && atoi(bits) == 2) && !ternary && K > 64 && K <= 128 && mfma_shape(K, ternary) &&
+           m2_enabled() && m2_regs(K);
+}
+inline bool r2w_shape(int K, bool ternary, int LW) { return LW <= 4 && r2w_plan_shape(K, ternary); }
 // One-byte pair-cache entries for 65..128-bit codes (k_scan_hist_m<2, .., BYTE> + k_scan_ap_c<., 8>, round 4): whenever those codes take
 // k_scan_hist_m at all.  XMH_SCAN_BYTE128=0 keeps the two-byte entries and the cached k_scan_ap_s (read per call: tests compare the two).
 inline bool byte128_shape(int K, bool ternary, int LW) {
@@ -2276,7 +2589,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const int S64 = slots_for(Wc, ternary != 0, 8);
     const int64_t lds_ap = nb * (64 / S64) * 8;
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
-    const bool m2 = m2_shape(K, ternary != 0);
+    const bool m2 = m2_shape(K, ternary != 0) || r2w_plan_shape(K, ternary != 0);
     int64_t nqt = xmh::ceil_div(Q, 64);
     const int m2q = m2_geom(K).queries();
     if (m2) {                                     // whole blocks of k_scan_hist_m2 AND whole 64-query tiles
@@ -2304,7 +2617,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
         nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
         if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
             const char* m2r_env = getenv("XMH_SCAN_M2_ROUNDS");                  // read per call, like the geometry
-            const int m2r_def = K > 32 && m2_regs(K) ? 1 : 2;                     // k_scan_hist_r2: one set of two 256-query blocks per CU (rounds 1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
+            const int m2r_def = K > 32 && K <= 64 && m2_regs(K) ? 1 : 2;          // k_scan_hist_r2: one set of two 256-query blocks per CU (rounds 1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
             const int m2r = m2r_env && atoi(m2r_env) > 0 ? atoi(m2r_env) : m2r_def;
             nchunk = (int64_t)m2r * xmh::device_cu_count() * m2_geom(K).blocks_per_cu / (nqt * 64 / m2q);
         }
@@ -2594,8 +2907,36 @@ int mfma_hist2(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbit
     return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_m2 instance for %d waves x %d query groups", g.nw, g.nq);
 }
 
+// 65..128 bits through k_scan_hist_r2w (4 waves x 2 query groups, the plan's geometry for these lengths)
+template <int NML>
+int mfma_hist_r2w(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+                  const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    constexpr int NW = 4, NQ = 2;
+    const M2Geom g = m2_geom(K);
+    if (g.nw != NW || g.nq != NQ) return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_r2w instance for %d waves x %d query groups", g.nw, g.nq);
+    hipLaunchKernelGGL(k_scan_touch, dim3((unsigned)(8 * kTouchPerChunk * xmh::ceil_div(p.nchunk, 8))), dim3(256), 0, st, rbits, rlab, R, W, LW, p.chunk,
+                       (int)p.nchunk, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
+    XMH_LAUNCH_CHECK("xmh_hamming_hist control words");
+    MfmaArgs a{nullptr, nullptr, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
+    a.rbits = rbits; a.rlab = rlab; a.qlab = qlab; a.LW = LW;
+    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
+    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4;
+    uint32_t* ovf = reinterpret_cast<uint32_t*>(base + L.gate) + kGateWrapped;
+    xmh::ProfScope prof("scan_hist", st);
+    auto go = [&](auto kern) {
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, ovf);
+        return (int)XMH_OK;
+    };
+    return cache ? go(k_scan_hist_r2w<NML, NW, NQ, true>) : go(k_scan_hist_r2w<NML, NW, NQ, false>);
+}
+
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    if (r2w_shape(K, false, LW))
+        return LW <= 2 ? mfma_hist_r2w<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
+                       : mfma_hist_r2w<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
     if (m2_shape(K, false))
         return LW <= 2 ? mfma_hist2<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
                        : mfma_hist2<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
@@ -2663,7 +3004,10 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     char p1[160], p2[200];
     const int NML = LW <= 2 ? 1 : 2;
     const int S4 = slots_for(Wc, tern, 4), S8 = slots_for(Wc, tern, 8);
-    if (use_mfma && m2_shape(K, tern)) {
+    if (use_mfma && r2w_shape(K, tern, LW)) {
+        const M2Geom g = m2_geom(K);
+        snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
+    } else if (use_mfma && m2_shape(K, tern)) {
         const M2Geom g = m2_geom(K);
         if (m2_regs(K)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
         else snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
