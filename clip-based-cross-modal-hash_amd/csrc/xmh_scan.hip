@@ -2725,7 +2725,7 @@ bool m2_selfcheck_ok() {
     const int64_t Q = 200, R = 9000;
     const int C = 80, LW = 3;
     bool same = true, ran = true;
-    for (int K : {64, 40, 16}) {                          // 4 waves x 2 query groups (two code words), one code word, 4 x 4 groups (<= 32 bits)
+    for (int K : {64, 40, 16, 100}) {                     // two code words, one + a partial one, <= 32 bits (all k_scan_hist_r2), 65..128 bits (k_scan_hist_r2w)
         const int W = (K + 31) / 32;
         std::vector<uint32_t> qb(Q * W), ql(Q * LW), rb(R * W), rl(R * LW);
         uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)K;
@@ -3115,7 +3115,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) || bits_shape(K, tern, LW) ? kRelHi16 : kRelScale) : 0u, below, tot,
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) || bits_shape(K, tern, LW) || r2w_shape(K, tern, LW) ? kRelHi16 : kRelScale) : 0u, below, tot,
                        reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
                        reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate), hist_all, hist_rel);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");

@@ -339,7 +339,8 @@ def test_scan_pair_cache_on_and_off_give_identical_bits():
                                         (200, 7000, 16, 24, "1"), (90, 5001, 32, 80, "1"), (65, 3000, 256, 24, "1"),
                                         (130, 6000, 64, 80, "0"), (300, 20011, 48, 80, "0"), (17, 63, 64, 5, "0"),
                                         (130, 6000, 64, 80, "m2"), (300, 20011, 48, 33, "m2"), (17, 63, 64, 5, "m2"), (200, 7000, 16, 24, "r2"), (90, 5001, 32, 80, "r2"),
-                                        (257, 9000, 33, 128, "r2")])
+                                        (257, 9000, 33, 128, "r2"), (129, 6463, 128, 80, "w0"), (70, 9001, 100, 24, "w0"), (70, 9001, 100, 24, "1"), (33, 4097, 97, 40, "1"),
+                                        (260, 20011, 128, 128, "1"), (150, 7000, 120, 64, "1"), (70, 9001, 96, 24, "1"), (70, 9001, 72, 24, "w0")])
 def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     """Every entry pass 1 leaves in the pair cache (distance << 1 | relevant; xmh_scan_pair_cache_offset documents the layout)
     against the oracle's distance and relevance of that (query, item) pair -- the MFMA-evaluated pass 1 writes the entry from a
@@ -350,11 +351,18 @@ def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     monkeypatch.setenv("XMH_SCAN_M2", "0" if m2 == "0" else "1")
     if m2 in ("m2", "r2"):
         monkeypatch.setenv("XMH_SCAN_M2_REGS", "1" if m2 == "r2" else "0")
+    if m2 == "w0":                                                     # 65..128 bits: k_scan_hist_m<2, .., BYTE> instead of k_scan_hist_r2w (round 4)
+        monkeypatch.setenv("XMH_SCAN_R2W", "0")
     import bench_roofline
+    Kc = K                                                             # the code as given (the oracle's side)
+    if (K + 31) // 32 == 3:
+        K = 128                                                        # the length the kernels see: three-word codes run as 128-bit codes with a zero word (xr.widened)
+    if 64 < K <= 128:
+        assert ("k_scan_hist_r2w" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (m2 == "1")
     if m2 != "0" and K <= 64:
         assert ("k_scan_hist_r2" in bench_roofline.scan_kernels(Q, R, K, C, False)[0]) == (m2 in ("r2", "1"))
     orc = _orc()
-    qB, rB, qL, rL = _synth(Q, R, K, C, seed=3 * K + R)
+    qB, rB, qL, rL = _synth(Q, R, Kc, C, seed=3 * Kc + R)
     q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
     ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
     scan = xr.RankingScan(q, ql, r, rl, C)
@@ -458,15 +466,20 @@ def test_scan_m2_self_check_failure_falls_back_with_one_warning():
         assert ("k_scan_hist_m2" in a[3] or "k_scan_hist_r2" in a[3]) and "k_scan_hist_m2" not in b[3] and "k_scan_hist_r2" not in b[3]
 
 
-def test_scan_one_byte_entries_for_65_to_128_bit_codes(xr, cu, monkeypatch):
+@pytest.mark.parametrize("r2w", ["1", "0"])
+def test_scan_one_byte_entries_for_65_to_128_bit_codes(xr, cu, monkeypatch, r2w):
     """Round 4: 65..128-bit codes keep ONE byte per pair (k_scan_hist_m<2, .., BYTE> + k_scan_ap_c) instead of two.  (i) Against the
     two-byte path (XMH_SCAN_BYTE128=0): histograms and divisors bit for bit, AP sums to float rounding (same chunking and credits; the
     one-byte entries are read 4 slots x 16 queries wide, the two-byte ones 8 x 8, so a chunk's float partial sums add in another order).
     (ii) The one distance a byte cannot hold -- 128, every bit of a 128-bit code differs -- wraps in the cache; pass 1 raises a control
     word and the stand-in kernel evaluates the pairs from the codes: a gallery seeded with the complements of the queries must still give
-    the oracle's mAP, at mAP@all and mAP@k, and the float-bit kernel must not have been the one that ran (same sums as with the cache off)."""
+    the oracle's mAP, at mAP@all and mAP@k, and the float-bit kernel must not have been the one that ran (same sums as with the cache off).
+    r2w: the two pass-1 kernels that write such entries -- k_scan_hist_r2w (default) and k_scan_hist_m<2, .., BYTE> (XMH_SCAN_R2W=0)."""
+    monkeypatch.setenv("XMH_SCAN_R2W", r2w)
     orc = _orc()
-    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 96, 24, .1, 50), (33, 4097, 65, 40, .02, 7), (200, 20011, 128, 128, .02, None)):
+    # (97..128 bits: four code words.  65..96 bits are three words, which the ranking kernels take as a 128-bit code with a zero plane --
+    # the ternary kernels, no pair cache)
+    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 100, 24, .1, 50), (33, 4097, 97, 40, .02, 7), (200, 20011, 128, 128, .02, None)):
         qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=9 * K + Rn, p=p)
         outs = []
         for flag in ("1", "0"):
@@ -508,7 +521,7 @@ def test_scan_pass2_eight_queries_wide_on_one_byte_entries(xr, monkeypatch):
     shorter codes) against the 4 x 16 reading of the same cache: divisors bit for bit, AP sums to float rounding (another lane geometry, so a
     chunk's partial sums add in another order) and equal to the oracle's ranking; ragged last batches, surplus query columns, capped and not."""
     orc = _orc()
-    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 96, 24, .1, 50), (150, 9100, 64, 80, .06, None), (37, 2501, 40, 11, .2, 9),
+    for (Q, Rn, K, C, p, k) in ((129, 6463, 128, 80, .05, None), (70, 9001, 100, 24, .1, 50), (150, 9100, 64, 80, .06, None), (37, 2501, 40, 11, .2, 9),
                                 (200, 20011, 16, 24, .1, None), (9, 70, 128, 5, .3, 3)):
         qB, rB, qL, rL = _synth(Q, Rn, K, C, seed=3 * K + Rn, p=p)
         outs = []

@@ -31,7 +31,7 @@ def _template_ints(name, kernel):
 
 def test_every_hand_scheduled_kernel_is_in_the_library(report):
     names = "\n".join(report)
-    for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_r2ILi2ELi4ELi4ELb1E", "k_scan_hist_r2ILi1ELi4ELi4ELb0E",
+    for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_r2ILi2ELi4ELi4ELb1E", "k_scan_hist_r2ILi1ELi4ELi4ELb0E", "k_scan_hist_r2wILi2ELi4ELi2ELb1E",
               "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
         assert k in names, k
     assert sum(st["n_mfma"] for _, st in report.values()) > 1000
@@ -66,8 +66,16 @@ def test_register_built_operands_keep_the_same_margins(report):
     margins above, every MFMA operand a VALU instruction wrote is at least 2 wait states old (R3 on A / B, covered by the `s_nop 3`
     that opens each statement) and a tile is not overwritten within 3 slots of the last MFMA that read it (R2: each group has its own
     tile set, kept alive one statement longer by an empty asm)."""
-    seen = 0
+    seen = wide = 0
     for name, (bad, st) in report.items():
+        if "k_scan_hist_r2w" in name:                                  # 65..128 bits: six MFMAs per statement, the cache word packed by a second statement
+            nml, nw, nq, cache = _template_ints(name, "k_scan_hist_r2w")
+            assert not bad, (name, bad[:3])
+            assert st["R1"] is not None and st["R1"] >= 8 and st["R3"] is not None and st["R3"] >= H.SRCC_WAIT, (name, st)
+            assert st["R2"] is None or st["R2"] >= H.WAR_WAIT, (name, st)
+            assert st["n_sdwa_preserve"] == (8 * nq if cache else 0), (name, st)
+            wide += 1
+            continue
         if "k_scan_hist_r2" not in name:
             continue
         nml, nw, nq, cache = _template_ints(name, "k_scan_hist_r2")
@@ -79,7 +87,7 @@ def test_register_built_operands_keep_the_same_margins(report):
         if H.hipcc_version().startswith(PINNED_COMPILER):
             assert st["n_snop3"] == 4 * nq + 1, (name, st)
         seen += 1
-    assert seen >= 20
+    assert seen >= 20 and wide == 4
 
 
 def test_the_checker_sees_a_planted_hazard():
