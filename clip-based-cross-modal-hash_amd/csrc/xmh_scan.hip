@@ -2032,6 +2032,8 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     float acc = 0.0f;
     auto credit = [&](unsigned long long old, uint32_t m) {
+        // (one v_pk_add_f32 with neg_hi does both subtractions on the returned register pair -- measured: 0.182 ms either way, the pass
+        // is not bound by its VALU instruction count alone; left as two plain operations)
         const float rank = __uint_as_float((uint32_t)old) - 8388608.0f;
         const float ord = 16777215.0f - __uint_as_float((uint32_t)(old >> 32));
         if (CAPPED) m = ord <= capf ? m : 0u;
@@ -3030,7 +3032,7 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
         const char* half_env = getenv("XMH_SCAN_AP_HALF");
         const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
         if (half) snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, true>");
-        else snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d>", b8 ? 8 : 16);
+        else snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d, false>", b8 ? 8 : 16);        // all three template arguments: the name a profile prints
     } else if (use_mfma && K <= 64 && mfma_ap_on()) {
         snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
