@@ -2501,10 +2501,10 @@ inline M2Geom m2_geom(int K) {
     // tile it builds (5-6 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
     // (first version, 8 operations per tile: pass 1 0.207-0.231 ms against 0.190)
     M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : (m2_regs(K) ? M2Geom{4, 4, 2} : table[0]);
-    if (K > 64) g = M2Geom{4, 2, 2};                                 // k_scan_hist_r2w: 129 bucket rows, 66 KB of counters per block with two groups per wave
     if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
     const char* b = getenv("XMH_SCAN_M2_BPC");
     if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
+    if (K > 64) g = M2Geom{4, 2, 2};                                 // k_scan_hist_r2w: 129 bucket rows, 66 KB of counters per block with two groups per wave -- its one instance
     return g;
 }
 inline bool m2_shape(int K, bool ternary) { return m2_enabled() && mfma_shape(K, ternary) && K <= 64; }

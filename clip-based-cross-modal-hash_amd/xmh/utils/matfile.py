@@ -104,14 +104,19 @@ def write_mat5(path, variables):
     text = ("MATLAB 5.0 MAT-file Platform: posix, Created on: %s (xmh.utils.matfile)" % time.asctime()).encode("latin1")[:116]
     header = text + b" " * (116 - len(text)) + b"\0" * 8 + struct.pack("<H", 0x0100) + b"IM"
     tmp = "%s.tmp%d" % (path, os.getpid())
-    with open(tmp, "wb") as f:
-        f.write(header)
-        for head, host, pad in elements:
-            f.write(head)
-            f.write(host.reshape(-1).view(np.uint8).data)
-            if pad:
-                f.write(b"\0" * pad)
-    os.replace(tmp, path)
+    try:
+        with open(tmp, "wb") as f:
+            f.write(header)
+            for head, host, pad in elements:
+                f.write(head)
+                f.write(host.reshape(-1).view(np.uint8).data)
+                if pad:
+                    f.write(b"\0" * pad)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):                                     # a full disk or an interrupt leaves no half-written file behind
+            os.remove(tmp)
+        raise
 
 
 def link_or_copy(src, dst):
