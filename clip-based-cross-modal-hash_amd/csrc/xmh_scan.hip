@@ -2056,25 +2056,31 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         const unsigned long long inc = 1ull | ((unsigned long long)m << 32);
         asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(old) : "v"(addr), "v"(inc) : "memory");     // same-address lanes resolve in lane = item order
     };
-    unsigned long long oldp[8], oldn[8];
-    uint32_t mp[8], mn[8];
-    bool prev = false;
-    // 8 steps = two cache words of one-byte entries, or all four words of a batch of two-byte entries
-    auto group = [&](uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd) {
+    // Two sets of result registers, A and B, used in turn.  The returns of a group are only ever named by the asm statement that issued them
+    // and by the `s_waitcnt` statement that later covers them (as in-out operands): between the two hipcc must not see a reason to touch
+    // them -- it believes an asm's result is there when the statement ends.  Round 4: the earlier form handed a group's results to "the
+    // previous group" by assignment (oldp = oldn); on the path of a chunk with exactly one whole batch hipcc made that eight v_mov_b64 in
+    // front of the wait, i.e. copies of registers the LDS had not written yet -- wrong APs a few evaluations in a thousand, only in the
+    // one-group-per-batch variants (tools/isa_hazards.py rule R5 now checks every pass-2 kernel for it at build time).
+    unsigned long long oldA[8], oldB[8];
+    uint32_t mA[8], mB[8];
+    // 8 steps = two cache words of one-byte entries, or all four words of a batch of two-byte entries / of the 8-query-wide reading
+    auto issue = [&](unsigned long long (&old)[8], uint32_t (&m)[8], uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int wi = u / EPW;
-            issue1(wi == 0 ? wa : (wi == 1 ? wb : (wi == 2 ? wc : wd)), u % EPW, oldn[u], mn[u]);
+            issue1(wi == 0 ? wa : (wi == 1 ? wb : (wi == 2 ? wc : wd)), u % EPW, old[u], m[u]);
         }
-        if (prev) {                                                   // the previous group's returns: 8 newer LDS operations are in flight
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
-                         "+v"(oldp[7])::"memory");
+    };
+    auto drain8 = [&](unsigned long long (&old)[8], uint32_t (&m)[8]) {      // this set's returns are in: 8 newer LDS operations are in flight
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
 #pragma unroll
-            for (int u = 0; u < 8; ++u) credit(oldp[u], mp[u]);
-        }
+        for (int u = 0; u < 8; ++u) credit(old[u], m[u]);
+    };
+    auto drain0 = [&](unsigned long long (&old)[8], uint32_t (&m)[8]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { oldp[u] = oldn[u]; mp[u] = mn[u]; }
-        prev = true;
+        for (int u = 0; u < 8; ++u) credit(old[u], m[u]);
     };
     const int nbatch = (a.chunk + 63) >> 6;
     const uint4* crow = HALF ? a.pair_cache + ((int64_t)chunk_id * (a.nqt >> 1) + (qtile >> 1)) * nbatch * 64 + (slot & 3) * 16 + (qtile & 1) * 8 + ql
@@ -2085,22 +2091,64 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     // takes longer than that (Q 5000 x R 117 218, 64 bit, pass 2 with the words one / two / three batches ahead: 0.187 / 0.178 / 0.181 ms)
     uint4 cw = crow[0];
     uint4 nw = crow[(int64_t)(1 < nbatch ? 1 : 0) * 64];
-    for (int bi = 0; bi < nfull; ++bi) {
-        const uint4 nw2 = crow[(int64_t)(bi + 2 < nbatch ? bi + 2 : nbatch - 1) * 64];      // unconditional: counted vmcnt, no predication
-        if (EB == 8 && !HALF) {
-            group(cw.x, cw.y, 0u, 0u);
-            group(cw.z, cw.w, 0u, 0u);
-        } else {
-            group(cw.x, cw.y, cw.z, cw.w);
-        }
-        cw = nw;
-        nw = nw2;
-    }
-    if (prev) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3]), "+v"(oldp[4]), "+v"(oldp[5]), "+v"(oldp[6]),
-                     "+v"(oldp[7])::"memory");
+    auto next_words = [&](int bi) {                                  // unconditional: counted vmcnt, no predication
+        const uint4 nw2 = crow[(int64_t)(bi + 2 < nbatch ? bi + 2 : nbatch - 1) * 64];
+        return nw2;
+    };
+    if (EB == 8 && !HALF) {
+        // two groups per batch.  Round 3's form, kept as it is: a group's results are handed to "the previous group" by assignment, which hipcc
+        // turns into register renaming in this loop (checked in the shipped ISA: rule R5 finds no touch of a pending result in this instance)
+        unsigned long long oldp[8];
+        uint32_t mp[8];
+        bool prev = false;
+        auto group = [&](uint32_t wa, uint32_t wb) {
+            issue(oldA, mA, wa, wb, 0u, 0u);
+            if (prev) drain8(oldp, mp);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) credit(oldp[u], mp[u]);
+            for (int u = 0; u < 8; ++u) { oldp[u] = oldA[u]; mp[u] = mA[u]; }
+            prev = true;
+        };
+        for (int bi = 0; bi < nfull; ++bi) {
+            const uint4 nw2 = next_words(bi);
+            group(cw.x, cw.y);
+            group(cw.z, cw.w);
+            cw = nw;
+            nw = nw2;
+        }
+        if (prev) drain0(oldp, mp);
+    } else {
+        // one group per batch (two-byte entries, or the 8-query-wide reading).  No result crosses a loop edge or a branch: an iteration
+        // issues and credits four batches (A B A B, each credited while the next one's atomics are in flight) and ends drained; the
+        // remainder does the same with two batches, then one.  One LDS round trip exposed per four batches is the price of results that
+        // hipcc cannot be tempted to copy early.
+        auto batch = [&](unsigned long long (&old)[8], uint32_t (&m)[8], int bi) {
+            const uint4 nw2 = next_words(bi);
+            issue(old, m, cw.x, cw.y, cw.z, cw.w);
+            cw = nw;
+            nw = nw2;
+        };
+        int bi = 0;
+        for (; bi + 3 < nfull; bi += 4) {
+            batch(oldA, mA, bi);
+            batch(oldB, mB, bi + 1);
+            drain8(oldA, mA);
+            batch(oldA, mA, bi + 2);
+            drain8(oldB, mB);
+            batch(oldB, mB, bi + 3);
+            drain8(oldA, mA);
+            drain0(oldB, mB);
+        }
+        if (bi + 1 < nfull) {
+            batch(oldA, mA, bi);
+            batch(oldB, mB, bi + 1);
+            drain8(oldA, mA);
+            drain0(oldB, mB);
+            bi += 2;
+        }
+        if (bi < nfull) {
+            batch(oldA, mA, bi);
+            drain0(oldA, mA);
+        }
     }
     const int cntb = (int)(hi - lo) - nfull * 64;                    // ragged last batch (cw holds its words)
 #pragma unroll

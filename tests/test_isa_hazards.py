@@ -90,6 +90,33 @@ def test_register_built_operands_keep_the_same_margins(report):
     assert seen >= 20 and wide == 4
 
 
+def test_no_result_of_a_returning_lds_operation_is_touched_before_its_wait():
+    """R5.  Pass 2 issues its returning atomics from asm statements and waits for them a group later with a counted lgkmcnt; hipcc takes
+    an asm's result as present when the statement ends.  Round 4: in the one-group-per-batch variants of k_scan_ap_c it copied eight
+    result pairs (v_mov_b64) in front of the wait on the path of a chunk with exactly one whole batch -- wrong APs a few evaluations in
+    a thousand, found by a long fuzz run, not by any test.  Every pass-2 kernel of the library is checked here instruction by instruction."""
+    res = H.analyse_lds_returns()
+    names = "\n".join(res)
+    for k in ("k_scan_ap_cILb0ELi8ELb0E", "k_scan_ap_cILb0ELi8ELb1E", "k_scan_ap_cILb0ELi16ELb0E", "k_scan_ap_cILb1ELi8ELb1E", "k_scan_ap_sI", "k_scan_ap_mI"):
+        assert k in names, k
+    bad = [v for vs, _ in res.values() for v in vs]
+    assert not bad, "\n".join("%s %s[%d] %s -- %s" % (v.rule, v.kernel[:60], v.index, v.text[:80], v.detail) for v in bad[:20])
+    assert sum(st["n_returning"] for _, st in res.values()) > 5000 and len(res) > 300
+
+
+def test_the_lds_return_rule_sees_a_planted_copy():
+    def stream(*lines):
+        return H.parse("0000 <probe>:\n" + "".join("\t%s // %08X: 0\n" % (l, 0x1000 + 4 * i) for i, l in enumerate(lines)))["probe"]
+    rules = lambda ins: [v.detail[:20] for v in H.check_lds_returns(ins, "probe")[0]]      # noqa: E731
+    at = "ds_add_rtn_u64 v[%d:%d], v2, v[4:5]"
+    assert rules(stream(at % (10, 11), "v_mov_b64_e32 v[20:21], v[10:11]")) != []                              # copied before any wait
+    assert rules(stream(at % (10, 11), "s_waitcnt lgkmcnt(0)", "v_mov_b64_e32 v[20:21], v[10:11]")) == []
+    assert rules(stream(at % (10, 11), at % (12, 13), "s_waitcnt lgkmcnt(1)", "v_add_f32_e32 v30, v10, v31")) == []   # the older of two is in
+    assert rules(stream(at % (10, 11), at % (12, 13), "s_waitcnt lgkmcnt(1)", "v_add_f32_e32 v30, v12, v31")) != []   # the newer is not
+    assert rules(stream(at % (10, 11), "s_cbranch_scc1 1", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v20, v10")) != []   # the branch skips the wait
+    assert rules(stream(at % (10, 11), "s_load_dword s4, s[0:1], 0x0", at % (12, 13), "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v20, v10")) != []   # scalar load in flight
+
+
 def test_the_checker_sees_a_planted_hazard():
     """the rules fire on a three-instruction stream with each hazard planted (the checker itself is not vacuous)"""
     def stream(*lines):

@@ -34,7 +34,7 @@ WAR_WAIT = 3      # VALU write onto the A / B / srcC registers of an MFMA issued
 SRCC_WAIT = 2     # VALU write -> MFMA srcC read
 
 Violation = collections.namedtuple("Violation", "rule kernel index text detail")
-Insn = collections.namedtuple("Insn", "mnem dst src text")
+Insn = collections.namedtuple("Insn", "mnem dst src text addr", defaults=(None,))
 
 _REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 
@@ -69,6 +69,8 @@ def parse(text):
         body = line.split("//")[0].strip()
         if not body:
             continue
+        am = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", line)
+        addr = int(am.group(1), 16) if am else None
         parts = body.split(None, 1)
         mnem = parts[0]
         ops = parts[1] if len(parts) > 1 else ""
@@ -91,7 +93,7 @@ def parse(text):
                 src.extend(r)
         if dst and (mnem.startswith(_DST_ALSO_READ) or "UNUSED_PRESERVE" in ops):
             src.extend(dst)
-        cur.append(Insn(mnem, tuple(dst), tuple(src), body))
+        cur.append(Insn(mnem, tuple(dst), tuple(src), body, addr))
     return kernels
 
 
@@ -165,6 +167,65 @@ def check(insns, kernel="", war=None):
     return out, stats
 
 
+def check_lds_returns(insns, kernel=""):
+    """R5: nothing touches the destination of a returning LDS operation before an `s_waitcnt lgkmcnt` has covered it.
+    The scan's pass 2 issues its returning atomics from `asm volatile` statements and waits for them a group later with a counted
+    lgkmcnt; hipcc believes the result is there when the statement ends, so any copy or use it schedules in between moves garbage
+    (round 4: a `v_mov_b64` of eight result pairs on the path of a chunk with exactly one whole batch -- wrong APs a few runs in a
+    thousand).  LDS operations of a wave complete in order, so the outstanding ones are a FIFO: `lgkmcnt(N)` retires all but the N newest.
+    Scalar loads share the counter and may return out of order: one of them in flight makes every counted wait inexact, which is flagged
+    as well.  Pending sets travel along branches (target address = next instruction + 4 * simm16) as well as along the fall-through."""
+    out = []
+    fifo = []                                   # [(kind, frozenset(dst regs), text)] oldest first; kind "ds" / "smem"
+    at_target = collections.defaultdict(list)   # address -> FIFOs arriving by a branch
+    stats = {"n_returning": 0, "max_outstanding": 0}
+
+    def merge(a, b):                            # union of two arrival states: keep every pending destination, order by the longer list
+        longer, other = (a, b) if len(a) >= len(b) else (b, a)
+        extra = [x for x in other if x not in longer]
+        return extra + list(longer)
+
+    for idx, ins in enumerate(insns):
+        if ins.addr is not None and ins.addr in at_target:
+            for f in at_target.pop(ins.addr):
+                fifo = merge(fifo, f)
+        m = ins.mnem
+        if m == "s_waitcnt":
+            g = re.search(r"lgkmcnt\((\d+)\)", ins.text)
+            if g:
+                n = int(g.group(1))
+                if n and any(k == "smem" for k, _, _ in fifo):
+                    out.append(Violation("R5", kernel, idx, ins.text, "counted lgkmcnt with a scalar load in flight (it may return out of order)"))
+                fifo = fifo[len(fifo) - n:] if n < len(fifo) else fifo
+                if n == 0:
+                    fifo = []
+            continue
+        pending = set().union(*[d for _, d, _ in fifo]) if fifo else set()
+        touched = pending.intersection(set(ins.src) | set(ins.dst))
+        if touched:
+            r = sorted(touched)[0]
+            out.append(Violation("R5", kernel, idx, ins.text, "%s%d is the destination of an LDS operation no s_waitcnt has covered yet" % (r[0], r[1])))
+        if m.startswith(("ds_", "s_load", "s_buffer_load")) and not m.startswith("ds_nop"):
+            returning = m.startswith(("s_load", "s_buffer_load")) or "_rtn" in m or m.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append"))
+            dst = frozenset(ins.dst) if (returning and not m.startswith("s_")) else frozenset()
+            fifo.append(("smem" if m.startswith("s_") else "ds", dst, ins.text))
+            if dst:
+                stats["n_returning"] += 1
+            stats["max_outstanding"] = max(stats["max_outstanding"], len(fifo))
+        if m.startswith(("s_branch", "s_cbranch")) and ins.addr is not None:
+            g = re.match(r"\S+\s+(-?\d+)", ins.text)
+            if g:
+                off = int(g.group(1))
+                if off >= 32768:
+                    off -= 65536
+                at_target[ins.addr + 4 + 4 * off].append(list(fifo))
+            if m.startswith("s_branch"):
+                fifo = []
+        if m.startswith(("s_endpgm", "s_setpc", "s_swappc")):
+            fifo = []
+    return out, stats
+
+
 def code_objects(lib=LIB, workdir=None):
     """extract the gfx950 code objects of the fat binary into workdir (a copy of the library is unbundled there) -> file paths"""
     objdump = os.path.join(LLVM_BIN, "llvm-objdump")
@@ -179,6 +240,26 @@ def code_objects(lib=LIB, workdir=None):
 
 def disassemble(path):
     return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", path], check=True, capture_output=True, text=True).stdout
+
+
+LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m")
+
+
+def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
+    """-> {kernel: (violations, stats)} of rule R5 for the pass-2 kernels (asm-issued returning atomics)"""
+    work = tempfile.mkdtemp(prefix="xmh_isa_")
+    try:
+        res = {}
+        for co in code_objects(lib, work):
+            text = disassemble(co)
+            if not any(n in text for n in name_filter):
+                continue
+            for name, insns in parse(text).items():
+                if any(n in name for n in name_filter):
+                    res[name] = check_lds_returns(insns, name)
+        return res
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_r2", "k_scan_hist_b", "k_scan_hist_m", "k_topk_filter_mfma")):
@@ -215,6 +296,14 @@ if __name__ == "__main__":
         short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:70]
         print("%-72s mfma %4d  s_nop3 %3d  sdwa %3d  min R1 %s R2 %s R3 %s  violations %d" % (short, st["n_mfma"], st["n_snop3"], st["n_sdwa_preserve"], st["R1"], st["R2"], st["R3"], len(v)))
         for x in v[:6]:
+            print("    ", x.rule, x.index, x.text[:100], "--", x.detail)
+        bad += len(v)
+    r5 = analyse_lds_returns(sys.argv[1] if len(sys.argv) > 1 else LIB)
+    for name in sorted(r5):
+        v, st = r5[name]
+        short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:70]
+        print("%-72s returning LDS ops %4d  max outstanding %2d  R5 violations %d" % (short, st["n_returning"], st["max_outstanding"], len(v)))
+        for x in v[:4]:
             print("    ", x.rule, x.index, x.text[:100], "--", x.detail)
         bad += len(v)
     sys.exit(1 if bad else 0)
