@@ -2096,26 +2096,34 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         return nw2;
     };
     if (EB == 8 && !HALF) {
-        // two groups per batch.  Round 3's form, kept as it is: a group's results are handed to "the previous group" by assignment, which hipcc
-        // turns into register renaming in this loop (checked in the shipped ISA: rule R5 finds no touch of a pending result in this instance)
-        unsigned long long oldp[8];
-        uint32_t mp[8];
-        bool prev = false;
-        auto group = [&](uint32_t wa, uint32_t wb) {
-            issue(oldA, mA, wa, wb, 0u, 0u);
-            if (prev) drain8(oldp, mp);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { oldp[u] = oldA[u]; mp[u] = mA[u]; }
-            prev = true;
-        };
-        for (int bi = 0; bi < nfull; ++bi) {
+        // two groups per batch (A = its first two words, B = the other two); an iteration issues and credits two batches and ends drained,
+        // like the one-group form below
+        int bi = 0;
+        for (; bi + 1 < nfull; bi += 2) {
             const uint4 nw2 = next_words(bi);
-            group(cw.x, cw.y);
-            group(cw.z, cw.w);
+            issue(oldA, mA, cw.x, cw.y, 0u, 0u);
+            issue(oldB, mB, cw.z, cw.w, 0u, 0u);
+            drain8(oldA, mA);
+            cw = nw;
+            nw = nw2;
+            const uint4 nw3 = next_words(bi + 1);
+            issue(oldA, mA, cw.x, cw.y, 0u, 0u);
+            drain8(oldB, mB);
+            issue(oldB, mB, cw.z, cw.w, 0u, 0u);
+            drain8(oldA, mA);
+            drain0(oldB, mB);
+            cw = nw;
+            nw = nw3;
+        }
+        if (bi < nfull) {
+            const uint4 nw2 = next_words(bi);
+            issue(oldA, mA, cw.x, cw.y, 0u, 0u);
+            issue(oldB, mB, cw.z, cw.w, 0u, 0u);
+            drain8(oldA, mA);
+            drain0(oldB, mB);
             cw = nw;
             nw = nw2;
         }
-        if (prev) drain0(oldp, mp);
     } else {
         // one group per batch (two-byte entries, or the 8-query-wide reading).  No result crosses a loop edge or a branch: an iteration
         // issues and credits four batches (A B A B, each credited while the next one's atomics are in flight) and ends drained; the
