@@ -538,6 +538,33 @@ def test_scan_pass2_eight_queries_wide_on_one_byte_entries(xr, monkeypatch):
         assert abs(outs[0][2] - want) < 1e-6 and abs(outs[1][2] - want) < 1e-6, (Q, Rn, K, C, outs[0][2], outs[1][2], want)
 
 
+@pytest.mark.parametrize("K,env", [(64, {}), (64, {"XMH_SCAN_AP_HALF": "1"}), (128, {}), (100, {"XMH_SCAN_R2W": "0"}),
+                                   (128, {"XMH_SCAN_BYTE128": "0", "XMH_SCAN_AP_C": "2"}), (16, {}), (256, {})])
+def test_scan_repeated_evaluations_are_bit_identical(xr, monkeypatch, K, env):
+    """The same scan evaluated 25 times gives the same bits 25 times: histograms, divisors and AP sums.  Round 4: in the one-group-per-batch
+    variants of k_scan_ap_c hipcc had copied atomic results in front of their s_waitcnt on the path of a chunk with exactly one whole batch
+    (the shape below: chunks of 256 items, a last chunk of 108), and every evaluation of such a shape differed from the one before in a few
+    queries -- within no tolerance.  The build-time ISA check (tests/test_isa_hazards.py, rule R5) is the gate; this is the symptom."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    Q, R, C = 513, 3180, 5
+    qB, rB, qL, rL = _synth(Q, R, K, C, seed=911, p=0.1)
+    scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+    assert scan.plan.chunk * (scan.plan.nchunk - 1) < R and (R - scan.plan.chunk * (scan.plan.nchunk - 1)) % 64 != 0      # a ragged last chunk
+    first = None
+    for i in range(25):
+        ha, hr = scan.histograms(True)
+        m, ap, cap = scan.map_all(None if i % 2 else 50)
+        m2, ap2, cap2 = scan.map_all(None)
+        cur = (ha.clone(), hr.clone(), cap2.clone(), ap2.clone(), float(m2))
+        if first is None:
+            first = cur
+            orc = _orc()
+            assert abs(cur[4] - float(orc.map_k(qB, rB, qL, rL, None, stable=True))) < 1e-6
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(cur[:4], first[:4])) and cur[4] == first[4], i
+
+
 def test_scan_float_bit_counters_give_identical_bits(xr, monkeypatch):
     """k_scan_ap_c (pass 2 with float-bit counters; the default up to 64 bits, XMH_SCAN_AP_C=2 switches it on for the two-byte
     entries of longer codes) against k_scan_ap_s on the same pair cache: the same credits in the same order, so the per-query sums
