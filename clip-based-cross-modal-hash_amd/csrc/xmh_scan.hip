@@ -1902,9 +1902,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
         const float of = (float)__umul24(ord, hit);
         apsum = fmaf(of, __builtin_amdgcn_rcpf((float)rank), apsum);
     };
-    CT oldp[4];
-    uint32_t hitp[4];
-    bool have_prev = false;
+    // Two result sets used in turn; no result crosses the batch loop (see k_scan_ap_c: hipcc takes an asm's result as present when the
+    // statement ends, so a result handed on by assignment can become a copy in front of its wait): a batch issues its four groups,
+    // credits each while the next one's atomics are in flight, and ends drained.
+    CT oldA[4], oldB[4];
+    uint32_t hitA[4], hitB[4];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // counters are in place (own wave's region only)
     ST::issue(a.gimg, ring, 0, bat0, lane, wave);
     for (int i = 0; i < nbat; ++i) {
@@ -1918,16 +1920,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
 #pragma unroll
             for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        auto issue_group = [&](int g, CT (&old)[4], uint32_t (&hit)[4]) {
             v4i acc = {cinit, cinit, cinit, cinit};
 #pragma unroll
             for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], acc, 0, 0, 0);
             v4i lab = {0, 0, 0, 0};
 #pragma unroll
             for (int m = NMC; m < NM; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], lab, 0, 0, 0);
-            CT oldn[4];
-            uint32_t hit[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 hit[j] = min((uint32_t)lab[j], 1u);
@@ -1935,30 +1934,32 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* 
                     const uint32_t v = (hit[j] << rank_bits) + 1u;
                     uint32_t o;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(acc[j]), "v"(v) : "memory");
-                    oldn[j] = (CT)o;
+                    old[j] = (CT)o;
                 } else {
                     const unsigned long long v = 1ull | ((unsigned long long)hit[j] << 32);
                     const int addr = acc[j] << 1;
                     unsigned long long o;
                     asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(o) : "v"(addr), "v"(v) : "memory");
-                    oldn[j] = (CT)o;
+                    old[j] = (CT)o;
                 }
             }
-            if (have_prev) {                                         // the previous group's returns: 4 newer LDS operations are in flight
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3])::"memory");
+        };
+        auto drain4 = [&](CT (&old)[4], uint32_t (&hit)[4]) {         // this set's returns are in: 4 newer LDS operations are in flight
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3])::"memory");
 #pragma unroll
-                for (int j = 0; j < 4; ++j) credit(oldp[j], hitp[j]);
-            }
+            for (int j = 0; j < 4; ++j) credit(old[j], hit[j]);
+        };
+        issue_group(0, oldA, hitA);
+        issue_group(1, oldB, hitB);
+        drain4(oldA, hitA);
+        issue_group(2, oldA, hitA);
+        drain4(oldB, hitB);
+        issue_group(3, oldB, hitB);
+        drain4(oldA, hitA);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldB[0]), "+v"(oldB[1]), "+v"(oldB[2]), "+v"(oldB[3])::"memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { oldp[j] = oldn[j]; hitp[j] = hit[j]; }
-            have_prev = true;
-        }
+        for (int j = 0; j < 4; ++j) credit(oldB[j], hitB[j]);
         __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
-    }
-    if (have_prev) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldp[0]), "+v"(oldp[1]), "+v"(oldp[2]), "+v"(oldp[3])::"memory");
-#pragma unroll
-        for (int j = 0; j < 4; ++j) credit(oldp[j], hitp[j]);
     }
     apsum += __shfl_xor(apsum, 16, 64);
     apsum += __shfl_xor(apsum, 32, 64);
