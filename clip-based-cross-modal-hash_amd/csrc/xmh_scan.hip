@@ -2065,6 +2065,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     // one-group-per-batch variants (tools/isa_hazards.py rule R5 now checks every pass-2 kernel for it at build time).
     unsigned long long oldA[8], oldB[8];
     uint32_t mA[8], mB[8];
+    constexpr bool kFourBatchIterations = true;
     // 8 steps = two cache words of one-byte entries, or all four words of a batch of two-byte entries / of the 8-query-wide reading
     auto issue = [&](unsigned long long (&old)[8], uint32_t (&m)[8], uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd) {
 #pragma unroll
@@ -2100,6 +2101,27 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         // two groups per batch (A = its first two words, B = the other two); an iteration issues and credits two batches and ends drained,
         // like the one-group form below
         int bi = 0;
+        if (kFourBatchIterations) {
+            for (; bi + 3 < nfull; bi += 4) {
+                const uint4 n0 = next_words(bi);
+                issue(oldA, mA, cw.x, cw.y, 0u, 0u);
+                issue(oldB, mB, cw.z, cw.w, 0u, 0u);
+                drain8(oldA, mA);
+                cw = nw;
+                nw = n0;
+#pragma unroll
+                for (int t = 1; t < 4; ++t) {
+                    const uint4 nt = next_words(bi + t);
+                    issue(oldA, mA, cw.x, cw.y, 0u, 0u);
+                    drain8(oldB, mB);
+                    issue(oldB, mB, cw.z, cw.w, 0u, 0u);
+                    drain8(oldA, mA);
+                    cw = nw;
+                    nw = nt;
+                }
+                drain0(oldB, mB);
+            }
+        }
         for (; bi + 1 < nfull; bi += 2) {
             const uint4 nw2 = next_words(bi);
             issue(oldA, mA, cw.x, cw.y, 0u, 0u);
