@@ -246,7 +246,8 @@ def disassemble(path):
     return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", path], check=True, capture_output=True, text=True).stdout
 
 
-LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m")
+# pass 2 (asm-issued returning atomics) and the pass-1 kernel that reads its A tiles with asm ds_read_b128 ahead of a counted wait
+LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m", "k_scan_hist_m2")
 
 
 def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
