@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     for (int v = 0; v < LWC; ++v) {
         const int wi = slot * LWC + v;
         const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
-        word_to_weights(w, -1, valid ? 1 : 0, bq[2 * v], bq[2 * v + 1]);
+        word_to_weights(w, -1, valid && wi < a.W ? 1 : 0, bq[2 * v], bq[2 * v + 1]);      // no such word: zero weights, whatever the item lane loads
     }
     word_to_weights(valid && slot < a.LW ? a.qlab[(int64_t)q * a.LW + slot] : 0u, 1, 0, bl[0], bl[1]);
     const int lanebase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4;     // this lane's bucket-0 counter
@@ -87,17 +87,33 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     uint4* crow = nullptr;
     if (CACHE) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
     uint32_t cur[4][LWC + 1], nxt[4][LWC + 1];
+    // a word index past the end of the record is clamped to the last word: the query operand of that lane quarter is zero (word_to_weights of
+    // a zero word with off = 0 for the labels; for the code see wq below), so what is loaded in its place counts for nothing
+    int wic[LWC];
+#pragma unroll
+    for (int v = 0; v < LWC; ++v) wic[v] = slot * LWC + v < a.W ? slot * LWC + v : a.W - 1;
+    const int wil = slot < a.LW ? slot : (a.LW > 0 ? a.LW - 1 : 0);
     auto load = [&](uint32_t (&dst)[4][LWC + 1], int i) {
+        const int64_t first = lo + (int64_t)i * 64;
+        if (first + 64 <= hi) {                                      // whole batch inside the chunk (wave-uniform): unconditional loads, constant strides
+            const uint32_t* __restrict__ pc = a.rbits + (first + rowitem) * a.W;
+            const uint32_t* __restrict__ pl = a.rlab + (first + rowitem) * a.LW + wil;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t it = lo + (int64_t)i * 64 + 16 * g + rowitem;
-            const bool ok = it < hi;                                // beyond the chunk: all-zero code, no labels (corrected below)
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int v = 0; v < LWC; ++v) {
-                const int wi = slot * LWC + v;
-                dst[g][v] = ok && wi < a.W ? a.rbits[it * a.W + wi] : 0u;
+                for (int v = 0; v < LWC; ++v) dst[g][v] = pc[g * 16 * a.W + wic[v]];
+                dst[g][LWC] = pl[g * 16 * a.LW];
             }
-            dst[g][LWC] = ok && slot < a.LW ? a.rlab[it * a.LW + slot] : 0u;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t item = first + 16 * g + rowitem;
+                const int64_t it = item < hi ? item : hi - 1;
+                const uint32_t ok = item < hi ? 0xffffffffu : 0u;    // beyond the chunk: all-zero code, no labels (corrected below)
+#pragma unroll
+                for (int v = 0; v < LWC; ++v) dst[g][v] = a.rbits[it * a.W + wic[v]] & ok;
+                dst[g][LWC] = a.rlab[it * a.LW + wil] & ok;
+            }
         }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the zeroed counters are in place (this wave's own cells)
