@@ -40,6 +40,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+import bench_emit  # noqa: E402
 import bench_roofline as RL  # noqa: E402
 
 
@@ -312,39 +313,6 @@ def strong_legs(args, world, rank, barrier):
     return out
 
 
-def front_loaded(out):
-    """the same line with a one-screen `summary` right behind the contract keys: a truncated tail of the line still shows the HBM-regime
-    fractions, the end-to-end valid() time and the CPU baseline"""
-    def pick(d, *keys):
-        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
-    summ = {}
-    for name, key in (("hbm_regime_q1", "roofline_hbm_regime"), ("hbm_regime_q8", "roofline_hbm_regime_q8"), ("hbm_regime_q64", "roofline_hbm_regime_q64")):
-        if key in out:
-            summ[name] = pick(out[key], "frac", "achieved", "whole_call_GBps", "whole_call_ms", "error")
-    cd = out.get("topk_infinity_cache_defeated", {})
-    for qn in ("Q1", "Q8"):
-        rot = [v for k, v in cd.get(qn, {}).items() if k.startswith("rotating")] if isinstance(cd.get(qn), dict) else []
-        if rot:
-            summ["hbm_regime_%s_cache_defeated" % qn.lower()] = pick(rot[0], "filter_frac_of_8TBps", "filter_GBps", "whole_call_GBps")
-    if "valid_e2e" in out:
-        summ["valid_e2e"] = pick(out["valid_e2e"], "valid_seconds", "encode_seconds", "retrieve_seconds", "encode_share", "cpu_estimate_seconds", "error")
-    if "encode" in out:
-        summ["encode"] = pick(out["encode"], "images_per_s_f32", "captions_per_s_f32", "captions_per_s_f32_padded_tower", "captions_rows_run_fraction", "images_per_s_f16", "error")
-        fb = out["encode"].get("fused_batches") if isinstance(out["encode"], dict) else None
-        if fb:
-            summ["encode_batch400"] = pick(fb, "images_per_s_f32", "images_per_s_f16")
-    for key in ("configs0_dcmht_16bit_mirflickr", "k16_coco_shape", "configs3_dsph_128bit", "configs4_shard_scan_256bit", "configs4_unsharded_scan_256bit",
-                "topk_q5000_10M_256bit"):
-        if key in out:
-            summ[key] = pick(out[key], "ms_per_step", "whole_call_ms", "pairs_per_s", "pairs_per_s_whole_call", "error")
-    head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "settle_steps", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "config", "mAP", "roofline", "cpu_baseline"]
-    ordered = {k: out[k] for k in head if k in out}
-    ordered["summary"] = summ
-    ordered.update({k: v for k, v in out.items() if k not in ordered})
-    return ordered
-
-
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,9 +331,14 @@ def main():
     os.dup2(2, 1)
 
     def emit(obj):
+        """stdout gets ONE compact contract line (bench_emit: <= 4 KB, strict JSON); the full object goes to
+        gpurun_out/bench_detail.json and stderr"""
         sys.stdout.flush()
         if rank == 0:
-            os.write(json_fd, (json.dumps(obj) + "\n").encode())
+            path = bench_emit.write_detail(obj, ROOT)
+            print("bench detail (%s): %s" % (path, json.dumps(bench_emit._num(obj, 9))), file=sys.stderr)
+            sys.stderr.flush()
+            os.write(json_fd, (bench_emit.compact_line(obj) + "\n").encode())
         os.close(json_fd)
 
     if args.dry_run:
@@ -544,7 +517,7 @@ def main():
                                          "how": "(Q + R) / cpu_baseline_encode rates + 4 Q R / cpu_baseline pairs/s, %d threads" % out["cpu_baseline"]["cores"]}
     if use_dist:
         dist.destroy_process_group()
-    emit(front_loaded(out))
+    emit(out)
 
 
 if __name__ == "__main__":
