@@ -2197,6 +2197,295 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_scan_ap_r2 (round 5): pass 2 WITHOUT a pair cache -- the operands of the i8 MFMAs built in registers from the packed words exactly as
+// in k_scan_hist_r2 (same load_words / build, same query bytes for the address chain), the MFMA emits the LDS address of counter
+// [distance][query], and the pair's relevance comes out of the label chain: query label bytes are 0 / -1, so the chain ends at minus
+// the (weighted) number of common labels and v_max_i32(acc, -1) is the mask 0 / ~0 -- which is both the high half of the 64-bit
+// increment {1, -relevant} of k_scan_ap_c's float-bit counters and the AND mask of its credit.  One statement per (16 items x 16
+// queries) holds that pair's MFMAs with the consumers of the PREVIOUS pair between them (four v_max, four ds_add_rtn_u64), as in
+// k_scan_hist_m2 (same hazards, same spacing: see there); the returns are credited two statements later behind a counted lgkmcnt
+// (k_scan_ap_c's arithmetic in k_scan_ap_c's order per lane: lane (slot, query) still owns the items = slot mod 4, ascending, so the
+// per-chunk sums are bit-identical to the cached path's).  Nothing crosses a batch: an iteration ends drained (tools/isa_hazards.py R5).
+//   * the increment pairs {1, mask} live in PINNED registers (v[112:127], two sets used in turn): the statement writes the high halves by
+//     name -- inline asm has no way to address half of a 64-bit operand -- and the low halves keep their 1 for the whole kernel;
+//   * counter rows are k_scan_ap_c's: 16 queries x 8 B = 128 bytes, so that the 16 lanes of one slot cover all 32 banks once (rows of 64
+//     bytes measured 49 % of the LDS cycles as bank conflicts).  A product of +128 does not fit an i8 operand: the item bytes are worth 2 and
+//     4 instead of 1 and 2 against the query bytes +-64 / +-32 of pass 1.
+// ---------------------------------------------------------------------------------------------------
+#define XMH_AP2_SETA "v113", "v115", "v117", "v119", "v[112:113]", "v[114:115]", "v[116:117]", "v[118:119]"
+#define XMH_AP2_SETB "v121", "v123", "v125", "v127", "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]"
+#define XMH_AP2_MFMA(D, A, B, C) "v_mfma_i32_16x16x64_i8 %[" D "], %[" A "], %[" B "], " C "\n\t"
+#define XMH_AP2_MAX(H, L) "v_max_i32 " H ", -1, %[" L "]\n\t"
+#define XMH_AP2_ADD(O, A, P) "ds_add_rtn_u64 %[" O "], %[" A "], " P "\n\t"
+// the consumers of the previous pair between the MFMAs of this one (two label tiles / one label tile), and alone (the last pair of a batch)
+#define XMH_AP2_FUSED2_(H0, H1, H2, H3, P0, P1, P2, P3)                                                                                   \
+    "s_nop 3\n\t" XMH_AP2_MFMA("lab", "a1", "q1", "0") XMH_AP2_MAX(H0, "l0") XMH_AP2_MAX(H1, "l1") XMH_AP2_MAX(H2, "l2")                \
+    XMH_AP2_MFMA("lab", "a2", "q2", "%[lab]") XMH_AP2_MAX(H3, "l3") XMH_AP2_ADD("o0", "p0", P0) XMH_AP2_ADD("o1", "p1", P1)            \
+    XMH_AP2_MFMA("addr", "a0", "q0", "%[c0]") XMH_AP2_ADD("o2", "p2", P2) XMH_AP2_ADD("o3", "p3", P3)
+#define XMH_AP2_FUSED1_(H0, H1, H2, H3, P0, P1, P2, P3)                                                                                   \
+    "s_nop 3\n\t" XMH_AP2_MFMA("lab", "a1", "q1", "0") XMH_AP2_MAX(H0, "l0") XMH_AP2_MAX(H1, "l1") XMH_AP2_MAX(H2, "l2") XMH_AP2_MAX(H3, "l3") \
+    XMH_AP2_MFMA("addr", "a0", "q0", "%[c0]") XMH_AP2_ADD("o0", "p0", P0) XMH_AP2_ADD("o1", "p1", P1) XMH_AP2_ADD("o2", "p2", P2)       \
+    XMH_AP2_ADD("o3", "p3", P3)
+#define XMH_AP2_TAIL_(H0, H1, H2, H3, P0, P1, P2, P3)                                                                                     \
+    XMH_AP2_MAX(H0, "l0") XMH_AP2_MAX(H1, "l1") XMH_AP2_MAX(H2, "l2") XMH_AP2_MAX(H3, "l3") XMH_AP2_ADD("o0", "p0", P0)                   \
+    XMH_AP2_ADD("o1", "p1", P1) XMH_AP2_ADD("o2", "p2", P2) XMH_AP2_ADD("o3", "p3", P3)
+#define XMH_AP2_FUSED2(...) XMH_AP2_FUSED2_(__VA_ARGS__)
+#define XMH_AP2_FUSED1(...) XMH_AP2_FUSED1_(__VA_ARGS__)
+#define XMH_AP2_TAIL(...) XMH_AP2_TAIL_(__VA_ARGS__)
+template <int NML, int NW, int NQ, bool CAPPED>
+__global__ __launch_bounds__(64 * NW) void k_scan_ap_r2(MfmaArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
+                                                        const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
+                                                        const uint32_t* __restrict__ items_total, uint32_t kcap) {
+    using u64 = unsigned long long;
+    constexpr int NMI = 1 + NML;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] 64-bit float-bit counters
+    int chunk_id, qtile;
+    if (!mfma_map_block(a, chunk_id, qtile)) return;                 // a.nqt counts tiles of NW * NQ * 16 queries here
+    if (items_total && (int64_t)*items_total > kFloatBitsMaxItems) return;      // sharded call: the integer-counter kernel takes it
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, slot = lane >> 4;
+    const int t16 = (qtile * NW + wave) * NQ;                        // first 16-query group of this wave
+    const int ncell = a.nb * 16;
+    u64* cnt = reinterpret_cast<u64*>(lds) + (wave * NQ) * ncell;
+    auto pack = [](uint2 x, uint2 y) {                               // k_scan_ap_c's counters: bits(2^23 + rank), bits(2^24 - 1 - ordinal)
+        return (u64)(kF23 + x.x + y.x + 1u) | ((u64)(kF23 + (0x7fffffu - (x.y + y.y + 1u))) << 32);
+    };
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + (t16 + h) * 16;
+        const uint2* __restrict__ pd = dpre + (t16 + h) * 16;
+        u64* c = cnt + h * ncell;
+        auto cell = [&](int e) { return e; };                          // [bucket][16 queries]: rows of 128 bytes
+        int e = lane;
+        for (; e + 3 * 64 < ncell; e += 4 * 64) {
+            uint2 x[4], y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ee = e + j * 64;
+                const int64_t at = (int64_t)(ee >> 4) * a.qpad + (ee & 15);
+                x[j] = pb[at];
+                y[j] = pd[at];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[cell(e + j * 64)] = pack(x[j], y[j]);
+        }
+        for (; e < ncell; e += 64) {
+            const int64_t at = (int64_t)(e >> 4) * a.qpad + (e & 15);
+            c[cell(e)] = pack(pb[at], pd[at]);
+        }
+    }
+    // query operands: the address chain with k_scan_hist_r2's query bytes (+-64 even registers, +-32 odd ones; the item bytes are doubled, see
+    // build), started 128 popcount(q) above the lane's counter; the label tiles 0 / -1
+    v4i bq[NQ], bl[NQ][NML], cq[NQ];
+    float capf[NQ], acc[NQ];
+    const int rsh = 4 * (slot & 1), rwi = slot >> 1;
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        const int64_t q = (int64_t)(t16 + h) * 16 + ql;
+        const bool valid = q < a.Q;
+        int pcq = 0;
+        uint32_t qw = 0u;
+        if (valid) {
+            for (int w = 0; w < a.W; ++w) pcq += __popc(a.qbits[q * a.W + w]);
+            if (rwi < a.W) qw = a.qbits[q * a.W + rwi];
+        }
+        qw >>= rsh;
+        const bool on = valid && rwi < a.W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = (qw >> j) & 0x01010101u;
+            if (j & 1) bq[h][j] = on ? (int)(0x20202020u ^ (t * 0xc0u)) : 0;       // +32 / -32
+            else bq[h][j] = on ? (int)(0x40404040u ^ (t << 7)) : 0;                // +64 / -64
+        }
+#pragma unroll
+        for (int m = 0; m < NML; ++m) {
+            uint32_t lw = 0u;
+            if (valid && 2 * m + rwi < a.LW) lw = a.qlab[q * a.LW + 2 * m + rwi];
+            lw >>= rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bl[h][m][j] = (int)(((lw >> j) & 0x01010101u) * 0xffu);
+        }
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) u64*)(cnt + h * ncell) + ql * 8 + (valid ? 128 * pcq : 0);
+        cq[h] = v4i{c0, c0, c0, c0};
+        asm volatile("" : "+v"(cq[h]));                                // opaque: kept in VGPRs (see k_scan_hist_m2, hazard iii)
+        capf[h] = CAPPED ? (float)min(cap_ws[q], kcap) : 0.0f;         // exact: below 2^23
+        acc[h] = 0.0f;
+    }
+    const int64_t lo = (int64_t)chunk_id * a.chunk;
+    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
+    const int nbat = (int)((hi - lo + 63) >> 6);
+    const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
+    uint32_t wcur[4][NMI], wnxt[4][NMI];
+    const int ritem = 4 * (lane & 3) + ((lane & 15) >> 2);
+    const int wi_c = rwi < a.W ? rwi : a.W - 1;
+    int wi_l[NML];
+#pragma unroll
+    for (int m = 0; m < NML; ++m) wi_l[m] = 2 * m + rwi < a.LW ? 2 * m + rwi : (a.LW > 0 ? a.LW - 1 : 0);
+    auto load_words = [&](int64_t batch, uint32_t (&w)[4][NMI]) {       // k_scan_hist_r2's: whole batches without clamps or masks
+        const int64_t first = batch * 64;
+        if (first + 64 <= (int64_t)a.R) {
+            const uint32_t* __restrict__ pc = a.rbits + (first + ritem) * a.W + wi_c;
+            const uint32_t* __restrict__ pl = a.rlab + (first + ritem) * a.LW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                w[g][0] = pc[g * 16 * a.W];
+#pragma unroll
+                for (int m = 0; m < NML; ++m) w[g][1 + m] = pl[g * 16 * a.LW + wi_l[m]];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t item = first + g * 16 + ritem;
+                const int64_t it = item < a.R ? item : (int64_t)a.R - 1;
+                const uint32_t ok = item < a.R ? 0xffffffffu : 0u;   // items past the end: all-zero codes, no labels -- they come after every real item
+                w[g][0] = a.rbits[it * a.W + wi_c] & ok;             // of their bucket and are never relevant, so they change no credit
+#pragma unroll
+                for (int m = 0; m < NML; ++m) w[g][1 + m] = a.rlab[it * a.LW + wi_l[m]] & ok;
+            }
+        }
+    };
+    // code tile: item bytes worth 2 (even registers) and 4 (odd ones) against the query bytes +-64 / +-32: products of +-128 = one counter row.
+    // Two rotations bring bits (0, 1) and (2, 3) of the lane's nibble to bits 1, 2 of their bytes (what wraps around lands outside the masks).
+    const uint32_t rot_a = (uint32_t)(rsh + 31) & 31u, rot_b = (uint32_t)rsh + 1u;
+    auto build = [&](v4i (&At)[NMI], const uint32_t (&w)[NMI]) {
+        const uint32_t xa = __builtin_amdgcn_alignbit(w[0], w[0], rot_a), xb = __builtin_amdgcn_alignbit(w[0], w[0], rot_b);
+        At[0][0] = (int)(xa & 0x02020202u);
+        At[0][1] = (int)(xa & 0x04040404u);
+        At[0][2] = (int)(xb & 0x02020202u);
+        At[0][3] = (int)(xb & 0x04040404u);
+#pragma unroll
+        for (int m = 1; m < NMI; ++m) {
+            const uint32_t y = w[m] >> rsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) At[m][j] = (int)(y & (0x01010101u << j));
+        }
+    };
+    auto credit = [&](u64 old, uint32_t m, int h) {                  // k_scan_ap_c's, operation for operation
+        const float rank = __uint_as_float((uint32_t)old) - 8388608.0f;
+        const float ord = 16777215.0f - __uint_as_float((uint32_t)(old >> 32));
+        if (CAPPED) m = ord <= capf[h] ? m : 0u;
+        acc[h] = fmaf(ord, __uint_as_float(__float_as_uint(__builtin_amdgcn_rcpf(rank)) & m), acc[h]);
+    };
+    // increment pairs {1, mask}: two sets of four, pinned (see the header); set = pair index & 1
+    v4i incA01 = {1, 0, 1, 0}, incA23 = {1, 0, 1, 0}, incB01 = {1, 0, 1, 0}, incB23 = {1, 0, 1, 0};
+    asm volatile("" : "+{v[112:115]}"(incA01), "+{v[116:119]}"(incA23), "+{v[120:123]}"(incB01), "+{v[124:127]}"(incB23));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the counters are in place (own wave's region only) before the first asm atomic
+    load_words(bat0, wcur);
+    for (int i = 0; i < nbat; ++i) {
+        load_words(bat0 + (i + 1 < nbat ? i + 1 : i), wnxt);
+        v4i A[4][NMI];                                               // one tile set per item group, each kept alive one statement past its last MFMA
+        build(A[0], wcur[0]);
+        build(A[1], wcur[1]);
+        build(A[2], wcur[2]);
+        build(A[3], wcur[3]);
+        u64 oldA[4], oldB[4];
+        v4i addr_p, lab_p;
+        auto evaluate = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& lab) {      // first pair of a batch: nothing to consume; closed by 8 wait states
+            if constexpr (NML == 2)
+                asm volatile("s_nop 3\n\t" XMH_AP2_MFMA("lab", "a1", "q1", "0") XMH_AP2_MFMA("lab", "a2", "q2", "%[lab]") XMH_AP2_MFMA("addr", "a0", "q0", "%[c0]") "s_nop 7"
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a2] "v"(At[NMI - 1]), [q2] "v"(bl[h][NML - 1]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]));
+            else
+                asm volatile("s_nop 3\n\t" XMH_AP2_MFMA("lab", "a1", "q1", "0") XMH_AP2_MFMA("addr", "a0", "q0", "%[c0]") "s_nop 7"
+                             : [lab] "=&v"(lab), [addr] "=&v"(addr)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]));
+        };
+#define XMH_AP2_OUTS(OLD) [lab] "=&v"(lab), [addr] "=&v"(addr), [o0] "=&v"(OLD[0]), [o1] "=&v"(OLD[1]), [o2] "=&v"(OLD[2]), [o3] "=&v"(OLD[3])
+#define XMH_AP2_PREV [p0] "v"(addr_p[0]), [p1] "v"(addr_p[1]), [p2] "v"(addr_p[2]), [p3] "v"(addr_p[3]), [l0] "v"(lab_p[0]), [l1] "v"(lab_p[1]), [l2] "v"(lab_p[2]), [l3] "v"(lab_p[3])
+        auto fusedA = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& lab) {          // consumers into set A
+            if constexpr (NML == 2)
+                asm volatile(XMH_AP2_FUSED2(XMH_AP2_SETA)
+                             : XMH_AP2_OUTS(oldA), "+{v[112:115]}"(incA01), "+{v[116:119]}"(incA23)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a2] "v"(At[NMI - 1]), [q2] "v"(bl[h][NML - 1]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]), XMH_AP2_PREV
+                             : "memory");
+            else
+                asm volatile(XMH_AP2_FUSED1(XMH_AP2_SETA)
+                             : XMH_AP2_OUTS(oldA), "+{v[112:115]}"(incA01), "+{v[116:119]}"(incA23)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]), XMH_AP2_PREV
+                             : "memory");
+        };
+        auto fusedB = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& lab) {          // consumers into set B
+            if constexpr (NML == 2)
+                asm volatile(XMH_AP2_FUSED2(XMH_AP2_SETB)
+                             : XMH_AP2_OUTS(oldB), "+{v[120:123]}"(incB01), "+{v[124:127]}"(incB23)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a2] "v"(At[NMI - 1]), [q2] "v"(bl[h][NML - 1]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]), XMH_AP2_PREV
+                             : "memory");
+            else
+                asm volatile(XMH_AP2_FUSED1(XMH_AP2_SETB)
+                             : XMH_AP2_OUTS(oldB), "+{v[120:123]}"(incB01), "+{v[124:127]}"(incB23)
+                             : [a1] "v"(At[1]), [q1] "v"(bl[h][0]), [a0] "v"(At[0]), [q0] "v"(bq[h]), [c0] "v"(cq[h]), XMH_AP2_PREV
+                             : "memory");
+        };
+        // the returns of set A / B are in (4 newer LDS operations in flight at most): credit them to query group h
+        auto drainA = [&](int h, auto newer) {
+            if constexpr (decltype(newer)::value == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(oldA[0]), "+v"(oldA[1]), "+v"(oldA[2]), "+v"(oldA[3])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldA[0]), "+v"(oldA[1]), "+v"(oldA[2]), "+v"(oldA[3])::"memory");
+            credit(oldA[0], (uint32_t)incA01[1], h);
+            credit(oldA[1], (uint32_t)incA01[3], h);
+            credit(oldA[2], (uint32_t)incA23[1], h);
+            credit(oldA[3], (uint32_t)incA23[3], h);
+        };
+        auto drainB = [&](int h, auto newer) {
+            if constexpr (decltype(newer)::value == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(oldB[0]), "+v"(oldB[1]), "+v"(oldB[2]), "+v"(oldB[3])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldB[0]), "+v"(oldB[1]), "+v"(oldB[2]), "+v"(oldB[3])::"memory");
+            credit(oldB[0], (uint32_t)incB01[1], h);
+            credit(oldB[1], (uint32_t)incB01[3], h);
+            credit(oldB[2], (uint32_t)incB23[1], h);
+            credit(oldB[3], (uint32_t)incB23[3], h);
+        };
+        using N4 = std::integral_constant<int, 4>;
+        using N0 = std::integral_constant<int, 0>;
+        // pair P = g * NQ + h.  Statement P evaluates pair P and issues the atomics of pair P - 1 into set (P - 1) & 1; behind it the returns of
+        // pair P - 2 (the same set as the NEXT statement writes) are credited.
+        auto step = [&](auto pc) {
+            constexpr int P = decltype(pc)::value, G = P / NQ, H = P % NQ;
+            v4i addr, lab;
+            if constexpr (P == 0) evaluate(A[0], 0, addr, lab);
+            else if constexpr ((P - 1) & 1) fusedB(A[G], H, addr, lab);
+            else fusedA(A[G], H, addr, lab);
+            addr_p = addr; lab_p = lab;
+            if constexpr (G > 0 && H == 0) {                          // the previous group's tiles may be reused from here on, not earlier
+                if constexpr (NMI == 2) asm volatile("" ::"v"(A[G - 1][0]), "v"(A[G - 1][1]));
+                else asm volatile("" ::"v"(A[G - 1][0]), "v"(A[G - 1][1]), "v"(A[G - 1][NMI - 1]));
+            }
+            if constexpr (P >= 2) {
+                if constexpr ((P - 2) & 1) drainB((P - 2) % NQ, N4{});
+                else drainA((P - 2) % NQ, N4{});
+            }
+        };
+        auto run = [&](auto self, auto pc) -> void {
+            step(pc);
+            if constexpr (decltype(pc)::value + 1 < 4 * NQ) self(self, std::integral_constant<int, decltype(pc)::value + 1>{});
+        };
+        run(run, std::integral_constant<int, 0>{});
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
+        {
+            constexpr int PL = 4 * NQ - 1;                            // the last pair's atomics, then everything drains
+            static_assert(PL & 1, "the last pair of a batch goes to set B");
+            asm volatile(XMH_AP2_TAIL(XMH_AP2_SETB)
+                         : [o0] "=&v"(oldB[0]), [o1] "=&v"(oldB[1]), [o2] "=&v"(oldB[2]), [o3] "=&v"(oldB[3]), "+{v[120:123]}"(incB01), "+{v[124:127]}"(incB23)
+                         : XMH_AP2_PREV, "v"(A[3][0]), "v"(A[3][1]), "v"(A[3][NMI - 1])
+                         : "memory");
+            drainA((PL - 1) % NQ, N4{});
+            drainB(PL % NQ, N0{});
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int m = 0; m < NMI; ++m) wcur[g][m] = wnxt[g][m];
+    }
+#undef XMH_AP2_OUTS
+#undef XMH_AP2_PREV
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        float s = acc[h];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + (t16 + h) * 16 + ql] = s;
+    }
+}
+
 // Does the LDS hand out same-address returning adds of one instruction in ascending lane order?  (see the header)
 __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ ok_out) {
     __shared__ unsigned long long c64[256];
@@ -2555,6 +2844,19 @@ inline bool mfma_ap_on() {                           // read per call (tests tog
     const char* e = getenv("XMH_SCAN_MFMA_AP");       // must of course see the same value
     return e && atoi(e) != 0;
 }
+// k_scan_ap_r2 (round 5): pass 2 evaluates the pairs again on the MFMA from the packed words instead of reading a pair cache (binary codes
+// of at most 64 bits whose pass 1 is k_scan_hist_r2).  Measured at Q 5000 x R 117 218 x 64 bit: pass 1 without the cache stores 0.157 ->
+// 0.128 ms, pass 2 0.173 (k_scan_ap_c on the cache) -> 0.262 ms, step 0.361 -> 0.416 ms -- so it is the pass 2 of evaluations that HAVE no
+// cache (XMH_SCAN_CACHE_MB exceeded or 0, not enough free memory), where it replaces the VALU re-evaluation of k_scan_ap_s.
+// XMH_SCAN_AP_R2=1 drops the cache for every such shape (the A/B of DESIGN 3.1), =0 never launches it (read per call; a histogram / ap
+// call pair must see the same value).
+inline int ap_r2_mode() {
+    const char* e = getenv("XMH_SCAN_AP_R2");
+    return e ? (atoi(e) != 0 ? 1 : 0) : 2;
+}
+inline bool ap_r2_on() { return ap_r2_mode() == 1; }      // the pair cache is given up for it
+constexpr int kAp2Waves = 4, kAp2Groups = 2;           // k_scan_ap_r2: waves per block x query groups of 16 per wave (66 KB of counters at 65 bucket rows, two
+                                                       // blocks per CU; 2 x 2, 1 x 2 and 1 x 1 measured the same 0.262-0.275 ms at the headline shape)
 constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
 // k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
 // two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
@@ -2630,6 +2932,7 @@ size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     const long long cap_mb = cap_env ? atoll(cap_env) : 131072;
     if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !m2_shape(K, ternary))) return 0;
     if (K <= 64 && mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
+    if (K <= 64 && m2_shape(K, ternary) && m2_regs(K) && ap_r2_on()) return 0;  // k_scan_ap_r2 likewise
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
@@ -3112,6 +3415,8 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
         const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
         if (half) snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, true>");
         else snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d, false>", b8 ? 8 : 16);        // all three template arguments: the name a profile prints
+    } else if (use_mfma && !cache && K <= 64 && m2_shape(K, tern) && m2_regs(K) && ap_r2_mode() != 0 && !packable && R <= kFloatBitsMaxItems) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_r2<%d, %d, %d, false>", NML, kAp2Waves, kAp2Groups);
     } else if (use_mfma && K <= 64 && mfma_ap_on()) {
         snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
@@ -3277,7 +3582,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const size_t cache_s = byte128 ? 0 : cache_bytes;                 // what the k_scan_ap_s launches below may read
     const bool apc = cache_bytes && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && rank_bits == 0 : apc_mode == 2 && K <= 256)) && !tern && !masked &&
                      (!base_all || byte128) && (sharded || R <= kFloatBitsMaxItems);
-    const uint32_t* fb_gate = apc && sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;
+    const uint32_t* fb_gate = apc && sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;      // (k_scan_ap_r2 sets it too, below)
     if (apc) {
         const bool b8 = K <= 64 || byte128;
         // one-byte entries read 8 slots x 8 queries wide (k_scan_ap_c<., 8, HALF>): where the counter rows of 16 queries leave few waves per CU
@@ -3301,6 +3606,28 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
              : b8 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
+    }
+    // k_scan_ap_r2: no pair cache, the pairs evaluated again on the MFMA from the packed words (same gating by the size word as k_scan_ap_c)
+    const bool apr2 = !cache_bytes && mfma_plan && K <= 64 && m2_shape(K, tern) && m2_regs(K) && ap_r2_mode() != 0 && LW <= 4 && !tern && !masked && !base_all &&
+                      rank_bits == 0 && (sharded || R <= kFloatBitsMaxItems);
+    if (apr2) {
+        fb_gate = sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;
+        constexpr int NW2 = kAp2Waves, NQ2 = kAp2Groups;
+        MfmaArgs ma{nullptr, nullptr, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW2 * NQ2 * 16)), (int)p.nbuckets, (int)p.qpad};
+        ma.rbits = rbits; ma.rlab = rlab; ma.qlab = qlab; ma.LW = LW;
+        const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));
+        const size_t lds = (size_t)NW2 * NQ2 * p.nbuckets * 16 * 8;
+        xmh::ProfScope prof("scan_ap", st);
+        auto go = [&](auto kern) {
+            const int r3 = raise_lds(kern, lds, "xmh_hamming_ap");
+            if (r3) return r3;
+            hipLaunchKernelGGL(kern, grid, dim3(64 * NW2), lds, st, ma, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap);
+            return (int)XMH_OK;
+        };
+        rc = LW <= 2 ? (capped ? go(k_scan_ap_r2<1, NW2, NQ2, true>) : go(k_scan_ap_r2<1, NW2, NQ2, false>))
+                     : (capped ? go(k_scan_ap_r2<2, NW2, NQ2, true>) : go(k_scan_ap_r2<2, NW2, NQ2, false>));
+        if (rc) return rc;
+        XMH_LAUNCH_CHECK("xmh_hamming_ap (MFMA from the packed words)");
     }
     // behind k_scan_ap_c on one-byte entries of 65..128-bit codes only the 64-bit stand-in is launched (always valid; it runs once in a blue moon)
     const int rb = (byte128 && apc) ? 0 : rank_bits;
@@ -3340,12 +3667,12 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             // behind a launched k_scan_ap_c (one-byte entries of 65..128-bit codes): the stand-in, gated by the wrap word / the size word
             const bool stand_in = byte128 && apc;
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rb, kcap, stand_in ? fb_gate : (const uint32_t*)nullptr, stand_in ? wrapped : (const uint32_t*)nullptr);
+                               (const uint32_t*)nrel_max, rb, kcap, stand_in || apr2 ? fb_gate : (const uint32_t*)nullptr, stand_in ? wrapped : (const uint32_t*)nullptr);
             return (int)XMH_OK;
         });
     };
-    if (apc && !fb_gate && !byte128) {
-        // k_scan_ap_c alone takes the call
+    if ((apc || apr2) && !fb_gate && !byte128) {
+        // k_scan_ap_c / k_scan_ap_r2 alone takes the call
     } else if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
         MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
                     (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)), (int)p.nbuckets, (int)p.qpad};

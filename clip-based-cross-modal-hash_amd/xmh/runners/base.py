@@ -419,7 +419,11 @@ class BaseTrainer:
         os.makedirs(save_dir, exist_ok=True)
         self.logger.info("Valid.")
         self._start_model_bytes()                            # the .pth a new best would write is serialised under the encode loop
-        (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(k)
+        try:
+            (mAPi2t, mAPt2i, mAPi2i, mAPt2t), codes = self._evaluate(k)
+        except BaseException:
+            self._drop_model_bytes()                         # never leave the serialising thread behind an exception
+            raise
         saved = False                                        # both bests in one epoch name the same model-<epoch>.pth: written once
         if self.max_mapi2t < mAPi2t:
             self.best_epoch_i = epoch
@@ -475,11 +479,18 @@ class BaseTrainer:
         model = self.model
         dev = next(model.parameters()).device
 
+        side = None
+        if dev.type == "cuda":
+            # valid() runs straight behind train_epoch(): the copies must not start before the optimizer step / load_state_dict kernels the
+            # caller's stream still holds -- the side stream is ordered behind it here, on the caller's thread
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+
         def work():
             try:
                 buf = io.BytesIO()
-                if dev.type == "cuda":
-                    with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+                if side is not None:
+                    with torch.cuda.device(dev), torch.cuda.stream(side):
                         torch.save(model.state_dict(), buf)
                 else:
                     torch.save(model.state_dict(), buf)
@@ -522,7 +533,17 @@ class BaseTrainer:
             if isinstance(t, matfile.Prepared):
                 return np.ascontiguousarray(t.host.T)
             return t.cpu().detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-        scio.savemat(os.path.join(save_file), dict(zip(names, (arr(v) for v in values))))
+        # scipy rewrites its target in place; valid() hard-links last.mat / *-best.mat to one file, so the fallback also writes
+        # a new inode and renames it over the name, like write_mat5
+        path = os.path.join(save_file)
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        try:
+            with open(tmp, "wb") as f:
+                scio.savemat(f, dict(zip(names, (arr(v) for v in values))))
+            os.replace(tmp, path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     @classmethod
     def from_config(cls, cfg, logger=None):

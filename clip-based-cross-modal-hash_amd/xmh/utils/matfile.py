@@ -72,7 +72,9 @@ def _column_major(value):
             raise UnsupportedMatValue("array of shape %s" % (a.shape,))
         rows, cols = int(a.shape[0]), int(a.shape[1])
         host = np.ascontiguousarray(a.T)
-    dt = host.dtype.newbyteorder("=") if host.dtype.byteorder not in ("=", "|", "<") else host.dtype
+    if host.dtype.byteorder not in ("=", "|", "<"):                # big-endian input: convert the BYTES, not only the label
+        host = host.astype(host.dtype.newbyteorder("="))
+    dt = host.dtype
     if np.dtype(dt) not in _CLASSES:
         raise UnsupportedMatValue("dtype %s" % host.dtype)
     if host.nbytes >= (1 << 32) - 64:

@@ -606,6 +606,39 @@ def test_scan_mfma_pass2_variant_gives_identical_bits(xr, monkeypatch):
             assert torch.equal(x, y), (Q, R, K, C)
 
 
+def test_scan_pass2_without_a_pair_cache_gives_identical_bits_and_matches_the_oracle(xr, monkeypatch):
+    """k_scan_ap_r2 (round 5): pass 2 evaluates the pairs again on the MFMA from the packed words (XMH_SCAN_AP_R2=1 drops the pair cache; it is
+    also what runs whenever a shape of at most 64 bits has no cache).  Same plan, same chunks, k_scan_ap_c's credits in k_scan_ap_c's order
+    per lane: AP sums, caps and capped sums bit for bit against the cached path; mAP against the oracle (common/calc_utils.py:58-92, stable
+    order).  One / two label tiles, one code word and two, a partial last word, ragged last batches, tiny galleries, surplus query rows."""
+    import ctypes as C_
+    from oracle import retrieval as orc
+    from xmh import _lib
+    for (Q, R, K, C, p, k) in ((150, 9001, 64, 80, 0.06, 9), (16, 2, 40, 64, 0.5, 1), (64, 8157, 48, 32, 0.5, 85), (127, 62, 64, 1, 0.01, 199),
+                               (300, 20011, 16, 24, 0.1, 50), (257, 4096, 33, 128, 0.05, 7), (90, 5001, 32, 80, 0.04, None)):
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=5 + K + R, p=p)
+        qL[:, 0] = 1
+        rL[::5, 0] = 1
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("XMH_SCAN_AP_R2", flag)
+            assert (int(_lib.lib.xmh_scan_pair_cache_bytes(Q, R, K, 0)) > 0) == (flag == "0")
+            scan = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+            scan.histograms(False)
+            ap, cap = scan.ap_sums(None)
+            apk, capk = scan.ap_sums(k)
+            outs.append((ap.clone(), cap.clone(), apk.clone(), capk.clone()))
+            if flag == "1":
+                buf = C_.create_string_buffer(512)
+                _lib.check(_lib.lib.xmh_scan_describe(Q, R, K, C, 0, buf, 512), "xmh_scan_describe")
+                assert "pass2=k_scan_ap_r2<%d, 4, 2, false>" % (1 if C <= 64 else 2) in buf.value.decode(), buf.value
+                m = float(scan.map_all(k)[0].item())
+                want = float(orc.map_k(qB, rB, qL, rL, k, stable=True))
+                assert abs(m - want) < 2e-6, (Q, R, K, C, m, want)
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (Q, R, K, C)
+
+
 def test_scan_mfma_pass1_for_65_to_256_bit_codes_matches_the_valu_pass1(xr, monkeypatch):
     """65..128-bit codes: pass 1 on the MFMA writes the pair cache in the layout of the 8-slot cached pass 2 (two 16-byte records per
     lane and batch).  Against the VALU pass 1 (XMH_SCAN_MFMA128=0): same histograms and caps bit for bit, same credits up to the

@@ -32,7 +32,7 @@ def _template_ints(name, kernel):
 def test_every_hand_scheduled_kernel_is_in_the_library(report):
     names = "\n".join(report)
     for k in ("k_scan_hist_m2ILi2ELi4ELi2ELb1ELb0E", "k_scan_hist_m2ILi1ELi4ELi4ELb1ELb0E", "k_scan_hist_r2ILi2ELi4ELi4ELb1E", "k_scan_hist_r2ILi1ELi4ELi4ELb0E", "k_scan_hist_r2wILi2ELi4ELi2ELb1E",
-              "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
+              "k_scan_ap_r2ILi2ELi4ELi2ELb0E", "k_scan_ap_r2ILi1ELi4ELi2ELb1E", "k_scan_hist_bILi2E", "k_scan_hist_bILi4E", "k_topk_filter_mfmaILi8E"):
         assert k in names, k
     assert sum(st["n_mfma"] for _, st in report.values()) > 1000
 

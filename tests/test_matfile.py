@@ -69,3 +69,27 @@ def test_save_mat_falls_back_to_scipy(tmp_path):
     BaseTrainer.save_mat(q, q, np.zeros((4, 2, 2)), q, q, torch.zeros(4, 3, dtype=torch.int64), save_file=path)   # 3-D labels: scipy's job
     m = scio.loadmat(path)
     assert m["q_l"].shape == (4, 2, 2) and m["r_l"].dtype == np.int64 and m["q_img"].dtype == np.float32
+
+
+def test_big_endian_arrays_are_converted_not_relabelled(tmp_path):
+    """a '>f4' array used to be written with its bytes unswapped under a little-endian header"""
+    a = np.arange(6, dtype=">f4").reshape(2, 3)
+    b = np.arange(6, dtype=">i8").reshape(3, 2)
+    path = str(tmp_path / "be.mat")
+    matfile.write_mat5(path, {"a": a, "b": b})
+    m = scio.loadmat(path)
+    assert np.array_equal(m["a"], np.arange(6, dtype=np.float32).reshape(2, 3)) and np.array_equal(m["b"], np.arange(6).reshape(3, 2))
+
+
+def test_scipy_fallback_writes_a_new_inode(tmp_path):
+    """valid() hard-links last.mat / i2t-best.mat to one file; the scipy fallback must not rewrite that inode in place"""
+    import xmh.runners  # noqa: F401
+    from xmh.runners.base import BaseTrainer
+    q = torch.ones(4, 8)
+    lab3 = np.zeros((4, 2, 2))                                  # 3-D labels: write_mat5 refuses, scipy takes it
+    first, link = str(tmp_path / "last.mat"), str(tmp_path / "i2t-best.mat")
+    BaseTrainer.save_mat(q, q, lab3, q, q, lab3, save_file=first)
+    matfile.link_or_copy(first, link)
+    BaseTrainer.save_mat(2 * q, q, lab3, q, q, lab3, save_file=first)
+    assert scio.loadmat(link)["q_img"][0, 0] == 1.0 and scio.loadmat(first)["q_img"][0, 0] == 2.0
+    assert sorted(os.listdir(tmp_path)) == ["i2t-best.mat", "last.mat"]

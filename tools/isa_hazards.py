@@ -247,7 +247,7 @@ def disassemble(path):
 
 
 # pass 2 (asm-issued returning atomics) and the pass-1 kernel that reads its A tiles with asm ds_read_b128 ahead of a counted wait
-LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m", "k_scan_hist_m2")
+LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m", "k_scan_ap_r2", "k_scan_hist_m2")
 
 
 def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
@@ -267,7 +267,7 @@ def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_r2", "k_scan_hist_b", "k_scan_hist_m", "k_topk_filter_mfma")):
+def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_r2", "k_scan_hist_b", "k_scan_hist_m", "k_scan_ap_r2", "k_topk_filter_mfma")):
     """-> {kernel: (violations, stats)} for every kernel whose mangled name contains one of name_filter"""
     work = tempfile.mkdtemp(prefix="xmh_isa_")
     try:
