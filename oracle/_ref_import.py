@@ -42,3 +42,45 @@ def setup():
         tc = types.ModuleType("termcolor")
         tc.colored = lambda s, *a, **k: s
         sys.modules["termcolor"] = tc
+    try:
+        import xlrd  # noqa: F401
+    except ImportError:
+        sys.modules["xlrd"] = _xlrd_stand_in()
+
+
+def _xlrd_stand_in():
+    """The one xlrd call chain the reference makes -- ``xlrd.open_workbook(path).sheet_by_index(0).row(i)[j].value``
+    (models/DSPH/DSPH.py:33-35: the HyP loss threshold out of models/DSPH/loss/codetable.xlsx) -- over the real workbook: an .xlsx is
+    a zip of XML, its numeric cells are read with zipfile + a regular expression.  Rows and columns are 0-based as in xlrd; an absent
+    cell has the value ''.  xlrd itself is not in the image (and has not read .xlsx since 2.0)."""
+    import re
+    import zipfile
+
+    class Cell:
+        def __init__(self, value):
+            self.value = value
+
+    class Sheet:
+        def __init__(self, xml):
+            self.cells = {}
+            for col, row, val in re.findall(r'<c r="([A-Z]+)(\d+)"[^>]*><v>([^<]*)</v>', xml):
+                c = 0
+                for ch in col:
+                    c = c * 26 + (ord(ch) - 64)
+                self.cells[(int(row) - 1, c - 1)] = float(val)
+            self.ncols = 1 + max(c for _, c in self.cells)
+
+        def row(self, i):
+            return [Cell(self.cells.get((i, j), "")) for j in range(self.ncols)]
+
+    class Book:
+        def __init__(self, path):
+            with zipfile.ZipFile(path) as z:
+                self.sheets = [Sheet(z.read("xl/worksheets/sheet1.xml").decode())]
+
+        def sheet_by_index(self, i):
+            return self.sheets[i]
+
+    m = types.ModuleType("xlrd")
+    m.open_workbook = Book
+    return m

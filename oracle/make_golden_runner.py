@@ -1,6 +1,6 @@
 """Generate tests/golden/runner.npz by RUNNING the reference's own runners and models on the 8-query / 24-gallery synthetic set
 (SURVEY 8c): DCMHTTrainer.get_code + valid (runners/base.py:242-266, :307-339), MITHTrainer's generate_hash override
-(runners/MITH/runner.py:125-131) through the same get_code/valid, and the TwDH class (models/TwDH/TwDH.py:34-85, instantiated
+(runners/MITH/runner.py:125-131) through the same get_code/valid, DSPHTrainer (runners/DSPH/runner.py; models/DSPH/DSPH.py:15-48) likewise, and the TwDH class (models/TwDH/TwDH.py:34-85, instantiated
 with the centre / transform matrices the reference SHIPS under data/transformer/TwDH/coco) through TwDHTrainer.get_code / valid
 (runners/TwDH/runner.py:145-228).  Recorded per method: the four code buffers, the four mAPs of the log line, the log line
 itself, the arrays of last.mat; for TwDH also the three shipped [1024, 2*short] transform matrices (inputs of the GPU test).
@@ -111,9 +111,16 @@ def main():
                 r = super().load_backbone(clipPath, return_patches)
                 return r[0], r[-1]
 
-        for arch, mcls, tcls in (("DCMHT", DCMHT, DCMHTTrainer), ("MITH", MITHLoadable, MITHTrainer)):
+        # DSPH (configs[3]'s method): the reference's own class and trainer; its constructor reads the HyP loss threshold
+        # out of models/DSPH/loss/codetable.xlsx through xlrd, which is not in the image -- _ref_import stands in for that one call chain
+        # over the real workbook.  DSPHTrainer has no overrides on the evaluation path: BaseTrainer.generate_hash / make_hash_code (sign_).
+        from models.DSPH.DSPH import DSPH
+        from runners.DSPH.runner import DSPHTrainer
+
+        for arch, mcls, tcls in (("DCMHT", DCMHT, DCMHTTrainer), ("MITH", MITHLoadable, MITHTrainer), ("DSPH", DSPH, DSPHTrainer)):
             K = RF.CASES[arch]
-            model = mcls.from_config({"clip_path": clip_file}, output_dim=K, train_num=RF.RETRIEVAL_NUM)
+            cfg_model = {"clip_path": clip_file, "numclass": RF.NUM_CLASSES} if arch == "DSPH" else {"clip_path": clip_file}
+            model = mcls.from_config(cfg_model, output_dim=K, train_num=RF.RETRIEVAL_NUM)
             sd = model.state_dict()
             sd.update(RF.head_state(W, "%s%d" % (arch, K), sd))
             model.load_state_dict(sd)

@@ -11,7 +11,7 @@ import torch
 SEED = 1814
 CLIP_LAYERS = 2
 QUERY_NUM, RETRIEVAL_NUM, NUM_CLASSES, BATCH = 8, 24, 24, 5          # "a 8-query/24-gallery synthetic set"
-CASES = {"DCMHT": 16, "MITH": 64, "TwDH": 512}
+CASES = {"DCMHT": 16, "MITH": 64, "TwDH": 512, "DSPH": 128}
 
 
 def head_state(W, tag, state_dict):

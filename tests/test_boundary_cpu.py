@@ -129,3 +129,66 @@ def test_loss_display_line_is_the_reference_format():
     assert lines == [">>>>>> Display (l1 loss-16) >>>>>> [3/100], [40/79]: All loss: 1.5, Intra: Positive: 0.25, Negative: 0.5, "
                      "Inter: Positive: i2t: 1, t2i: 2, Negative: i2t: 3, t2i: 4, Quan: Image: 0.4, Text: 0.3, "
                      "lr: 0.000010000-0.001000000"]
+
+
+def _scripted_archive(state_dict, path):
+    """a TorchScript archive whose ``state_dict()`` has exactly these dotted names -- what OpenAI's ViT-B-32.pt is to the reference
+    (models/base.py:21-23: ``torch.jit.load(clipPath).state_dict()``; every shipped config names ./ViT-B-32.pt)"""
+    class Holder(torch.nn.Module):
+        def forward(self):
+            return torch.zeros(1)
+
+    root = Holder()
+    for key, value in state_dict.items():
+        node, parts = root, key.split(".")
+        for name in parts[:-1]:
+            if not hasattr(node, name):
+                node.add_module(name, Holder())
+            node = getattr(node, name)
+        if value.is_floating_point() and value.dim() > 0:
+            node.register_parameter(parts[-1], torch.nn.Parameter(value.clone(), requires_grad=False))
+        else:
+            node.register_buffer(parts[-1], value.clone())
+    torch.jit.save(torch.jit.script(root), path)
+
+
+def test_load_backbone_takes_the_torchscript_branch(tmp_path):
+    """models/base.py:21-23 -- the branch every shipped config takes.  A scripted module holding a 1-layer
+    CLIP-shaped state_dict (plus the three scalar buffers OpenAI's archive carries, which build_model deletes, model.py:471-473) is
+    saved with torch.jit.save and loaded through load_backbone; the plain-state_dict file of the same tensors must give the same model."""
+    import xmh.models  # noqa: F401
+    from xmh.models import weights as W
+    sd = W.synth_clip_state_dict(5, vision_layers=1, transformer_layers=1, vocab_size=600)
+    sd["input_resolution"], sd["context_length"], sd["vocab_size"] = torch.tensor(224), torch.tensor(77), torch.tensor(600)
+    jit_path, plain_path = str(tmp_path / "ViT-tiny.pt"), str(tmp_path / "plain.pt")
+    _scripted_archive(sd, jit_path)
+    torch.save(dict(sd), plain_path)
+    loaded = torch.jit.load(jit_path, map_location="cpu").state_dict()              # the archive really is TorchScript and carries the names
+    assert set(loaded) == set(sd) and torch.equal(loaded["visual.conv1.weight"], sd["visual.conv1.weight"])
+    with pytest.raises(RuntimeError):
+        torch.jit.load(plain_path)                                                  # ... and the plain file really takes the other branch
+    a = registry.get_model_class("DSPH").from_config(Config({"clip_path": jit_path}), output_dim=32)
+    b = registry.get_model_class("DSPH").from_config(Config({"clip_path": plain_path}), output_dim=32)
+    sa, sb = a.backbone.state_dict(), b.backbone.state_dict()
+    assert set(sa) == set(sb) and len(a.backbone.visual.transformer.resblocks) == 1 and a.backbone.vocab_size == 600
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert torch.equal(sa["visual.conv1.weight"], sd["visual.conv1.weight"].half().float())
+
+
+def test_dsph_state_dict_has_the_reference_checkpoint_keys():
+    """the key list of the REFERENCE's DSPH class (tests/golden/runner.npz, DSPH_state_keys, written by
+    oracle/make_golden_runner.py from models/DSPH/DSPH.py) -- including ``hyp.proxies`` of its loss module -- equals this package's,
+    so a reference DSPH checkpoint loads strictly (runners/base.py:103-105)."""
+    import numpy as np
+    import xmh.models  # noqa: F401
+    from conftest import GOLDEN
+    from oracle import runner_fixture as RF
+    g = np.load(os.path.join(GOLDEN, "runner.npz"))
+    want = sorted(str(k) for k in g["DSPH_state_keys"])
+    K = RF.CASES["DSPH"]
+    model = registry.get_model_class("DSPH").from_config(
+        Config({"clip_path": "synthetic:%d:vision_layers=%d,transformer_layers=%d" % (RF.SEED, RF.CLIP_LAYERS, RF.CLIP_LAYERS), "numclass": RF.NUM_CLASSES}), output_dim=K)
+    sd = model.state_dict()
+    assert sorted(k for k in sd if not k.endswith("num_batches_tracked")) == want and "hyp.proxies" in want
+    assert tuple(sd["hyp.proxies"].shape) == (RF.NUM_CLASSES, K)
+    model.load_state_dict({k: torch.zeros_like(v) for k, v in sd.items()}, strict=True)

@@ -290,11 +290,12 @@ def _check_maps_against_reference_log(mine, ref_logged, trainer, code_pairs, exa
             assert lo - 1e-6 <= got <= hi + 1e-6
 
 
-@pytest.mark.parametrize("arch,runner", [("DCMHT", "DCMHTTrainer"), ("MITH", "MITHTrainer")])
+@pytest.mark.parametrize("arch,runner", [("DCMHT", "DCMHTTrainer"), ("MITH", "MITHTrainer"), ("DSPH", "DSPHTrainer")])
 def test_runner_reproduces_reference_runner_golden(tmp_path, arch, runner):
     """SURVEY 8c / VERDICT r1 a-7: get_code buffers, valid() mAPs, log line and .mat arrays of the REFERENCE's own
-    DCMHTTrainer / MITHTrainer (run by oracle/make_golden_runner.py on the 8-query / 24-gallery synthetic set) against this
-    package's runners on the same weights and data."""
+    DCMHTTrainer / MITHTrainer / DSPHTrainer (run by oracle/make_golden_runner.py on the 8-query / 24-gallery synthetic set) against
+    this package's runners on the same weights and data.  DSPH (configs[3]'s method, 128 bit): the reference
+    class is constructed with its HyP threshold read from the workbook it ships (oracle/_ref_import.py stands in for xlrd)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import logging
