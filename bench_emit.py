@@ -95,6 +95,9 @@ def compact(out):
         alg = out["roofline"].get("algorithmic")
         if "frac_step" not in r and isinstance(alg, dict) and "frac_step" in alg:
             r["frac_step"] = alg["frac_step"]
+        hbm = out["roofline"].get("hbm")
+        if isinstance(hbm, dict) and "frac" in hbm:                     # the same launch against the HBM roof (Q queries share every byte)
+            r["hbm_frac"] = hbm["frac"]
         r["kernel"] = _short(r.get("kernel"), 96)
         line["roofline"] = r
     if isinstance(out.get("cpu_baseline"), dict):

@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 // operand planes of the GEMM that consumes it (xmh_planes.h) -- the same values either way.
 __global__ __launch_bounds__(256) void k_layernorm4(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, float* __restrict__ y, int64_t ldy,
-                                                    xmh::Planes p, int64_t rows, int D) {
+                                                    xmh::Planes p, int64_t rows, int D, const int32_t* __restrict__ rows_dev) {
     constexpr int NV = kLnMaxPerLane / 4;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    if (row >= rows || (rows_dev && row >= *rows_dev)) return;       // rows_dev: the real row count, known on the device only
     const float* xr = x + row * ldx;
     float4 v[NV];
     float s = 0.0f;
@@ -290,7 +290,7 @@ void k_attention_mfma64(const float* __restrict__ qkv, int Lmax, int H, int caus
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const int j = 32 * kk + t;
-        const uint32_t m = (kpm && j < L) ? (uint32_t)kpm[(int64_t)b * L + j] : 0u;
+        const uint32_t m = (kpm && j < L) ? (uint32_t)kpm[(int64_t)b * Lmax + j] : 0u;      // the mask keeps the padded [B, Lmax] layout in packed mode too
         dead_keys |= ((j >= L || m != 0u) ? 1u : 0u) << t;
     }
     float kb[2][S16 ? 1 : 32], vb[2][S16 ? 1 : 32];
@@ -489,6 +489,73 @@ __global__ __launch_bounds__(256) void k_text_embed_packed(const int64_t* __rest
     for (int c = lane; c < D; c += 64) dst[c] = tok[id * D + c] + pos[(int64_t)l * D + c];
 }
 
+// Caption lengths, counted where the ids are (xmh_text_forward_packed_dev): one block; thread t takes captions t, t + 1024, ...;
+// eos = first maximum of the ids (what CLIP.encode_text's argmax picks, models/CLIP/model.py:392); rows kept = up to EOS, or up to the last
+// position the key padding mask leaves visible if that lies further back (rows the mask hides behind it are never kept: nothing may read
+// them); offs = exclusive prefix over the captions in tiles of 1024 with a running carry.
+__global__ __launch_bounds__(1024) void k_caption_offsets(const int64_t* __restrict__ ids, const uint8_t* __restrict__ kpm, int64_t B, int L,
+                                                          int32_t* __restrict__ offs, int32_t* __restrict__ eos) {
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < B; b0 += 1024) {
+        const int64_t b = b0 + t;
+        int len = 0;
+        if (b < B) {
+            int best = 0;
+            int64_t bv = ids[b * L];
+            for (int j = 1; j < L; ++j) {
+                const int64_t v = ids[b * L + j];
+                if (v > bv) { bv = v; best = j; }
+            }
+            len = best + 1;
+            if (kpm)
+                for (int j = L - 1; j > best; --j)
+                    if (kpm[b * L + j] == 0) { len = j + 1; break; }
+            if (eos) eos[b] = best;
+        }
+        part[t] = len;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                          // inclusive scan of the tile (Hillis-Steele: 10 steps)
+            const int v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        if (b < B) offs[b] = carry + part[t] - len;
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) offs[B] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rows(const float* __restrict__ packed, int64_t ldp, const int32_t* __restrict__ offs, float* __restrict__ out,
+                                                     int64_t B, int L, int D4) {
+    const int64_t total = B * L * D4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / D4;
+        const int c = (int)(e % D4) * 4;
+        const int64_t b = row / L;
+        const int l = (int)(row % L);
+        const int o0 = offs[b];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < offs[b + 1] - o0) v = *reinterpret_cast<const float4*>(packed + (int64_t)(o0 + l) * ldp + c);
+        *reinterpret_cast<float4*>(out + row * (int64_t)D4 * 4 + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_packed_rows(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ offs, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ out, int64_t rows, int D) {
+    const int64_t total = rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D;
+        out[e] = x[(int64_t)(offs[r] + idx[r]) * ldx + (int)(e % D)];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gather_last_rows(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ offs, float* __restrict__ out,
                                                           int64_t rows, int D) {
     const int64_t total = rows * D;
@@ -640,14 +707,15 @@ inline int grid1d(int64_t work, int per_block = 256) {
 namespace xmh {
 
 int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y, int64_t ldy, const Planes& p,
-                     int64_t rows, int D, hipStream_t st) {
+                     int64_t rows, int D, hipStream_t st, const int32_t* rows_dev) {
     if (rows < 0 || D <= 0 || D > 64 * kLnMaxPerLane) return fail(XMH_EINVAL, "xmh_layernorm_f32: bad shape rows=%lld D=%d (D <= %d)", (long long)rows, D, 64 * kLnMaxPerLane);
     if (rows == 0) return XMH_OK;
     if (!x || !gamma || !beta || (!y && !p.hi)) return fail(XMH_EINVAL, "xmh_layernorm_f32: null pointer");
     const bool vec = D % 4 == 0 && ldx % 4 == 0 && (!y || ldy % 4 == 0) && (!p.hi || p.ld % 4 == 0) &&
                      (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0 &&
                      (reinterpret_cast<uintptr_t>(p.hi) | reinterpret_cast<uintptr_t>(p.lo)) % 8 == 0;
-    if (vec) hipLaunchKernelGGL(k_layernorm4, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, p, rows, D);
+    if (vec) hipLaunchKernelGGL(k_layernorm4, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, p, rows, D, rows_dev);
+    else if (rows_dev) return fail(XMH_ENOTSUP, "xmh layernorm: a device-side row count needs D %% 4 == 0 and 16-byte aligned rows (D=%d)", D);
     else if (p.hi) return fail(XMH_ENOTSUP, "xmh layernorm: operand planes need D %% 4 == 0 and 16-byte aligned rows (D=%d)", D);
     else hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, y, ldy, rows, D);
     XMH_LAUNCH_CHECK("xmh_layernorm_f32");
@@ -662,7 +730,7 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
     if (L > 128) return fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
     if (!qkv || (!out && !p.hi)) return fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
     static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
-    if (row_offsets && (L > 64 || key_padding_mask)) return fail(XMH_ENOTSUP, "xmh attention: packed sequences need L <= 64 and no key padding mask (L=%d)", L);
+    if (row_offsets && L > 64) return fail(XMH_ENOTSUP, "xmh attention: packed sequences need L <= 64 (L=%d)", L);
     if (L <= 64 && (!valu_only || row_offsets)) {                    // fp32-MFMA kernel: one wave per head
         if (split16) hipLaunchKernelGGL(k_attention_mfma64<true>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p, row_offsets);
         else hipLaunchKernelGGL(k_attention_mfma64<false>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p, row_offsets);
@@ -694,6 +762,33 @@ int gather_last_rows(const float* x, int64_t ldx, const int32_t* row_offsets, fl
     if (!x || !out || !row_offsets) return fail(XMH_EINVAL, "xmh gather_last_rows: null pointer");
     hipLaunchKernelGGL(k_gather_last_rows, dim3(grid1d(B * D)), dim3(256), 0, st, x, ldx, row_offsets, out, B, D);
     XMH_LAUNCH_CHECK("xmh gather_last_rows");
+    return XMH_OK;
+}
+
+int caption_offsets(const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L, int32_t* offs, int32_t* eos, hipStream_t st) {
+    if (B < 0 || L <= 0) return fail(XMH_EINVAL, "xmh caption_offsets: bad shape");
+    if (!ids || !offs) return fail(XMH_EINVAL, "xmh caption_offsets: null pointer");
+    if (B * (int64_t)L >= (1ll << 31)) return fail(XMH_ENOTSUP, "xmh caption_offsets: %lld x %d tokens", (long long)B, L);
+    hipLaunchKernelGGL(k_caption_offsets, dim3(1), dim3(1024), 0, st, ids, key_padding_mask, B, L, offs, eos);
+    XMH_LAUNCH_CHECK("xmh caption_offsets");
+    return XMH_OK;
+}
+
+int unpack_rows(const float* packed, int64_t ldp, const int32_t* offs, float* out, int64_t B, int L, int D, hipStream_t st) {
+    if (B < 0 || L <= 0 || D <= 0 || D % 4 || ldp % 4) return fail(XMH_EINVAL, "xmh unpack_rows: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!packed || !offs || !out || (reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) % 16) return fail(XMH_EINVAL, "xmh unpack_rows: null or unaligned pointer");
+    hipLaunchKernelGGL(k_unpack_rows, dim3(grid1d(B * L * (D / 4))), dim3(256), 0, st, packed, ldp, offs, out, B, L, D / 4);
+    XMH_LAUNCH_CHECK("xmh unpack_rows");
+    return XMH_OK;
+}
+
+int gather_packed_rows(const float* packed, int64_t ldp, const int32_t* offs, const int32_t* idx, float* out, int64_t B, int D, hipStream_t st) {
+    if (B < 0 || D <= 0) return fail(XMH_EINVAL, "xmh gather_packed_rows: bad shape");
+    if (B == 0) return XMH_OK;
+    if (!packed || !offs || !idx || !out) return fail(XMH_EINVAL, "xmh gather_packed_rows: null pointer");
+    hipLaunchKernelGGL(k_gather_packed_rows, dim3(grid1d(B * D)), dim3(256), 0, st, packed, ldp, offs, idx, out, B, D);
+    XMH_LAUNCH_CHECK("xmh gather_packed_rows");
     return XMH_OK;
 }
 

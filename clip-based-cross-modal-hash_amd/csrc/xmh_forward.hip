@@ -67,7 +67,7 @@ bool planes_layer(const xmh_linear& l) { return l.w_hi && l.k % 32 == 0; }
 
 // act(A @ W^T + bias) (+ residual) from operand planes; C and / or the result's own planes
 int linear_p(const xmh_linear& l, const xmh::Planes& A, const float* residual, int64_t ldr, float* C, int64_t ldc, const xmh::Planes* out,
-             int64_t M, int act, int precision, xmh_stream_t st) {
+             int64_t M, int act, int precision, xmh_stream_t st, const int32_t* m_dev = nullptr) {
     xmh::GemmPlanes g{};
     g.A_hi = A.hi; g.A_lo = precision == kPrecParity ? A.lo : nullptr; g.lda = A.ld;
     g.W_hi = static_cast<const _Float16*>(l.w_hi);
@@ -76,6 +76,7 @@ int linear_p(const xmh_linear& l, const xmh::Planes& A, const float* residual, i
     g.bias = l.bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc;
     if (out) g.O = *out;
     g.M = M; g.N = l.n; g.K = l.k; g.act = act;
+    g.m_dev = m_dev;
     return xmh::gemm_planes(g, xmh::as_stream(st));
 }
 
@@ -108,7 +109,9 @@ struct TailRows {
 // rows [offs[b], offs[b + 1])
 int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L, int causal,
                const uint8_t* kpm, int precision, const BlockScratch& s, xmh_stream_t st, const int32_t* offs = nullptr, int64_t M_packed = 0,
-               TailRows tail = TailRows{}) {
+               TailRows tail = TailRows{}, const int32_t* m_dev = nullptr) {
+    // m_dev (xmh_text_forward_packed_dev): the packed row count lives in a device word; M_packed is then its upper bound (B * L), which
+    // sizes the launches -- the row-wise kernels return on the rows behind the real count.  Parity / fast mode only.
     static const bool tail_off = getenv("XMH_TAIL_ROWS") && atoi(getenv("XMH_TAIL_ROWS")) == 0;      // A/B switch: 0 = the full last block + a gather
     const bool want_tail = tail.mode != 0;
     const bool tail_fused = want_tail && !tail_off && width % 2 == 0;
@@ -127,6 +130,7 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
             return xmh::fail(-22, "xmh forward: block %d has layer shapes that do not fit width %d", i, D);
         int rc;
         if (precision == kPrecExact) {
+            if (m_dev) return xmh::fail(-95, "xmh forward: a device-side row count needs parity or fast mode");
             if (!b.qkv.w_f32 || !b.out.w_f32 || !b.fc.w_f32 || !b.proj.w_f32) return xmh::fail(-22, "xmh forward: block %d lacks fp32 weights (exact mode)", i);
             rc = xmh_layernorm_f32(x, D, b.ln1_w, b.ln1_b, kLnEps, s.h, D, M, D, st);
             if (rc) return rc;
@@ -157,9 +161,9 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
         }
         if (!planes_layer(b.qkv) || !planes_layer(b.out) || !planes_layer(b.fc) || !planes_layer(b.proj))
             return xmh::fail(-22, "xmh forward: block %d lacks fp16 weights (w_hi) for width %d", i, D);
-        rc = xmh::layernorm_planes(x, D, b.ln1_w, b.ln1_b, kLnEps, nullptr, 0, s.hP, M, D, hs);
+        rc = xmh::layernorm_planes(x, D, b.ln1_w, b.ln1_b, kLnEps, nullptr, 0, s.hP, M, D, hs, m_dev);
         if (rc) return rc;
-        rc = linear_p(b.qkv, s.hP, nullptr, 0, s.qkv, 3 * D, nullptr, M, kActNone, precision, st);
+        rc = linear_p(b.qkv, s.hP, nullptr, 0, s.qkv, 3 * D, nullptr, M, kActNone, precision, st, m_dev);
         if (rc) return rc;
         rc = xmh::attention_planes(s.qkv, B, L, heads, D / heads, causal, kpm, nullptr, s.aP, true, hs, offs);
         if (rc) return rc;
@@ -175,13 +179,13 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
             if ((rc = linear_p(b.proj, fc, xt, D, xt, D, nullptr, B, kActNone, precision, st))) return rc;
             return 0;
         }
-        rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st);
+        rc = linear_p(b.out, s.aP, x, D, x, D, nullptr, M, kActNone, precision, st, m_dev);
         if (rc) return rc;
-        rc = xmh::layernorm_planes(x, D, b.ln2_w, b.ln2_b, kLnEps, nullptr, 0, s.hP, M, D, hs);
+        rc = xmh::layernorm_planes(x, D, b.ln2_w, b.ln2_b, kLnEps, nullptr, 0, s.hP, M, D, hs, m_dev);
         if (rc) return rc;
-        rc = linear_p(b.fc, s.hP, nullptr, 0, nullptr, 0, &s.fP, M, kActQuickGelu, precision, st);
+        rc = linear_p(b.fc, s.hP, nullptr, 0, nullptr, 0, &s.fP, M, kActQuickGelu, precision, st, m_dev);
         if (rc) return rc;
-        rc = linear_p(b.proj, s.fP, x, D, x, D, nullptr, M, kActNone, precision, st);
+        rc = linear_p(b.proj, s.fP, x, D, x, D, nullptr, M, kActNone, precision, st, m_dev);
         if (rc) return rc;
     }
     (void)none;
@@ -276,6 +280,7 @@ struct TowerScratch {
     float *x, *cols, *patches, *row_a, *row_b, *y;
     xmh::Planes colsP;                               // parity / fast mode: im2col writes the conv1 GEMM's operand planes
     int32_t* eos;
+    int32_t* offs;                                   // [B + 1] packed row offsets counted on the device (xmh_text_forward_packed_dev)
 };
 
 // conv_k > 0: image tower (im2col columns + patch embeddings); out_dim > 0: all tokens go through the final LN + projection
@@ -292,6 +297,7 @@ TowerScratch carve_tower(Arena& ar, int64_t B, int L, int width, int conv_k, int
     t.row_b = ar.take<float>((size_t)B * width);
     t.y = out_dim > 0 ? ar.take<float>((size_t)M * width) : nullptr;
     t.eos = ar.take<int32_t>((size_t)B);
+    t.offs = ar.take<int32_t>((size_t)B + 1);
     return t;
 }
 
@@ -453,6 +459,62 @@ extern "C" int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t*
     rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, nullptr, precision, t.blk, stream, row_offsets, total_rows, tail);
     if (rc) return rc;
     return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
+}
+
+// The packed text forward with the caption lengths counted ON THE DEVICE (round 5): no host synchronisation, so the two towers' streams
+// never wait on each other's host thread and the call can be captured in a hipGraph.  The lengths (xmh::caption_offsets) stay in the
+// workspace; every row-wise launch is sized for B * L rows and returns on the rows behind offs[B] (GArgsP::m_dev, k_layernorm4).
+//   * key_padding_mask (MITH: models/MITH/MITH.py:59-66 -> models/CLIP/model.py:378): applied to the keys as in the padded call; a caption
+//     keeps its rows up to EOS or up to the last position the mask leaves visible, whichever is further back, so every row that any later
+//     consumer may read unmasked is computed exactly as in xmh_text_forward;
+//   * out_tokens ([B, L, out_dim], return_patches): the kept rows in the reference's padded layout, the dropped rows (all hidden by the
+//     mask) ZERO where the padded call returns what attention made of padding -- callers that read masked rows must use xmh_text_forward.
+// out_eos is bit-identical to xmh_text_forward's, and so is every kept row of out_tokens.  Parity / fast mode (exact mode: -ENOTSUP).
+extern "C" int xmh_text_forward_packed_dev(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
+                                           int precision, float* out_eos, float* out_tokens, void* workspace, size_t workspace_bytes,
+                                           xmh_stream_t stream) {
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == kPrecExact) return xmh::fail(-95, "xmh_text_forward_packed_dev: parity or fast mode only");
+    if (B == 0) return 0;
+    if (!w || !ids || !workspace || (!out_eos && !out_tokens)) return xmh::fail(-22, "xmh_text_forward_packed_dev: bad arguments");
+    if (L <= 0 || L > w->context || L > 64) return xmh::fail(-22, "xmh_text_forward_packed_dev: %d tokens (positional embedding %d, packed attention 64)", L, w->context);
+    const int D = w->width;
+    if (w->heads <= 0 || D % w->heads || w->proj.n != w->out_dim || w->proj.k != D) return xmh::fail(-22, "xmh_text_forward_packed_dev: shapes do not fit the tower");
+    Arena ar(workspace);
+    const TowerScratch t = carve_tower(ar, B, L, D, 0, out_tokens ? w->out_dim : 0, precision);
+    if (ar.used > workspace_bytes) return xmh::fail(-12, "xmh_text_forward_packed_dev: workspace of %zu bytes, %zu needed", workspace_bytes, ar.used);
+    hipStream_t hs = xmh::as_stream(stream);
+    const int64_t Mub = B * L;
+    const int32_t* m_dev = t.offs + B;
+    int rc = xmh::caption_offsets(ids, key_padding_mask, B, L, t.offs, t.eos, hs);
+    if (rc) return rc;
+    rc = xmh::text_embed_packed(ids, w->tok_emb, w->pos, t.x, t.offs, B, L, D, w->vocab, hs);
+    if (rc) return rc;
+    if (!out_tokens) {
+        TailRows tail;
+        if (key_padding_mask) { tail.mode = 0; }                     // the kept rows may run past EOS: the EOS row is picked by index below
+        else { tail.mode = 3; tail.x_tail = t.row_a; }
+        rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream, t.offs, Mub, tail, m_dev);
+        if (rc) return rc;
+        if (key_padding_mask) {
+            rc = xmh::gather_packed_rows(t.x, D, t.offs, t.eos, t.row_a, B, D, hs);
+            if (rc) return rc;
+        }
+        return ln_linear(t.row_a, B, D, w->ln_final_w, w->ln_final_b, w->proj, t.row_b, out_eos, precision, t.blk, stream);
+    }
+    rc = run_blocks(w->blocks, w->layers, D, w->heads, t.x, B, L, 1, key_padding_mask, precision, t.blk, stream, t.offs, Mub, TailRows{}, m_dev);
+    if (rc) return rc;
+    // ln_final + text_projection on the packed rows (t.y holds the projected rows, [rows, out_dim] inside its M * width floats), then the
+    // reference's padded layout
+    if (!planes_layer(w->proj) || !t.blk.hP.hi || w->out_dim > D) return xmh::fail(-95, "xmh_text_forward_packed_dev: the projection needs fp16 weights and out_dim <= width");
+    rc = xmh::layernorm_planes(t.x, D, w->ln_final_w, w->ln_final_b, kLnEps, nullptr, 0, t.blk.hP, Mub, D, hs, m_dev);
+    if (rc) return rc;
+    rc = linear_p(w->proj, t.blk.hP, nullptr, 0, t.y, w->out_dim, nullptr, Mub, kActNone, precision, stream, m_dev);
+    if (rc) return rc;
+    rc = xmh::unpack_rows(t.y, w->out_dim, t.offs, out_tokens, B, L, w->out_dim, hs);
+    if (rc) return rc;
+    if (out_eos) rc = xmh::gather_packed_rows(t.y, w->out_dim, t.offs, t.eos, out_eos, B, w->out_dim, hs);
+    return rc;
 }
 
 // ---- hash heads ---------------------------------------------------------------------------------------

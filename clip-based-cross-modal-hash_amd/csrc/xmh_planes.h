@@ -83,6 +83,7 @@ struct GemmPlanes {
     Planes O;
     int64_t M, N, K;
     int act;
+    const int32_t* m_dev = nullptr;   // device word with the real row count (<= M); M then only sizes the grid (xmh_gemm.hip, GArgsP)
 };
 bool gemm_planes_ok(int64_t K, int64_t lda, int64_t ldw, const void* A, const void* W);
 int gemm_planes(const GemmPlanes& g, hipStream_t st);
@@ -91,7 +92,7 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st);
 // producers that emit operand planes directly (xmh_encode.hip); the fp32 output pointer may be null when only planes are wanted,
 // p.hi may be null when only fp32 is wanted
 int layernorm_planes(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y, int64_t ldy, const Planes& p,
-                     int64_t rows, int D, hipStream_t st);
+                     int64_t rows, int D, hipStream_t st, const int32_t* rows_dev = nullptr);      // rows_dev: the real row count on the device (<= rows)
 // split16: the products on the fp16 MFMA with hi/lo split operands (parity / fast mode) instead of the fp32 MFMA (exact mode)
 // row_offsets (device, [B + 1] i32, may be null): PACKED sequences -- sequence b owns rows [row_offsets[b], row_offsets[b + 1]) of qkv
 // and of the outputs and is that many (1 .. L) tokens long; null: B sequences of exactly L rows each.  Packed form: L <= 64, no key
@@ -103,6 +104,13 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
 int text_embed_packed(const int64_t* ids, const float* tok_emb, const float* pos, float* x, const int32_t* row_offsets, int64_t B, int L, int D,
                       int vocab, hipStream_t st);
 int gather_last_rows(const float* x, int64_t ldx, const int32_t* row_offsets, float* out, int64_t B, int D, hipStream_t st);
+// caption lengths counted ON THE DEVICE: eos[b] = first maximum of ids[b] (CLIP.encode_text's argmax, models/CLIP/model.py:392), kept rows of
+// caption b = max(eos[b] + 1, 1 + last position the key padding mask leaves visible), offs = their exclusive prefix (offs[B] = all rows)
+int caption_offsets(const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L, int32_t* offs, int32_t* eos, hipStream_t st);
+// out[b][l] = l < offs[b + 1] - offs[b] ? packed[offs[b] + l] : 0   (the padded [B, L, D] layout of the reference; dropped rows are zero)
+int unpack_rows(const float* packed, int64_t ldp, const int32_t* offs, float* out, int64_t B, int L, int D, hipStream_t st);
+// out[b] = packed[offs[b] + idx[b]]
+int gather_packed_rows(const float* packed, int64_t ldp, const int32_t* offs, const int32_t* idx, float* out, int64_t B, int D, hipStream_t st);
 // f = QuickGELU(u) elementwise on [rows, cols] (cols % 4 == 0), as fp32 and / or operand planes: the c_fc epilogue's activation as a
 // pass of its own, for the saved-activation forward (xmh_gemm.hip)
 int quickgelu_planes(const float* u, int64_t rows, int64_t cols, float* f, const Planes& p, hipStream_t st);

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "xmh_vit_b32_forward": (i32, [C.POINTER(VitWeights), vp, i64, i32, vp, vp, vp, sz, vp]),
     "xmh_text_forward": (i32, [C.POINTER(TextWeights), vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "xmh_text_forward_packed": (i32, [C.POINTER(TextWeights), vp, vp, i64, i64, i32, i32, vp, vp, sz, vp]),
+    "xmh_text_forward_packed_dev": (i32, [C.POINTER(TextWeights), vp, vp, i64, i32, i32, vp, vp, vp, sz, vp]),
     "xmh_head_workspace_bytes": (sz, [i64, i32, i32]),
     "xmh_head_dcmht": (i32, [C.POINTER(DcmhtHead), vp, i64, i32, vp, vp, vp, vp, sz, vp]),
     "xmh_head_dsph": (i32, [C.POINTER(Linear), vp, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]),

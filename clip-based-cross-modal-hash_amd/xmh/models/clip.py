@@ -273,7 +273,7 @@ class CLIP(nn.Module):
         yield from self.transformer.parameters()
         yield from (self.token_embedding.weight, self.positional_embedding, self.ln_final.weight, self.ln_final.bias, self.text_projection)
 
-    def _encode_text_native(self, text, key_padding_mask):
+    def _encode_text_native(self, text, key_padding_mask, masked_rows="exact"):
         if not text.is_cuda:
             raise RuntimeError("xmh ops need CUDA/HIP tensors; there is no CPU fallback")
         ids = text.to(torch.int64).contiguous()
@@ -284,11 +284,17 @@ class CLIP(nn.Module):
         nbytes = lib.xmh_clip_workspace_bytes(B, L, desc.width, 0, out_dim if self.return_patches else 0, precision)
         ws = _workspace(nbytes, ids.device)
         eos_tok = torch.empty(B, out_dim, dtype=torch.float32, device=ids.device)
-        if not self.return_patches and kpm is None and L <= 64 and TEXT_PACKING:
+        packable = L <= 64 and TEXT_PACKING and precision != 2 and out_dim <= desc.width
+        if packable and not self.return_patches:
             # only the EOS embedding is wanted and the attention is causal: the tokens behind a caption's EOS cannot reach it, so the
-            # tower runs on the rows up to EOS only (xmh_text_forward_packed: bit-identical output, sum(lengths) / (B L) of the work).
-            # The launches are sized by the row count, hence one small device-to-host copy (the stream this forward is enqueued on has
-            # at most the previous text forward in flight).
+            # tower runs on the rows up to EOS only (bit-identical output, sum(lengths) / (B L) of the work).  Round 5: the lengths are
+            # counted on the device and every launch is sized by its upper bound (xmh_text_forward_packed_dev) -- round 4 read the row
+            # count back with .item(), a host sync per caption batch that serialised the two towers' streams.
+            check(lib.xmh_text_forward_packed_dev(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), None, ptr(ws), nbytes,
+                                                  current_stream()), "xmh_text_forward_packed_dev")
+            return eos_tok
+        if not self.return_patches and kpm is None and L <= 64 and TEXT_PACKING and precision == 2:
+            # exact mode (fp32 MFMA; diagnostics): round 4's form of the same packing, the row count read back by the host
             offs = torch.zeros(B + 1, dtype=torch.int32, device=ids.device)
             offs[1:] = torch.cumsum(ids.argmax(dim=1) + 1, 0)
             total = int(offs[B].item())
@@ -301,15 +307,24 @@ class CLIP(nn.Module):
                                        current_stream()), "xmh_text_forward")
             return eos_tok
         y = torch.empty(B, L, out_dim, dtype=torch.float32, device=ids.device)
+        new_mask = None if kpm is None else (kpm.bool() | (ids == self.vocab_size - 1))
+        if packable and masked_rows == "zero" and kpm is not None:
+            # the caller reads no row the mask hides (MITH: every consumer of the tokens applies new_mask, models/MITH/hash/hash.py:142-148):
+            # the rows behind the last visible position are not computed and come back as zeros; every other row is the padded call's
+            check(lib.xmh_text_forward_packed_dev(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), ptr(y), ptr(ws), nbytes,
+                                                  current_stream()), "xmh_text_forward_packed_dev")
+            return eos_tok, y.permute(1, 0, 2), None, new_mask
         check(lib.xmh_text_forward(ctypes.byref(desc), ptr(ids), ptr(kpm), B, L, precision, ptr(eos_tok), ptr(y), None, ptr(ws), nbytes,
                                    current_stream()), "xmh_text_forward")
-        new_mask = None if kpm is None else (kpm.bool() | (ids == self.vocab_size - 1))
         return eos_tok, y.permute(1, 0, 2), None, new_mask
 
     @torch.no_grad()
-    def encode_text(self, text, key_padding_mask=None):
+    def encode_text(self, text, key_padding_mask=None, masked_rows="exact"):
+        """reference models/CLIP/model.py:373-396.  ``masked_rows`` (this package's callers only): "exact" returns every token row as the
+        reference computes it; "zero" lets the rows that ``key_padding_mask`` hides behind the last visible position come back as zeros
+        (not computed) -- for callers that apply the returned mask to everything they read, like the MITH head."""
         if NATIVE_FORWARD:
-            return self._encode_text_native(text, key_padding_mask)
+            return self._encode_text_native(text, key_padding_mask, masked_rows)
         x, eos = ops.text_embed(text, self.token_embedding.weight, self.positional_embedding)
         B, L, _ = x.shape
         kpm = None if key_padding_mask is None else key_padding_mask.to(x.device)

@@ -171,7 +171,9 @@ class MITH(BaseModel):
     def encode_text(self, text, key_padding_mask=None):
         if key_padding_mask is not None and key_padding_mask.device != text.device:
             key_padding_mask = key_padding_mask.to(text.device)
-        txt_eos, txt_tokens, _, new_mask = self.backbone.encode_text(text, key_padding_mask=key_padding_mask)
+        # every consumer of the tokens below applies new_mask (LocalizedTokenAggregation, models/MITH/hash/hash.py:142-148), so the rows
+        # the mask hides need not be computed (xmh_text_forward_packed_dev; XMH_TEXT_PACKING=0 runs them)
+        txt_eos, txt_tokens, _, new_mask = self.backbone.encode_text(text, key_padding_mask=key_padding_mask, masked_rows="zero")
         return self.hash.encode_txt(txt_eos, txt_tokens, new_mask)
 
     def forward(self, image, text, key_padding_mask=None, labels=None, indexs=None, return_loss=False):

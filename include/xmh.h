@@ -373,6 +373,21 @@ int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_
  * workspace as for xmh_text_forward (xmh_clip_workspace_bytes(B, L, width, 0, 0, precision)). */
 int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t* ids, const int32_t* row_offsets, int64_t total_rows, int64_t B,
                             int L, int precision, float* out_eos, void* workspace, size_t workspace_bytes, xmh_stream_t stream);
+/* The packed tower with the caption lengths counted ON THE DEVICE: no host value sizes anything, so the call never synchronises (the
+ * image and text towers' streams do not wait on a host thread; the call can be captured in a hipGraph).  Launches are sized for B * L
+ * rows and return on the rows behind the real count.
+ *   key_padding_mask [B, L] bytes or NULL (MITH: models/MITH/MITH.py:59-66 -> models/CLIP/model.py:378): applied to the keys as in
+ *     xmh_text_forward.  Caption b keeps its rows up to EOS, or up to the last position the mask leaves visible if that lies further
+ *     back: every row a consumer may read unmasked is computed exactly as in xmh_text_forward.
+ *   out_tokens [B, L, out_dim] or NULL (return_patches, models/CLIP/model.py:391-395): kept rows bit-identical to xmh_text_forward's;
+ *     the dropped rows -- all of them hidden by key_padding_mask, or behind EOS when there is no mask -- are returned as ZERO, where the
+ *     reference returns what attention made of padding.  A caller that reads those rows (the reference's own consumers mask them:
+ *     models/MITH/hash/hash.py:142-148) must use xmh_text_forward.
+ *   out_eos [B, out_dim] or NULL: bit-identical to xmh_text_forward's.
+ * Parity / fast mode only (-ENOTSUP in exact mode); L <= 64; workspace = xmh_clip_workspace_bytes(B, L, width, 0, out_tokens ? out_dim : 0, precision). */
+int xmh_text_forward_packed_dev(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
+                                int precision, float* out_eos, float* out_tokens, void* workspace, size_t workspace_bytes,
+                                xmh_stream_t stream);
 
 /* One modality of the DCMHT head in eval mode (models/DCMHT/hash/hash.py:15-82): MultiheadAttention over a length-1
  * sequence == out_proj(v_proj(x)) (softmax over one key is 1), BatchNorm1d with running statistics (image) or LayerNorm

@@ -326,6 +326,58 @@ def test_text_tower_without_its_padding_rows_is_bit_identical(ops, clip_models):
     assert lib.xmh_text_forward_packed(None, None, None, 0, 4, 32, 0, None, None, 0, None) != 0
 
 
+def test_packed_text_tower_with_key_padding_mask_and_token_outputs(ops, clip_models):
+    """xmh_text_forward_packed_dev (round 5): caption lengths counted on the device, key_padding_mask applied to the keys, token outputs in
+    the reference's padded layout (MITH's call: models/MITH/MITH.py:59-66 -> models/CLIP/model.py:373-396 with return_patches).  Against the
+    padded xmh_text_forward: the EOS embeddings and every KEPT token row bit for bit; the dropped rows -- all hidden by the mask, behind
+    the last visible position -- zero.  Masks: the dataset's (ids == 0), one that hides a token in front of EOS, one that leaves a padding
+    position visible, none of which the packing may get wrong; and the EOS-only output with a mask."""
+    import xmh.models.clip as C
+    g, W, m, m_rp = clip_models
+    gen = torch.Generator().manual_seed(78)
+    B, L = 67, 32
+    ids = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = [1, 30, 29, 2][b] if b < 4 else int(torch.randint(2, 30, (1,), generator=gen))
+        ids[b, 0] = 49406
+        ids[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=gen)
+        ids[b, 1 + n] = 49407
+    kpm = ids == 0
+    kpm[5, 2] = True                                              # a hidden token in front of EOS
+    eos = ids.argmax(dim=1)
+    kpm[6, min(L - 1, int(eos[6]) + 3)] = False                   # a visible position behind EOS: the kept rows reach that far
+    kpm[7, :] = False                                             # no padding hidden at all: every row is kept
+    ids, kpm = ids.cuda(), kpm.cuda()
+    last_visible = torch.where(~kpm, torch.arange(L, device="cuda").expand(B, L), torch.full((B, L), -1, device="cuda")).max(dim=1).values
+    length = torch.maximum(ids.argmax(dim=1), last_visible) + 1   # rows kept per caption
+    kept = (torch.arange(L, device="cuda")[None, :] < length[:, None]).T      # [L, B]: the token outputs are LND
+    assert int(length[6]) == min(L, int(eos[6]) + 4) and int(length[7]) == L and int(length[0]) == 3
+    before = ops.get_precision()
+    assert C.TEXT_PACKING
+    try:
+        for prec in ("f32", "f16"):
+            ops.set_precision(prec)
+            e1, t1, _, m1 = m_rp.encode_text(ids, key_padding_mask=kpm, masked_rows="zero")
+            e1, t1 = e1.clone(), t1.clone()
+            e0, t0, _, m0 = m_rp.encode_text(ids, key_padding_mask=kpm)                  # "exact": the padded call
+            assert torch.equal(m0, m1) and torch.equal(e0, e1), prec
+            assert torch.equal(t1[kept], t0[kept]), prec
+            assert not bool(t1[~kept].any()) and bool(t0[~kept].any()), prec
+            assert not bool((~m1.T)[~kept].any())                 # every dropped row is one the returned mask hides
+            # without token outputs: the EOS embedding under a mask, packed against padded
+            p1 = m.encode_text(ids, key_padding_mask=kpm).clone()
+            C.TEXT_PACKING = False
+            try:
+                p0 = m.encode_text(ids, key_padding_mask=kpm)
+            finally:
+                C.TEXT_PACKING = True
+            assert torch.equal(p0, p1), prec
+    finally:
+        ops.set_precision(before)
+    from xmh._lib import lib
+    assert lib.xmh_text_forward_packed_dev(None, None, None, 4, 32, 0, None, None, None, 0, None) != 0
+
+
 def _vit_front(m, image):
     """the image tower up to the block stack, through the primitives (VisionTransformer.run's chain)"""
     from xmh import ops as o
