@@ -45,18 +45,30 @@ res["kernel_stats"].sort(key=lambda r: -r["total_ns"])
 res["kernel_stats"] = res["kernel_stats"][:30]
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
-        agg = collections.defaultdict(lambda: collections.defaultdict(float))
-        disp = collections.defaultdict(set)
+        # One kernel instance may serve several SHAPES in one process (k_topk_filter_mfma<8, 4>: the Q = 64 leg, one pass over the gallery, and
+        # the Q = 5000 leg, 79 passes): a per-launch average over all of them is nobody's number -- round 4's profile read "1.47 GB per
+        # launch, 4.6 x the gallery" out of exactly that mix (profiles/r05_topk_q64_pmc.txt: 320.5 MB at Q = 64 alone).  Rows are therefore
+        # averaged per (kernel, grid size); the headline per_launch is the grid launched most often, the others are listed beside it.
+        agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+        disp = collections.defaultdict(lambda: collections.defaultdict(set))
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            disp[k].add(r["Dispatch_Id"])
-        for k, v in agg.items():
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X") or ""
+            agg[k][grid][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[k][grid].add(r["Dispatch_Id"])
+        for k, grids in agg.items():
             e = res["pmc"].setdefault(k, {"per_launch": {}})
-            n = max(1, len(disp[k]))
+            main = max(grids, key=lambda g: len(disp[k][g]))
+            n = max(1, len(disp[k][main]))
             e["launches_seen"] = n
-            for c, val in v.items():
+            e["grid"] = main
+            for c, val in grids[main].items():
                 e["per_launch"][c] = val / n
+            for g in grids:
+                if g != main:
+                    og = e.setdefault("other_grids", {}).setdefault(g, {"launches_seen": len(disp[k][g])})
+                    for c, val in grids[g].items():
+                        og[c] = val / max(1, len(disp[k][g]))
 # HBM traffic per launch as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
 # the bytes of a wide (16 B/lane) coalesced streaming read -> doubled for the kernels whose reads are of that kind.
 WIDE = ("k_topk_filter", "k_gemm_nt", "k_gemm_g16", "k_topk_stream", "k_im2col_patch", "k_scan_hist_m", "k_scan_ap_c")   # coalesced streaming reads of 8-16 bytes per lane: LDS-DMA of the operand images, the pair cache, the gallery stream (k_topk_filter_mfma's 8-byte loads are halved by FETCH_SIZE too: 160 MB raw against TCC_MISS_sum x 128 B = 327 MB)
