@@ -56,3 +56,13 @@ struct ProfScope {
 };
 
 }  // namespace xmh
+
+// Tuning switches (tile rules, query-group shapes, A/B toggles of tools/) exist only in a library built with -DXMH_EXPERIMENTS; the shipped
+// build reads none of them (the library keeps no process-wide state beyond the eight documented XMH_* switches).
+#ifdef XMH_EXPERIMENTS
+#include <stdlib.h>
+inline const char* xmh_experiment_env(const char* name) { return getenv(name); }
+#else
+inline const char* xmh_experiment_env(const char*) { return nullptr; }
+#endif
+

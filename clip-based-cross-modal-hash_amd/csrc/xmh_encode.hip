@@ -729,7 +729,7 @@ int attention_planes(const float* qkv, int64_t B, int L, int H, int dh, int caus
     if (dh != 64) return fail(XMH_ENOTSUP, "xmh_attention_f32: head dim %d (only 64, CLIP's width/heads)", dh);
     if (L > 128) return fail(XMH_ENOTSUP, "xmh_attention_f32: L=%d > 128 (whole head must fit LDS)", L);
     if (!qkv || (!out && !p.hi)) return fail(XMH_EINVAL, "xmh_attention_f32: null pointer");
-    static const bool valu_only = getenv("XMH_ATTENTION_VALU") != nullptr;
+    static const bool valu_only = xmh_experiment_env("XMH_ATTENTION_VALU") != nullptr;
     if (row_offsets && L > 64) return fail(XMH_ENOTSUP, "xmh attention: packed sequences need L <= 64 (L=%d)", L);
     if (L <= 64 && (!valu_only || row_offsets)) {                    // fp32-MFMA kernel: one wave per head
         if (split16) hipLaunchKernelGGL(k_attention_mfma64<true>, dim3((unsigned)(B * H)), dim3(64), 0, st, qkv, L, H, causal, key_padding_mask, out, p, row_offsets);

@@ -112,7 +112,7 @@ int run_blocks(const xmh_clip_block* blocks, int layers, int width, int heads, f
                TailRows tail = TailRows{}, const int32_t* m_dev = nullptr) {
     // m_dev (xmh_text_forward_packed_dev): the packed row count lives in a device word; M_packed is then its upper bound (B * L), which
     // sizes the launches -- the row-wise kernels return on the rows behind the real count.  Parity / fast mode only.
-    static const bool tail_off = getenv("XMH_TAIL_ROWS") && atoi(getenv("XMH_TAIL_ROWS")) == 0;      // A/B switch: 0 = the full last block + a gather
+    static const bool tail_off = xmh_experiment_env("XMH_TAIL_ROWS") && atoi(xmh_experiment_env("XMH_TAIL_ROWS")) == 0;      // A/B switch: 0 = the full last block + a gather
     const bool want_tail = tail.mode != 0;
     const bool tail_fused = want_tail && !tail_off && width % 2 == 0;
     // rows of a float-typed [*, cols] view (fp16 planes: two halves per float) -> the B kept rows

@@ -771,8 +771,8 @@ int gemm_planes(const GemmPlanes& g, hipStream_t st) {
     //   a grid that needs a second, mostly empty round of 128x128 tiles: 192x128 (fast) / 128x192 (parity) when those fit one round
     //   (5000 x 2304 x 768 parity 53.4 -> 51.5 us);
     //   large grids: 256x256 (fast), 128x256 with 8 waves (parity).
-    static const bool no_wide = getenv("XMH_GEMM_NO_WIDE") != nullptr;
-    static const int tile_rules = getenv("XMH_GEMM_TILE_RULES") ? atoi(getenv("XMH_GEMM_TILE_RULES")) : 30;    // bit 4: 8-wave tiles for the three-term product; bit 3: 64x128 tiles of 8 waves for grids of at most two 128x128 tiles per CU; bit 0: 64-row tiles already for grids of <= one 128x128 tile per CU (measured slower with the real epilogues: off), bit 1: 192-wide tiles, bit 2: 8-wave 128x128 tiles
+    static const bool no_wide = xmh_experiment_env("XMH_GEMM_NO_WIDE") != nullptr;
+    static const int tile_rules = xmh_experiment_env("XMH_GEMM_TILE_RULES") ? atoi(xmh_experiment_env("XMH_GEMM_TILE_RULES")) : 30;    // bit 4: 8-wave tiles for the three-term product; bit 3: 64x128 tiles of 8 waves for grids of at most two 128x128 tiles per CU; bit 0: 64-row tiles already for grids of <= one 128x128 tile per CU (measured slower with the real epilogues: off), bit 1: 192-wide tiles, bit 2: 8-wave 128x128 tiles
     const bool under = (tile_rules & 1) ? n128 <= cus : 2 * n128 < cus;
     const bool k64 = g.K % 64 == 0;
     if (!g.A_lo) {

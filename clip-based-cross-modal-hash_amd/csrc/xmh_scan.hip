@@ -742,118 +742,16 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
 // the ring.  Returning adds are waited for with counted lgkmcnt statements naming their destinations (LDS returns in order).
 // ===================================================================================================
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr uint32_t kRelScale = 127u * 64u;
-constexpr int kMfmaMaxChunk = 8064;                  // < kRelScale, multiple of 64
 
 struct MfmaArgs {
-    const uint4* gimg;
-    const uint4* qimg;
     const uint32_t* qbits;
     int Q, R, K, W;
     int chunk, nchunk, nqt, nb, qpad;
-    // k_scan_hist_r2 only (operands built in registers from the packed words)
+    // the packed words the operands are built from
     const uint32_t* rbits = nullptr;
     const uint32_t* rlab = nullptr;
     const uint32_t* qlab = nullptr;
     int LW = 0;
-};
-
-template <int NMC, int NML>
-__device__ __forceinline__ void expand_query_piece(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qlab, int64_t Q, int W, int LW, int K,
-                                                   uint4* __restrict__ out32, int64_t p);
-
-// one launch builds both operand images: blocks [0, gblocks) the gallery image, the rest the query image
-template <int NMC, int NML>
-__global__ __launch_bounds__(256) void k_scan_expand(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int K,
-                                                     uint4* __restrict__ out, int64_t npieces, unsigned gblocks, const uint32_t* __restrict__ qbits,
-                                                     const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces,
-                                                     uint32_t* __restrict__ ctl, int ctl_words) {
-    constexpr int NM = NMC + NML;
-    if (blockIdx.x == gridDim.x - 1)                               // the control words of this call (tile tickets, gate, finalize ticket):
-        for (int e = threadIdx.x; e < ctl_words; e += 256) ctl[e] = 0u;   // this launch precedes their users, so no memset launch
-    if (blockIdx.x >= gblocks) {
-        const int64_t qp = (int64_t)(blockIdx.x - gblocks) * 256 + threadIdx.x;
-        if (qp < qpieces) expand_query_piece<NMC, NML>(qbits, qlab, Q, W, LW, K, qout, qp);
-        return;
-    }
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npieces) return;
-    const int lane = (int)(p & 63);
-    const int m = (int)((p >> 6) % NM);
-    const int64_t grp = (p >> 6) / NM;                             // batch * 4 + group
-    const int rho = lane & 15, c = lane >> 4;
-    const int64_t item = grp * 16 + 4 * (rho & 3) + (rho >> 2);
-    uint32_t by[4] = {0u, 0u, 0u, 0u};
-    if (m < NMC) {                                                 // items past the end: all-zero-bit codes (bytes -1), no labels
-        const int k0 = m * 64 + c * 16;
-        uint32_t bits = 0u;
-        if (item < R && k0 < W * 32) bits = (rbits[item * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) by[t >> 2] |= ((k0 + t < K) ? (((bits >> t) & 1u) ? 0x01u : 0xffu) : 0u) << (8 * (t & 3));
-    } else {
-        const int k0 = (m - NMC) * 64 + c * 16;
-        uint32_t bits = 0u;
-        if (item < R && k0 < LW * 32) bits = (rlab[item * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) by[t >> 2] |= (((bits >> t) & 1u) ? 127u : 0u) << (8 * (t & 3));
-    }
-    out[p] = make_uint4(by[0], by[1], by[2], by[3]);
-}
-
-// query image piece: code bytes -+32 (half the 64-byte bucket row of the 4-byte counters per unit of the dot product), labels 64
-template <int NMC, int NML>
-__device__ __forceinline__ void expand_query_piece(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qlab, int64_t Q, int W, int LW, int K,
-                                                   uint4* __restrict__ out32, int64_t p) {
-    constexpr int NM = NMC + NML;
-    const int lane = (int)(p & 63);
-    const int m = (int)((p >> 6) % NM);
-    const int64_t q = ((p >> 6) / NM) * 16 + (lane & 15);
-    const int c = lane >> 4;
-    uint32_t a[4] = {0u, 0u, 0u, 0u};
-    if (q < Q) {                                                   // queries past the end: all-zero operand (dot = 0 -> their own bucket 0)
-        if (m < NMC) {
-            const int k0 = m * 64 + c * 16;
-            uint32_t bits = 0u;
-            if (k0 < W * 32) bits = (qbits[q * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                if (k0 + t < K) a[t >> 2] |= (((bits >> t) & 1u) ? 0xe0u : 0x20u) << (8 * (t & 3));       // -32 / +32
-            }
-        } else {
-            const int k0 = (m - NMC) * 64 + c * 16;
-            uint32_t bits = 0u;
-            if (k0 < LW * 32) bits = (qlab[q * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) a[t >> 2] |= (((bits >> t) & 1u) ? 64u : 0u) << (8 * (t & 3));
-        }
-    }
-    out32[p] = make_uint4(a[0], a[1], a[2], a[3]);
-}
-
-template <int NM, int NW>
-struct MfmaStage {
-    static constexpr int PIECES = 4 * NM;                        // 1 KB pieces per 64-item batch
-    static constexpr int PPW = PIECES / NW;
-    static_assert(PIECES % NW == 0, "pieces per wave");
-    static __device__ __forceinline__ void issue(const uint4* gimg, char* ring, int buf, int64_t batch, int lane, int wave) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int p = j * NW + wave;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gimg + (batch * PIECES + p) * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(ring + buf * (PIECES * 1024) + p * 1024), 16, 0, 0);
-        }
-    }
-    // this wave's pieces of the batch staged ONE iteration ago have landed (the PPW pieces issued since may still fly)
-    static __device__ __forceinline__ void wait_prev(bool more_in_flight) {
-        if (!more_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (PPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
 };
 
 __device__ __forceinline__ bool mfma_map_block(const MfmaArgs& a, int& chunk_id, int& qtile) {
@@ -864,260 +762,37 @@ __device__ __forceinline__ bool mfma_map_block(const MfmaArgs& a, int& chunk_id,
     return chunk_id < a.nchunk;
 }
 
-// CACHE: also leaves the pair cache of k_scan_hist_s (one byte per pair, distance << 1 | relevant, 16 bytes per lane and batch in
-// the same lane geometry) so that the cached k_scan_ap_s runs as pass 2.
-// BYTE (round 4, NMC = 2: codes of 65..128 bits): ONE-byte entries in the layout of the codes of at most 64 bits, so that pass 2 is
-// k_scan_ap_c on half the bytes (the two-byte cache made this length traffic-bound: 1.19 GB written and read back per evaluation at
-// the COCO shape).  A byte holds distance << 1 | relevant for distances up to 127; the one distance it cannot hold, 128 = every
-// bit of a 128-bit code differs, wraps to 0 and raises *ovf (a control word cleared with the others at the start of the call): pass 2
-// then runs the kernel that evaluates the pairs from the codes instead of k_scan_ap_c (both are launched, the word lets one run).
-// The bucket counters are not affected: bucket 128 is counted where it belongs.
-template <int NMC, int NML, int NW, bool CACHE, bool BYTE = false>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_m(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
-                                                         uint32_t* __restrict__ ovf = nullptr) {
-    static_assert(!BYTE || (NMC == 2 && CACHE), "byte entries beyond 64 bits: 65..128-bit codes with the pair cache");
-    constexpr bool B8 = NMC == 1 || BYTE;                            // one-byte entries, 4 slots x 16 queries per cache tile
-    constexpr int NM = NMC + NML;
-    using ST = MfmaStage<NM, NW>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters, then the 2-deep ring
-    int chunk_id, qtile;
-    if (!mfma_map_block(a, chunk_id, qtile)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ql = lane & 15, slot = lane >> 4;
-    const int q0 = (qtile * NW + wave) * 16;
-    const int q = q0 + ql;
-    const int ncell = a.nb * 16;
-    uint32_t* cnt = lds + wave * ncell;
-    for (int e = lane; e < ncell; e += 64) cnt[e] = 0u;
-    char* ring = reinterpret_cast<char*>(lds + NW * ncell);
-    v4i bq[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) bq[m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(q0 >> 4) * NM + m) * 64 + lane);
-    const bool valid = q < a.Q;
-    const int cinit = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4 + (valid ? 32 * a.K : 0);
-    const int64_t lo = (int64_t)chunk_id * a.chunk;
-    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
-    const int nbat = (int)((hi - lo + 63) >> 6);
-    const int64_t bat0 = lo >> 6;                                    // chunks start on 64-item boundaries
-    const int lanebase = cinit - (valid ? 32 * a.K : 0);            // address of this lane's bucket-0 counter
-    // NMC == 1 (33..64 bits): the cached pass 2 has this kernel's lane geometry (4 slots x 16 queries), a lane stores its 16 one-byte
-    // entries of a batch.  NMC >= 2 (65..256 bits): the cached pass 2 runs 8 slots x 8 queries with 16-bit entries, lane
-    // (slot8, query) taking item 8t + slot8 at step t.  This lane (slot4, query) holds items 16g + 4j + slot4: its even j are
-    // exactly the 8 steps of lane (slot4, query) there, its odd j those of lane (slot4 + 4, query) -- no exchange between lanes,
-    // two 16-byte records per batch, 32 uint4 apart in the row of the query's 8-query tile.
-    uint4* crow = nullptr;
-    if (CACHE && B8) crow = pair_cache + ((int64_t)chunk_id * (a.nqt * NW) + (qtile * NW + wave)) * ((a.chunk + 63) >> 6) * 64 + lane;
-    if (CACHE && !B8) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
-    uint32_t amax = 0u;
-    ST::issue(a.gimg, ring, 0, bat0, lane, wave);
-    for (int i = 0; i < nbat; ++i) {
-        if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
-        ST::wait_prev(i + 1 < nbat);
-        __builtin_amdgcn_s_barrier();                                // every wave's pieces of batch i are in the ring
-        const char* base = ring + (i & 1) * (ST::PIECES * 1024) + lane * 16;
-        v4i am[4][NM];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
-        }
-        uint32_t cw[4], cw2[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4i acc = {cinit, cinit, cinit, cinit};
-#pragma unroll
-            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], acc, 0, 0, 0);
-            v4i lab = {1, 1, 1, 1};
-#pragma unroll
-            for (int m = NMC; m < NM; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], lab, 0, 0, 0);
-            uint32_t e[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t inc = min((uint32_t)lab[j], 1u + kRelScale);        // 1 or 0x1fc1: bit 7 = relevant
-                asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
-                if (CACHE) e[j] = ((inc >> 7) & 1u) | ((uint32_t)(acc[j] - lanebase) >> 5);     // entry: distance << 1 | relevant (8 or 16 bits)
-            }
-            if (BYTE) {
-                // distance 128 does not fit the byte: it wraps to 0 (the byte selects below drop bit 8) and pass 2 is told.  Seen through the
-                // largest counter address of the lane (address = lanebase + 64 * distance; lanes of absent queries stay at distance 0).
-                amax = max(max((uint32_t)acc[0], (uint32_t)acc[1]), amax);
-                amax = max(max((uint32_t)acc[2], (uint32_t)acc[3]), amax);
-                cw[g] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0c0c0400u), __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0400u), 0x05040100u);
-            } else if (CACHE && B8) cw[g] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
-            if (CACHE && !B8) {                                      // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (see below)
-                cw[g] = e[0] | (e[2] << 16);
-                cw2[g] = e[1] | (e[3] << 16);
-            }
-        }
-        if (CACHE && B8) {                                           // streamed once each way: non-temporal (see k_scan_hist_s)
-            uint4* dst = crow + (int64_t)i * 64;
-            __builtin_nontemporal_store(cw[0], &dst->x);
-            __builtin_nontemporal_store(cw[1], &dst->y);
-            __builtin_nontemporal_store(cw[2], &dst->z);
-            __builtin_nontemporal_store(cw[3], &dst->w);
-        }
-        if (CACHE && !B8) {
-            uint4* dst = crow + (int64_t)i * 64;
-            __builtin_nontemporal_store(cw[0], &dst->x);
-            __builtin_nontemporal_store(cw[1], &dst->y);
-            __builtin_nontemporal_store(cw[2], &dst->z);
-            __builtin_nontemporal_store(cw[3], &dst->w);
-            __builtin_nontemporal_store(cw2[0], &dst[32].x);
-            __builtin_nontemporal_store(cw2[1], &dst[32].y);
-            __builtin_nontemporal_store(cw2[2], &dst[32].z);
-            __builtin_nontemporal_store(cw2[3], &dst[32].w);
-        }
-        __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
-    }
-    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
-    const int npad = nbat * 64 - (int)(hi - lo);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (npad > 0 && slot == 0 && valid) {
-        int dpad = 0;
-        for (int w = 0; w < a.W; ++w) dpad += __popc(a.qbits[(int64_t)q * a.W + w]);
-        cnt[dpad * 16 + ql] -= (uint32_t)npad;
-    }
-    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
-    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
-    if (BYTE && amax >= (uint32_t)lanebase + 64u * 128u) *ovf = 1u;   // every writer stores the same 1; read by the next launch
-}
-
 // ---------------------------------------------------------------------------------------------------
-// k_scan_hist_m2: pass 1 for binary codes of at most 64 bits (round 3).  Same idea as k_scan_hist_m -- the MFMA emits the LDS
-// address of counter [distance][query] -- rebuilt around what limited that kernel (no unit above 0.4 busy, two barriers per
-// batch, 8.2 VALU instructions per pair of which 5 packed the pair-cache byte, 2 moved MFMA results out of the AGPRs):
+// k_scan_hist_r2: pass 1 for binary codes of at most 64 bits (rounds 3-4).  The i8 MFMA emits the LDS address of counter
+// [distance][query]; everything around it is arranged so that the VALU does two instructions per pair:
 //   * VGPR-form MFMAs (inline asm): results are consumed where they land, no v_accvgpr_read.  Every instruction that touches
 //     an MFMA result is asm volatile in program order, software-pipelined one (item group, query group) behind its MFMAs, so
 //     the MFMA -> VALU / DS read hazard (8 wait states, hipcc inserts them only for its own instructions) is covered by the 12
 //     consumer instructions of the previous group that sit in between.
-//   * the pair-cache byte comes out of the matrix pipe too: a second code chain with query bytes -+1 started at K IS
-//     2 * distance, and the label chain counts into (all << 16 | relevant) counters -- item and query label bytes 1, started at
-//     0x10000, min(acc, 0x10001) is the add operand and its low byte the relevance bit -- so one SDWA OR per pair
-//     (byte0(2d) | byte0(inc) written to byte j of the cache word) replaces five instructions: 2 VALU per pair in all.
-//   * a 3-deep LDS ring with ONE barrier per batch: the LDS-DMA of batch i + 2 is issued after the barrier of batch i, by when
-//     every wave has consumed batch i - 1, whose buffer it overwrites.
-//   * NQ query groups of 16 per wave: every A operand read from the ring (ds_read_b128) feeds NQ MFMAs, and a block covers
-//     NW * NQ * 16 queries per staged batch -- the L2 -> LDS traffic of the launch, R * 64 * (1 + NML) bytes per block row of
-//     queries (1.8 GB at configs[1] with 64 queries per block), halves with 128.
-// Counter rows are 64 bytes (16 queries x u32) as in k_scan_hist_m; chunks may now hold up to 32768 items (16-bit halves).
+//   * the pair-cache byte comes out of the matrix pipe too: a second code chain with query bytes -+2 IS 2 * distance, and the label
+//     chain counts into (all << 16 | relevant) counters -- started at 0x10000, min(acc, 0x10001) is the add operand and its low byte the
+//     relevance bit -- so one SDWA OR per pair (byte0(2d) | byte0(inc) written to byte j of the cache word) assembles the entry.
+//   * the A operands are built in registers from the packed gallery words (round 4): no operand image, no LDS-DMA, no ring, no
+//     barrier.  Lane (row, slot) loads the word of its item that holds its 16 bits (fetched one batch ahead) and spreads it with 5-6
+//     VALU operations per tile; waves are independent, LDS holds the counters only.
+//   * NQ query groups of 16 per wave: every tile built feeds NQ MFMA groups.
+// Counter rows are 64 bytes (16 queries x u32); chunks hold up to 32768 items (16-bit halves).  Round 3's form of the same statements
+// (k_scan_hist_m2: operand images through a 3-deep LDS ring) and round 2's k_scan_hist_m were removed in round 5 (DESIGN 3.1 keeps their
+// measurements).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ v4i mfma_i8_vgpr(v4i a, v4i b, v4i c) {
-    v4i d;
-    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-// the A tiles of 16-item group G of the staged batch (NMI pieces of 1 KB, 16 bytes per lane) -> registers; asm, so that hipcc neither
-// sees the loads nor waits for them: the caller does, with counted lgkmcnt
-template <int OFF> __device__ __forceinline__ void lds_read128(v4i& d, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int G, int NMI> __device__ __forceinline__ void lds_read_group(v4i (&A)[NMI], uint32_t abase) {
-    lds_read128<(G * NMI + 0) * 1024>(A[0], abase);
-    if constexpr (NMI > 1) lds_read128<(G * NMI + 1) * 1024>(A[1], abase);
-    if constexpr (NMI > 2) lds_read128<(G * NMI + 2) * 1024>(A[2], abase);
-}
-
-// operand images of k_scan_hist_m2: gallery [64-item batch][16-item group][tile: code, labels...][lane][16 B] with code bytes +-1 and
-// label bytes 1; queries [16-query tile][tile: code -+32, code -+1, labels...][lane][16 B]
-template <int NML>
-__global__ __launch_bounds__(256) void k_scan_expand2(const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rlab, int64_t R, int W, int LW, int K,
-                                                      uint4* __restrict__ out, int64_t npieces, unsigned gblocks, const uint32_t* __restrict__ qbits,
-                                                      const uint32_t* __restrict__ qlab, int64_t Q, uint4* __restrict__ qout, int64_t qpieces,
-                                                      uint32_t* __restrict__ ctl, int ctl_words) {
+template <int NML, int NW, int NQ, bool CACHE>
+__device__ __forceinline__ void scan_hist_r2_body(const MfmaArgs& a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
     constexpr int NMI = 1 + NML, NMQ = 2 + NML;
-    if (blockIdx.x == gridDim.x - 1)                               // the control words of this call (see k_scan_expand)
-        for (int e = threadIdx.x; e < ctl_words; e += 256) ctl[e] = 0u;
-    if (blockIdx.x >= gblocks) {
-        const int64_t p = (int64_t)(blockIdx.x - gblocks) * 256 + threadIdx.x;
-        if (p >= qpieces) return;
-        const int lane = (int)(p & 63);
-        const int m = (int)((p >> 6) % NMQ);
-        const int64_t q = ((p >> 6) / NMQ) * 16 + (lane & 15);
-        const int c = lane >> 4;
-        uint32_t a[4] = {0u, 0u, 0u, 0u};
-        if (q < Q) {                                               // queries past the end: all-zero operands
-            const int k0 = c * 16 + (m >= 2 ? (m - 2) * 64 : 0);
-            uint32_t bits = 0u;
-            if (m < 2) {
-                if (k0 < W * 32) bits = (qbits[q * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#ifdef XMH_ABL_SUB2
-                const uint32_t set = m == 0 ? 0xc0u : 0xffu, clr = m == 0 ? 0x40u : 0x01u;      // rows of 128 bytes
-#else
-                const uint32_t set = m == 0 ? 0xe0u : 0xffu, clr = m == 0 ? 0x20u : 0x01u;      // -32 / +32 (address), -1 / +1 (2 * distance)
-#endif
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    if (k0 + t < K) a[t >> 2] |= (((bits >> t) & 1u) ? set : clr) << (8 * (t & 3));
-                }
-            } else {
-                if (k0 < LW * 32) bits = (qlab[q * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) a[t >> 2] |= ((bits >> t) & 1u) << (8 * (t & 3));
-            }
-        }
-        qout[p] = make_uint4(a[0], a[1], a[2], a[3]);
-        return;
-    }
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npieces) return;
-    const int lane = (int)(p & 63);
-    const int m = (int)((p >> 6) % NMI);
-    const int64_t grp = (p >> 6) / NMI;                            // batch * 4 + group
-    const int rho = lane & 15, c = lane >> 4;
-    const int64_t item = grp * 16 + 4 * (rho & 3) + (rho >> 2);
-    uint32_t by[4] = {0u, 0u, 0u, 0u};
-    if (m == 0) {                                                  // items past the end: all-zero-bit codes (bytes -1), no labels
-        const int k0 = c * 16;
-        uint32_t bits = 0u;
-        if (item < R && k0 < W * 32) bits = (rbits[item * W + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-        // four bits -> four bytes with one multiply (the shifted copies do not overlap: no carries), then 0 / 1 -> -1 / +1
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const uint32_t sp = (((bits >> (4 * x)) & 0xfu) * 0x00204081u) & 0x01010101u;
-            by[x] = 0xffffffffu ^ (sp * 0xfeu);
-        }
-        if (k0 + 16 > K) {                                         // the code ends inside these 16 positions: bytes past it are 0
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if (k0 + t >= K) by[t >> 2] &= ~(0xffu << (8 * (t & 3)));
-        }
-    } else {
-        const int k0 = (m - 1) * 64 + c * 16;
-        uint32_t bits = 0u;
-        if (item < R && k0 < LW * 32) bits = (rlab[item * LW + (k0 >> 5)] >> (k0 & 31)) & 0xffffu;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) by[x] = (((bits >> (4 * x)) & 0xfu) * 0x00204081u) & 0x01010101u;
-    }
-    out[p] = make_uint4(by[0], by[1], by[2], by[3]);
-}
-
-// STAMP (tools/stamp_m2.hip only): s_memtime stamps around the phases of a batch, summed per wave into stamps[wave id][8]
-// REGS (round 4, k_scan_hist_r2): the A operands are built in registers from the packed gallery words -- no operand image, no LDS-DMA, no
-// ring, no barrier; see k_scan_hist_r2 below.
-template <int NML, int NW, int NQ, bool CACHE, bool STAMP, bool REGS>
-__device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
-                                                  unsigned long long* __restrict__ stamps) {
-    constexpr int NMI = 1 + NML, NMQ = 2 + NML;
-    constexpr int PIECES = 4 * NMI;                                  // 1 KB pieces per 64-item batch
-    constexpr int PPW = (PIECES + NW - 1) / NW;                      // LDS-DMA pieces a wave issues per batch
-    constexpr int NST = CACHE ? NQ : 0;                              // cache stores a wave issues per batch (they share vmcnt)
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters, then the 3-deep ring (none with REGS)
+    constexpr bool REGS = true;                                      // (the operands come from the packed words; kept as a name in the expressions below)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x NQ x [nb][16] u32 counters
     int chunk_id, qtile;
     if (!mfma_map_block(a, chunk_id, qtile)) return;                 // a.nqt counts tiles of NW * NQ * 16 queries here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & 15, slot = lane >> 4;
     const int t16 = (qtile * NW + wave) * NQ;                        // first 16-query tile of this wave
-#ifdef XMH_ABL_SUB2      // tools/stamp_m2.hip only: one counter copy per slot parity (bank-conflict-free adds) -- timing experiment, totals not merged
-    const int ncell = a.nb * 32;
-#else
     const int ncell = a.nb * 16;
-#endif
     uint32_t* cnt = lds + (wave * NQ) * ncell;
     for (int e = lane; e < NQ * ncell; e += 64) cnt[e] = 0u;
-    char* ring = reinterpret_cast<char*>(lds + NW * NQ * ncell);
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     v4i bq[NQ][NMQ], cq[NQ], kqv[REGS ? NQ : 1];                    // the image kernels start every 2 * distance chain at K: one quad
     bool valid[NQ];
     // REGS: byte b of operand register j of lane (row, slot) stands for bit 4 (slot & 1) + j + 8 b of word slot >> 1 (of the code, or of the
@@ -1129,7 +804,7 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
     for (int h = 0; h < NQ; ++h) {
         valid[h] = (t16 + h) * 16 + ql < a.Q;
         int pcq = 0;
-        if (REGS) {
+        {
             const int64_t q = (int64_t)(t16 + h) * 16 + ql;
             uint32_t qw = 0u;
             if (valid[h]) {
@@ -1159,18 +834,9 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
                 for (int j = 0; j < 4; ++j) bq[h][2 + m][j] = (int)((lw >> j) & 0x01010101u);
             }
             const int k2 = 2 * pcq;
-            kqv[REGS ? h : 0] = v4i{k2, k2, k2, k2};
-        } else {
-#pragma unroll
-            for (int m = 0; m < NMQ; ++m) bq[h][m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(t16 + h) * NMQ + m) * 64 + lane);
-            kqv[0] = v4i{a.K, a.K, a.K, a.K};
+            kqv[h] = v4i{k2, k2, k2, k2};
         }
-#ifdef XMH_ABL_SUB2
-        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (slot & 1) * 64 + (valid[h] ? 64 * a.K : 0);
-#else
-        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 +
-                       (valid[h] ? (REGS ? 64 * pcq : 32 * a.K) : 0);
-#endif
+        const int c0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt + h * ncell) + ql * 4 + (valid[h] ? 64 * pcq : 0);
         cq[h] = v4i{c0, c0, c0, c0};
     }
     v4i lab0 = {0x10000, 0x10000, 0x10000, 0x10000};
@@ -1187,23 +853,6 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
 #pragma unroll
     for (int h = 0; h < NQ; ++h)
         crow[h] = CACHE ? pair_cache + ((int64_t)chunk_id * (a.qpad >> 4) + (t16 + h)) * ((a.chunk + 63) >> 6) * 64 + lane : nullptr;
-    auto stage = [&](int buf, int64_t batch) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int p = (j * NW + wave) < PIECES ? j * NW + wave : PIECES - 1;     // surplus slots repeat the last piece (same bytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.gimg + (batch * PIECES + p) * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(ring + buf * (PIECES * 1024) + p * 1024), 16, 0, 0);
-        }
-    };
-    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-    auto stamp = [&](int k) {                                         // STAMP only: cycles since the previous stamp go to slot k
-        if (!STAMP) return;
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        acc_t[k] += t - t_prev;
-        t_prev = t;
-    };
-    if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     // REGS: the packed words of this lane's four items of a batch (row r of group g is item 16 g + 4 (r & 3) + (r >> 2): accumulator register j
     // of a lane is its step j, as in the image), fetched one batch ahead with unconditional loads (clamped item, word index clamped to
     // the last one and masked: no predication, so hipcc waits with counted vmcnt only where the words are used; two batches ahead measured
@@ -1257,30 +906,9 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
             for (int j = 0; j < 4; ++j) At[m][j] = (int)(y & (0x01010101u << j));
         }
     };
-    if (REGS) load_words(bat0, wcur);
-    else {
-        stage(0, bat0);
-        if (nbat > 1) stage(1, bat0 + 1);
-    }
-    int buf = 0;
-    stamp(0);
+    load_words(bat0, wcur);
     for (int i = 0; i < nbat; ++i) {
-        uint32_t abase = 0u;
-        if (REGS) {
-            load_words(bat0 + (i + 1 < nbat ? i + 1 : i), wnxt);
-        } else {
-        // this wave's pieces of batch i have landed: newer in flight are the pieces of batch i + 1 and the cache stores of batch i - 1
-        if (i + 1 >= nbat) wait_vmcnt<0>();
-        else if (i == 0) wait_vmcnt<PPW>();
-        else wait_vmcnt<PPW + NST>();
-        stamp(1);
-        __builtin_amdgcn_s_barrier();                                // all pieces of batch i are in; every wave is done with batch i - 1
-        stamp(2);
-        if (i + 2 < nbat) stage(buf >= 1 ? buf - 1 : 2, bat0 + i + 2);      // (i + 2) % 3 == (i - 1) % 3
-        stamp(3);
-        abase = ring_lds + buf * (PIECES * 1024) + lane * 16;      // LDS byte address of this lane's 16 bytes of piece 0
-        buf = buf == 2 ? 0 : buf + 1;
-        }
+        load_words(bat0 + (i + 1 < nbat ? i + 1 : i), wnxt);
         // A tiles of item group g live in set g & 1; read (asm: hipcc would wait for ALL outstanding reads at the first use) one group
         // ahead of the MFMAs that use them, waited for with counted lgkmcnt (LDS operations of a wave complete in order):
         //   R(0) R(1) | group 0 | R(2) | group 1 | R(3) | group 2 | group 3      with 4 adds per statement behind the first
@@ -1299,17 +927,8 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
         //     all results are early-clobber outputs of the statement that also names the A tiles as inputs;
         //   * MFMA -> MFMA srcC dependencies are interlocked in hardware.
         // The consumers: inc = min(label overlap chain, 0x10001) in place; cache byte j = byte0(2 * distance) | byte0(inc); the add.
-// ablation switches of tools/stamp_m2.hip (-DXMH_ABL_NOADD: the LDS adds become s_nop; -DXMH_ABL_NOMFMA: the MFMAs do): never set in the library build
-#ifdef XMH_ABL_NOADD
-#define XMH_ADD(A, D) "s_nop 0\n\t"
-#else
 #define XMH_ADD(A, D) "ds_add_u32 " A ", " D "\n\t"
-#endif
-#ifdef XMH_ABL_NOMFMA
-#define XMH_MFMA(D, A, B, C) "s_nop 0\n\t"
-#else
 #define XMH_MFMA(D, A, B, C) "v_mfma_i32_16x16x64_i8 " D ", " A ", " B ", " C "\n\t"
-#endif
 #define XMH_SDWA(J) "dst_sel:BYTE_" #J " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
         auto fused = [&](const v4i (&At)[NMI], int h, v4i& addr, v4i& d2, v4i& lab, uint32_t& w) {
             uint32_t i0, i1, i2, i3;                                  // min results: fresh registers (in-place on the MFMA's result tuple made hipcc copy them)
@@ -1423,12 +1042,6 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
         auto group = [&](auto gc) {
             constexpr int G = decltype(gc)::value;
             constexpr int SET = REGS ? G : (G & 1);
-            if (!REGS) {
-                // the reads of this group have returned: operations issued behind them (see the sequence above), at most 15 countable
-                constexpr int newer = G == 0 ? NMI : (G == 1 ? 4 * (NQ - 1) + NMI : (G == 2 ? 4 * NQ + NMI : 4 * NQ));
-                wait_lgkmcnt<(newer < 15 ? newer : 15)>();
-            }
-            if (STAMP && G == 0) stamp(4);
 #pragma unroll
             for (int h = 0; h < NQ; ++h) {
                 v4i addr, d2, lab;
@@ -1440,24 +1053,17 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
                     else asm volatile("" ::"v"(A[REGS ? G - 1 : 0][0]), "v"(A[REGS ? G - 1 : 0][1]), "v"(A[REGS ? G - 1 : 0][NMI - 1]));
                 }
             }
-            if (!REGS && G + 2 < 4) lds_read_group<G + 2, NMI>(A[G & 1], abase);          // this set's MFMAs have been issued (operands are read at issue)
         };
-        if (REGS) {
-            build(A[0], wcur[0]);
-            build(A[1], wcur[1]);
-            build(A[REGS ? 2 : 0], wcur[2]);
-            build(A[REGS ? 3 : 1], wcur[3]);
-        } else {
-            lds_read_group<0, NMI>(A[0], abase);
-            lds_read_group<1, NMI>(A[1], abase);
-        }
+        build(A[0], wcur[0]);
+        build(A[1], wcur[1]);
+        build(A[2], wcur[2]);
+        build(A[3], wcur[3]);
         group(std::integral_constant<int, 0>{});
         group(std::integral_constant<int, 1>{});
         group(std::integral_constant<int, 2>{});
         group(std::integral_constant<int, 3>{});
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");              // the last MFMAs' results: 8 wait states before a VALU / DS read
-        consume(cw[NQ - 1][3], A[REGS ? 3 : 1]);
-        stamp(5);
+        consume(cw[NQ - 1][3], A[3]);
         if (CACHE) {                                                 // streamed once each way: non-temporal (see k_scan_hist_s)
 #pragma unroll
             for (int h = 0; h < NQ; ++h) {
@@ -1468,22 +1074,14 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
                 __builtin_nontemporal_store(cw[h][3], &dst->w);
             }
         }
-        stamp(7);
-        if (REGS) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int m = 0; m < NMI; ++m) wcur[g][m] = wnxt[g][m];
-        }
+            for (int m = 0; m < NMI; ++m) wcur[g][m] = wnxt[g][m];
     }
     // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
     const int npad = nbat * 64 - (int)(hi - lo);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp(6);
-    if (STAMP && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) stamps[((int64_t)blockIdx.x * NW + wave) * 8 + k] = acc_t[k];
-    }
     if (npad > 0 && slot == 0) {
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
@@ -1499,12 +1097,6 @@ __device__ __forceinline__ void scan_hist_m2_body(const MfmaArgs& a, uint32_t* _
         uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + (t16 + h) * 16;
         for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[h * ncell + e];
     }
-}
-
-template <int NML, int NW, int NQ, bool CACHE, bool STAMP = false>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_m2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache,
-                                                          unsigned long long* __restrict__ stamps = nullptr) {
-    scan_hist_m2_body<NML, NW, NQ, CACHE, STAMP, false>(a, chunk_hist, pair_cache, stamps);
 }
 
 // What is left of k_scan_expand2 for k_scan_hist_r2: the control words of the call are cleared, and the packed words of every chunk are
@@ -1537,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_scan_touch(const uint32_t* __restrict__
 // operations per tile.  Waves are independent (no barrier, no shared staging); LDS holds the counters only.
 template <int NML, int NW, int NQ, bool CACHE>
 __global__ __launch_bounds__(64 * NW) void k_scan_hist_r2(MfmaArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
-    scan_hist_m2_body<NML, NW, NQ, CACHE, false, true>(a, chunk_hist, pair_cache, nullptr);
+    scan_hist_r2_body<NML, NW, NQ, CACHE>(a, chunk_hist, pair_cache);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1840,131 +1432,6 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_r2w(MfmaArgs a, uint32_t*
 #undef XMH_W_MFMA
 #undef XMH_W_MIN
 #undef XMH_W_ADD
-
-// Pass 2 on the same operand images: the MFMA emits the counter address and the label overlap, ONE returning ds_add per pair
-// advances {rank, ordinal} of (bucket, query) and hands back the pair's own rank and ordinal (same-address lanes of one
-// instruction resolve in ascending lane = item order, lane_order_ok), relevant pairs are credited ordinal / rank one group of
-// 16 items later, so the returns are never waited for.  No pair cache: pass 1 then runs without the 5 packing instructions per
-// pair and the 600 MB round trip.  Counters as in k_scan_ap_s: P32 packs {rank | ordinal << rank_bits} in 32 bits when the
-// device word nrel_max says it fits (bucket rows of 64 bytes, the query image's -+32 scaling lands on them directly), else
-// 64-bit {rank, ordinal} (rows of 128 bytes: the accumulator runs at half scale and is doubled, one shift per pair).
-// The atomics and their waits are inline asm naming the destination registers (hipcc would drain the LDS-DMA before an LDS
-// atomic it cannot prove disjoint from the ring, and does not know that an asm's result arrives later).
-template <int NMC, int NML, int NW, bool P32, bool CAPPED>
-__global__ __launch_bounds__(64 * NW) void k_scan_ap_m(MfmaArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
-                                                       const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                       const uint32_t* __restrict__ nrel_max, int rank_bits, uint32_t kcap) {
-    using CT = typename std::conditional<P32, uint32_t, unsigned long long>::type;
-    constexpr int NM = NMC + NML, CW = (int)(sizeof(CT) / 4);
-    using ST = MfmaStage<NM, NW>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] counters, then the 2-deep ring
-    int chunk_id, qtile;
-    if (!mfma_map_block(a, chunk_id, qtile)) return;
-    {
-        const bool fits32 = rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits));
-        if (P32 != fits32) return;                                   // the other variant takes this call
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ql = lane & 15;
-    const int q0 = (qtile * NW + wave) * 16;
-    const int q = q0 + ql;
-    const int ncell = a.nb * 16;
-    CT* cnt = reinterpret_cast<CT*>(lds + wave * ncell * CW);
-    {
-        const uint2* __restrict__ pb = below + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
-        const uint2* __restrict__ pd = dpre + q0;
-        for (int e = lane; e < ncell; e += 64) {
-            const int64_t at = (int64_t)(e >> 4) * a.qpad + (e & 15);
-            const uint2 x = pb[at], y = pd[at];
-            if (P32) cnt[e] = (CT)((x.x + y.x + 1u) | ((x.y + y.y + 1u) << rank_bits));
-            else cnt[e] = (CT)((unsigned long long)(x.x + y.x + 1u) | ((unsigned long long)(x.y + y.y + 1u) << 32));
-        }
-    }
-    char* ring = reinterpret_cast<char*>(lds + NW * ncell * CW);
-    v4i bq[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) bq[m] = *reinterpret_cast<const v4i*>(a.qimg + ((int64_t)(q0 >> 4) * NM + m) * 64 + lane);
-    const bool valid = q < a.Q;
-    const int cbase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)reinterpret_cast<uint32_t*>(cnt);
-    const int cinit = (P32 ? cbase : (cbase >> 1)) + ql * 4 + (valid ? 32 * a.K : 0);
-    const uint32_t cap = CAPPED ? min(cap_ws[q], kcap) : 0u;      // cap_ws[q] = relevant items of query q
-    const uint32_t rmask = P32 ? (1u << rank_bits) - 1u : 0xffffffffu;
-    const int64_t lo = (int64_t)chunk_id * a.chunk;
-    const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
-    const int nbat = (int)((hi - lo + 63) >> 6);
-    const int64_t bat0 = lo >> 6;
-    float apsum = 0.0f;
-    auto credit = [&](CT old, uint32_t hit) {
-        uint32_t rank, ord;
-        if (P32) { rank = (uint32_t)old & rmask; ord = (uint32_t)old >> rank_bits; }
-        else { rank = (uint32_t)old; ord = (uint32_t)((unsigned long long)old >> 32); }
-        if (CAPPED) hit = ord <= cap ? hit : 0u;
-        const float of = (float)__umul24(ord, hit);
-        apsum = fmaf(of, __builtin_amdgcn_rcpf((float)rank), apsum);
-    };
-    // Two result sets used in turn; no result crosses the batch loop (see k_scan_ap_c: hipcc takes an asm's result as present when the
-    // statement ends, so a result handed on by assignment can become a copy in front of its wait): a batch issues its four groups,
-    // credits each while the next one's atomics are in flight, and ends drained.
-    CT oldA[4], oldB[4];
-    uint32_t hitA[4], hitB[4];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // counters are in place (own wave's region only)
-    ST::issue(a.gimg, ring, 0, bat0, lane, wave);
-    for (int i = 0; i < nbat; ++i) {
-        if (i + 1 < nbat) ST::issue(a.gimg, ring, (i + 1) & 1, bat0 + i + 1, lane, wave);
-        ST::wait_prev(i + 1 < nbat);
-        __builtin_amdgcn_s_barrier();                                // every wave's pieces of batch i are in the ring
-        const char* base = ring + (i & 1) * (ST::PIECES * 1024) + lane * 16;
-        v4i am[4][NM];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int m = 0; m < NM; ++m) am[g][m] = *reinterpret_cast<const v4i*>(base + (g * NM + m) * 1024);
-        }
-        auto issue_group = [&](int g, CT (&old)[4], uint32_t (&hit)[4]) {
-            v4i acc = {cinit, cinit, cinit, cinit};
-#pragma unroll
-            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], acc, 0, 0, 0);
-            v4i lab = {0, 0, 0, 0};
-#pragma unroll
-            for (int m = NMC; m < NM; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[g][m], bq[m], lab, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hit[j] = min((uint32_t)lab[j], 1u);
-                if (P32) {
-                    const uint32_t v = (hit[j] << rank_bits) + 1u;
-                    uint32_t o;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(acc[j]), "v"(v) : "memory");
-                    old[j] = (CT)o;
-                } else {
-                    const unsigned long long v = 1ull | ((unsigned long long)hit[j] << 32);
-                    const int addr = acc[j] << 1;
-                    unsigned long long o;
-                    asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(o) : "v"(addr), "v"(v) : "memory");
-                    old[j] = (CT)o;
-                }
-            }
-        };
-        auto drain4 = [&](CT (&old)[4], uint32_t (&hit)[4]) {         // this set's returns are in: 4 newer LDS operations are in flight
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3])::"memory");
-#pragma unroll
-            for (int j = 0; j < 4; ++j) credit(old[j], hit[j]);
-        };
-        issue_group(0, oldA, hitA);
-        issue_group(1, oldB, hitB);
-        drain4(oldA, hitA);
-        issue_group(2, oldA, hitA);
-        drain4(oldB, hitB);
-        issue_group(3, oldB, hitB);
-        drain4(oldA, hitA);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oldB[0]), "+v"(oldB[1]), "+v"(oldB[2]), "+v"(oldB[3])::"memory");
-#pragma unroll
-        for (int j = 0; j < 4; ++j) credit(oldB[j], hitB[j]);
-        __builtin_amdgcn_s_barrier();                                // all reads of this buffer are done before it is staged again
-    }
-    apsum += __shfl_xor(apsum, 16, 64);
-    apsum += __shfl_xor(apsum, 32, 64);
-    if (lane < 16) ap_part[(int64_t)chunk_id * a.qpad + q] = apsum;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // k_scan_ap_c: pass 2 from the one-byte pair cache (binary codes of at most 64 bits), round 3.  Same counters-in-LDS scheme and
@@ -2803,142 +2270,81 @@ constexpr int waves_for(int W, bool tern) { return (W >= 32 && !tern) ? 8 : 1; }
 inline size_t aos_ring_bytes(int W, int LW, bool tern) { return (size_t)64 * (((W * (tern ? 2 : 1) + LW) + 3) / 4 * 4) * 4; }
 
 struct WsLayout {
-    size_t chunk_hist, below, tot, dpre, cap, tick, gate, ap_part, pair_cache, gimg, qimg32, total;
+    size_t chunk_hist, below, tot, dpre, cap, tick, gate, ap_part, pair_cache, total;
 };
 
-// 65..128 bits (two code tiles per group, 129 bucket rows, 2 blocks per CU; round 2): Q 5000 x R 117 218, K = 128: pass 1 0.427 -> 0.325 ms,
-// whole step 0.759 -> 0.663 ms; the pair cache is written in the layout of the 8-slot cached pass 2 (see k_scan_hist_m).  XMH_SCAN_MFMA128=0
-// turns it off.
-// the MFMA-evaluated pass 1 (k_scan_hist_m): binary codes of 33..64 bits, i.e. where the pair cache hands pass 2 the evaluated
-// pairs (measured at Q 5000 x R 117 218, whole step: K=64 0.512 -> 0.489 ms; at K <= 32, where pass 2 evaluates the pairs itself
-// and the VALU pass 1 is cheap, it loses: K=16 0.452 -> 0.471 ms).  XMH_SCAN_MFMA=0 turns it off.
-inline bool mfma_ap_on();
-// k_scan_hist_m2 (round 3) also takes codes of at most 32 bits, the pair cache with it: XMH_SCAN_M2=0 brings back k_scan_hist_m for
-// 33..64 bits and the VALU kernels below that
-// k_scan_hist_m2 keeps five hazards the compiler cannot see apart by hand (s_nop counts, early-clobber operands, statement order: see
+// ---- which kernels take a shape (round 5: one MFMA path + the VALU kernels per code-length band; DESIGN 3.1 has the table) ----------
+//   binary, K <= 64        k_scan_hist_r2            one-byte pair cache -> k_scan_ap_c     (no cache: k_scan_ap_r2)
+//   binary, 65 .. 128      k_scan_hist_r2w           one-byte pair cache -> k_scan_ap_c<., 8, HALF>; a distance of 128 wraps: stand-in k_scan_ap_s
+//   binary, 129 .. 256     k_scan_hist_b             two-byte pair cache -> cached k_scan_ap_s
+//   anything else, more than 128 classes, XMH_SCAN_MFMA=0, a failed self-check or lane-order probe: k_scan_hist_s / k_scan_ap_s (VALU)
+// k_scan_hist_r2 / r2w keep hazards the compiler cannot see apart by hand (s_nop counts, early-clobber operands, statement order: see
 // the kernel), each of which was a wrong result on hardware before it was a comment.  A hipcc or ROCm change could break one of them
-// silently, so the kernel has to EARN its place once per device and process: m2_selfcheck_ok runs a small scan (several chunks, ties,
-// both geometries) with and without it and compares histograms and divisors bit for bit, AP sums to float rounding; a mismatch prints one line to stderr
-// and every later plan of this process uses the round-2 kernels (k_scan_hist_m / the VALU kernels), as XMH_SCAN_M2=0 does.
-// XMH_SCAN_M2_SELFCHECK=0 skips it, =2 runs it and pretends it failed (the test of the fallback); g_m2_force pins the answer while the
+// silently, so the kernels have to EARN their place once per device and process: r2_selfcheck_ok runs a small scan (several chunks,
+// ties, every geometry) with and without them and compares histograms and divisors bit for bit, AP sums to float rounding; a mismatch
+// prints one line to stderr and every later plan of this process uses the VALU kernels, as XMH_SCAN_MFMA=0 does.
+// XMH_SCAN_M2_SELFCHECK=0 skips it, =2 runs it and pretends it failed (the test of the fallback); g_r2_force pins the answer while the
 // check itself runs.
-static thread_local int g_m2_force = -1;
-bool m2_selfcheck_ok();
-inline bool m2_enabled() {
-    if (g_m2_force >= 0) return g_m2_force != 0 && !mfma_ap_on();
-    const char* e = getenv("XMH_SCAN_M2");            // read per call (tests switch it)
-    return !(e && atoi(e) == 0) && !mfma_ap_on() && m2_selfcheck_ok();
+static thread_local int g_r2_force = -1;
+bool r2_selfcheck_ok();
+inline bool mfma_env_on() {                              // read per call: the tests compare the two families in one process
+    const char* e = getenv("XMH_SCAN_MFMA");
+    return !(e && atoi(e) == 0);
 }
-inline bool mfma_shape(int K, bool ternary) {
-    static const bool on = !(getenv("XMH_SCAN_MFMA") && atoi(getenv("XMH_SCAN_MFMA")) == 0);
-    const char* e128 = getenv("XMH_SCAN_MFMA128");                 // read per call (tests switch it)
-    const char* e256 = getenv("XMH_SCAN_MFMA256");
-    const bool on128 = !(e128 && atoi(e128) == 0), on256 = !(e256 && atoi(e256) == 0);
-    return on && !ternary && (K > 32 || m2_enabled()) && (K <= 64 || (on128 && K <= 128) || (on128 && on256 && K <= 256));
+inline bool r2_enabled() {
+    if (g_r2_force >= 0) return g_r2_force != 0;
+    return mfma_env_on() && r2_selfcheck_ok();
 }
-// MFMA-evaluated pass 2 (k_scan_ap_m) instead of the pair cache + cached k_scan_ap_s: XMH_SCAN_MFMA_AP=1.  Bit-identical results,
-// measured at Q 5000 x R 117 218, K = 64: pass 1 without the cache 0.239 -> 0.196 ms, but pass 2 0.195 -> 0.349 ms (64-bit returning
-// atomics behind a staged ring with two barriers per batch at 2 waves per SIMD, against a cache reader with no staging and no
-// barrier): whole step 0.491 -> 0.595 ms.  Off by default; kept for the 65..128-bit shapes it may suit once tuned.
-inline bool mfma_ap_on() {                           // read per call (tests toggle it in one process); a histogram / ap call pair
-    const char* e = getenv("XMH_SCAN_MFMA_AP");       // must of course see the same value
-    return e && atoi(e) != 0;
-}
+inline bool r2_shape(int K, bool ternary) { return !ternary && K <= 64 && r2_enabled(); }
+inline bool r2w_shape(int K, bool ternary) { return !ternary && K > 64 && K <= 128 && r2_enabled(); }
+// k_scan_hist_b (xmh_scan_bits.hip, round 3): 129..256-bit binary codes build their MFMA operands from the packed bits in registers;
+// counters in the (all << 16 | relevant) form of k_scan_hist_r2.  Compiler-scheduled intrinsics: no hand-kept hazard, no self-check.
+inline bool bits_shape(int K, bool ternary) { return !ternary && K > 128 && K <= 256 && mfma_env_on() && g_r2_force != 0; }
+inline bool mfma_shape(int K, bool ternary) { return r2_shape(K, ternary) || r2w_shape(K, ternary) || bits_shape(K, ternary); }
 // k_scan_ap_r2 (round 5): pass 2 evaluates the pairs again on the MFMA from the packed words instead of reading a pair cache (binary codes
 // of at most 64 bits whose pass 1 is k_scan_hist_r2).  Measured at Q 5000 x R 117 218 x 64 bit: pass 1 without the cache stores 0.157 ->
 // 0.128 ms, pass 2 0.173 (k_scan_ap_c on the cache) -> 0.262 ms, step 0.361 -> 0.416 ms -- so it is the pass 2 of evaluations that HAVE no
-// cache (XMH_SCAN_CACHE_MB exceeded or 0, not enough free memory), where it replaces the VALU re-evaluation of k_scan_ap_s.
+// cache (XMH_SCAN_CACHE_MB exceeded or 0, a workspace without room for it), where it replaces the VALU re-evaluation of k_scan_ap_s.
 // XMH_SCAN_AP_R2=1 drops the cache for every such shape (the A/B of DESIGN 3.1), =0 never launches it (read per call; a histogram / ap
 // call pair must see the same value).
 inline int ap_r2_mode() {
     const char* e = getenv("XMH_SCAN_AP_R2");
     return e ? (atoi(e) != 0 ? 1 : 0) : 2;
 }
-inline bool ap_r2_on() { return ap_r2_mode() == 1; }      // the pair cache is given up for it
 constexpr int kAp2Waves = 4, kAp2Groups = 2;           // k_scan_ap_r2: waves per block x query groups of 16 per wave (66 KB of counters at 65 bucket rows, two
                                                        // blocks per CU; 2 x 2, 1 x 2 and 1 x 1 measured the same 0.262-0.275 ms at the headline shape)
-constexpr int kMfmaWaves = 4;                          // waves (16 queries each) per block sharing one staged gallery batch
-// k_scan_hist_m2 (binary codes of at most 64 bits): waves per block x query groups of 16 per wave = 128 queries per staged batch,
-// two blocks per CU.  XMH_SCAN_M2=0 falls back to k_scan_hist_m; the MFMA pass 2 (XMH_SCAN_MFMA_AP=1) reads k_scan_hist_m's images.
-struct M2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
-// k_scan_hist_r2 (operands from the packed words, no image / ring / barrier) instead of k_scan_hist_m2: the default for every length
-// k_scan_hist_m2 takes (Q 5000 x R 117 218, pass 1 + the launch in front of it, m2 / r2: 16 bit 0.158 + 0.009 / 0.154 + 0.005 ms,
-// 32 bit 0.162 + 0.010 / 0.157 + 0.005, 64 bit 0.194 + 0.010 / 0.160 + 0.005).  XMH_SCAN_M2_REGS=0 brings k_scan_hist_m2 back
-// (read per call: the tests compare the two).
-inline bool m2_regs(int K) {
-    const char* e = getenv("XMH_SCAN_M2_REGS");
-    (void)K;
-    return e ? atoi(e) != 0 : true;
-}
-inline M2Geom m2_geom(int K) {
-    // XMH_SCAN_M2_GEOM / _BPC pick one of the instantiated shapes / the blocks per CU the chunk count is sized for (tuning; read per call).
-    // Default: 4 waves x 2 query groups, two blocks per CU (70 KB of LDS each at 65 buckets); codes of at most 32 bits have so few
-    // buckets that 4 query groups per wave fit -- half the A-tile reads, LDS-DMA pieces and barriers per pair; the chunk count that
-    // measured best there is two blocks of 256 queries per CU in all (Q 5000 x R 117 218, blocks per CU x rounds = 1 / 2 / 3 / 4 / 6:
-    // K=16 0.416 / 0.350 / 0.367 / 0.352 / 0.368 ms per step, K=32 0.426 / 0.362 / 0.385 / 0.375 / 0.393).
-    static const M2Geom table[] = {{4, 2, 2}, {8, 1, 2}, {4, 4, 1}, {8, 2, 1}, {4, 1, 3}, {6, 1, 2}, {5, 2, 2}};
-    const char* e = getenv("XMH_SCAN_M2_GEOM");
-    // k_scan_hist_r2 has no ring: 4 query groups per wave fit at 65 bucket rows as well (66 KB of counters, two blocks per CU), and every A
-    // tile it builds (5-6 VALU operations) then feeds four MFMA groups -- with 2 groups and three blocks per CU it loses to k_scan_hist_m2
-    // (first version, 8 operations per tile: pass 1 0.207-0.231 ms against 0.190)
-    M2Geom g = K <= 32 ? M2Geom{4, 4, 1} : (m2_regs(K) ? M2Geom{4, 4, 2} : table[0]);
-    if (e && atoi(e) >= 0 && atoi(e) < 7) g = table[atoi(e)];
-    const char* b = getenv("XMH_SCAN_M2_BPC");
-    if (b && atoi(b) > 0) g.blocks_per_cu = atoi(b);
-    if (K > 64) g = M2Geom{4, 2, 2};                                 // k_scan_hist_r2w: 129 bucket rows, 66 KB of counters per block with two groups per wave -- its one instance
-    return g;
-}
-inline bool m2_shape(int K, bool ternary) { return m2_enabled() && mfma_shape(K, ternary) && K <= 64; }
-// k_scan_hist_b (xmh_scan_bits.hip, round 3): 65..256-bit binary codes with at most 128 classes build their MFMA operands from the
-// packed bits in registers -- no operand image, no LDS ring; counters in the (all << 16 | relevant) form of k_scan_hist_m2.
-// Measured (Q 5000, C 80): 256 bit x R 117 218 pass 1 0.561 -> 0.514 ms, x R 1.25 M (configs[4] shard) 5.84 -> 4.61 ms; at 128 bit the
-// expansion of the label words (as many VALU operations as for the code) makes it lose, 0.381 against 0.326 ms, so 65..128 bits stay
-// on k_scan_hist_m.  XMH_SCAN_BITS=0 brings k_scan_hist_m back for all lengths, =2 takes 65..128 bits as well (read per call: tests
-// switch it); the MFMA pass 2 reads k_scan_hist_m's images.
-static_assert(xmh::kScanBitsWaves == kMfmaWaves, "k_scan_hist_b shares the plan's query tiles with k_scan_hist_m");
-inline bool bits_shape(int K, bool ternary, int LW) {
-    const char* e = getenv("XMH_SCAN_BITS");
-    const int mode = e ? atoi(e) : 1;
-    return mode != 0 && !mfma_ap_on() && mfma_shape(K, ternary) && K > (mode == 2 ? 64 : 128) && K <= 256 && LW <= 4;
-}
-// k_scan_hist_r2w (round 4): pass 1 of 65..128-bit codes in the manner of k_scan_hist_r2 (operands from the packed words, one-byte entries).
-// The plan follows it (4 waves x 2 query groups, two blocks per CU, chunks of up to 32768 items); XMH_SCAN_R2W=0 keeps k_scan_hist_m.
-// Needs what it builds on: the self-checked statements (m2_enabled), the one-byte entries (XMH_SCAN_BYTE128), no k_scan_hist_b by request.
-inline bool r2w_plan_shape(int K, bool ternary) {
-    const char* e = getenv("XMH_SCAN_R2W");
-    const char* b = getenv("XMH_SCAN_BYTE128");
-    const char* bits = getenv("XMH_SCAN_BITS");
-    return !(e && atoi(e) == 0) && !(b && atoi(b) == 0) && !(bits && atoi(bits) == 2) && !ternary && K > 64 && K <= 128 && mfma_shape(K, ternary) &&
-           m2_enabled() && m2_regs(K);
-}
-inline bool r2w_shape(int K, bool ternary, int LW) { return LW <= 4 && r2w_plan_shape(K, ternary); }
-// One-byte pair-cache entries for 65..128-bit codes (k_scan_hist_m<2, .., BYTE> + k_scan_ap_c<., 8>, round 4): whenever those codes take
-// k_scan_hist_m at all.  XMH_SCAN_BYTE128=0 keeps the two-byte entries and the cached k_scan_ap_s (read per call: tests compare the two).
-inline bool byte128_shape(int K, bool ternary, int LW) {
-    const char* e = getenv("XMH_SCAN_BYTE128");
-    return !(e && atoi(e) == 0) && !ternary && K > 64 && K <= 128 && LW <= 4 && mfma_shape(K, ternary) && !bits_shape(K, ternary, LW) && !mfma_ap_on();
-}
-// operand images in the workspace: gallery 64 B of code + up to 128 B of label bytes per item, queries likewise (two scalings)
-inline size_t mfma_gimg_bytes(int64_t R) { return (size_t)xmh::ceil_div(R, 64) * 4 * 6 * 1024; }      // up to 4 code + 2 label tiles per group
-inline size_t mfma_qimg_bytes(int64_t qpad) { return (size_t)(qpad / 16) * 6 * 1024; }
+constexpr int kMfmaWaves = 4;                          // k_scan_hist_b: waves (16 queries each) per block
+static_assert(xmh::kScanBitsWaves == kMfmaWaves, "k_scan_hist_b takes the plan's query tiles of 64");
+constexpr int kBitsMaxChunk = 8064;                    // chunks of k_scan_hist_b's plan (the size its configs[4] numbers were tuned at), multiple of 64
+// waves per block x query groups of 16 per wave of k_scan_hist_r2 / r2w, and the blocks per CU the chunk count is sized for: codes of at
+// most 32 bits have so few buckets that one block of 256 queries per CU measured best (Q 5000 x R 117 218, blocks per CU x rounds: K=16
+// 0.416 / 0.350 / 0.367 / 0.352 / 0.368 ms per step for 1 / 2 / 3 / 4 / 6); 33..64 bits: 66 KB of counters per block, two per CU;
+// 65..128 bits: 129 bucket rows, two groups per wave (66 KB), two blocks per CU.
+struct R2Geom { int nw, nq, blocks_per_cu; int queries() const { return nw * nq * 16; } };
+inline R2Geom r2_geom(int K) { return K <= 32 ? R2Geom{4, 4, 1} : (K <= 64 ? R2Geom{4, 4, 2} : R2Geom{4, 2, 2}); }
 
-// Pair cache (k_scan_hist_s): only for the geometries it is laid out for -- binary codes of 33..64 bits (S = 4, one byte per
-// pair) and 65..256 bits (S = 8, two bytes per pair) -- and while it stays under XMH_SCAN_CACHE_MB (default 131072; 0 = off).
+// Pair cache: binary codes of at most 64 bits and of 65..128 bits (one byte per pair: distance << 1 | relevant) and 129..256 bits (two
+// bytes), while it stays under XMH_SCAN_CACHE_MB (default 131072: an MI355X has 288 GB of HBM and up to there the cache still pays --
+// the UNSHARDED configs[4] gallery, Q 5000 x R 10 M x 256 bit = 100 GB of entries, runs 89.6 -> 67.3 ms per step with it; 0 = off).
+// The VALU kernels write and read the same layouts (k_scan_hist_s / k_scan_ap_s<.., CACHE>: 33..256 bits).
+inline long long cache_cap_mb() {
+    const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call
+    return cap_env ? atoll(cap_env) : 131072;
+}
+inline bool ap_c_on() {                                  // XMH_SCAN_AP_C=0: the integer-counter kernels take every pass 2 (tests: the path of galleries beyond 2^23 items)
+    const char* e = getenv("XMH_SCAN_AP_C");
+    return !(e && atoi(e) == 0);
+}
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
-    const char* cap_env = getenv("XMH_SCAN_CACHE_MB");              // read per call, like XMH_SCAN_MFMA_AP
-    // default 128 GB: an MI355X has 288 GB of HBM, and up to there the cache still pays -- the UNSHARDED configs[4] gallery (Q 5000 x
-    // R 10 M x 256 bit: 100 GB of two-byte entries) runs 89.6 -> 67.3 ms per step with it (round 4; the cap was 32 GB), one GPU's shard of it (Q 5000 x
-    // R 1 250 000 x 256 bit: 12.7 GB of two-byte entries) runs 13.3 -> 10.2 ms per step with it (round 2's cap was 4 GB)
-    const long long cap_mb = cap_env ? atoll(cap_env) : 131072;
-    if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !m2_shape(K, ternary))) return 0;
-    if (K <= 64 && mfma_shape(K, ternary) && mfma_ap_on()) return 0;          // pass 2 evaluates the pairs on the MFMA itself
-    if (K <= 64 && m2_shape(K, ternary) && m2_regs(K) && ap_r2_on()) return 0;  // k_scan_ap_r2 likewise
+    const long long cap_mb = cache_cap_mb();
+    if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !r2_shape(K, ternary))) return 0;
+    if (r2_shape(K, ternary) && ap_r2_mode() == 1) return 0;        // k_scan_ap_r2 evaluates the pairs itself
     const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
 }
 
-WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes, int64_t R = 0, bool mfma = false) {
+WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes) {
     WsLayout L;
     const size_t cells = (size_t)p.nchunk * p.nbuckets * p.qpad;
     size_t o = 0;
@@ -2955,11 +2361,17 @@ WsLayout ws_layout(const xmh_scan_plan& p, size_t cache_bytes, int64_t R = 0, bo
     L.tick = take((size_t)p.nqtile * 4);     // k_scan_below tickets, one per 64-query tile; ends where `gate` starts: one memset clears both
     L.gate = take(256 + 8 * 4096);           // [0]: nrel_max gate word, [1]: finalize ticket, +256: per-block partial sums (<= 4096 blocks)
     L.ap_part = take((size_t)p.nchunk * p.qpad * 4);
-    L.pair_cache = take(cache_bytes);
-    L.gimg = take(mfma ? mfma_gimg_bytes(R) : 0);
-    L.qimg32 = take(mfma ? mfma_qimg_bytes(p.qpad) : 0);
+    L.pair_cache = take(cache_bytes);        // LAST: a workspace that ends in front of it is a workspace without a cache (cache_for_workspace)
     L.total = o;
     return L;
+}
+
+// The cache a call may use given the workspace it was handed: the plan's, or none when the caller's buffer ends in front of it (a device
+// that has no room for Q x R bytes next to a resident encoder: xmh_scan_ws_bytes_nocache).  Both calls of a pair see the same ws_bytes
+// and so take the same decision -- no process-wide state (round 4 lowered XMH_SCAN_CACHE_MB in the environment for this: ADVICE r4).
+size_t cache_for_workspace(const xmh_scan_plan& p, int K, bool ternary, size_t ws_bytes) {
+    const size_t c = pair_cache_bytes(p, K, ternary);
+    return c && ws_bytes < ws_layout(p, c).total ? 0 : c;
 }
 
 int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
@@ -2973,37 +2385,30 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     const int S64 = slots_for(Wc, ternary != 0, 8);
     const int64_t lds_ap = nb * (64 / S64) * 8;
     if (lds_ap > 150 * 1024) return xmh::fail(XMH_ENOTSUP, "scan plan: %lld distance buckets need %lld B of LDS per wave; K=%d%s", (long long)nb, (long long)lds_ap, K, ternary ? " ternary" : "");
-    const bool m2 = m2_shape(K, ternary != 0) || r2w_plan_shape(K, ternary != 0);
+    const bool r2 = r2_shape(K, ternary != 0) || r2w_shape(K, ternary != 0);
     int64_t nqt = xmh::ceil_div(Q, 64);
-    const int m2q = m2_geom(K).queries();
-    if (m2) {                                     // whole blocks of k_scan_hist_m2 AND whole 64-query tiles
-        int64_t l = m2q;
-        while (l % 64) l += m2q;
+    const int r2q = r2_geom(K).queries();
+    if (r2) {                                     // whole blocks of k_scan_hist_r2 AND whole 64-query tiles
+        int64_t l = r2q;
+        while (l % 64) l += r2q;
         nqt = xmh::ceil_div(nqt * 64, l) * l / 64;
     }
-    const int64_t wpc = 8;                        // resident waves per CU the kernels are sized for (two per SIMD)
+    const int64_t wpc = 8;                        // resident waves per CU the VALU kernels are sized for (two per SIMD)
     // one chunk x 64-query tile per resident wave slot (`rounds` sets of them); slotted kernels run S waves per tile
     const int64_t slots = (int64_t)xmh::device_cu_count() * wpc;
-    static const int rounds_env = getenv("XMH_SCAN_ROUNDS") ? atoi(getenv("XMH_SCAN_ROUNDS")) : 0;
     // two resident sets of waves balance the tail better, but the [chunk][bucket][query] tables double: pays up to 65 buckets
-    // (K=64: 0.640 -> 0.624 ms, K=16: 0.502 -> 0.476), costs at 257 (K=256: 1.45 -> 1.54)
-    // with the pair cache (binary codes of 33..64 bits) the passes are shorter and the tables weigh more: one set (0.543 -> 0.536 ms)
-    const bool cache_shape = !ternary && K > 32 && K <= 64 && !(getenv("XMH_SCAN_CACHE_MB") && atoll(getenv("XMH_SCAN_CACHE_MB")) <= 0);
-    // codes of 32 bits and less: three sets (Q 5000 x R 117 218, rounds 2 / 3 / 4: K=16 0.438 / 0.421 / 0.428 ms, K=32 0.461 / 0.444 / 0.451)
-    const int64_t rounds = rounds_env > 0 ? rounds_env : (nb <= 33 ? 3 : (nb <= 65 && !cache_shape ? 2 : 1));
+    // (K=64: 0.640 -> 0.624 ms, K=16: 0.502 -> 0.476), costs at 257 (K=256: 1.45 -> 1.54); with the pair cache (33..64 bits) the passes
+    // are shorter and the tables weigh more: one set (0.543 -> 0.536 ms); codes of 32 bits and less: three sets
+    const bool cache_shape = !ternary && K > 32 && K <= 64 && cache_cap_mb() > 0;
+    const int64_t rounds = nb <= 33 ? 3 : (nb <= 65 && !cache_shape ? 2 : 1);
     int64_t nchunk = rounds * slots / nqt;
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     const bool mfma = mfma_shape(K, ternary != 0);
     if (mfma) {
-        // blocks of kMfmaWaves waves = one 64-query tile x one chunk; 3 blocks fit a CU (pass 1), `rounds` sets of them
-        static const int mr = getenv("XMH_SCAN_MFMA_ROUNDS") ? atoi(getenv("XMH_SCAN_MFMA_ROUNDS")) : 3;
-        // 65..128 bits: 129 bucket rows, 2 blocks per CU; 129..256 bits: 257 rows, one block per CU
-        nchunk = (int64_t)(mr > 0 ? mr : 3) * xmh::device_cu_count() * (K <= 64 ? 3 : (K <= 128 ? 2 : 1)) / nqt;
-        if (m2) {                                 // two blocks of 128 queries per CU, `m2r` sets of them
-            const char* m2r_env = getenv("XMH_SCAN_M2_ROUNDS");                  // read per call, like the geometry
-            const int m2r_def = K > 32 && K <= 64 && m2_regs(K) ? 1 : 2;          // k_scan_hist_r2: one set of two 256-query blocks per CU (rounds 1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
-            const int m2r = m2r_env && atoi(m2r_env) > 0 ? atoi(m2r_env) : m2r_def;
-            nchunk = (int64_t)m2r * xmh::device_cu_count() * m2_geom(K).blocks_per_cu / (nqt * 64 / m2q);
+        nchunk = (int64_t)3 * xmh::device_cu_count() / nqt;          // k_scan_hist_b: 257 bucket rows, one block of 64 queries per CU, three sets
+        if (r2) {                                 // blocks of r2q queries, blocks_per_cu of them per CU, `sets` sets of them
+            const int sets = K > 32 && K <= 64 ? 1 : 2;             // k_scan_hist_r2 at 33..64 bits: one set (1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
+            nchunk = (int64_t)sets * xmh::device_cu_count() * r2_geom(K).blocks_per_cu / (nqt * 64 / r2q);
         }
     }
     if (nchunk < 1) nchunk = 1;
@@ -3012,10 +2417,10 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (chunk < kMinChunk) chunk = kMinChunk;
     if (chunk > kMaxChunk) chunk = kMaxChunk;
     chunk = xmh::ceil_div(chunk, 8) * 8;
-    if (mfma) {                                   // batches of 64 items aligned to the gallery image; counters hold all + 8128 * relevant
+    if (mfma) {                                   // batches of 64 items
         chunk = xmh::ceil_div(chunk, 64) * 64;
-        if (!m2 && chunk > kMfmaMaxChunk) {                       // capped: whole XCD groups of equal chunks again
-            nchunk = xmh::ceil_div(xmh::ceil_div(R, (int64_t)kMfmaMaxChunk), 8) * 8;
+        if (!r2 && chunk > kBitsMaxChunk) {                         // capped: whole XCD groups of equal chunks again
+            nchunk = xmh::ceil_div(xmh::ceil_div(R, (int64_t)kBitsMaxChunk), 8) * 8;
             chunk = xmh::ceil_div(xmh::ceil_div(R, nchunk), 64) * 64;
         }
     }
@@ -3025,7 +2430,7 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     p->nqtile = nqt;
     p->qpad = nqt * 64;
     p->nbuckets = nb;
-    p->ws_bytes = ws_layout(*p, pair_cache_bytes(*p, K, ternary != 0), R, mfma).total;
+    p->ws_bytes = ws_layout(*p, pair_cache_bytes(*p, K, ternary != 0)).total;
     return XMH_OK;
 }
 
@@ -3064,7 +2469,7 @@ struct DevBuf {
 bool selfcheck_eval(int K, int force, const std::vector<uint32_t>& qb, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rb,
                     const std::vector<uint32_t>& rl, int64_t Q, int64_t R, int C, std::vector<uint32_t>& hist, std::vector<double>& ap,
                     std::vector<int32_t>& cap) {
-    g_m2_force = force;
+    g_r2_force = force;
     bool ok = false;
     do {
         xmh_scan_plan p;
@@ -3091,12 +2496,12 @@ bool selfcheck_eval(int K, int force, const std::vector<uint32_t>& qb, const std
             break;
         ok = true;
     } while (false);
-    g_m2_force = -1;
+    g_r2_force = -1;
     return ok;
 }
 }  // namespace
 
-bool m2_selfcheck_ok() {
+bool r2_selfcheck_ok() {
     static int state[64];                                 // 0 unknown, 1 passed, 2 failed
     static std::mutex mu;
     int dev = 0;
@@ -3105,7 +2510,7 @@ bool m2_selfcheck_ok() {
     if (e && atoi(e) == 0) return true;
     std::lock_guard<std::mutex> lock(mu);
     if (state[dev]) return state[dev] == 1;
-    state[dev] = 1;                                       // the evaluations below re-enter through g_m2_force only
+    state[dev] = 1;                                       // the evaluations below re-enter through g_r2_force only
     const int64_t Q = 200, R = 9000;
     const int C = 80, LW = 3;
     bool same = true, ran = true;
@@ -3141,8 +2546,8 @@ bool m2_selfcheck_ok() {
     }
     if (!same) {
         state[dev] = 2;
-        fprintf(stderr, "xmh: k_scan_hist_m2 self-check FAILED on device %d (results differ from the reference kernels): falling back to k_scan_hist_m / the VALU "
-                        "pass 1 for this process.  Please report the hipcc / ROCm versions.\n", dev);
+        fprintf(stderr, "xmh: k_scan_hist_r2 self-check FAILED on device %d (results differ from the VALU kernels): falling back to the VALU scan "
+                        "for this process.  Please report the hipcc / ROCm versions.\n", dev);
     }
     return state[dev] == 1;
 }
@@ -3171,7 +2576,8 @@ int check_common(const char* who, const uint32_t* qbits, const uint32_t* qzero, 
     if (!qbits || !rbits || !qlab || !rlab || !ws) return xmh::fail(XMH_EINVAL, "%s: null pointer", who);
     if ((qzero == nullptr) != (rzero == nullptr)) return xmh::fail(XMH_EINVAL, "%s: zero masks must be given for both sides or neither", who);
     if (C <= 0) return xmh::fail(XMH_EINVAL, "%s: C=%d", who, C);
-    if (ws_bytes < p.ws_bytes) return xmh::fail(XMH_EINVAL, "%s: workspace too small (%zu < %zu)", who, ws_bytes, p.ws_bytes);
+    const size_t need = ws_layout(p, 0).total;                       // at least the plan without its pair cache (xmh_scan_ws_bytes_nocache)
+    if (ws_bytes < need) return xmh::fail(XMH_EINVAL, "%s: workspace too small (%zu < %zu; %zu with the pair cache)", who, ws_bytes, need, (size_t)p.ws_bytes);
     return XMH_OK;
 }
 
@@ -3195,114 +2601,38 @@ int raise_lds(KernT kern, size_t lds, const char* who) { return xmh::raise_dynam
 
 
 namespace {
-template <int NMC, int NML>
-int mfma_hist_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
-                const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    constexpr int NM = NMC + NML, NW = kMfmaWaves;
-    uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
-    uint4* q32 = reinterpret_cast<uint4*>(base + L.qimg32);
-    const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NM * 64, qpieces = (p.qpad / 16) * NM * 64;
-    const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
-    hipLaunchKernelGGL((k_scan_expand<NMC, NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
-                       q32, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
-    XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
-    MfmaArgs a{gimg, q32, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * NW)), (int)p.nbuckets, (int)p.qpad};
-    const size_t lds = (size_t)NW * p.nbuckets * 16 * 4 + 2 * 4 * NM * 1024;
-    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
-    xmh::ProfScope prof("scan_hist", st);
-    if (cache) {
-        if constexpr (NMC == 2) {
-            if (byte128_shape(K, false, LW)) {
-                auto kern = k_scan_hist_m<NMC, NML, NW, true, true>;
-                const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-                if (r2) return r2;
-                hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, reinterpret_cast<uint32_t*>(base + L.gate) + kGateWrapped);
-                return XMH_OK;
-            }
-        }
-        auto kern = k_scan_hist_m<NMC, NML, NW, true, false>;
-        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-        if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (uint32_t*)nullptr);
-    } else {
-        auto kern = k_scan_hist_m<NMC, NML, NW, false, false>;
-        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-        if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (uint32_t*)nullptr);
-    }
-    return XMH_OK;
-}
-
-template <int NML, int NW, int NQ>
-int mfma_hist2_t(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
-                 const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    constexpr int NMI = 1 + NML, NMQ = 2 + NML;
-    uint4* gimg = reinterpret_cast<uint4*>(base + L.gimg);
-    uint4* qimg = reinterpret_cast<uint4*>(base + L.qimg32);
-    const int64_t gpieces = xmh::ceil_div(R, 64) * 4 * NMI * 64, qpieces = (p.qpad / 16) * NMQ * 64;
-    const unsigned gblocks = (unsigned)xmh::ceil_div(gpieces, 256), qblocks = (unsigned)xmh::ceil_div(qpieces, 256);
-    const bool regs = m2_regs(K);
-    if (regs) {                                                      // no operand images
-        hipLaunchKernelGGL(k_scan_touch, dim3((unsigned)(8 * kTouchPerChunk * xmh::ceil_div(p.nchunk, 8))), dim3(256), 0, st, rbits, rlab, R, W, LW, p.chunk,
-                           (int)p.nchunk, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
-        XMH_LAUNCH_CHECK("xmh_hamming_hist control words");
-    } else {
-        hipLaunchKernelGGL((k_scan_expand2<NML>), dim3(gblocks + qblocks), dim3(256), 0, st, rbits, rlab, R, W, LW, K, gimg, gpieces, gblocks, qbits, qlab, Q,
-                           qimg, qpieces, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
-        XMH_LAUNCH_CHECK("xmh_hamming_hist operand images");
-    }
-    MfmaArgs a{gimg, qimg, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
-    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
-    xmh::ProfScope prof("scan_hist", st);
-    if (regs) {
-        a.rbits = rbits; a.rlab = rlab; a.qlab = qlab; a.LW = LW;
-        const size_t lds_r = (size_t)NW * NQ * p.nbuckets * 16 * 4;
-        auto go = [&](auto kern) {
-            const int r2 = raise_lds(kern, lds_r, "xmh_hamming_hist");
-            if (r2) return r2;
-            hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds_r, st, a, chunk_hist, cache);
-            return (int)XMH_OK;
-        };
-        return cache ? go(k_scan_hist_r2<NML, NW, NQ, true>) : go(k_scan_hist_r2<NML, NW, NQ, false>);
-    }
-    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4 + 3 * 4 * NMI * 1024;
-    if (cache) {
-        auto kern = k_scan_hist_m2<NML, NW, NQ, true>;
-        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-        if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (unsigned long long*)nullptr);
-    } else {
-        auto kern = k_scan_hist_m2<NML, NW, NQ, false>;
-        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
-        if (r2) return r2;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache, (unsigned long long*)nullptr);
-    }
-    return XMH_OK;
-}
-
-template <int NML>
-int mfma_hist2(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
-               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    const M2Geom g = m2_geom(K);
-#define XMH_M2(NWW, NQQ) \
-    if (g.nw == NWW && g.nq == NQQ) return mfma_hist2_t<NML, NWW, NQQ>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    XMH_M2(4, 2) XMH_M2(8, 1) XMH_M2(4, 4) XMH_M2(8, 2) XMH_M2(4, 1) XMH_M2(6, 1) XMH_M2(5, 2)
-#undef XMH_M2
-    return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_m2 instance for %d waves x %d query groups", g.nw, g.nq);
-}
-
-// 65..128 bits through k_scan_hist_r2w (4 waves x 2 query groups, the plan's geometry for these lengths)
-template <int NML>
-int mfma_hist_r2w(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
-                  const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    constexpr int NW = 4, NQ = 2;
-    const M2Geom g = m2_geom(K);
-    if (g.nw != NW || g.nq != NQ) return xmh::fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_r2w instance for %d waves x %d query groups", g.nw, g.nq);
+// the launch in front of pass 1: clears the control words of the call and reads every chunk's packed words on the XCD that will scan it
+void launch_touch(const uint32_t* rbits, const uint32_t* rlab, int64_t R, int W, int LW, const xmh_scan_plan& p, char* base, const WsLayout& L, hipStream_t st) {
     hipLaunchKernelGGL(k_scan_touch, dim3((unsigned)(8 * kTouchPerChunk * xmh::ceil_div(p.nchunk, 8))), dim3(256), 0, st, rbits, rlab, R, W, LW, p.chunk,
                        (int)p.nchunk, reinterpret_cast<uint32_t*>(base + L.tick), (int)((L.gate + 256 - L.tick) / 4));
-    XMH_LAUNCH_CHECK("xmh_hamming_hist control words");
-    MfmaArgs a{nullptr, nullptr, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW * NQ * 16)), (int)p.nbuckets, (int)p.qpad};
+}
+
+MfmaArgs r2_args(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
+                 const xmh_scan_plan& p, int queries_per_block) {
+    MfmaArgs a{qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / queries_per_block), (int)p.nbuckets, (int)p.qpad};
     a.rbits = rbits; a.rlab = rlab; a.qlab = qlab; a.LW = LW;
+    return a;
+}
+
+// binary codes of at most 64 bits: k_scan_hist_r2 in the plan's geometry (r2_geom)
+template <int NML, int NW, int NQ>
+int hist_r2_t(const MfmaArgs& a, const xmh_scan_plan& p, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
+    const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4;
+    xmh::ProfScope prof("scan_hist", st);
+    auto go = [&](auto kern) {
+        const int r2 = raise_lds(kern, lds, "xmh_hamming_hist");
+        if (r2) return r2;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        return (int)XMH_OK;
+    };
+    return cache ? go(k_scan_hist_r2<NML, NW, NQ, true>) : go(k_scan_hist_r2<NML, NW, NQ, false>);
+}
+
+// 65..128 bits: k_scan_hist_r2w (4 waves x 2 query groups)
+template <int NML>
+int hist_r2w_t(const MfmaArgs& a, const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+    constexpr int NW = 4, NQ = 2;
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(p.nchunk, 8)));
     const size_t lds = (size_t)NW * NQ * p.nbuckets * 16 * 4;
     uint32_t* ovf = reinterpret_cast<uint32_t*>(base + L.gate) + kGateWrapped;
@@ -3318,26 +2648,18 @@ int mfma_hist_r2w(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* r
 
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    if (r2w_shape(K, false, LW))
-        return LW <= 2 ? mfma_hist_r2w<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                       : mfma_hist_r2w<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    if (m2_shape(K, false))
-        return LW <= 2 ? mfma_hist2<1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                       : mfma_hist2<2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    if (K <= 64)
-        return LW <= 2 ? mfma_hist_t<1, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                       : mfma_hist_t<1, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    if (bits_shape(K, false, LW)) {
-        XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words k_scan_expand clears for the image kernels
+    if (bits_shape(K, false)) {
+        XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words of the call
         const xmh::ScanBitsArgs a{rbits, rlab, qbits, qlab, (int)Q, (int)R, K, W, LW, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)),
                                   (int)p.nbuckets, (int)p.qpad};
-        return xmh::launch_scan_hist_bits(a, K <= 128 ? 2 : 4, chunk_hist, cache, st);
+        return xmh::launch_scan_hist_bits(a, 4, chunk_hist, cache, st);
     }
-    if (K <= 128)
-        return LW <= 2 ? mfma_hist_t<2, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                       : mfma_hist_t<2, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
-    return LW <= 2 ? mfma_hist_t<4, 1>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st)
-                   : mfma_hist_t<4, 2>(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist, cache, st);
+    launch_touch(rbits, rlab, R, W, LW, p, base, L, st);
+    XMH_LAUNCH_CHECK("xmh_hamming_hist control words");
+    const R2Geom g = r2_geom(K);
+    const MfmaArgs a = r2_args(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, g.queries());
+    if (K > 64) return LW <= 2 ? hist_r2w_t<1>(a, p, base, L, chunk_hist, cache, st) : hist_r2w_t<2>(a, p, base, L, chunk_hist, cache, st);
+    return LW <= 2 ? hist_r2_t<1, 4, 4>(a, p, chunk_hist, cache, st) : hist_r2_t<2, 4, 4>(a, p, chunk_hist, cache, st);
 }
 
 }  // namespace
@@ -3356,17 +2678,28 @@ extern "C" size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ter
 extern "C" size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary) {
     xmh_scan_plan p;
     if (make_plan(Q, R, K, ternary, &p)) return (size_t)-1;
-    return ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0)).pair_cache;
+    return ws_layout(p, pair_cache_bytes(p, K, ternary != 0)).pair_cache;
+}
+
+// The workspace of the same plan WITHOUT the pair cache: a caller whose device has no room for xmh_scan_plan.ws_bytes (Q x R bytes of
+// cache next to a resident encoder) hands xmh_hamming_hist / _ap a buffer of this size instead, and both passes run uncached (pass 2 of
+// codes of at most 64 bits: k_scan_ap_r2).  The decision follows from the size handed in, per call: no process-wide state.
+extern "C" size_t xmh_scan_ws_bytes_nocache(int64_t Q, int64_t R, int K, int ternary) {
+    xmh_scan_plan p;
+    if (make_plan(Q, R, K, ternary, &p)) return 0;
+    return ws_layout(p, 0).total;
 }
 
 // Width of the rank field of the packed 32-bit pass-2 counters for an UNSHARDED evaluation of this shape, 0 = only the 64-bit kernels
 // are launched.  One function for the launch path (hamming_ap_impl) and for xmh_scan_describe, so that the kernel name the bench looks
 // up in a profile is the kernel that ran (the two had drifted apart on XMH_SCAN_NO_PACK32).
-int packed_rank_bits(int K, int64_t R, bool mfma_plan) {
-    if (!(K > 64 || getenv("XMH_SCAN_PACK32_ALL") != nullptr) || getenv("XMH_SCAN_NO_PACK32") != nullptr) return 0;
-    // the MFMA pass 2 also counts the padding items of a ragged last batch (after the real ones, hit = 0): the rank field
-    // must hold them too, or it wraps to 0 and 0 * rcp(0) poisons the sum
-    const int64_t rank_max = (mfma_plan && K <= 64 && mfma_ap_on() ? ((R + 63) & ~(int64_t)63) : R) + 2;
+int packed_rank_bits(int K, int64_t R) {
+    // XMH_SCAN_PACK32: "0" = never, "all" = every code length (tests); default: from 65 bits on (measured at Q 5000 x R 117 218, sparse
+    // relevance, pass 2 packed / 64-bit: K=16 0.275 / 0.251 ms, K=64 0.199 / 0.195, K=128 0.274 / 0.286, K=256 0.347 / 0.412)
+    const char* e = getenv("XMH_SCAN_PACK32");
+    if (e && e[0] == '0') return 0;
+    if (!(K > 64 || (e && e[0] == 'a'))) return 0;
+    const int64_t rank_max = R + 2;
     int rank_bits = 0;
     while ((1ll << rank_bits) < rank_max) ++rank_bits;
     return rank_bits > 24 ? 0 : rank_bits;
@@ -3388,48 +2721,34 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     char p1[160], p2[200];
     const int NML = LW <= 2 ? 1 : 2;
     const int S4 = slots_for(Wc, tern, 4), S8 = slots_for(Wc, tern, 8);
-    if (use_mfma && r2w_shape(K, tern, LW)) {
-        const M2Geom g = m2_geom(K);
-        snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
-    } else if (use_mfma && m2_shape(K, tern)) {
-        const M2Geom g = m2_geom(K);
-        if (m2_regs(K)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
-        else snprintf(p1, sizeof(p1), "k_scan_hist_m2<%d, %d, %d, %s, false>", NML, g.nw, g.nq, cache ? "true" : "false");
-    } else if (use_mfma) {
-        if (bits_shape(K, tern, LW)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s>", K <= 128 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
-        else snprintf(p1, sizeof(p1), "k_scan_hist_m<%d, %d, %d, %s, %s>", K <= 64 ? 1 : (K <= 128 ? 2 : 4), NML, kMfmaWaves, cache ? "true" : "false",
-                      cache && byte128_shape(K, tern, LW) ? "true" : "false");
-    } else {
+    const R2Geom g = r2_geom(K);
+    if (use_mfma && r2w_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
+    else if (use_mfma && r2_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
+    else if (use_mfma) snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %s>", kMfmaWaves, cache ? "true" : "false");
+    else {
         const bool cached = cache && !tern && Wc <= 8;
         const int S = cached ? cache_slots(Wc) : S4;
         snprintf(p1, sizeof(p1), "k_scan_hist_s<%d, %d, %s, %d, %d, %s>", Wc, LW, tern ? "true" : "false", S, S == 64 ? waves_for(Wc, tern) : 1,
                  cached ? "true" : "false");
     }
-    const char* apc_env = getenv("XMH_SCAN_AP_C");
-    const bool packable = packed_rank_bits(K, R, use_mfma) > 0;       // exactly what hamming_ap_impl launches for an unsharded evaluation
-    const int apc_mode = apc_env ? atoi(apc_env) : 1;
-    const bool byte128 = cache && use_mfma && byte128_shape(K, tern, LW);
-    if (cache && !tern && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && !packable : apc_mode == 2 && K <= 256)) && R <= kFloatBitsMaxItems) {
-        const bool b8 = K <= 64 || byte128;
-        const char* half_env = getenv("XMH_SCAN_AP_HALF");
-        const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
-        if (half) snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, true>");
-        else snprintf(p2, sizeof(p2), "k_scan_ap_c<false, %d, false>", b8 ? 8 : 16);        // all three template arguments: the name a profile prints
-    } else if (use_mfma && !cache && K <= 64 && m2_shape(K, tern) && m2_regs(K) && ap_r2_mode() != 0 && !packable && R <= kFloatBitsMaxItems) {
+    const bool packable = packed_rank_bits(K, R) > 0;                 // exactly what hamming_ap_impl launches for an unsharded evaluation
+    const bool apc_on = ap_c_on();
+    const bool byte128 = cache && use_mfma && r2w_shape(K, tern);     // one-byte entries of 65..128-bit codes
+    if (cache && !tern && K <= 128 && apc_on && (byte128 || (K <= 64 && !packable)) && R <= kFloatBitsMaxItems) {
+        snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, %s>", byte128 ? "true" : "false");     // all three template arguments: the name a profile prints
+    } else if (use_mfma && !cache && r2_shape(K, tern) && ap_r2_mode() != 0 && !packable && R <= kFloatBitsMaxItems) {
         snprintf(p2, sizeof(p2), "k_scan_ap_r2<%d, %d, %d, false>", NML, kAp2Waves, kAp2Groups);
-    } else if (use_mfma && K <= 64 && mfma_ap_on()) {
-        snprintf(p2, sizeof(p2), "k_scan_ap_m<1, %d, %d, false, false>", NML, kMfmaWaves);
     } else {
         const bool cached = cache && !tern && Wc <= 8;
         // codes of 65 bits and more launch both counter widths, a device word picks one: both names, packed first
         char a32[96] = "";
         if (packable) {
             const int S = cached ? cache_slots(Wc) : S4;
-            snprintf(a32, sizeof(a32), "k_scan_ap_s<%d, %d, %s, false, %d, true, false, %d, %s>|", Wc, LW, tern ? "true" : "false", S,
+            snprintf(a32, sizeof(a32), "k_scan_ap_s<%d, %d, %s, false, %d, true, false, %d, %s>|", Wc, cached ? 1 : LW, tern ? "true" : "false", S,
                      S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
         }
         const int S = cached ? cache_slots(Wc) : S8;
-        snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, false, %d, false, false, %d, %s>", a32, Wc, LW, tern ? "true" : "false", S,
+        snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, false, %d, false, false, %d, %s>", a32, Wc, cached ? 1 : LW, tern ? "true" : "false", S,
                  S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
     }
     if ((size_t)snprintf(out, out_bytes, "pass1=%s;pass2=%s", p1, p2) >= out_bytes) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
@@ -3447,9 +2766,9 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     rc = check_common("xmh_hamming_hist", qbits, qzero, qlab, rbits, rzero, rlab, C, ws, ws_bytes, p);
     if (rc) return rc;
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    const size_t cache_bytes = pair_cache_bytes(p, K, tern);
+    const size_t cache_bytes = cache_for_workspace(p, K, tern, ws_bytes);
     const bool mfma_plan = mfma_shape(K, tern);
-    const WsLayout L = ws_layout(p, cache_bytes, R, mfma_plan);
+    const WsLayout L = ws_layout(p, cache_bytes);
     char* base = static_cast<char*>(ws);
     uint32_t* chunk_hist = reinterpret_cast<uint32_t*>(base + L.chunk_hist);
     uint2* below = reinterpret_cast<uint2*>(base + L.below);
@@ -3458,7 +2777,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool use_mfma = mfma_plan && LW <= 4 && lane_order_ok(st);
     // the tile tickets of k_scan_below, the nrel_max gate word and the finalize ticket of the evaluation calls on this workspace
-    if (!use_mfma) XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // (the MFMA path clears them in k_scan_expand)
+    if (!use_mfma) XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // (the MFMA path clears them in its first launch)
     if (use_mfma) {
         rc = mfma_hist(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist,
                        cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st);
@@ -3501,7 +2820,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     }
     XMH_LAUNCH_CHECK("xmh_hamming_hist");
     hipLaunchKernelGGL(k_scan_below, dim3((unsigned)p.nqtile, (unsigned)xmh::ceil_div(p.nbuckets, 4)), dim3(256), 0, st, chunk_hist,
-                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? (m2_shape(K, tern) || bits_shape(K, tern, LW) || r2w_shape(K, tern, LW) ? kRelHi16 : kRelScale) : 0u, below, tot,
+                       (int)p.qpad, (int)p.nbuckets, (int)p.nchunk, use_mfma ? kRelHi16 : 0u, below, tot,
                        reinterpret_cast<uint32_t*>(base + L.tick), (int)Q, reinterpret_cast<uint2*>(base + L.dpre),
                        reinterpret_cast<uint32_t*>(base + L.cap), reinterpret_cast<uint32_t*>(base + L.gate), hist_all, hist_rel);
     XMH_LAUNCH_CHECK("xmh_hamming_hist below");
@@ -3524,9 +2843,9 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const int ext = (base_all != nullptr) + (base_rel != nullptr) + (nrel_total != nullptr);
     if (ext != 0 && ext != 3) return xmh::fail(XMH_EINVAL, "xmh_hamming_ap: base_all, base_rel and nrel_total go together");
     const ScanArgs a = make_args(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, p);
-    const size_t cache_bytes = pair_cache_bytes(p, K, tern);
+    const size_t cache_bytes = cache_for_workspace(p, K, tern, ws_bytes);
     const bool mfma_plan = mfma_shape(K, tern);
-    const WsLayout L = ws_layout(p, cache_bytes, R, mfma_plan);
+    const WsLayout L = ws_layout(p, cache_bytes);
     char* base = static_cast<char*>(ws);
     const uint2* below = reinterpret_cast<const uint2*>(base + L.below);
     const uint2* tot = reinterpret_cast<const uint2*>(base + L.tot);
@@ -3541,7 +2860,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // below that only the 64-bit kernel is launched (and no gated launch returns at once); XMH_SCAN_PACK32_ALL=1 brings the packed
     // kernels back for every length (tests).
     const bool sharded = base_all != nullptr || hist_g != nullptr;
-    const int rank_bits = sharded ? 0 : packed_rank_bits(K, R, mfma_plan);
+    const bool masked = !lane_order_ok(xmh::as_stream(stream));
+    const int rank_bits = sharded || masked ? 0 : packed_rank_bits(K, R);      // (the masked fallback has 64-bit counters only)
     // unsharded: k_scan_below left dpre, nrel and the gate word behind (xmh_hamming_hist).  Sharded: the offsets come from the caller.
     if (hist_g && rank < 0) {                                        // the all-to-all form: this shard's offset rows, by slice owner
         const int S = (int)(p.qpad / world);
@@ -3560,7 +2880,6 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     const uint32_t kcap = k > 0 && k < (int64_t)0xffffffffll ? (uint32_t)k : 0xffffffffu;
     const int W = (K + 31) / 32, LW = (C + 31) / 32;
     const bool capped = k > 0;
-    const bool masked = !lane_order_ok(st);
 
     // k_scan_ap_c (float-bit counters): one-byte pair cache present, 64-bit counters, lane order holds, and the gallery over ALL
     // shards small enough -- known here for an unsharded call; for the totals-table form of the sharded call the offsets kernel leaves
@@ -3568,28 +2887,23 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // widths); the explicit-offsets form stays on k_scan_ap_s, except on one-byte entries
     // of 65..128-bit codes (which that kernel cannot read), where k_scan_dpre leaves the largest rank of the shard in the word instead.
     // XMH_SCAN_AP_C=0 turns it off.
-    const char* apc_env = getenv("XMH_SCAN_AP_C");
-    // Beyond 64 bits (two-byte entries, 8 x 8 queries) the same kernel measured no better than k_scan_ap_s (Q 5000 x R 117 218, K=128:
-    // 0.286 against 0.288 ms; K=256, R 60 000: 0.233 against the packed 32-bit counters' 0.204), so it is used there only on request
-    // (XMH_SCAN_AP_C=2; the tests hold it to bit identity with the default).
-    const int apc_mode = apc_env ? atoi(apc_env) : 1;
-    // 65..128-bit codes whose pass 1 left ONE-byte entries (k_scan_hist_m<2, .., BYTE>; the same predicate as in xmh_hamming_hist: the MFMA
-    // pass 1 ran iff the lane order holds and the labels fit): k_scan_ap_c reads them like those of shorter codes.  A distance of 128
-    // does not fit a byte and wrapped; pass 1 raised a control word then, k_scan_ap_c returns at once and the kernel that evaluates the
-    // pairs from the codes (launched behind it, gated the other way) takes the call.  The cached k_scan_ap_s cannot read these entries.
-    const bool byte128 = cache_bytes && mfma_plan && LW <= 4 && !masked && byte128_shape(K, tern, LW);
+    const bool apc_on = ap_c_on();
+    // 65..128-bit codes whose pass 1 (k_scan_hist_r2w: the MFMA pass 1 ran iff the lane order holds and the labels fit -- the same predicate
+    // as in xmh_hamming_hist) left ONE-byte entries: k_scan_ap_c reads them like those of shorter codes, 8 slots x 8 queries wide.  A
+    // distance of 128 does not fit a byte and wrapped; pass 1 raised a control word then, k_scan_ap_c returns at once and the kernel that
+    // evaluates the pairs from the codes (launched behind it, gated the other way) takes the call.  The cached k_scan_ap_s cannot read
+    // these entries.
+    const bool byte128 = cache_bytes && mfma_plan && LW <= 4 && !masked && r2w_shape(K, tern);
     const uint32_t* wrapped = byte128 ? (const uint32_t*)(nrel_max + kGateWrapped) : nullptr;
     const size_t cache_s = byte128 ? 0 : cache_bytes;                 // what the k_scan_ap_s launches below may read
-    const bool apc = cache_bytes && (byte128 ? apc_mode != 0 : (K <= 64 ? apc_mode != 0 && rank_bits == 0 : apc_mode == 2 && K <= 256)) && !tern && !masked &&
-                     (!base_all || byte128) && (sharded || R <= kFloatBitsMaxItems);
+    const bool apc = cache_bytes && apc_on && (byte128 || (K <= 64 && rank_bits == 0)) && !tern && !masked && (!base_all || byte128) &&
+                     (sharded || R <= kFloatBitsMaxItems);
     const uint32_t* fb_gate = apc && sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;      // (k_scan_ap_r2 sets it too, below)
     if (apc) {
-        const bool b8 = K <= 64 || byte128;
-        // one-byte entries read 8 slots x 8 queries wide (k_scan_ap_c<., 8, HALF>): where the counter rows of 16 queries leave few waves per CU
-        // -- 65..128-bit codes (129 rows: 16.5 KB per wave).  XMH_SCAN_AP_HALF=0 / 1 forces it off / on for every one-byte shape (read per call).
-        const char* half_env = getenv("XMH_SCAN_AP_HALF");
-        const bool half = b8 && (half_env ? atoi(half_env) != 0 : byte128);
-        const int SC = b8 && !half ? 4 : 8;                              // slots of the geometry pass 2 runs: 64 / SC queries per wave
+        // one-byte entries are read 8 slots x 8 queries wide (k_scan_ap_c<., 8, HALF>) where the counter rows of 16 queries leave few waves per
+        // CU -- 65..128-bit codes (129 rows: 16.5 KB per wave); 16 / 64 / 128 bit, 4 x 16 against 8 x 8: 0.154 / 0.185, 0.171 / 0.182, 0.220 / 0.189 ms
+        const bool half = byte128;
+        const int SC = half ? 8 : 4;                                     // slots of the geometry pass 2 runs: 64 / SC queries per wave
         ScanArgs as = a;
         as.nqt = a.nqt * SC;
         as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
@@ -3602,19 +2916,17 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap, wrapped);
             return (int)XMH_OK;
         };
-        rc = half ? (capped ? go(k_scan_ap_c<true, 8, true>) : go(k_scan_ap_c<false, 8, true>))
-             : b8 ? (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>)) : (capped ? go(k_scan_ap_c<true, 16>) : go(k_scan_ap_c<false, 16>));
+        rc = half ? (capped ? go(k_scan_ap_c<true, 8, true>) : go(k_scan_ap_c<false, 8, true>)) : (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>));
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters)");
     }
     // k_scan_ap_r2: no pair cache, the pairs evaluated again on the MFMA from the packed words (same gating by the size word as k_scan_ap_c)
-    const bool apr2 = !cache_bytes && mfma_plan && K <= 64 && m2_shape(K, tern) && m2_regs(K) && ap_r2_mode() != 0 && LW <= 4 && !tern && !masked && !base_all &&
+    const bool apr2 = !cache_bytes && mfma_plan && K <= 64 && r2_shape(K, tern) && ap_r2_mode() != 0 && LW <= 4 && !tern && !masked && !base_all &&
                       rank_bits == 0 && (sharded || R <= kFloatBitsMaxItems);
     if (apr2) {
         fb_gate = sharded ? (const uint32_t*)(nrel_max + 2) : nullptr;
         constexpr int NW2 = kAp2Waves, NQ2 = kAp2Groups;
-        MfmaArgs ma{nullptr, nullptr, qbits, (int)Q, (int)R, K, W, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (NW2 * NQ2 * 16)), (int)p.nbuckets, (int)p.qpad};
-        ma.rbits = rbits; ma.rlab = rlab; ma.qlab = qlab; ma.LW = LW;
+        const MfmaArgs ma = r2_args(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, NW2 * NQ2 * 16);
         const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));
         const size_t lds = (size_t)NW2 * NQ2 * p.nbuckets * 16 * 8;
         xmh::ProfScope prof("scan_ap", st);
@@ -3639,6 +2951,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         constexpr bool MK = decltype(masked_c)::value;
         return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
+            if constexpr (P32 && MK) return xmh::fail(XMH_ENOTSUP, "xmh_hamming_ap: the masked fallback runs 64-bit counters only");      // (never launched: rank_bits is 0 when masked)
+            else {
             constexpr int S = slots_for(WW, T, P32 ? 4 : 8);
             constexpr int NW = S == 64 ? waves_for(WW, T) : 1;
             const size_t cells = (size_t)p.nbuckets * (64 / S);
@@ -3649,7 +2963,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             if constexpr (kPairCacheShape<WW, T> && !MK) {
                 if (cache_s) {                                        // pass 1 of this call pair left the pairs in the workspace
                     constexpr int SC = cache_slots(WW);
-                    auto kc = k_scan_ap_s<WW, LL, T, CP, SC, P32, MK, 1, true>;
+                    auto kc = k_scan_ap_s<WW, 1, T, CP, SC, P32, MK, 1, true>;      // the cached kernel reads no label word: one instance for every class count
                     const size_t cellsc = (size_t)p.nbuckets * (64 / SC);
                     const size_t lds = P32 ? ((cellsc + 3) & ~(size_t)3) * 4 : ((cellsc * 2 + 3) & ~(size_t)3) * 4;   // counters only: no gallery ring
                     const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
@@ -3669,37 +2983,11 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             hipLaunchKernelGGL(kern, dim3(scan_grid(p) * S / NW), dim3(64 * NW), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
                                (const uint32_t*)nrel_max, rb, kcap, stand_in || apr2 ? fb_gate : (const uint32_t*)nullptr, stand_in ? wrapped : (const uint32_t*)nullptr);
             return (int)XMH_OK;
+            }
         });
     };
     if ((apc || apr2) && !fb_gate && !byte128) {
         // k_scan_ap_c / k_scan_ap_r2 alone takes the call
-    } else if (mfma_plan && K <= 64 && mfma_ap_on() && LW <= 4 && !masked && !tern) {       // both widths launched, the device word picks one
-        MfmaArgs ma{reinterpret_cast<const uint4*>(base + L.gimg), reinterpret_cast<const uint4*>(base + L.qimg32), qbits, (int)Q, (int)R, K, W,
-                    (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)), (int)p.nbuckets, (int)p.qpad};
-        const dim3 grid((unsigned)(8 * ma.nqt * xmh::ceil_div(p.nchunk, 8)));
-        auto launch_m = [&](auto nml_c, auto p32_c, auto cap_c) {
-            constexpr int NML = decltype(nml_c)::value;
-            constexpr bool P32 = decltype(p32_c)::value, CP = decltype(cap_c)::value;
-            auto kern = k_scan_ap_m<1, NML, kMfmaWaves, P32, CP>;
-            const size_t lds = (size_t)kMfmaWaves * p.nbuckets * 16 * (P32 ? 4 : 8) + 2 * 4 * (1 + NML) * 1024;
-            const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
-            if (r2) return r2;
-            xmh::ProfScope prof(P32 ? "scan_ap32" : "scan_ap", st);
-            hipLaunchKernelGGL(kern, grid, dim3(64 * kMfmaWaves), lds, st, ma, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
-                               (const uint32_t*)nrel_max, rank_bits, kcap);
-            return (int)XMH_OK;
-        };
-        auto by_shape = [&](auto p32_c) {
-            if (LW <= 2) return capped ? launch_m(std::integral_constant<int, 1>{}, p32_c, std::true_type{}) : launch_m(std::integral_constant<int, 1>{}, p32_c, std::false_type{});
-            return capped ? launch_m(std::integral_constant<int, 2>{}, p32_c, std::true_type{}) : launch_m(std::integral_constant<int, 2>{}, p32_c, std::false_type{});
-        };
-        if (rank_bits) {
-            rc = by_shape(std::true_type{});
-            if (rc) return rc;
-        }
-        rc = by_shape(std::false_type{});
-        if (rc) return rc;
-        XMH_LAUNCH_CHECK("xmh_hamming_ap (MFMA)");
     } else {
     using T1 = std::true_type;
     using T0 = std::false_type;
@@ -3754,7 +3042,7 @@ extern "C" int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, con
 extern "C" size_t xmh_scan_totals_offset(int64_t Q, int64_t R, int K, int ternary, size_t* bytes) {
     xmh_scan_plan p;
     if (make_plan(Q, R, K, ternary, &p)) return (size_t)-1;
-    const WsLayout L = ws_layout(p, pair_cache_bytes(p, K, ternary != 0), R, mfma_shape(K, ternary != 0));
+    const WsLayout L = ws_layout(p, pair_cache_bytes(p, K, ternary != 0));
     if (bytes) *bytes = (size_t)p.nbuckets * p.qpad * 8;
     return L.tot;
 }

@@ -194,7 +194,6 @@ int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hip
 namespace xmh {
 
 int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    if (nmc == 2) return launch_t<2, kScanBitsWaves>(a, chunk_hist, cache, st);
     if (nmc == 4) return launch_t<4, kScanBitsWaves>(a, chunk_hist, cache, st);
     return fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_b instance for %d code tiles", nmc);
 }

@@ -1091,11 +1091,11 @@ FilterChoice topk_filter_choice(int W, int64_t Q) {
     c.qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));
     if (W < 16 && Q >= 5 && Q <= 8) { c.qn = 4; c.qg = 2; }
     else if (W < 16 && Q >= 16) c.qg = Q >= 32 ? 4 : 2;
-    if (const char* e = getenv("XMH_TOPK_QG")) {                           // tuning: "<queries per group>x<groups per block>"
+    if (const char* e = xmh_experiment_env("XMH_TOPK_QG")) {                           // tuning: "<queries per group>x<groups per block>"
         int a = 0, b = 0;
         if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4 || a == 8) && a <= qmax && (b == 1 || b == 2 || b == 4) && (a > 1 || b == 1) && W < 16) { c.qn = a; c.qg = b; }
     }
-    static const int mfma_min_q = [] { const char* e = getenv("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
+    static const int mfma_min_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
     if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? (Q >= 5 || Q == 3) : (mfma_min_q > 0 && Q >= mfma_min_q))) {
         const int qtmax = W == 16 ? 2 : 4;
         c.mfma = true;

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "xmh_scan_plan_make": (i32, [i64, i64, i32, i32, C.POINTER(ScanPlan)]),
     "xmh_scan_pair_cache_bytes": (sz, [i64, i64, i32, i32]),
     "xmh_scan_pair_cache_offset": (sz, [i64, i64, i32, i32]),
+    "xmh_scan_ws_bytes_nocache": (sz, [i64, i64, i32, i32]),
     "xmh_scan_describe": (i32, [i64, i64, i32, i32, i32, C.c_char_p, sz]),
     "xmh_hamming_hist": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp]),
     "xmh_hamming_ap": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, vp, vp, i64, vp, vp, vp]),

@@ -203,9 +203,9 @@ def scan_plan(Q: int, R: int, K: int, ternary: bool) -> _lib.ScanPlan:
 def _plan_and_workspace(Q: int, R: int, K: int, ternary: bool, device):
     """Plan the scan and allocate its workspace.  The plan includes the pair cache (one or two bytes per (query, item) pair, up to
     XMH_SCAN_CACHE_MB, default 128 GB) whenever the shape has one -- sized for an empty 288 GB device, not for what is free next to
-    a resident encoder.  When the workspace does not fit, the cache cap is lowered for this process to just under this shape's cache
-    (the library reads XMH_SCAN_CACHE_MB per call, so plan, pass 1 and pass 2 all see the same value; smaller shapes keep their
-    caches) and the scan runs uncached: slower, never an out-of-memory error for a shape that ran before the cache existed."""
+    a resident encoder.  When that does not fit, the workspace is allocated WITHOUT the cache (xmh_scan_ws_bytes_nocache): the library
+    takes the size it is handed as the decision, per call, and runs the same plan uncached -- slower, never an out-of-memory error for
+    a shape that ran before the cache existed, and no process-wide state (round 4 lowered XMH_SCAN_CACHE_MB in the environment here)."""
     plan = scan_plan(Q, R, K, ternary)
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # the caching allocator's idle blocks count
@@ -214,13 +214,12 @@ def _plan_and_workspace(Q: int, R: int, K: int, ternary: bool, device):
             return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
         except torch.cuda.OutOfMemoryError:
             pass
-    before = plan.ws_bytes
-    cache = int(lib.xmh_scan_pair_cache_bytes(Q, R, K, 1 if ternary else 0))
-    os.environ["XMH_SCAN_CACHE_MB"] = str(max(0, (cache - 1) >> 20))
-    plan = scan_plan(Q, R, K, ternary)
-    warnings.warn("xmh: scan workspace of %.1f GB does not fit in %.1f GB of free device memory; pair caches of %.1f GB and more switched "
-                  "off for this process (workspace now %.1f GB)" % (before / 2**30, free / 2**30, cache / 2**30, plan.ws_bytes / 2**30))
-    return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)
+    small = int(lib.xmh_scan_ws_bytes_nocache(Q, R, K, 1 if ternary else 0))
+    if small <= 0 or small >= plan.ws_bytes:
+        return plan, torch.empty(plan.ws_bytes, dtype=torch.uint8, device=device)       # no cache in this plan: the allocator raises for real
+    warnings.warn("xmh: scan workspace of %.1f GB does not fit in %.1f GB of free device memory; this evaluation runs without its pair cache "
+                  "(workspace %.1f GB)" % (plan.ws_bytes / 2**30, free / 2**30, small / 2**30))
+    return plan, torch.empty(small, dtype=torch.uint8, device=device)
 
 
 class RankingScan:
@@ -238,7 +237,7 @@ class RankingScan:
 
     def _common(self):
         return (ptr(self.q.bits), ptr(self.qz), ptr(self.qlab), ptr(self.r.bits), ptr(self.rz), ptr(self.rlab),
-                self.q.n, self.r.n, self.q.K, self.C, ptr(self.ws), self.plan.ws_bytes)
+                self.q.n, self.r.n, self.q.K, self.C, ptr(self.ws), self.ws.numel())      # the size decides: a buffer without room for the pair cache runs uncached
 
     def histograms(self, want_totals: bool = True):
         """pass 1.  Returns (hist_all, hist_rel) int32 [Q, nbuckets] shard totals (or (None, None))."""

@@ -188,7 +188,7 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
         world = dist.get_world_size(group)
         nb, qpad = t.shape[0], t.shape[1]
         # which collective follows is decided from the table shape, and the padded query count depends on per-process
-        # environment switches (XMH_SCAN_M2, XMH_SCAN_M2_GEOM, XMH_SCAN_MFMA_AP): ranks that disagree would enter different
+        # environment switches (XMH_SCAN_MFMA, XMH_SCAN_CACHE_MB, XMH_SCAN_AP_R2): ranks that disagree would enter different
         # collectives and hang until the group's timeout.  One 16-byte MIN/MAX all-reduce turns that into an error.
         _require_same_shape(nb, qpad, hasattr(ops, "slice_offsets"), t.device, group)
         if exchange != "gather" and hasattr(ops, "slice_offsets") and qpad % world == 0:

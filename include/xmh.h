@@ -118,6 +118,11 @@ size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
  * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant (mod 256).  Two-byte form:
  * [chunk][8-query tile][batch][lane][8 x u16], lane = slot * 8 + query-in-tile, entry t = item 64 * batch + 8 * t + slot. */
 size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary);
+/* The workspace of the same plan WITHOUT its pair cache.  xmh_hamming_hist / xmh_hamming_ap / xmh_hamming_map take the size they are handed
+ * as the decision: a buffer of at least xmh_scan_plan.ws_bytes runs with the cache, one of at least this size (and smaller than that) runs
+ * the same plan uncached -- for devices that have no room for Q x R bytes next to a resident encoder.  Both calls of a pair must be given
+ * the same size.  (The reference keeps a [Q, R] fp32 matrix and its sort on the host: common/calc_utils.py:76-77.) */
+size_t xmh_scan_ws_bytes_nocache(int64_t Q, int64_t R, int K, int ternary);
 /* Diagnostics for the measurement harness: writes "pass1=<kernel instance>;pass2=<kernel instance>[|<second width>]" -- the kernels
  * an unsharded mAP@all evaluation of this shape launches, spelled as rocprofv3 prints them -- so that a profile row is matched by
  * its exact name.  out_bytes >= 64. */

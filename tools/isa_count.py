@@ -25,15 +25,13 @@ SRC = os.path.join(ROOT, "clip-based-cross-modal-hash_amd", "csrc", "xmh_scan.hi
 #   k_scan_hist_s<W, LW, TERN, S, NW, CACHE>;  k_scan_ap_s<W, LW, TERN, CAPPED, S, P32, MASKED, NW, CACHE>;
 #   k_scan_hist_m<NMC, NML, NW, CACHE, BYTE>;  k_scan_hist_m2<NML, NW, NQ, CACHE, STAMP>;  k_scan_ap_c<CAPPED>
 KERNELS = [
-    "k_scan_hist_m2<2, 4, 2, true, false>", "k_scan_hist_m2<2, 4, 2, false, false>", "k_scan_hist_m2<1, 4, 4, true, false>",
-    "k_scan_hist_m2<2, 4, 4, true, false>", "k_scan_hist_r2<2, 4, 4, true>", "k_scan_hist_r2<2, 4, 4, false>", "k_scan_hist_r2w<2, 4, 2, true>", "k_scan_ap_c<false, 8, false>", "k_scan_ap_c<false, 8, true>",
-    "k_scan_ap_c<false, 16, false>",
-    "k_scan_hist_m<1, 2, 4, true, false>", "k_scan_hist_m<2, 2, 4, true, true>", "k_scan_hist_m<2, 2, 4, true, false>", "k_scan_hist_m<4, 2, 4, false, false>",
+    "k_scan_hist_r2<2, 4, 4, true>", "k_scan_hist_r2<2, 4, 4, false>", "k_scan_hist_r2w<2, 4, 2, true>", "k_scan_ap_c<false, 8, false>", "k_scan_ap_c<false, 8, true>",
+    "k_scan_ap_r2<2, 4, 2, false>",
     "k_scan_hist_s<2, 3, false, 4, 1, true>", "k_scan_hist_s<2, 3, false, 4, 1, false>", "k_scan_hist_s<1, 3, false, 2, 1, false>",
-    "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, false>",
+    "k_scan_ap_s<2, 1, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, false>",
     "k_scan_ap_s<1, 3, false, false, 2, false, false, 1, false>",
-    "k_scan_ap_s<4, 3, false, false, 8, true, false, 1, true>", "k_scan_ap_s<4, 3, false, false, 8, false, false, 1, true>",
-    "k_scan_ap_s<8, 3, false, false, 8, false, false, 1, false>",
+    "k_scan_ap_s<4, 1, false, false, 8, true, false, 1, true>", "k_scan_ap_s<4, 1, false, false, 8, false, false, 1, true>",
+    "k_scan_ap_s<8, 1, false, false, 8, false, false, 1, true>", "k_scan_ap_s<8, 3, false, false, 8, false, false, 1, false>",
 ]
 
 

@@ -107,7 +107,7 @@ def check(insns, kernel="", war=None):
     """-> (violations, stats).  stats: smallest distance seen per rule (None when the pattern does not occur).
     war: apply R2 (default: only to k_scan_hist_m2, the kernel whose MFMAs are inline asm)."""
     if war is None:
-        war = "k_scan_hist_m2" in kernel or "k_scan_hist_r2" in kernel
+        war = "k_scan_hist_r2" in kernel or "k_scan_ap_r2" in kernel
     out = []
     stats = {"R1": None, "R2": None, "R3": None, "n_mfma": 0, "n_snop3": 0, "n_sdwa_preserve": 0}
     writer = {}           # reg -> ("mfma" | "valu" | "other", wait-state clock at issue)
@@ -247,7 +247,7 @@ def disassemble(path):
 
 
 # pass 2 (asm-issued returning atomics) and the pass-1 kernel that reads its A tiles with asm ds_read_b128 ahead of a counted wait
-LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_m", "k_scan_ap_r2", "k_scan_hist_m2")
+LDS_RETURN_KERNELS = ("k_scan_ap_c", "k_scan_ap_s", "k_scan_ap_r2")
 
 
 def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
@@ -267,7 +267,7 @@ def analyse_lds_returns(lib=LIB, name_filter=LDS_RETURN_KERNELS):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def analyse(lib=LIB, name_filter=("k_scan_hist_m2", "k_scan_hist_r2", "k_scan_hist_b", "k_scan_hist_m", "k_scan_ap_r2", "k_topk_filter_mfma")):
+def analyse(lib=LIB, name_filter=("k_scan_hist_r2", "k_scan_hist_b", "k_scan_ap_r2", "k_topk_filter_mfma")):
     """-> {kernel: (violations, stats)} for every kernel whose mangled name contains one of name_filter"""
     work = tempfile.mkdtemp(prefix="xmh_isa_")
     try:
