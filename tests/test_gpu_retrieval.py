@@ -619,6 +619,35 @@ def test_scan_pass2_without_a_pair_cache_gives_identical_bits_and_matches_the_or
             assert torch.equal(x, y), (Q, R, K, C)
 
 
+def test_scan_workspace_without_room_for_the_pair_cache_runs_uncached(xr):
+    """A workspace of xmh_scan_ws_bytes_nocache bytes (a device without room for the Q x R cache next to a resident encoder) runs the same
+    plan without the cache -- decided per call from the size handed in, no environment write.  Up to 64 bits the uncached pass 2
+    is k_scan_ap_r2: AP sums and caps bit for bit; 128 / 256 bits: the kernels that evaluate the pairs from the codes, sums to float
+    rounding.  A buffer smaller than that is refused."""
+    from xmh import _lib
+    for (Q, R, K, C, k) in ((150, 9001, 64, 80, None), (70, 5000, 16, 24, 9), (129, 6463, 128, 80, None), (40, 3000, 256, 24, 5)):
+        qB, rB, qL, rL = _synth(Q, R, K, C, seed=K + R, p=0.08)
+        qL[:, 0] = 1
+        rL[::5, 0] = 1
+        full = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+        full.histograms(False)
+        ap0, cap0 = full.ap_sums(k)
+        small = int(_lib.lib.xmh_scan_ws_bytes_nocache(Q, R, K, 0))
+        assert 0 < small < full.plan.ws_bytes and int(_lib.lib.xmh_scan_pair_cache_bytes(Q, R, K, 0)) > 0
+        lean = xr.RankingScan(xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda()), xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda()), C)
+        lean.ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+        ha, hr = lean.histograms(True)
+        ap1, cap1 = lean.ap_sums(k)
+        assert torch.equal(cap0, cap1), (Q, R, K)
+        if K <= 64:
+            assert torch.equal(ap0, ap1), (Q, R, K)
+        else:
+            assert torch.allclose(ap0, ap1, rtol=2e-6, atol=1e-9), (Q, R, K)
+        lean.ws = torch.empty(small - 4096, dtype=torch.uint8, device="cuda")
+        with pytest.raises(RuntimeError, match="workspace too small"):
+            lean.histograms(False)
+
+
 def test_scan_mfma_pass1_for_65_to_256_bit_codes_matches_the_valu_pass1(xr, monkeypatch):
     """65..256-bit codes: the MFMA pass 1 (k_scan_hist_r2w up to 128 bits, k_scan_hist_b beyond) against the VALU pass 1
     (XMH_SCAN_MFMA=0): same histograms and caps bit for bit, same credits up to the order of the per-chunk partial sums (the two plans
