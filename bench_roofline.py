@@ -77,7 +77,7 @@ def _newest_summary():
 
 
 def pmc_row(kernel_instance):
-    """The PMC entry of EXACTLY this kernel instance (e.g. "k_scan_hist_m2<2, 4, 2, true, false>", from xmh_scan_describe) in the
+    """The PMC entry of EXACTLY this kernel instance (e.g. "k_scan_hist_r2<2, 4, 4, true>", from xmh_scan_describe) in the
     newest committed rocprofv3 summary, or (None, source).  Round 2 matched by prefix and kept the last hit, which handed the
     64-bit headline the 128-bit kernel's counters; an exact name cannot do that, and two rows normalising to one name raise."""
     d, src = _newest_summary()
@@ -190,10 +190,10 @@ def scan_roofline(scan, Q, Rn, K, C, steps=20, step_s=None):
                     e["issue_utilisation"][c] = v[0]
         return e
     v1, v2 = pass_entry(k1, t_hist), pass_entry(k2, t_ap)
-    if k1.startswith(("k_scan_hist_m", "k_scan_hist_r2")):
+    if k1.startswith(("k_scan_hist_r2", "k_scan_hist_b")):
         nml = 1 if Lw <= 2 else 2
         nmc = 1 if K <= 64 else (2 if K <= 128 else 4)
-        chains = (2 * nmc if (k1.startswith(("k_scan_hist_m2", "k_scan_hist_r2")) and cache_bytes) else nmc) + nml
+        chains = (2 * nmc if (k1.startswith("k_scan_hist_r2") and cache_bytes) else nmc) + nml       # address chain (+ the 2 * distance chain of the cache byte) + label tiles
         v1["mfma"] = {"instruction": "v_mfma_i32_16x16x64_i8", "per_64_pairs": chains / 4.0, "cycles_each": 16,
                       "matrix_pipe_frac": pairs / 64.0 * (chains / 4.0) * 16 / (t_hist * CLOCK_HZ * SIMDS)}
     dom_is_hist = t_hist > t_ap
@@ -208,6 +208,7 @@ def scan_roofline(scan, Q, Rn, K, C, steps=20, step_s=None):
         "kernel": "%s (pass %d of the fused mAP scan), HIP events around the launch, %d launches" % (kd, 1 if dom_is_hist else 2, n_dom),
         "bound": "valu", "achieved": alg["achieved"], "peak": VALU_PEAK_GUIDE, "unit": "G lane-ops/s", "frac": alg["frac_dominant"],
         "algorithmic": alg, "issue_utilisation": vd.get("issue_utilisation"),
+        "frac_step": alg.get("frac_step"),
         "traffic": (traffic or {}).get("bytes"), "traffic_detail": traffic,
         "hbm": {"bound": "hbm", "algorithmic_bytes": alg_bytes, "achieved": alg_bytes / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS,
