@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -321,7 +323,24 @@ def gather_rows_to(t: torch.Tensor, counts: Sequence[int], dst: int = 0, group=N
 
 
 _pinned = {}          # record bytes -> pinned host staging buffer for the gathered lists (reused over calls)
-_topk_ws = {}         # the prepared top-k workspace of the last (Q, R, K, k, device) topk_sharded ran
+# The prepared top-k workspace of the last (Q, R, K, k, device, stream) topk_sharded ran on THIS thread: a query loop over one gallery
+# shard calls with the same shape every time.  One entry per thread (a workspace is for one stream at a time), dropped when a call through
+# it fails (its control words may be dirty) and by release_topk_workspace() -- a 10 M x 256-bit shape holds its device buffer otherwise
+# (ADVICE r4).
+_topk_local = threading.local()
+
+
+def release_topk_workspace() -> None:
+    """free the prepared top-k workspace (and the pinned staging buffers) topk_sharded keeps between calls"""
+    _topk_local.__dict__.pop("entry", None)
+    _pinned.clear()
+
+
+def _prepared_topk_workspace(shape, make):
+    entry = _topk_local.__dict__.get("entry")
+    if entry is None or entry[0] != shape:
+        entry = _topk_local.entry = (shape, make())
+    return entry[1]
 
 
 def merge_topk_records(gathered: torch.Tensor, world: int, nq: int, k: int):
@@ -369,16 +388,21 @@ def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
         from . import retrieval as R
         # a query loop over one gallery shard calls with the same shape every time: keep the prepared workspace of the last shape
         # (cleared once, left clean by every call) instead of allocating and clearing a scratch one per call
-        shape = (nq, n_rows, q.K, int(k), dev)
-        if _topk_ws.get("shape") != shape:
-            _topk_ws["shape"], _topk_ws["ws"] = shape, R.TopkWorkspace(nq, n_rows, q.K, int(k), dev)
-        R.hamming_topk(q, r_shard, k, base_index, workspace=_topk_ws["ws"], out=(d_view, i_view))
+        shape = (nq, n_rows, q.K, int(k), dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _prepared_topk_workspace(shape, lambda: R.TopkWorkspace(nq, n_rows, q.K, int(k), dev))
+        try:
+            R.hamming_topk(q, r_shard, k, base_index, workspace=ws, out=(d_view, i_view))
+        except Exception:
+            _topk_local.__dict__.pop("entry", None)                          # its control words may be dirty: the next call prepares a fresh one
+            raise
     else:
         d, i = topk_fn(q, r_shard, k, base_index)
         d_view.copy_(d.to(torch.int16) if d.dtype != torch.int16 else d)
         i_view.copy_(i.to(torch.int32))
     if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
-        dist.all_gather_into_tensor(out, mine, group=group)                 # in place: rank r's record is already at out[r]
+        # in place (NCCL / RCCL semantics: the input may be the rank's own slot of the output): rank r's record is already at out[r]
+        assert mine.data_ptr() == out.data_ptr() + dist.get_rank(group) * rec and mine.is_contiguous()
+        dist.all_gather_into_tensor(out, mine, group=group)
     else:
         dist.all_gather(list(out.unbind(0)), mine.clone(), group=group)
     return merge_topk_records(out, world, nq, k)
