@@ -431,6 +431,11 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x4 (&acc)[2 * M
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kFixedCol) bv = bias_at(col0 + (lane % LPR) * 4);
     constexpr int NIT = 32 * LPR / 64;                             // passes of the 64 lanes over one 32-row slab
+    // The passes read the slab back from LDS, so only the slab WRITE needs the accumulators by constant index.  The towers' two
+    // activations keep the passes unrolled (the residual loads of later passes issue above the stores of earlier ones); erf-GELU,
+    // tanh and ReLU -- the heads' small GEMMs -- and the ragged-N path loop instead: their inlined bodies times 16 passes times
+    // every tile shape were most of the library's code (2.8 MB of GEMM objects, round 5).
+    constexpr int kUnroll = (ACT == ACT_NONE || ACT == ACT_QUICKGELU) ? NIT : 1;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -439,24 +444,33 @@ __device__ __forceinline__ void g16_epilogue(const GArgsP& g, f32x4 (&acc)[2 * M
             for (int j = 0; j < 2 * NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) reg[(i2 * 16 + 4 * g4 + e) * RS + j * 16 + c16] = acc[2 * i + i2][j][e];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int f = it * 64 + lane;
-            const int r = f / LPR, col = col0 + (f % LPR) * 4;
-            const float4 v4 = *reinterpret_cast<const float4*>(reg + r * RS + (f % LPR) * 4);
-            const int64_t row = row0 + i * 32 + r;
-            if (row >= Mr || col >= g.N) continue;
-            if (!kFixedCol) bv = bias_at(col);
-            float4 v = make_float4(act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w));
-            if (vec) {
+        if (vec) {
+#pragma unroll kUnroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = it * 64 + lane;
+                const int r = f / LPR, col = col0 + (f % LPR) * 4;
+                const float4 v4 = *reinterpret_cast<const float4*>(reg + r * RS + (f % LPR) * 4);
+                const int64_t row = row0 + i * 32 + r;
+                if (row >= Mr || col >= g.N) continue;
+                if (!kFixedCol) bv = bias_at(col);
+                float4 v = make_float4(act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w));
                 if (resid) {
                     const float4 rr = *reinterpret_cast<const float4*>(resid + row * g.ldr + col);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (cout) *reinterpret_cast<float4*>(cout + row * g.ldc + col) = v;
                 if (g.O_hi) xmh::store_planes4(op, row, col, v.x, v.y, v.z, v.w);
-            } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < NIT; ++it) {
+                const int f = it * 64 + lane;
+                const int r = f / LPR, col = col0 + (f % LPR) * 4;
+                const float4 v4 = *reinterpret_cast<const float4*>(reg + r * RS + (f % LPR) * 4);
+                const int64_t row = row0 + i * 32 + r;
+                if (row >= Mr || col >= g.N) continue;
+                if (!kFixedCol) bv = bias_at(col);
+                const float vv[4] = {act_ct<ACT>(v4.x + bv.x), act_ct<ACT>(v4.y + bv.y), act_ct<ACT>(v4.z + bv.z), act_ct<ACT>(v4.w + bv.w)};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (col + t < g.N) {

@@ -1487,12 +1487,12 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
         char a32[96] = "";
         if (packable) {
             const int S = cached ? cache_slots(Wc) : S4;
-            snprintf(a32, sizeof(a32), "k_scan_ap_s<%d, %d, %s, false, %d, true, false, %d, %s>|", Wc, cached ? 1 : LW, tern ? "true" : "false", S,
+            snprintf(a32, sizeof(a32), "k_scan_ap_s<%d, %d, %s, %s, %d, true, false, %d, %s>|", Wc, cached ? 1 : LW, tern ? "true" : "false", cached ? "false" : "true", S,
                      S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
         }
         const int S = cached ? cache_slots(Wc) : S8;
-        snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, false, %d, false, false, %d, %s>", a32, Wc, cached ? 1 : LW, tern ? "true" : "false", S,
-                 S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
+        snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, %s, %d, false, false, %d, %s>", a32, Wc, cached ? 1 : LW, tern ? "true" : "false", cached ? "false" : "true", S,
+                 S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");     // (uncached kernels: the capped form serves both)
     }
     if ((size_t)snprintf(out, out_bytes, "pass1=%s;pass2=%s", p1, p2) >= out_bytes) return xmh::fail(XMH_EINVAL, "xmh_scan_describe: buffer too small");
     return XMH_OK;
@@ -1718,7 +1718,10 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
                     return (int)XMH_OK;
                 }
             }
-            auto kern = k_scan_ap_s<WW, LL, T, CP, S, P32, MK, NW, false>;
+            // the kernels that evaluate the pairs from the codes exist in the capped form only: uncapped, kcap is 0xffffffff and the cap of a
+            // query its relevant count, which no ordinal exceeds -- the same credits bit for bit, half the instances (round 5)
+            (void)CP;
+            auto kern = k_scan_ap_s<WW, LL, T, true, S, P32, MK, NW, false>;
             const int r2 = raise_lds(kern, lds, "xmh_hamming_ap");
             if (r2) return r2;
             // behind a launched k_scan_ap_c (one-byte entries of 65..128-bit codes): the stand-in, gated by the wrap word / the size word

@@ -105,7 +105,7 @@ def test_no_result_of_a_returning_lds_operation_is_touched_before_its_wait():
         assert k in names, k
     bad = [v for vs, _ in res.values() for v in vs]
     assert not bad, "\n".join("%s %s[%d] %s -- %s" % (v.rule, v.kernel[:60], v.index, v.text[:80], v.detail) for v in bad[:20])
-    assert sum(st["n_returning"] for _, st in res.values()) > 3000 and len(res) > 200
+    assert sum(st["n_returning"] for _, st in res.values()) > 3000 and len(res) > 140     # every pass-2 instance of the library (156 in round 5)
 
 
 def test_the_lds_return_rule_sees_a_planted_copy():

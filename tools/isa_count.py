@@ -28,10 +28,10 @@ KERNELS = [
     "k_scan_hist_r2<2, 4, 4, true>", "k_scan_hist_r2<2, 4, 4, false>", "k_scan_hist_r2w<2, 4, 2, true>", "k_scan_ap_c<false, 8, false>", "k_scan_ap_c<false, 8, true>",
     "k_scan_ap_r2<2, 4, 2, false>",
     "k_scan_hist_s<2, 3, false, 4, 1, true>", "k_scan_hist_s<2, 3, false, 4, 1, false>", "k_scan_hist_s<1, 3, false, 2, 1, false>",
-    "k_scan_ap_s<2, 1, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, false, 4, false, false, 1, false>",
-    "k_scan_ap_s<1, 3, false, false, 2, false, false, 1, false>",
+    "k_scan_ap_s<2, 1, false, false, 4, false, false, 1, true>", "k_scan_ap_s<2, 3, false, true, 4, false, false, 1, false>",
+    "k_scan_ap_s<1, 3, false, true, 2, false, false, 1, false>",
     "k_scan_ap_s<4, 1, false, false, 8, true, false, 1, true>", "k_scan_ap_s<4, 1, false, false, 8, false, false, 1, true>",
-    "k_scan_ap_s<8, 1, false, false, 8, false, false, 1, true>", "k_scan_ap_s<8, 3, false, false, 8, false, false, 1, false>",
+    "k_scan_ap_s<8, 1, false, false, 8, false, false, 1, true>", "k_scan_ap_s<8, 3, false, true, 8, false, false, 1, false>",
 ]
 
 
