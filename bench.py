@@ -183,6 +183,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-configs", action="store_true", help="N=1: skip the configs[3] (K=128) and MITH encode legs")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU exchange path even with one rank (RCCL smoke test)")
     ap.add_argument("--force-strong", action="store_true", help="with --force-sharded: also run the N>1 fixed-gallery legs on the one rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST HOOK, never a measurement: every rank uses cuda:0 and the group is gloo (RCCL refuses two ranks on one device), "
+                         "so the N>1 code path -- shard ops on device tensors, the collectives on workspace views, the fixed-gallery legs -- "
+                         "runs with world > 1 on a one-GPU box; the line says so in `launcher`")
     ap.add_argument("--query-blocks", type=int, default=1,
                     help="sharded path: query blocks whose histogram gathers are pipelined (default 1: on one GPU every extra "
                          "block costs 0.18 ms per step, more than the gather it would hide)")
@@ -346,6 +350,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_sharded
     ranks_in_group = 1
@@ -353,8 +359,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),   # "nccl" is RCCL on ROCm
-                                timeout=datetime.timedelta(minutes=5))          # every collective here is sub-second: fail fast, do not hang
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),   # "nccl" is RCCL on ROCm
+                                    timeout=datetime.timedelta(minutes=5))      # every collective here is sub-second: fail fast, do not hang
         ranks_in_group = dist.get_world_size()
         if ranks_in_group != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus %d" % (ranks_in_group, args.gpus))
@@ -416,7 +425,7 @@ def main():
                    "Q": Q, "R_per_gpu": Rn, "K": K, "C": C, "parallelism": "gallery-shard x%d" % world,
                    "query_blocks": nqb if use_dist else 1,
                    "collectives_in_step": collectives},
-        "rccl_ranks": ranks_in_group, "launcher": "torch.distributed.run" if world > 1 else "single process",
+        "rccl_ranks": ranks_in_group, "launcher": ("torch.distributed.run" if world > 1 else "single process") + (" (--share-gpu: all ranks on cuda:0 over gloo, a code-path check and not a measurement)" if args.share_gpu else ""),
         "mAP": map_value, "roofline": roofline,
     }
 

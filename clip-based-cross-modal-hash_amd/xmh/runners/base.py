@@ -71,7 +71,7 @@ class BaseTrainer:
         if distributed:
             self._init_distribution(rank=device, world_size=world_size)
         self.logger.info(f"parameters: {dict(cfg)}")
-        self.device = device
+        self.device = 0 if distributed and cfg.run.get("share_gpu") else device       # the reference: device == rank (runners/base.py:82-96)
         if not distributed and torch.cuda.is_available() and device is not None:
             # libxmh launches on the CURRENT device's stream: make run.device current (the reference reaches any device
             # through .to(self.device), runners/base.py:105-107)
@@ -103,9 +103,12 @@ class BaseTrainer:
         assert self.cfg.run.get("distributed_port"), "DDP needs the 'distributed_port' field"
         os.environ["MASTER_ADDR"] = str(self.cfg.run.distributed_addr)
         os.environ["MASTER_PORT"] = str(self.cfg.run.distributed_port)
-        torch.cuda.set_device(rank)
+        # run.share_gpu -- a TEST HOOK that is not in the reference's configs: every rank on cuda:0 and the group over gloo (which takes
+        # device tensors; RCCL refuses two ranks on one device), so the sharded evaluation runs with world_size > 1 on a one-GPU box
+        share = bool(self.cfg.run.get("share_gpu"))
+        torch.cuda.set_device(0 if share else rank)
         if not dist.is_initialized():
-            dist.init_process_group("nccl", rank=rank, world_size=world_size)     # "nccl" is RCCL on ROCm
+            dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world_size)     # "nccl" is RCCL on ROCm
 
     # ---- builders ---------------------------------------------------------------------------------------
     def build_model(self, cfg_model, output_dim=16, **kwags):

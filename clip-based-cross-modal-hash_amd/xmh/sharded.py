@@ -134,6 +134,13 @@ def rank_offsets(hist_all: torch.Tensor, hist_rel: torch.Tensor, rank: int):
     return base_a.to(i32).contiguous(), base_r.to(i32).contiguous(), nrel.to(i32).contiguous()
 
 
+def _all_gather_stacked(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """all_gather_into_tensor with ``out`` = [world, *inp.shape], handed over as the concatenation along dim 0 (the same memory): RCCL takes
+    either form, gloo -- which carries device tensors in the one-GPU two-rank tests -- only the concatenated one."""
+    flat = out.view((out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:]))
+    return dist.all_gather_into_tensor(flat, inp, group=group, async_op=async_op)
+
+
 def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None, async_op: bool = False):
     """both histogram planes of every shard in ONE collective -> [world, 2, Q, nb] (async_op: (tensor, work handle))."""
     world = dist.get_world_size(group)
@@ -144,7 +151,7 @@ def _gather_hist_pair(ha: torch.Tensor, hr: torch.Tensor, group=None, async_op: 
         pair = torch.stack([ha, hr]).contiguous()
     out = torch.empty((world,) + tuple(pair.shape), dtype=pair.dtype, device=pair.device)
     if hasattr(dist, "all_gather_into_tensor") and pair.is_cuda:
-        work = dist.all_gather_into_tensor(out, pair, group=group, async_op=async_op)
+        work = _all_gather_stacked(out, pair, group=group, async_op=async_op)
     else:                                                        # gloo (CPU tests) has no all_gather_into_tensor
         work = dist.all_gather(list(out.unbind(0)), pair, group=group, async_op=async_op)
     return (out, work) if async_op else out
@@ -211,7 +218,7 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
             raise ValueError("map_k_sharded: the all-to-all exchange needs qpad %% world == 0 (qpad=%d, world=%d)" % (qpad, world))
         g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
-            dist.all_gather_into_tensor(g, t, group=group)       # [world, nb, qpad, 2]
+            _all_gather_stacked(g, t, group=group)                # [world, nb, qpad, 2]
         else:
             dist.all_gather(list(g.unbind(0)), t, group=group)
         m = ops.map_partial(k, g, rank)                          # offsets, pass 2, this shard's share of the mean
@@ -402,7 +409,7 @@ def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
     if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
         # in place (NCCL / RCCL semantics: the input may be the rank's own slot of the output): rank r's record is already at out[r]
         assert mine.data_ptr() == out.data_ptr() + dist.get_rank(group) * rec and mine.is_contiguous()
-        dist.all_gather_into_tensor(out, mine, group=group)
+        _all_gather_stacked(out, mine, group=group)
     else:
         dist.all_gather(list(out.unbind(0)), mine.clone(), group=group)
     return merge_topk_records(out, world, nq, k)

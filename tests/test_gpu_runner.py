@@ -213,6 +213,47 @@ def test_bench_sharded_path_over_rccl_single_rank():
     assert detail["roofline"]["hbm"]["bound"] == "hbm" and len(json.dumps(a)) < 4096
 
 
+def test_bench_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` END TO END on the one-GPU box ("has never executed with N > 1 on any machine"): the self
+    launcher, two ranks, ShardedQueries.gather, the all-to-all exchange of map_k_sharded on workspace views, the fixed-gallery legs
+    (configs[2], configs[4] top-k with its all-gather into one tensor and pinned D2H) -- with --share-gpu, i.e. both ranks on cuda:0 and
+    gloo moving the device tensors, because RCCL refuses two ranks on one device.  The mAP of the weak-scaling step must be the mAP of
+    one scan over both shards."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    Q, Rn = 300, 20000
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--settle", "0", "--Q", str(Q),
+           "--R", str(Rn), "--no-cpu-baseline", "--no-hbm-regime", "--no-encode"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XMH_BENCH_CHILD")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert any("all_to_all" in c for c in line["config"]["collectives_in_step"])
+    detail = json.load(open(os.path.join(root, "gpurun_out", "bench_detail.json")))
+    assert detail["rccl_ranks"] == 2 and "share-gpu" in detail["launcher"]
+    assert "error" not in detail["strong_scaling"] and "configs4_topk_10M_256bit" in detail["strong_scaling"], detail["strong_scaling"]
+    # the same synthetic shards in one process, one scan
+    spec = importlib.util.spec_from_file_location("xmh_bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from xmh import retrieval as R
+    qB, qL, _, _ = bench.synth(Q, 8, 64, 80, seed=1814, p=0.04)
+    shards = [bench.synth(8, Rn, 64, 80, seed=1814 + 1 + rank, p=0.04)[2:] for rank in range(2)]
+    rB, rL = torch.cat([s_[0] for s_ in shards]), torch.cat([s_[1] for s_ in shards])
+    whole = R.RankingScan(R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda()), 80)
+    whole.histograms(False)
+    want = float(whole.map_all(None)[0].item())
+    assert abs(detail["mAP"] - want) < 1e-9, (detail["mAP"], want)
+
+
 def test_runner_distributed_code_path_world_size_1(tmp_path):
     """the sharded eval path of the runner (contiguous shard sampler, RCCL all-gather of packed query codes, histogram
     exchange, all-reduce) with a 1-rank process group must reproduce the single-process result."""
@@ -237,6 +278,59 @@ def test_runner_distributed_code_path_world_size_1(tmp_path):
             dist.destroy_process_group()
     for a, b in zip(got, want):
         assert abs(a - b) < 1e-9
+
+
+def _runner_two_rank_worker(rank, world, port, tmp, want):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "clip-based-cross-modal-hash_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from xmh.common.register import registry
+    import pathlib
+    cfg = make_cfg(pathlib.Path(tmp), "DSPH", "DSPHTrainer", 64, layers=1)
+    cfg.run.distributed_addr, cfg.run.distributed_port, cfg.run.share_gpu = "127.0.0.1", port, True
+    cfg.run.save_dir = cfg.run.log_dir = os.path.join(tmp, "dist")
+    try:
+        shard = registry.get_runner_class("DSPHTrainer").from_config(rank, world, True, cfg, None, autorun=False)
+        assert dist.get_world_size() == world and shard.rank == rank
+        got = shard.valid(0, k=None)
+        lo, hi = shard._shard(shard.retrieval_num)
+        assert hi - lo in (shard.retrieval_num // world, shard.retrieval_num - shard.retrieval_num // world) and (lo == 0) == (rank == 0)
+        for a, b in zip(got, want):
+            assert abs(a - b) < 1e-7, (rank, got, want)      # fp32 credits added per shard first: another order than one scan's
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("%r %r" % (lo, hi))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_runner_distributed_two_ranks_sharing_the_gpu(tmp_path):
+    """the runner's sharded evaluation (what replaces runners/base.py:82-96,259-264 / main.py:38-51) with world_size = 2 on this one-GPU
+    box: two processes on cuda:0, run.share_gpu puts the group on gloo.  Each rank encodes ITS contiguous half of the queries and of the
+    gallery, the packed query codes are all-gathered, the totals tables exchanged, the mAP all-reduced: all four mAPs of valid() on every
+    rank equal the single-process ones."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.multiprocessing as mp
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, "DSPH", "DSPHTrainer", 64, layers=1)
+    single = registry.get_runner_class("DSPHTrainer").from_config(cfg=cfg, autorun=False)
+    want = [float(m) for m in single.valid(0, k=None)]
+    del single
+    torch.cuda.empty_cache()
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mp.spawn(_runner_two_rank_worker, args=(2, port, str(tmp_path), want), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(2))
 
 
 def _mask_numbers(line):
