@@ -598,118 +598,6 @@ __global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, i
     }
 }
 
-// rare path of the filter, kept out of line so the streaming loop stays small: wave-aggregated append
-__device__ __noinline__ void append_candidates(int64_t it, int d, bool hit, uint32_t* cnt_q, unsigned long long* cand_q) {
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    const int lane = lane_id();
-    const int lead = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == lead) base = atomicAdd(cnt_q, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, lead);
-    if (hit) {
-        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < (uint32_t)kCandCap) cand_q[pos] = ((unsigned long long)d << 32) | (uint32_t)it;
-    }
-}
-
-// queries are processed in groups of QN: their words and thresholds are loaded ONCE per wave and stay resident over the whole
-// stream, so the tile loop is loads + XOR/popcount only.  QG (round 3) = query groups per BLOCK: the block's waves split into QG
-// sub-blocks that walk the SAME tiles, each with its own QN queries -- the second and later readers of a tile hit in the CU's L1
-// instead of every query group streaming the gallery again from L2 / HBM (blockIdx.y alone: 8 passes over the tiles at Q = 64), and at
-// Q = 8 two groups of 4 halve the integer work and the 64 query-word registers per wave that made the VALU co-critical.
-template <int W, int IPT, int QN, int QG>
-__global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
-                                                          int Q, int64_t R, const uint32_t* __restrict__ t_est,
-                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
-    constexpr int SUBT = kThreads / QG;                     // threads (whole waves) per query group
-    static_assert(SUBT % 64 == 0, "query groups are whole waves");
-    constexpr int TILE = SUBT * IPT;
-    const int sub = threadIdx.x / SUBT, tl = threadIdx.x % SUBT;
-    const int q0 = (blockIdx.y * QG + sub) * QN;
-    const int64_t ntiles = (R + TILE - 1) / TILE;
-    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * SUBT + tl; };
-    uint32_t qw[QN][W];
-    int thr[QN];
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // clamp: surplus slots repeat the last query and are ignored below
-#pragma unroll
-        for (int x = 0; x < W; ++x) {
-            qw[q][x] = qbits[(int64_t)qq * W + x];
-            asm volatile("" : "+v"(qw[q][x]));              // keep the 8x8 query words in VGPRs: 64+ SGPRs would spill through v_readlane
-        }
-        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
-    }
-    Rec<W> cur[IPT], nxt[IPT];
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const int64_t it = item_of(tile, j);
-            load_rec<W>(cur[j], rbits, it, it < R);
-        }
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t tn = tile + gridDim.x;
-        if (tn < ntiles) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const int64_t it = item_of(tn, j);
-                load_rec<W>(nxt[j], rbits, it, it < R);
-            }
-        }
-        // all QN x IPT distances first, ONE wave vote over every comparison, and the (rare) append code behind it: per-query
-        // votes put the argument set-up of the out-of-line append on the common path (22 v_mov per query in the ISA)
-        int dd[QN][IPT];
-        bool hit_any = false;
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) dd[q][j] = 0;
-#pragma unroll
-            for (int x = 0; x < W; ++x)                     // word-major: IPT independent popcount chains interleave
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) dd[q][j] += __popc(cur[j].w[x] ^ qw[q][x]);
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) hit_any |= item_of(tile, j) < R && dd[q][j] <= thr[q];
-        }
-        if (__ballot(hit_any)) {                            // uncommon: some lane holds a candidate for some query of the group
-#pragma unroll
-            for (int q = 0; q < QN; ++q) {
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) {
-                    // vote per (query, item slot) here: the out-of-line call (argument moves, swappc, return) is paid only by the
-                    // slots that hold a candidate, not by all QN x IPT slots of a tile that holds one somewhere (2-4 % at Q = 8)
-                    const bool hit = item_of(tile, j) < R && dd[q][j] <= thr[q];
-                    if (__ballot(hit)) append_candidates(item_of(tile, j), dd[q][j], hit, cnt + (int64_t)(q0 + q) * kCntStride, cand + (int64_t)(q0 + q) * kCandCap);
-                }
-            }
-        }
-        if (tn < ntiles) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
-        }
-    }
-}
-
-// ---- the filter for MANY queries on the matrix cores -------------------------------------------------------------------------
-// From a handful of queries on the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery
-// stream.
-// v_mfma_i32_16x16x64_i8 takes that work: the Hamming distance of query q and item x is popcount(q) + sum_i s_i x_i with
-// s_i = 1 - 2 q_i.  The item's bits become bytes WITHOUT being moved: word & (0x01010101 << p) leaves bits p, p + 8, p + 16, p + 24 of
-// a 32-bit word each alone in its byte, worth 2^p there (p = 7 goes through (word >> 1) & 0x40404040: +128 is not an int8) -- 9
-// operations for 32 bits, independent of the number of queries.  The query side (B operand, built once per wave and kept in
-// registers) carries the matching weight: its byte for that bit is s_i * 64 / 2^p, so every product is 64 s_i x_i, and with the
-// accumulator started at 64 (popcount(q) - threshold(q) - 1) one chain of K/64 MFMAs leaves 64 (distance - threshold - 1) for 16
-// items x 16 queries: lane l holds query l & 15 and the items 4 * (l >> 4) + r, r = 0..3.  A candidate is a NEGATIVE result, so ONE
-// vote on the OR of a lane's 4 * QT results covers all of them.  Lane (row = l & 15, quarter = l >> 4) supplies the quarter
-// `quarter` of item `row`; which of its bits sits in which k slot of which MFMA is the same on both operands and otherwise free (a
-// sum over k does not care).
-// Candidates go to the same per-query lists as in k_topk_filter, through a wave-private staging list (below).  W % 4 == 0
-// (128-bit steps of the code length); QT = query tiles of 16 per pass over the gallery.
-typedef int topk_v4i __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ void append_one(int q, uint32_t d, uint32_t it, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     const uint32_t pos = atomicAdd(cnt + (int64_t)q * kCntStride, 1u);
     if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)d << 32) | it;
@@ -748,6 +636,220 @@ __device__ __noinline__ void flush_staged(const uint2* stage, uint32_t* count, i
     if (lane == 0) *count = 0;
     __builtin_amdgcn_wave_barrier();
 }
+
+// Candidates of the VALU filters go through the same wave-private LDS list as the matrix-core filter's (round 5).  The direct append --
+// a global atomic whose return the wave waits for -- shares vmcnt with the prefetched tile: every candidate held its wave for a whole
+// memory round trip with nothing of its own in flight behind it.  Measured on 10 M x 256 bit, per-piece filter, 512 blocks: 45.6 us
+// with ~1 candidate per launch, 49.6 with 380, 58.9 with 2 900; staged: 46.3 with 380.
+constexpr int kStageV = 128;                                // entries per wave; flushed from 64 on, the overflow goes out directly
+__device__ __forceinline__ void stage_candidate(bool hit, uint32_t item, uint32_t d, int ql, uint2* stage, uint32_t* count, int q0,
+                                                uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    if (hit) {
+        const uint32_t pos = atomicAdd(count, 1u);
+        if (pos < (uint32_t)kStageV) stage[pos] = make_uint2(item, d | ((uint32_t)ql << 16));
+        else append_one(q0 + ql, d, item, cnt, cand);
+    }
+}
+
+// queries are processed in groups of QN: their words and thresholds are loaded ONCE per wave and stay resident over the whole
+// stream, so the tile loop is loads + XOR/popcount only.  QG (round 3) = query groups per BLOCK: the block's waves split into QG
+// sub-blocks that walk the SAME tiles, each with its own QN queries -- the second and later readers of a tile hit in the CU's L1
+// instead of every query group streaming the gallery again from L2 / HBM (blockIdx.y alone: 8 passes over the tiles at Q = 64), and at
+// Q = 8 two groups of 4 halve the integer work and the 64 query-word registers per wave that made the VALU co-critical.
+template <int W, int IPT, int QN, int QG>
+__global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                          int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    constexpr int SUBT = kThreads / QG;                     // threads (whole waves) per query group
+    static_assert(SUBT % 64 == 0, "query groups are whole waves");
+    constexpr int TILE = SUBT * IPT;
+    const int sub = threadIdx.x / SUBT, tl = threadIdx.x % SUBT;
+    const int q0 = (blockIdx.y * QG + sub) * QN;
+    const int64_t ntiles = (R + TILE - 1) / TILE;
+    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * SUBT + tl; };
+    uint32_t qw[QN][W];
+    int thr[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // clamp: surplus slots repeat the last query and are ignored below
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            qw[q][x] = qbits[(int64_t)qq * W + x];
+            asm volatile("" : "+v"(qw[q][x]));              // keep the 8x8 query words in VGPRs: 64+ SGPRs would spill through v_readlane
+        }
+        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+    }
+    __shared__ uint2 stage_all[kThreads / 64][kStageV];
+    __shared__ uint32_t stage_n[kThreads / 64];
+    uint2* mine_stage = stage_all[wave_id()];
+    uint32_t* mine_n = stage_n + wave_id();
+    if (lane_id() == 0) *mine_n = 0;
+    __builtin_amdgcn_wave_barrier();
+    Rec<W> cur[IPT], nxt[IPT];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t it = item_of(tile, j);
+            load_rec<W>(cur[j], rbits, it, it < R);
+        }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int64_t it = item_of(tn, j);
+                load_rec<W>(nxt[j], rbits, it, it < R);
+            }
+        }
+        // all QN x IPT distances first, ONE wave vote over every comparison, and the (rare) append code behind it: per-query
+        // votes put the argument set-up of the out-of-line append on the common path (22 v_mov per query in the ISA)
+        int dd[QN][IPT];
+        bool hit_any = false;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) dd[q][j] = 0;
+#pragma unroll
+            for (int x = 0; x < W; ++x)                     // word-major: IPT independent popcount chains interleave
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) dd[q][j] += __popc(cur[j].w[x] ^ qw[q][x]);
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) hit_any |= item_of(tile, j) < R && dd[q][j] <= thr[q];
+        }
+        if (__ballot(hit_any)) {                            // uncommon: some lane holds a candidate for some query of the group
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j)
+                    stage_candidate(item_of(tile, j) < R && dd[q][j] <= thr[q], (uint32_t)item_of(tile, j), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+        }
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
+        }
+    }
+    flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+}
+
+// ---- the same filter for codes of whole 128-bit pieces (W % 4 == 0), round 5 ---------------------------------------------------
+// k_topk_filter gives every lane an ITEM: at 256 bits two 16-byte loads per lane, 32 bytes apart between neighbouring lanes, so each
+// load instruction of a wave touches 2 KB and uses half of it.  Here every lane takes a 16-byte PIECE and a wave's load instruction
+// covers 1 KB contiguous; the W / 4 lanes of an item add their partial distances with DPP moves (no LDS), every lane of the group ends
+// with the whole distance and its first lane reports.  On such loads the non-temporal hint pays (on the per-item form it costs):
+// measured on 10 M x 256 bit, four galleries in rotation so that the Infinity Cache cannot help (tools/proto_stream_read.hip):
+// per-item loads 6.1-6.5 TB/s, per-piece 6.1-6.3, per-piece + nt 6.7-7.0 = 0.84-0.87 of the 8 TB/s peak; 96 / 192 MB galleries (cache
+// resident) 6.5 / 6.9 -> 7.4 / 7.2.  Two blocks per CU were best or within 2 % of it at every size.
+// The query words a lane needs are those of ITS piece: 4 registers per query instead of W.
+typedef uint32_t topk_u4 __attribute__((ext_vector_type(4)));
+
+template <int LPI>
+__device__ __forceinline__ int join_pieces(int h) {
+    if constexpr (LPI >= 2) h += __builtin_amdgcn_mov_dpp(h, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    if constexpr (LPI >= 4) h += __builtin_amdgcn_mov_dpp(h, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    if constexpr (LPI >= 8) h += __builtin_amdgcn_mov_dpp(h, 0x141, 0xf, 0xf, true);    // row_half_mirror: lane i <-> 7 - i, the other quad's sum
+    if constexpr (LPI >= 16) h += __builtin_amdgcn_mov_dpp(h, 0x140, 0xf, 0xf, true);   // row_mirror: lane i <-> 15 - i, the other half's sum
+    return h;
+}
+
+template <int W, int NLD, int QN>
+__global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                              int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                              uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    static_assert(W % 4 == 0 && W <= 64, "whole 16-byte pieces, at most 16 lanes per item");
+    constexpr int LPI = W / 4;                              // lanes (pieces) per item
+    constexpr int LOGL = LPI == 1 ? 0 : (LPI == 2 ? 1 : (LPI == 4 ? 2 : (LPI == 8 ? 3 : 4)));
+    static_assert((1 << LOGL) == LPI, "a power of two");
+    constexpr int TILE = kThreads * NLD;                    // pieces per tile
+    const int part = threadIdx.x & (LPI - 1);
+    const int q0 = blockIdx.y * QN;
+    const int64_t npieces = R * LPI;
+    const int64_t nfull = npieces / TILE, ntiles = (npieces + TILE - 1) / TILE;
+    const topk_u4* __restrict__ g = reinterpret_cast<const topk_u4*>(rbits);
+    topk_u4 qw[QN];
+    int thr[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // surplus slots repeat the last query and are ignored below
+        qw[q] = *reinterpret_cast<const topk_u4*>(qbits + (int64_t)qq * W + 4 * part);
+        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+    }
+    auto piece_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    auto load_tile = [&](topk_u4 (&dst)[NLD], int64_t tile) {
+        if (tile < nfull) {                                 // uniform: whole tiles load without a bounds check
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) dst[j] = __builtin_nontemporal_load(g + piece_of(tile, j));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int64_t pc = piece_of(tile, j);
+                dst[j] = pc < npieces ? __builtin_nontemporal_load(g + pc) : topk_u4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    __shared__ uint2 stage_all[kThreads / 64][kStageV];
+    __shared__ uint32_t stage_n[kThreads / 64];
+    uint2* mine_stage = stage_all[wave_id()];
+    uint32_t* mine_n = stage_n + wave_id();
+    if (lane_id() == 0) *mine_n = 0;
+    __builtin_amdgcn_wave_barrier();
+    topk_u4 cur[NLD], nxt[NLD];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(cur, tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) load_tile(nxt, tn);
+        int dd[QN][NLD];
+        bool hit_any = false;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int h = __popc(cur[j].x ^ qw[q].x) + __popc(cur[j].y ^ qw[q].y) + __popc(cur[j].z ^ qw[q].z) + __popc(cur[j].w ^ qw[q].w);
+                dd[q][j] = join_pieces<LPI>(h);
+                hit_any |= dd[q][j] <= thr[q];              // every lane of the item sees it; pieces past the end are sorted out below
+            }
+        }
+        if (__ballot(hit_any)) {                            // uncommon
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int64_t pc = piece_of(tile, j);
+                    stage_candidate(part == 0 && pc < npieces && dd[q][j] <= thr[q], (uint32_t)(pc >> LOGL), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+        }
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) cur[j] = nxt[j];
+        }
+    }
+    flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+}
+
+// ---- the filter for MANY queries on the matrix cores -------------------------------------------------------------------------
+// From a handful of queries on the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery
+// stream.
+// v_mfma_i32_16x16x64_i8 takes that work: the Hamming distance of query q and item x is popcount(q) + sum_i s_i x_i with
+// s_i = 1 - 2 q_i.  The item's bits become bytes WITHOUT being moved: word & (0x01010101 << p) leaves bits p, p + 8, p + 16, p + 24 of
+// a 32-bit word each alone in its byte, worth 2^p there (p = 7 goes through (word >> 1) & 0x40404040: +128 is not an int8) -- 9
+// operations for 32 bits, independent of the number of queries.  The query side (B operand, built once per wave and kept in
+// registers) carries the matching weight: its byte for that bit is s_i * 64 / 2^p, so every product is 64 s_i x_i, and with the
+// accumulator started at 64 (popcount(q) - threshold(q) - 1) one chain of K/64 MFMAs leaves 64 (distance - threshold - 1) for 16
+// items x 16 queries: lane l holds query l & 15 and the items 4 * (l >> 4) + r, r = 0..3.  A candidate is a NEGATIVE result, so ONE
+// vote on the OR of a lane's 4 * QT results covers all of them.  Lane (row = l & 15, quarter = l >> 4) supplies the quarter
+// `quarter` of item `row`; which of its bits sits in which k slot of which MFMA is the same on both operands and otherwise free (a
+// sum over k does not care).
+// Candidates go to the same per-query lists as in k_topk_filter, through a wave-private staging list (below).  W % 4 == 0
+// (128-bit steps of the code length); QT = query tiles of 16 per pass over the gallery.
+typedef int topk_v4i __attribute__((ext_vector_type(4)));
 
 template <int W, int QT>
 // four query tiles: 172 registers would leave two waves per SIMD; capped to three (4 spilled outside the loop): 0.149 -> 0.132 ms at Q = 64
@@ -1080,13 +1182,21 @@ extern "C" int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, si
 
 namespace {
 // Which instance of the streaming filter a (code words, queries) call launches: k_topk_filter_mfma<W, qt> (distances on the matrix
-// cores: 3 and >= 5 queries at 128 / 256 / 512 bits; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never) or
-// k_topk_filter<W, items per thread, qn, qg> (qn queries per group in VGPRs, qg groups per block sharing each tile through L1: Q = 8 runs
-// as 2 x 4, 16 and more queries as up to 4 x 8; XMH_TOPK_QG = "<qn>x<qg>" overrides).  Measured (10 M x 256 bit): one matrix-core pass
-// over 16 queries 63 us whatever their number, against 54 / 58 / 95 / 61 / 79 / 80 us for 1 / 2 / 3 / 4 / 6 / 8 queries on the VALU.
-struct FilterChoice { bool mfma; int qt, qn, qg; };
+// cores: >= 5 queries at 128 / 256 / 512 bits; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never),
+// k_topk_filter_seq<W, loads, qn> (round 5: codes of whole 16-byte pieces, every other case with W % 4 == 0) or
+// k_topk_filter<W, items per thread, qn, qg> (32- and 64-bit codes: qn queries per group in VGPRs, qg groups per block sharing each tile
+// through L1: Q = 8 runs as 2 x 4, 16 and more queries as up to 4 x 8; XMH_TOPK_QG = "<qn>x<qg>" overrides).  Measured (10 M x 256 bit):
+// one matrix-core pass over 16 queries 62-64 us whatever their number; per-item VALU filter 54 / 58 / 95 / 61 / 79 / 80 us for 1 / 2 / 3 /
+// 4 / 6 / 8 queries; per-piece filter 49 / 50 / 51.5 / 52 us for 1 / 2 / 3 / 4 queries (3 run as 4; the matrix cores took 67) and 74-78 us
+// for 5-8 as one group of 8 -- VALU-bound, so the matrix cores keep those.
+constexpr int kSeqLoads = 4;                                 // 16-byte loads in flight per lane and tile of k_topk_filter_seq (8 measured 2-4 % behind)
+bool topk_seq_on() {
+    static const bool on = [] { const char* e = xmh_experiment_env("XMH_TOPK_SEQ"); return !e || e[0] != '0'; }();
+    return on;
+}
+struct FilterChoice { bool mfma; int qt, qn, qg; bool seq; };
 FilterChoice topk_filter_choice(int W, int64_t Q) {
-    FilterChoice c{false, 0, 1, 1};
+    FilterChoice c{false, 0, 1, 1, false};
     const int qmax = W >= 64 ? 1 : (W >= 32 ? 2 : (W >= 16 ? 4 : 8));      // query words live in VGPRs
     c.qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));
     if (W < 16 && Q >= 5 && Q <= 8) { c.qn = 4; c.qg = 2; }
@@ -1096,10 +1206,15 @@ FilterChoice topk_filter_choice(int W, int64_t Q) {
         if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4 || a == 8) && a <= qmax && (b == 1 || b == 2 || b == 4) && (a > 1 || b == 1) && W < 16) { c.qn = a; c.qg = b; }
     }
     static const int mfma_min_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
-    if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? (Q >= 5 || Q == 3) : (mfma_min_q > 0 && Q >= mfma_min_q))) {
+    if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? (Q >= 5 || (Q == 3 && !topk_seq_on())) : (mfma_min_q > 0 && Q >= mfma_min_q))) {
         const int qtmax = W == 16 ? 2 : 4;
         c.mfma = true;
         c.qt = Q <= 16 ? 1 : (Q <= 32 || qtmax == 2 ? 2 : 4);
+    }
+    if (!c.mfma && W % 4 == 0 && topk_seq_on()) {           // codes of whole 16-byte pieces: k_topk_filter_seq, 4 query registers per query
+        c.seq = true;
+        c.qg = 1;
+        c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
     }
     return c;
 }
@@ -1170,7 +1285,24 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     on_mfma = true;                                                                                        \
                 }                                                                                                          \
             }                                                                                                              \
-            if (!on_mfma) {                                                                                                \
+            bool on_seq = false;                                                                                           \
+            if constexpr (WW % 4 == 0) {                                                                                   \
+                if (!on_mfma && fc_.seq) {                          /* 16-byte pieces, non-temporal, two blocks per CU */         \
+                    const unsigned gy_ = (unsigned)xmh::ceil_div(Q, qn);                                                   \
+                    int64_t fb_ = (int64_t)xmh::device_cu_count() * 2;                                                     \
+                    const int64_t ft_ = xmh::ceil_div(R * (WW / 4), (int64_t)kThreads * kSeqLoads);                        \
+                    if (fb_ > ft_) fb_ = ft_;                                                                              \
+                    xmh::ProfScope prof("topk_filter", st);                                                                \
+                    auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                                                                     (const uint32_t*)f.t_est, f.cnt, f.cand); };           \
+                    if (qn == 1) gos_(k_topk_filter_seq<WW, kSeqLoads, 1>);                                                 \
+                    if (qn == 2) gos_(k_topk_filter_seq<WW, kSeqLoads, 2>);                                                 \
+                    if (qn == 4) gos_(k_topk_filter_seq<WW, kSeqLoads, 4>);                                                 \
+                    if (qn == 8) gos_(k_topk_filter_seq<WW, kSeqLoads, 8>);                                                 \
+                    on_seq = true;                                                                                         \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (!on_mfma && !on_seq) {                                                                                     \
             const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
             const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
             int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;     /* 2..32 blocks per CU measured within 5 % */        \
@@ -1275,6 +1407,7 @@ extern "C" int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, 
     const FilterChoice c = topk_filter_choice(p.W, Q);
     const int ipt = p.W <= 2 ? 8 : (p.W == 4 ? 4 : (p.W == 8 ? 2 : 1));      // items per thread of the VALU filter (XMH_FAST table)
     if (c.mfma) snprintf(out, out_bytes, "filter=k_topk_filter_mfma<%d, %d>", p.W, c.qt);
+    else if (c.seq) snprintf(out, out_bytes, "filter=k_topk_filter_seq<%d, %d, %d>", p.W, kSeqLoads, c.qn);
     else snprintf(out, out_bytes, "filter=k_topk_filter<%d, %d, %d, %d>", p.W, ipt, c.qn, c.qg);
     return XMH_OK;
 }
