@@ -134,7 +134,8 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
 
 
 def _result(alg, t, t_call, launches, R, K, Q, k, kind):
-    name = "k_topk_filter_mfma (distances on v_mfma_i32_16x16x64_i8)" if filter_on_matrix_cores(K, Q) else "k_topk_filter"
+    inst = filter_instance(K, Q)
+    name = "k_topk_filter_mfma (distances on v_mfma_i32_16x16x64_i8)" if inst.startswith("k_topk_filter_mfma") else inst
     return {"kernel": "%s, the streaming pass of xmh_hamming_topk; HIP events around the launch, %d launches" % (name, launches),
             "bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
             "traffic": _traffic(K, Q), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,

@@ -1190,10 +1190,6 @@ namespace {
 // 4 / 6 / 8 queries; per-piece filter 49 / 50 / 51.5 / 52 us for 1 / 2 / 3 / 4 queries (3 run as 4; the matrix cores took 67) and 74-78 us
 // for 5-8 as one group of 8 -- VALU-bound, so the matrix cores keep those.
 constexpr int kSeqLoads = 4;                                 // 16-byte loads in flight per lane and tile of k_topk_filter_seq (8 measured 2-4 % behind)
-bool topk_seq_on() {
-    static const bool on = [] { const char* e = xmh_experiment_env("XMH_TOPK_SEQ"); return !e || e[0] != '0'; }();
-    return on;
-}
 struct FilterChoice { bool mfma; int qt, qn, qg; bool seq; };
 FilterChoice topk_filter_choice(int W, int64_t Q) {
     FilterChoice c{false, 0, 1, 1, false};
@@ -1206,12 +1202,12 @@ FilterChoice topk_filter_choice(int W, int64_t Q) {
         if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4 || a == 8) && a <= qmax && (b == 1 || b == 2 || b == 4) && (a > 1 || b == 1) && W < 16) { c.qn = a; c.qg = b; }
     }
     static const int mfma_min_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
-    if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? (Q >= 5 || (Q == 3 && !topk_seq_on())) : (mfma_min_q > 0 && Q >= mfma_min_q))) {
+    if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? Q >= 5 : (mfma_min_q > 0 && Q >= mfma_min_q))) {
         const int qtmax = W == 16 ? 2 : 4;
         c.mfma = true;
         c.qt = Q <= 16 ? 1 : (Q <= 32 || qtmax == 2 ? 2 : 4);
     }
-    if (!c.mfma && W % 4 == 0 && topk_seq_on()) {           // codes of whole 16-byte pieces: k_topk_filter_seq, 4 query registers per query
+    if (!c.mfma && W % 4 == 0) {           // codes of whole 16-byte pieces: k_topk_filter_seq, 4 query registers per query
         c.seq = true;
         c.qg = 1;
         c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
@@ -1302,6 +1298,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     on_seq = true;                                                                                         \
                 }                                                                                                          \
             }                                                                                                              \
+            if constexpr (WW < 4) {                                 /* 32- and 64-bit codes: several items per 16 bytes, per-item filter */ \
             if (!on_mfma && !on_seq) {                                                                                     \
             const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
             const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
@@ -1311,7 +1308,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
             xmh::ProfScope prof("topk_filter", st);                                                                        \
             const dim3 grid_((unsigned)fb, gy);                                                                            \
             auto go_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, grid_, dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); }; \
-            if constexpr (WW < 16) {                                                                                       \
+            {                                                                                                              \
                 if (qn == 8 && qg == 1) go_(k_topk_filter<WW, II, 8, 1>);                                                   \
                 if (qn == 8 && qg == 2) go_(k_topk_filter<WW, II, 8, 2>);                                                   \
                 if (qn == 8 && qg == 4) go_(k_topk_filter<WW, II, 8, 4>);                                                   \
@@ -1320,13 +1317,10 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 if (qn == 2 && qg == 2) go_(k_topk_filter<WW, II, 2, 2>);                                                   \
                 if (qn == 2 && qg == 4) go_(k_topk_filter<WW, II, 2, 4>);                                                   \
             }                                                                                                              \
-            if constexpr (WW < 32) {                                                                                       \
-                if (qn == 4 && qg == 1) go_(k_topk_filter<WW, II, 4, 1>);                                                   \
-            }                                                                                                              \
-            if constexpr (WW < 64) {                                                                                       \
-                if (qn == 2 && qg == 1) go_(k_topk_filter<WW, II, 2, 1>);                                                   \
-            }                                                                                                              \
+            if (qn == 4 && qg == 1) go_(k_topk_filter<WW, II, 4, 1>);                                                       \
+            if (qn == 2 && qg == 1) go_(k_topk_filter<WW, II, 2, 1>);                                                       \
             if (qn == 1) go_(k_topk_filter<WW, II, 1, 1>);                                                                 \
+            }                                                                                                              \
             }                                                                                                              \
         }
         switch (p.W) {

@@ -1233,10 +1233,31 @@ def test_topk_whole_query_set_over_the_unsharded_10m_gallery(xr):
     assert np.array_equal(d[sub].cpu().numpy().view(np.uint16), wd)
 
 
-@pytest.mark.parametrize("Q,R,K,k", [(3, 50001, 128, 10), (16, 33333, 128, 100), (17, 70001, 256, 100), (33, 40007, 256, 5), (70, 25013, 256, 100),
+@pytest.mark.parametrize("Q,R,K,k", [(1, 100_003, 128, 10), (2, 64_001, 128, 100), (3, 50_001, 128, 7), (4, 77_777, 128, 100),
+                                     (1, 1_000_001, 256, 100), (2, 33_333, 256, 50), (3, 41_001, 256, 100), (4, 200_003, 256, 9),
+                                     (1, 60_001, 512, 100), (3, 25_013, 512, 20), (4, 30_011, 512, 100),
+                                     (1, 20_001, 1024, 100), (2, 9_999, 1024, 10), (5, 12_345, 1024, 33), (9, 8_191, 1024, 100),
+                                     (1, 7_001, 2048, 50), (3, 5_003, 2048, 100), (11, 4_099, 2048, 8), (1, 15, 256, 3), (4, 255, 128, 100)])
+def test_topk_per_piece_filter(xr, Q, R, K, k):
+    """k_topk_filter_seq (round 5: codes of whole 16-byte pieces, 1-4 queries at 128 / 256 / 512 bits and every query count at 1024 /
+    2048 bits): 1, 2, 4, 8 and 16 lanes per item joined by DPP, groups of 1 / 2 / 4 / 8 queries with surplus slots and several groups,
+    ragged last tiles, galleries below and above the sampling size, more rows than one tile per block and fewer than one; and a
+    duplicate-heavy gallery whose candidates outgrow the wave's staging list (flushes inside the loop, direct appends, then the
+    robust path)."""
+    import ctypes
+    from xmh._lib import check, lib
+    buf = ctypes.create_string_buffer(256)
+    check(lib.xmh_topk_describe(Q, R, K, k, buf, 256), "xmh_topk_describe")
+    assert b"k_topk_filter_seq<%d, " % (K // 32) in buf.value, buf.value
+    _topk_check(xr, Q, R, K, k, seed=5 * Q + R + K + k, base_index=1234)
+    if R < 100000:
+        _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
+
+
+@pytest.mark.parametrize("Q,R,K,k", [(5, 50001, 128, 10), (16, 33333, 128, 100), (17, 70001, 256, 100), (33, 40007, 256, 5), (70, 25013, 256, 100),
                                      (20, 30011, 512, 50), (40, 9999, 512, 100), (5, 15, 256, 3), (64, 1_200_003, 256, 100), (12, 900_001, 128, 20)])
 def test_topk_matrix_core_filter(xr, Q, R, K, k):
-    """k_topk_filter_mfma (3 and >= 5 queries at 128 / 256 / 512 bits): one, two and four query tiles per pass, several passes,
+    """k_topk_filter_mfma (>= 5 queries at 128 / 256 / 512 bits): one, two and four query tiles per pass, several passes,
     ragged last groups, galleries below and above the sampling size; and a duplicate-heavy gallery whose candidates outgrow the
     wave's staging list and the per-query lists (direct appends, then the robust path)."""
     _topk_check(xr, Q, R, K, k, seed=3 * Q + R + K + k, base_index=77)
