@@ -621,10 +621,15 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         const int nbatch = (a.chunk + 63) >> 6;
         const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
         const int nfull = (int)((hi - lo) >> 6);                     // whole batches of this chunk
-        uint4 cw = crow[0];
+        auto cache_words = [&](int64_t batch) -> uint4 {             // read once, 1 KB contiguous per wave instruction: non-temporal (see k_scan_ap_c)
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        };
+        uint4 cw = cache_words(0);
         bool prev = false;
         for (int bi = 0; bi < nfull; ++bi) {
-            const uint4 nw = crow[(int64_t)(bi + 1 < nbatch ? bi + 1 : bi) * 64];      // unconditional: counted vmcnt, no predication
+            const uint4 nw = cache_words(bi + 1 < nbatch ? bi + 1 : bi);               // unconditional: counted vmcnt, no predication
             issue(cw.x, cw.y, prev);
             prev = true;
             issue(cw.z, cw.w, true);

@@ -952,13 +952,24 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the counters are in place before the first asm atomic is counted
     // the cache words are fetched TWO batches ahead: a batch is ~1.2 us of this wave's time at 5 waves per SIMD, an HBM miss under load
     // takes longer than that (Q 5000 x R 117 218, 64 bit, pass 2 with the words one / two / three batches ahead: 0.187 / 0.178 / 0.181 ms)
-    uint4 cw = crow[0];
-    uint4 nw = crow[(int64_t)(1 < nbatch ? 1 : 0) * 64];
+    // the cache is read once, 1 KB contiguous per wave instruction: the non-temporal hint pays on exactly this form (round 5, see
+    // k_topk_filter_seq): pass 2 at the headline shape 0.192-0.194 -> 0.185-0.187 ms in the ablation harness (XMH_ABL_AP_PLAIN = without)
+    auto cache_words = [&](int64_t batch) -> uint4 {
+#ifdef XMH_ABL_AP_PLAIN
+        return crow[batch * 64];
+#else
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
+        return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+    };
+    uint4 cw = cache_words(0);
+    uint4 nw = cache_words(1 < nbatch ? 1 : 0);
     auto next_words = [&](int bi) {                                  // unconditional: counted vmcnt, no predication
 #ifdef XMH_ABL_AP_NOLOAD
         const uint4 nw2 = make_uint4(0x10203040u + bi + lane, 0x18283848u ^ lane, 0x11223344u + 3 * lane, 0x21314151u + bi);      // (ablation: no cache stream)
 #else
-        const uint4 nw2 = crow[(int64_t)(bi + 2 < nbatch ? bi + 2 : nbatch - 1) * 64];
+        const uint4 nw2 = cache_words(bi + 2 < nbatch ? bi + 2 : nbatch - 1);
 #endif
         return nw2;
     };
