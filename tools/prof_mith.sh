@@ -1,33 +1,42 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the MITH encode (image + text, B=100) -- run on the GPU box; summary in gpurun_out/prof_mith.txt
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+# kernel trace of the MITH encode legs (batch 100, parity mode): tools/prof_mith.sh -> gpurun_out/mith_{images,captions}_stats.txt
+cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_mith
-rm -rf $OUT; mkdir -p $OUT
-cat > /tmp/mith_once.py <<'PY'
-import os, sys
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "clip-based-cross-modal-hash_amd")]
-import torch
-import xmh.models  # noqa
+mkdir -p gpurun_out
+cat > /tmp/mith_loop.py <<'PY'
+import sys, os, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", ".")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")]
+import xmh.models
 from xmh.common.register import registry
-from xmh.utils.config import Config
 from xmh.models import weights as W
-B = 100
-image = W.synth_images(5, B).cuda(); ids, _ = W.synth_text(5, B); ids = ids.cuda(); kpm = ids == 0
+from xmh.utils.config import Config
+what = sys.argv[1]
 model = registry.get_model_class("MITH").from_config(Config({"clip_path": "synthetic:1814"}), output_dim=64, train_num=1000).cuda().eval()
+image = W.synth_images(5, 100).cuda()
+ids, _ = W.synth_text(5, 100); ids = ids.cuda(); kpm = ids == 0
+fn = (lambda: model.encode_image(image)) if what == "images" else (lambda: model.encode_text(ids, kpm))
 with torch.no_grad():
-    for _ in range(5):
-        model.encode_image(image); model.encode_text(ids, kpm)
+    for _ in range(30): fn()
 torch.cuda.synchronize()
 PY
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o m -- python /tmp/mith_once.py > $OUT/trace.log 2>&1
-python - <<'PY'
-import csv, glob
-f = glob.glob("gpurun_out/prof_mith/trace/**/m_kernel_stats.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
+for w in images captions; do
+  timeout 300 rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/mith_$w -o m -- python /tmp/mith_loop.py $w > /tmp/mith_$w.log 2>&1
+  python - /tmp/mith_$w/m_kernel_stats.csv $w <<'PY' | tee gpurun_out/mith_${w}_stats.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel time per (image+text) pass: %.3f ms" % (tot / 5 / 1e6))
+print("MITH %s, batch 100, 30 forwards: GPU time per forward %.3f ms" % (sys.argv[2], tot / 30 / 1e6))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
-    print("%-70s calls/pass %6.1f  avg %8.2f us  %5.1f %%" % (r["Name"][:70], int(r["Calls"]) / 5, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    print("%6.2f %%  %6d calls  avg %8.1f us  %s" % (100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]), float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:110]))
 PY
-rm -rf $OUT/trace
+done
+python - <<'PY' | tee gpurun_out/mith_images_sequence.txt
+import csv
+rows = sorted(csv.DictReader(open("/tmp/mith_images/m_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+n = len(rows)
+last = rows[-(n // 30):]
+print("kernels of the last forward, in order (duration us):")
+for r in last:
+    print("%7.1f  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:90]))
+PY
