@@ -834,6 +834,113 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
     flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
 }
 
+// ---- short codes (32 / 64 bits per item: W = 1, 2) as 16-byte pieces, round 5 --------------------------------------------------------
+// The per-item filter reads 4 or 8 bytes per lane: 256 / 512 bytes per wave instruction, and 40 M x 32-bit codes streamed at 3.4 TB/s,
+// bound by the number of load instructions, not by HBM or the VALU.  Here a lane loads 16 bytes = 4 / 2 ITEMS (contiguous 1 KB per
+// wave instruction, non-temporal).  The common path keeps only a running minimum per query (v_min3 takes two distances at a time) and
+// compares once per tile; a tile with a candidate recomputes its distances in the rare path.  Query words and thresholds are uniform:
+// scalar registers.  A gallery view that does not start on a 16-byte boundary (a shard cut at any row) is read from the boundary
+// below it; the pieces at either end that are not whole are loaded word by word.
+template <int W, int NLD, int QN>
+__global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+                                                                int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                                uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    static_assert(W == 1 || W == 2, "4 or 2 items per 16-byte piece");
+    constexpr int IPP = 4 / W;
+    constexpr int TILE = kThreads * NLD;                    // pieces per tile
+    const int q0 = blockIdx.y * QN;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(rbits) & 15) >> 2);           // words between the 16-byte boundary below and the first item
+    const topk_u4* __restrict__ g = reinterpret_cast<const topk_u4*>(reinterpret_cast<uintptr_t>(rbits) & ~(uintptr_t)15);
+    const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(g);
+    const int64_t nwords = (int64_t)mis + R * W;            // words from the boundary to the end of the gallery
+    const int64_t npieces = (nwords + 3) >> 2;
+    const int64_t ntiles = (npieces + TILE - 1) / TILE;
+    uint32_t qw[QN][W];
+    int thr[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // surplus slots repeat the last query and never hit
+#pragma unroll
+        for (int x = 0; x < W; ++x) qw[q][x] = qbits[(int64_t)qq * W + x];
+        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+    }
+    auto piece_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    auto load_tile = [&](topk_u4 (&dst)[NLD], int64_t tile) {
+        const bool whole = (tile > 0 || mis == 0) && (tile + 1) * (int64_t)TILE * 4 <= nwords;      // uniform
+        if (whole) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) dst[j] = __builtin_nontemporal_load(g + piece_of(tile, j));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int64_t w0 = piece_of(tile, j) * 4;
+                uint32_t v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = (w0 + x >= mis && w0 + x < nwords) ? gw[w0 + x] : 0u;
+                dst[j] = topk_u4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    };
+    auto dist_of = [&](const topk_u4& pc, int s, int q) -> int {
+        if constexpr (W == 1) return __popc(pc[s] ^ qw[q][0]);
+        else return __popc(pc[2 * s] ^ qw[q][0]) + __popc(pc[2 * s + 1] ^ qw[q][1]);
+    };
+    __shared__ uint2 stage_all[kThreads / 64][kStageV];
+    __shared__ uint32_t stage_n[kThreads / 64];
+    uint2* mine_stage = stage_all[wave_id()];
+    uint32_t* mine_n = stage_n + wave_id();
+    if (lane_id() == 0) *mine_n = 0;
+    __builtin_amdgcn_wave_barrier();
+    topk_u4 cur[NLD], nxt[NLD];
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(cur, tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) load_tile(nxt, tn);
+        bool hit_any = false;
+        unsigned qhit = 0;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            int m = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                if constexpr (IPP == 4) {
+                    m = min(m, min(dist_of(cur[j], 0, q), dist_of(cur[j], 1, q)));
+                    m = min(m, min(dist_of(cur[j], 2, q), dist_of(cur[j], 3, q)));
+                } else {
+                    m = min(m, min(dist_of(cur[j], 0, q), dist_of(cur[j], 1, q)));
+                }
+            }
+            const bool h = m <= thr[q];                     // zero words of a ragged end may vote: sorted out below
+            hit_any |= h;
+            qhit |= (__ballot(h) != 0ull ? 1u : 0u) << q;
+        }
+        if (__ballot(hit_any)) {                            // uncommon: recompute the tile's distances for the queries that voted
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                if (!((qhit >> q) & 1u)) continue;          // wave-uniform
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int64_t w0 = piece_of(tile, j) * 4 - mis;      // word index of the piece's first word, relative to the gallery
+#pragma unroll
+                    for (int s = 0; s < IPP; ++s) {
+                        const int64_t wi = w0 + s * W;
+                        const int d = dist_of(cur[j], s, q);
+                        stage_candidate(wi >= 0 && wi < R * W && d <= thr[q], (uint32_t)(wi / W), (uint32_t)d, q, mine_stage, mine_n, q0, cnt, cand);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+        }
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) cur[j] = nxt[j];
+        }
+    }
+    flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+}
+
 // ---- the filter for MANY queries on the matrix cores -------------------------------------------------------------------------
 // From a handful of queries on the filter is bound by its integer work (17 VALU operations per query and item), not by the gallery
 // stream.
@@ -1190,9 +1297,9 @@ namespace {
 // 4 / 6 / 8 queries; per-piece filter 49 / 50 / 51.5 / 52 us for 1 / 2 / 3 / 4 queries (3 run as 4; the matrix cores took 67) and 74-78 us
 // for 5-8 as one group of 8 -- VALU-bound, so the matrix cores keep those.
 constexpr int kSeqLoads = 4;                                 // 16-byte loads in flight per lane and tile of k_topk_filter_seq (8 measured 2-4 % behind)
-struct FilterChoice { bool mfma; int qt, qn, qg; bool seq; };
+struct FilterChoice { bool mfma; int qt, qn, qg; bool seq, shrt; };
 FilterChoice topk_filter_choice(int W, int64_t Q) {
-    FilterChoice c{false, 0, 1, 1, false};
+    FilterChoice c{false, 0, 1, 1, false, false};
     const int qmax = W >= 64 ? 1 : (W >= 32 ? 2 : (W >= 16 ? 4 : 8));      // query words live in VGPRs
     c.qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));
     if (W < 16 && Q >= 5 && Q <= 8) { c.qn = 4; c.qg = 2; }
@@ -1206,6 +1313,12 @@ FilterChoice topk_filter_choice(int W, int64_t Q) {
         const int qtmax = W == 16 ? 2 : 4;
         c.mfma = true;
         c.qt = Q <= 16 ? 1 : (Q <= 32 || qtmax == 2 ? 2 : 4);
+    }
+    static const int short_max_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_SHORT"); return e ? atoi(e) : (1 << 30); }();
+    if (W < 4 && Q <= short_max_q) {        // 32- / 64-bit codes: 4 / 2 items per 16-byte piece, k_topk_filter_short (XMH_TOPK_SHORT = largest Q on it)
+        c.shrt = true;
+        c.qg = 1;
+        c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
     }
     if (!c.mfma && W % 4 == 0) {           // codes of whole 16-byte pieces: k_topk_filter_seq, 4 query registers per query
         c.seq = true;
@@ -1298,7 +1411,21 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     on_seq = true;                                                                                         \
                 }                                                                                                          \
             }                                                                                                              \
-            if constexpr (WW < 4) {                                 /* 32- and 64-bit codes: several items per 16 bytes, per-item filter */ \
+            if constexpr (WW < 4) {                                 /* 32- and 64-bit codes: several items per 16 bytes */          \
+            if (fc_.shrt) {                                                                                                \
+                const unsigned gy_ = (unsigned)xmh::ceil_div(Q, qn);                                                       \
+                int64_t fb_ = (int64_t)xmh::device_cu_count() * 2;                                                         \
+                const int64_t ft_ = xmh::ceil_div(xmh::ceil_div(R * WW + 3, (int64_t)4), (int64_t)kThreads * kSeqLoads);   \
+                if (fb_ > ft_) fb_ = ft_;                                                                                  \
+                xmh::ProfScope prof("topk_filter", st);                                                                    \
+                auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                                                                 (const uint32_t*)f.t_est, f.cnt, f.cand); };               \
+                if (qn == 1) gos_(k_topk_filter_short<WW, kSeqLoads, 1>);                                                   \
+                if (qn == 2) gos_(k_topk_filter_short<WW, kSeqLoads, 2>);                                                   \
+                if (qn == 4) gos_(k_topk_filter_short<WW, kSeqLoads, 4>);                                                   \
+                if (qn == 8) gos_(k_topk_filter_short<WW, kSeqLoads, 8>);                                                   \
+                on_seq = true;                                                                                             \
+            }                                                                                                              \
             if (!on_mfma && !on_seq) {                                                                                     \
             const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
             const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
@@ -1402,6 +1529,7 @@ extern "C" int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, 
     const int ipt = p.W <= 2 ? 8 : (p.W == 4 ? 4 : (p.W == 8 ? 2 : 1));      // items per thread of the VALU filter (XMH_FAST table)
     if (c.mfma) snprintf(out, out_bytes, "filter=k_topk_filter_mfma<%d, %d>", p.W, c.qt);
     else if (c.seq) snprintf(out, out_bytes, "filter=k_topk_filter_seq<%d, %d, %d>", p.W, kSeqLoads, c.qn);
+    else if (c.shrt) snprintf(out, out_bytes, "filter=k_topk_filter_short<%d, %d, %d>", p.W, kSeqLoads, c.qn);
     else snprintf(out, out_bytes, "filter=k_topk_filter<%d, %d, %d, %d>", p.W, ipt, c.qn, c.qg);
     return XMH_OK;
 }

@@ -174,6 +174,31 @@ int main(int argc, char** argv) {
             runlib("LIB k_topk_filter_seq<8,4,1>", k_topk_filter_seq<8, 4, 1>, grid);
             runlib("LIB k_topk_filter<8,2,1,1>", k_topk_filter<8, 2, 1, 1>, grid);
         }
+        // the same bytes as 64-bit and 32-bit codes (4 x / 8 x the items; thresholds low enough for a few hundred candidates)
+        const int64_t R8 = R;
+        auto runshort = [&](const char* name, auto kern, int grid, int64_t Rs, uint32_t ths) {
+            CK(hipMemcpy(t_est, &ths, 4, hipMemcpyHostToDevice));
+            for (int i = 0; i < 2 * ngal; ++i) { CK(hipMemsetAsync(cnt, 0, 4096, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, cnt, cand); }
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, cnt, cand);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double t = ms / iters * 1e-3;
+            unsigned got = 0;
+            CK(hipMemcpy(&got, cnt, 4, hipMemcpyDeviceToHost));
+            printf("%-28s grid %5d  %7.2f us  %5.2f TB/s  (%.3f of 8)  candidates %u (over %d launches)\n", name, grid, t * 1e6, bytes / t / 1e12, bytes / t / 8e12, got, iters);
+        };
+        for (int grid : {512, 1024}) {
+            runshort("LIB k_topk_filter_short<2,4,1>", k_topk_filter_short<2, 4, 1>, grid, R8 * 4, (uint32_t)(getenv("LIB_THR2") ? atoi(getenv("LIB_THR2")) : 12));
+            runshort("LIB k_topk_filter<2,8,1,1>", k_topk_filter<2, 8, 1, 1>, grid, R8 * 4, (uint32_t)(getenv("LIB_THR2") ? atoi(getenv("LIB_THR2")) : 12));
+            runshort("LIB k_topk_filter_short<1,4,1>", k_topk_filter_short<1, 4, 1>, grid, R8 * 8, 3u);
+            runshort("LIB k_topk_filter<1,8,1,1>", k_topk_filter<1, 8, 1, 1>, grid, R8 * 8, 3u);
+            runshort("LIB k_topk_filter_short<2,4,8>", k_topk_filter_short<2, 4, 8>, grid, R8 * 4, 12u);
+            runshort("LIB k_topk_filter_short<1,4,8>", k_topk_filter_short<1, 4, 8>, grid, R8 * 8, 3u);
+        }
     }
 #endif
     for (int grid : {512, 1024, 2048}) {
