@@ -453,6 +453,12 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
 // counters that share a cache line share one memory channel (64 queries on two lines: 45 us of a 160 us pass at Q = 64)
 constexpr int kCntStride = 64;
 constexpr int kCandCap = 8192;        // candidates kept per query (keys of 8 B)
+// Round 5: a query's list is kSub sub-lists of kSubCap keys, each with its own counter (kCntStride words apart like the queries').  The
+// filters flush their staged candidates when a wave ends, i.e. all at about the same time, and one counter per query serialised those
+// atomics in the L2: 10 M x 256 bit with 380 candidates per launch lost ~1 us to it, 40 M x 64 bit with 1 600 lost 7 us of 54.  A wave
+// takes the sub-list (its number + its flush count) mod kSub, so a run of equal codes that one wave meets still spreads.
+constexpr int kSub = 8;
+constexpr int kSubCap = kCandCap / kSub;
 constexpr int kSampleBlocks = 256;
 constexpr int kSamplePerBlock = 1024;
 constexpr int kFoldPickQ = 16;        // up to this many queries the last sample block picks the thresholds (no pick launch)
@@ -574,10 +580,8 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
     const int lane = lane_id();
     for (int q = wave_id(); q < Q; q += kWaves) {
         const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane);
-        if (lane == 0) {
-            t_est[q] = (uint32_t)t;
-            cnt[(int64_t)q * kCntStride] = 0u;
-        }
+        if (lane == 0) t_est[q] = (uint32_t)t;
+        if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
     }
     if (threadIdx.x == 0) {
         *fail = 0;
@@ -593,14 +597,16 @@ __global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, i
     const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane);
     if (lane == 0) {
         t_est[q] = (uint32_t)t;
-        cnt[(int64_t)q * kCntStride] = 0u;
         if (q == 0) *fail = 0;
     }
+    if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
 }
 
-__device__ __forceinline__ void append_one(int q, uint32_t d, uint32_t it, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
-    const uint32_t pos = atomicAdd(cnt + (int64_t)q * kCntStride, 1u);
-    if (pos < (uint32_t)kCandCap) cand[(int64_t)q * kCandCap + pos] = ((unsigned long long)d << 32) | it;
+__device__ __forceinline__ int sub_of_wave(int turn) { return (int)((blockIdx.x * (kThreads / 64) + wave_id() + turn) & (kSub - 1)); }
+
+__device__ __forceinline__ void append_one(int q, uint32_t d, uint32_t it, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand, int sub) {
+    const uint32_t pos = atomicAdd(cnt + ((int64_t)q * kSub + sub) * kCntStride, 1u);
+    if (pos < (uint32_t)kSubCap) cand[(int64_t)q * kCandCap + sub * kSubCap + pos] = ((unsigned long long)d << 32) | it;
 }
 
 // the wave's staged candidates -> the per-query lists, 64 per round trip; *count (the wave's own LDS word) goes back to zero
@@ -611,6 +617,7 @@ __device__ __noinline__ void flush_staged(const uint2* stage, uint32_t* count, i
     int n = (int)*count;
     n = __builtin_amdgcn_readfirstlane(n < cap ? n : cap);      // entries past the capacity went out directly
     for (int b = 0; b < n; b += 64) {
+        const int sub = sub_of_wave(b >> 6);
         const bool have = b + lane < n;
         const uint2 e = have ? stage[b + lane] : make_uint2(0u, 0u);
         const int ql = have ? (int)(e.y >> 16) : -1;
@@ -622,15 +629,15 @@ __device__ __noinline__ void flush_staged(const uint2* stage, uint32_t* count, i
             const int qcur = __shfl(ql, lead);
             const unsigned long long m = __ballot(ql == qcur) & todo;
             uint32_t base = 0;
-            if (lane == lead) base = atomicAdd(cnt + (int64_t)(q0 + qcur) * kCntStride, (uint32_t)__popcll(m));
+            if (lane == lead) base = atomicAdd(cnt + ((int64_t)(q0 + qcur) * kSub + sub) * kCntStride, (uint32_t)__popcll(m));
             base = (uint32_t)__shfl((int)base, lead);
             if (have && ql == qcur) {
                 const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < (uint32_t)kCandCap) cand[(int64_t)(q0 + qcur) * kCandCap + pos] = ((unsigned long long)(e.y & 0xffffu) << 32) | e.x;
+                if (pos < (uint32_t)kSubCap) cand[(int64_t)(q0 + qcur) * kCandCap + sub * kSubCap + pos] = ((unsigned long long)(e.y & 0xffffu) << 32) | e.x;
             }
             todo &= ~m;
         }
-        if ((todo >> lane) & 1ull) append_one(q0 + ql, e.y & 0xffffu, e.x, cnt, cand);
+        if ((todo >> lane) & 1ull) append_one(q0 + ql, e.y & 0xffffu, e.x, cnt, cand, sub);
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) *count = 0;
@@ -647,7 +654,7 @@ __device__ __forceinline__ void stage_candidate(bool hit, uint32_t item, uint32_
     if (hit) {
         const uint32_t pos = atomicAdd(count, 1u);
         if (pos < (uint32_t)kStageV) stage[pos] = make_uint2(item, d | ((uint32_t)ql << 16));
-        else append_one(q0 + ql, d, item, cnt, cand);
+        else append_one(q0 + ql, d, item, cnt, cand, sub_of_wave((int)(pos >> 6)));
     }
 }
 
@@ -1070,7 +1077,7 @@ __global__ __launch_bounds__(kThreads, (QT == 4 ? 3 : 1)) void k_topk_filter_mfm
                                 const uint32_t d = (uint32_t)((acc[t][r] >> 6) + thr[t] + 1);
                                 const uint32_t pos = atomicAdd(mine_n, 1u);
                                 if (pos < (uint32_t)kStage) mine_stage[pos] = make_uint2((uint32_t)(it0 + r), d | ((uint32_t)(16 * t + row) << 16));
-                                else append_one(q0 + 16 * t + row, d, (uint32_t)(it0 + r), cnt, cand);
+                                else append_one(q0 + 16 * t + row, d, (uint32_t)(it0 + r), cnt, cand, sub_of_wave((int)(pos >> 6)));
                             }
                         }
                     }
@@ -1138,12 +1145,28 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     int* sc = reinterpret_cast<int*>(hist + nh);               // [0] d*, [1] count below d*, [2] bin*, [3] count below bin*, [4] survivors, [5] keys in the last bin, [8..11] wave totals
     uint32_t* wtot = reinterpret_cast<uint32_t*>(sc + 8);
     const int q = blockIdx.x;
-    // the first 512 keys are requested together with the count (lists are a few hundred keys: one miss latency instead of two)
+    // the list is kSub sub-lists (see kSub).  The first 128 keys of each are requested together with the counts (lists are a few hundred
+    // keys: one miss latency instead of two): 32 threads per sub-list, four keys each
+    static_assert(kThreads == 32 * kSub, "32 threads per sub-list");
     const unsigned long long* cq = cand + (int64_t)q * kCandCap;
-    const unsigned long long k0 = cq[threadIdx.x], k1 = cq[threadIdx.x + kThreads];
-    const uint32_t n = cnt[(int64_t)q * kCntStride];
+    const int sub = threadIdx.x >> 5, sl = threadIdx.x & 31;
+    unsigned long long kspec[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kspec[i] = cq[sub * kSubCap + sl + 32 * i];
+    uint32_t nsub[kSub], n = 0, base = 0;
+    bool over = false;
+#pragma unroll
+    for (int s_ = 0; s_ < kSub; ++s_) {
+        nsub[s_] = cnt[((int64_t)q * kSub + s_) * kCntStride];
+        over |= nsub[s_] > (uint32_t)kSubCap;
+        if (s_ < sub) base += nsub[s_];
+        n += nsub[s_];
+    }
+    uint32_t mine_n = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < kSub; ++s_) mine_n = s_ == sub ? nsub[s_] : mine_n;
     const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
-    if (n > (uint32_t)kCandCap || n < want) {
+    if (over || n < want) {                                     // a sub-list overflowed (its counter ran on) or too few candidates
         if (threadIdx.x == 0) atomicOr(fail, 1);
         return;
     }
@@ -1151,9 +1174,10 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     // Radix selection instead of sorting all candidates: a distance histogram finds the bucket d* where the k-th result lies;
     // everything below it survives, inside it a histogram over the top 10 index bits finds the bin, and only the (few)
     // candidates of that last bin are ranked against each other.  The <= k survivors are then placed by counting.
-    key[threadIdx.x] = k0;
-    key[threadIdx.x + kThreads] = k1;
-    for (int p = threadIdx.x + 2 * kThreads; p < (int)n; p += kThreads) key[p] = cq[p];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((uint32_t)(sl + 32 * i) < mine_n) key[base + sl + 32 * i] = kspec[i];
+    for (uint32_t e = 128 + sl; e < mine_n; e += 32) key[base + e] = cq[sub * kSubCap + e];
     for (int e = threadIdx.x; e < nb; e += kThreads) hist[e] = 0u;
     if (threadIdx.x == 0) sc[4] = 0;
     __syncthreads();
@@ -1258,7 +1282,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->off_ctl = take(256);                           // ctl, hist, t_est, cnt, fail are contiguous: one memset clears them
     p->off_hist = take((size_t)Q * (K + 1) * 4);
     p->off_test = take((size_t)Q * 4);
-    p->off_cnt = take((size_t)Q * kCntStride * 4);
+    p->off_cnt = take((size_t)Q * kSub * kCntStride * 4);
     p->off_fail = take(256);
     p->off_cand = take((size_t)Q * kCandCap * 8);
     p->ws_bytes = o;
