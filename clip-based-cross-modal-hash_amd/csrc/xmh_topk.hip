@@ -658,91 +658,6 @@ __device__ __forceinline__ void stage_candidate(bool hit, uint32_t item, uint32_
     }
 }
 
-// queries are processed in groups of QN: their words and thresholds are loaded ONCE per wave and stay resident over the whole
-// stream, so the tile loop is loads + XOR/popcount only.  QG (round 3) = query groups per BLOCK: the block's waves split into QG
-// sub-blocks that walk the SAME tiles, each with its own QN queries -- the second and later readers of a tile hit in the CU's L1
-// instead of every query group streaming the gallery again from L2 / HBM (blockIdx.y alone: 8 passes over the tiles at Q = 64), and at
-// Q = 8 two groups of 4 halve the integer work and the 64 query-word registers per wave that made the VALU co-critical.
-template <int W, int IPT, int QN, int QG>
-__global__ __launch_bounds__(kThreads) void k_topk_filter(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
-                                                          int Q, int64_t R, const uint32_t* __restrict__ t_est,
-                                                          uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
-    constexpr int SUBT = kThreads / QG;                     // threads (whole waves) per query group
-    static_assert(SUBT % 64 == 0, "query groups are whole waves");
-    constexpr int TILE = SUBT * IPT;
-    const int sub = threadIdx.x / SUBT, tl = threadIdx.x % SUBT;
-    const int q0 = (blockIdx.y * QG + sub) * QN;
-    const int64_t ntiles = (R + TILE - 1) / TILE;
-    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * SUBT + tl; };
-    uint32_t qw[QN][W];
-    int thr[QN];
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        const int qq = q0 + q < Q ? q0 + q : Q - 1;            // clamp: surplus slots repeat the last query and are ignored below
-#pragma unroll
-        for (int x = 0; x < W; ++x) {
-            qw[q][x] = qbits[(int64_t)qq * W + x];
-            asm volatile("" : "+v"(qw[q][x]));              // keep the 8x8 query words in VGPRs: 64+ SGPRs would spill through v_readlane
-        }
-        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
-    }
-    __shared__ uint2 stage_all[kThreads / 64][kStageV];
-    __shared__ uint32_t stage_n[kThreads / 64];
-    uint2* mine_stage = stage_all[wave_id()];
-    uint32_t* mine_n = stage_n + wave_id();
-    if (lane_id() == 0) *mine_n = 0;
-    __builtin_amdgcn_wave_barrier();
-    Rec<W> cur[IPT], nxt[IPT];
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const int64_t it = item_of(tile, j);
-            load_rec<W>(cur[j], rbits, it, it < R);
-        }
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t tn = tile + gridDim.x;
-        if (tn < ntiles) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const int64_t it = item_of(tn, j);
-                load_rec<W>(nxt[j], rbits, it, it < R);
-            }
-        }
-        // all QN x IPT distances first, ONE wave vote over every comparison, and the (rare) append code behind it: per-query
-        // votes put the argument set-up of the out-of-line append on the common path (22 v_mov per query in the ISA)
-        int dd[QN][IPT];
-        bool hit_any = false;
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) dd[q][j] = 0;
-#pragma unroll
-            for (int x = 0; x < W; ++x)                     // word-major: IPT independent popcount chains interleave
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) dd[q][j] += __popc(cur[j].w[x] ^ qw[q][x]);
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) hit_any |= item_of(tile, j) < R && dd[q][j] <= thr[q];
-        }
-        if (__ballot(hit_any)) {                            // uncommon: some lane holds a candidate for some query of the group
-#pragma unroll
-            for (int q = 0; q < QN; ++q) {
-#pragma unroll
-                for (int j = 0; j < IPT; ++j)
-                    stage_candidate(item_of(tile, j) < R && dd[q][j] <= thr[q], (uint32_t)item_of(tile, j), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
-        }
-        if (tn < ntiles) {
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
-        }
-    }
-    flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
-}
-
 // ---- the same filter for codes of whole 128-bit pieces (W % 4 == 0), round 5 ---------------------------------------------------
 // k_topk_filter gives every lane an ITEM: at 256 bits two 16-byte loads per lane, 32 bytes apart between neighbouring lanes, so each
 // load instruction of a wave touches 2 KB and uses half of it.  Here every lane takes a 16-byte PIECE and a wave's load instruction
@@ -1312,43 +1227,27 @@ extern "C" int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, si
 }
 
 namespace {
-// Which instance of the streaming filter a (code words, queries) call launches: k_topk_filter_mfma<W, qt> (distances on the matrix
-// cores: >= 5 queries at 128 / 256 / 512 bits; XMH_TOPK_MFMA = smallest query count that takes it, 0 = never),
-// k_topk_filter_seq<W, loads, qn> (round 5: codes of whole 16-byte pieces, every other case with W % 4 == 0) or
-// k_topk_filter<W, items per thread, qn, qg> (32- and 64-bit codes: qn queries per group in VGPRs, qg groups per block sharing each tile
-// through L1: Q = 8 runs as 2 x 4, 16 and more queries as up to 4 x 8; XMH_TOPK_QG = "<qn>x<qg>" overrides).  Measured (10 M x 256 bit):
-// one matrix-core pass over 16 queries 62-64 us whatever their number; per-item VALU filter 54 / 58 / 95 / 61 / 79 / 80 us for 1 / 2 / 3 /
-// 4 / 6 / 8 queries; per-piece filter 49 / 50 / 51.5 / 52 us for 1 / 2 / 3 / 4 queries (3 run as 4; the matrix cores took 67) and 74-78 us
-// for 5-8 as one group of 8 -- VALU-bound, so the matrix cores keep those.
-constexpr int kSeqLoads = 4;                                 // 16-byte loads in flight per lane and tile of k_topk_filter_seq (8 measured 2-4 % behind)
-struct FilterChoice { bool mfma; int qt, qn, qg; bool seq, shrt; };
+// Which instance of the streaming filter a (code words, queries) call launches -- one decision for the launch and for xmh_topk_describe:
+//   k_topk_filter_mfma<W, qt>      distances on the matrix cores: >= 5 queries at 128 / 256 / 512 bits, qt tiles of 16 queries per pass
+//                                  (XMH_TOPK_MFMA, experiments builds only: the smallest query count that takes it, 0 = never);
+//   k_topk_filter_seq<W, 4, qn>    codes of whole 16-byte pieces (128 ... 2048 bits), every other case: qn queries per pass;
+//   k_topk_filter_short<W, 4, qn>  32- and 64-bit codes, 4 / 2 items per 16-byte piece.
+// Measured (10 M x 256 bit, filter launch): one matrix-core pass over 16 queries 62-64 us whatever their number; per-piece filter 49 / 50 /
+// 51.5 / 52 us for 1 / 2 / 3 / 4 queries (3 run as 4; the matrix cores took 67) and 74-78 us for 5-8 as one group of 8 -- VALU-bound, so
+// the matrix cores keep those.  The per-item filter of rounds 1-4 (k_topk_filter: one lane per item, 54 / 58 / 95 / 61 / 79 / 80 us for 1 /
+// 2 / 3 / 4 / 6 / 8 queries; query groups sharing tiles through L1 for short codes) is gone: behind on every shape
+// (tools/proto_stream_read.hip keeps its load form as "rec" for the record).
+constexpr int kSeqLoads = 4;                                 // 16-byte loads in flight per lane and tile (8 measured 2-4 % behind)
+struct FilterChoice { bool mfma; int qt, qn; bool shrt; };
 FilterChoice topk_filter_choice(int W, int64_t Q) {
-    FilterChoice c{false, 0, 1, 1, false, false};
-    const int qmax = W >= 64 ? 1 : (W >= 32 ? 2 : (W >= 16 ? 4 : 8));      // query words live in VGPRs
-    c.qn = (Q >= 8 && qmax >= 8) ? 8 : ((Q >= 4 && qmax >= 4) ? 4 : ((Q >= 2 && qmax >= 2) ? 2 : 1));
-    if (W < 16 && Q >= 5 && Q <= 8) { c.qn = 4; c.qg = 2; }
-    else if (W < 16 && Q >= 16) c.qg = Q >= 32 ? 4 : 2;
-    if (const char* e = xmh_experiment_env("XMH_TOPK_QG")) {                           // tuning: "<queries per group>x<groups per block>"
-        int a = 0, b = 0;
-        if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4 || a == 8) && a <= qmax && (b == 1 || b == 2 || b == 4) && (a > 1 || b == 1) && W < 16) { c.qn = a; c.qg = b; }
-    }
+    FilterChoice c{false, 0, 1, W < 4};
     static const int mfma_min_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_MFMA"); return e ? atoi(e) : -1; }();
     if ((W == 4 || W == 8 || W == 16) && (mfma_min_q < 0 ? Q >= 5 : (mfma_min_q > 0 && Q >= mfma_min_q))) {
         const int qtmax = W == 16 ? 2 : 4;
         c.mfma = true;
         c.qt = Q <= 16 ? 1 : (Q <= 32 || qtmax == 2 ? 2 : 4);
     }
-    static const int short_max_q = [] { const char* e = xmh_experiment_env("XMH_TOPK_SHORT"); return e ? atoi(e) : (1 << 30); }();
-    if (W < 4 && Q <= short_max_q) {        // 32- / 64-bit codes: 4 / 2 items per 16-byte piece, k_topk_filter_short (XMH_TOPK_SHORT = largest Q on it)
-        c.shrt = true;
-        c.qg = 1;
-        c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
-    }
-    if (!c.mfma && W % 4 == 0) {           // codes of whole 16-byte pieces: k_topk_filter_seq, 4 query registers per query
-        c.seq = true;
-        c.qg = 1;
-        c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
-    }
+    c.qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));    // 4 query registers per query (pieces) / scalar registers (short codes)
     return c;
 }
 
@@ -1391,14 +1290,14 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         const double frac = exact ? 1.0 : (double)((int64_t)sblocks * per_block) / (double)R;
         const uint32_t target = exact ? (uint32_t)((int64_t)k < R ? (int64_t)k : R) : (uint32_t)(2.0 * k * frac + 8.0);
         const size_t slds = (size_t)16 * nb * 4;
-#define XMH_FAST(WW, II)                                                                                                   \
+#define XMH_FAST(WW)                                                                                                       \
         {                                                                                                                  \
             hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096)), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
                                per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
             const FilterChoice fc_ = topk_filter_choice(WW, Q);      /* one decision for the launch and for xmh_topk_describe */        \
-            const int qn = fc_.qn, qg = fc_.qg;                                                                            \
+            const int qn = fc_.qn;                                                                                         \
             bool on_mfma = false;                                                                                          \
             if constexpr (WW == 4 || WW == 8 || WW == 16) {                                                                 \
                 if (fc_.mfma) {                                                                                            \
@@ -1418,9 +1317,8 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     on_mfma = true;                                                                                        \
                 }                                                                                                          \
             }                                                                                                              \
-            bool on_seq = false;                                                                                           \
             if constexpr (WW % 4 == 0) {                                                                                   \
-                if (!on_mfma && fc_.seq) {                          /* 16-byte pieces, non-temporal, two blocks per CU */         \
+                if (!on_mfma) {                                     /* 16-byte pieces, non-temporal, two blocks per CU */         \
                     const unsigned gy_ = (unsigned)xmh::ceil_div(Q, qn);                                                   \
                     int64_t fb_ = (int64_t)xmh::device_cu_count() * 2;                                                     \
                     const int64_t ft_ = xmh::ceil_div(R * (WW / 4), (int64_t)kThreads * kSeqLoads);                        \
@@ -1432,11 +1330,10 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     if (qn == 2) gos_(k_topk_filter_seq<WW, kSeqLoads, 2>);                                                 \
                     if (qn == 4) gos_(k_topk_filter_seq<WW, kSeqLoads, 4>);                                                 \
                     if (qn == 8) gos_(k_topk_filter_seq<WW, kSeqLoads, 8>);                                                 \
-                    on_seq = true;                                                                                         \
                 }                                                                                                          \
             }                                                                                                              \
             if constexpr (WW < 4) {                                 /* 32- and 64-bit codes: several items per 16 bytes */          \
-            if (fc_.shrt) {                                                                                                \
+            {                                                                                                              \
                 const unsigned gy_ = (unsigned)xmh::ceil_div(Q, qn);                                                       \
                 int64_t fb_ = (int64_t)xmh::device_cu_count() * 2;                                                         \
                 const int64_t ft_ = xmh::ceil_div(xmh::ceil_div(R * WW + 3, (int64_t)4), (int64_t)kThreads * kSeqLoads);   \
@@ -1448,40 +1345,17 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 if (qn == 2) gos_(k_topk_filter_short<WW, kSeqLoads, 2>);                                                   \
                 if (qn == 4) gos_(k_topk_filter_short<WW, kSeqLoads, 4>);                                                   \
                 if (qn == 8) gos_(k_topk_filter_short<WW, kSeqLoads, 8>);                                                   \
-                on_seq = true;                                                                                             \
-            }                                                                                                              \
-            if (!on_mfma && !on_seq) {                                                                                     \
-            const int64_t ft = xmh::ceil_div(R, (int64_t)(kThreads / qg) * II);                                            \
-            const unsigned gy = (unsigned)xmh::ceil_div(Q, qn * qg);                                                       \
-            int64_t fb = (int64_t)xmh::device_cu_count() * 8 / gy;     /* 2..32 blocks per CU measured within 5 % */        \
-            if (fb < xmh::device_cu_count()) fb = xmh::device_cu_count();                                                  \
-            if (fb > ft) fb = ft;                                                                                          \
-            xmh::ProfScope prof("topk_filter", st);                                                                        \
-            const dim3 grid_((unsigned)fb, gy);                                                                            \
-            auto go_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, grid_, dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, (const uint32_t*)f.t_est, f.cnt, f.cand); }; \
-            {                                                                                                              \
-                if (qn == 8 && qg == 1) go_(k_topk_filter<WW, II, 8, 1>);                                                   \
-                if (qn == 8 && qg == 2) go_(k_topk_filter<WW, II, 8, 2>);                                                   \
-                if (qn == 8 && qg == 4) go_(k_topk_filter<WW, II, 8, 4>);                                                   \
-                if (qn == 4 && qg == 2) go_(k_topk_filter<WW, II, 4, 2>);                                                   \
-                if (qn == 4 && qg == 4) go_(k_topk_filter<WW, II, 4, 4>);                                                   \
-                if (qn == 2 && qg == 2) go_(k_topk_filter<WW, II, 2, 2>);                                                   \
-                if (qn == 2 && qg == 4) go_(k_topk_filter<WW, II, 2, 4>);                                                   \
-            }                                                                                                              \
-            if (qn == 4 && qg == 1) go_(k_topk_filter<WW, II, 4, 1>);                                                       \
-            if (qn == 2 && qg == 1) go_(k_topk_filter<WW, II, 2, 1>);                                                       \
-            if (qn == 1) go_(k_topk_filter<WW, II, 1, 1>);                                                                 \
             }                                                                                                              \
             }                                                                                                              \
         }
         switch (p.W) {
-            case 1: XMH_FAST(1, 8) break;
-            case 2: XMH_FAST(2, 8) break;
-            case 4: XMH_FAST(4, 4) break;
-            case 8: XMH_FAST(8, 2) break;       // 2 items per thread: 4 and 1 measured 2-5 % slower at Q = 1, 8, 64
-            case 16: XMH_FAST(16, 1) break;
-            case 32: XMH_FAST(32, 1) break;
-            default: XMH_FAST(64, 1) break;
+            case 1: XMH_FAST(1) break;
+            case 2: XMH_FAST(2) break;
+            case 4: XMH_FAST(4) break;
+            case 8: XMH_FAST(8) break;
+            case 16: XMH_FAST(16) break;
+            case 32: XMH_FAST(32) break;
+            default: XMH_FAST(64) break;
         }
 #undef XMH_FAST
         XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
@@ -1550,11 +1424,9 @@ extern "C" int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, 
     if (const int rc = plan_topk(Q, R, K, k, &p)) return rc;
     if (!out || out_bytes < 64) return xmh::fail(XMH_EINVAL, "xmh_topk_describe: buffer too small");
     const FilterChoice c = topk_filter_choice(p.W, Q);
-    const int ipt = p.W <= 2 ? 8 : (p.W == 4 ? 4 : (p.W == 8 ? 2 : 1));      // items per thread of the VALU filter (XMH_FAST table)
     if (c.mfma) snprintf(out, out_bytes, "filter=k_topk_filter_mfma<%d, %d>", p.W, c.qt);
-    else if (c.seq) snprintf(out, out_bytes, "filter=k_topk_filter_seq<%d, %d, %d>", p.W, kSeqLoads, c.qn);
     else if (c.shrt) snprintf(out, out_bytes, "filter=k_topk_filter_short<%d, %d, %d>", p.W, kSeqLoads, c.qn);
-    else snprintf(out, out_bytes, "filter=k_topk_filter<%d, %d, %d, %d>", p.W, ipt, c.qn, c.qg);
+    else snprintf(out, out_bytes, "filter=k_topk_filter_seq<%d, %d, %d>", p.W, kSeqLoads, c.qn);
     return XMH_OK;
 }
 

@@ -1254,6 +1254,40 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("Q,R,K,k", [(1, 100_003, 64, 10), (2, 64_001, 64, 100), (3, 50_001, 32, 7), (4, 77_777, 32, 100), (5, 33_333, 64, 50),
+                                     (8, 41_001, 16, 100), (9, 200_003, 64, 9), (17, 60_001, 32, 100), (1, 1_000_001, 32, 100), (1, 3, 64, 2),
+                                     (6, 1023, 24, 5), (2, 4097, 64, 100)])
+def test_topk_short_code_filter(xr, Q, R, K, k):
+    """k_topk_filter_short (round 5: 32- and 64-bit codes as 16-byte pieces of 4 / 2 items): groups of 1 / 2 / 4 / 8 queries and several
+    passes, ragged last pieces, and -- what a shard cut at any row hands over -- gallery views that do NOT start on a 16-byte boundary
+    (1, 2, 3 rows into a buffer: the kernel reads from the boundary below and masks the foreign words), with and without duplicates."""
+    import ctypes
+    from oracle import c_oracle as co
+    from xmh._lib import check, lib
+    buf = ctypes.create_string_buffer(256)
+    check(lib.xmh_topk_describe(Q, R, K, k, buf, 256), "xmh_topk_describe")
+    assert b"k_topk_filter_short<%d, " % ((K + 31) // 32) in buf.value, buf.value
+    _topk_check(xr, Q, R, K, k, seed=7 * Q + R + K + k, base_index=99)
+    if 5 <= R < 100000:
+        _topk_check(xr, Q, R, K, k, seed=Q + K + 2, dup=True)
+    rng = np.random.default_rng(R + K)
+    W = (K + 31) // 32
+    qb = rng.integers(0, 2**32, size=(Q, W), dtype=np.uint32)
+    big = rng.integers(0, 2**32, size=(R + 3, W), dtype=np.uint32)
+    if K % 32:
+        qb[:, -1] &= (1 << (K % 32)) - 1
+        big[:, -1] &= (1 << (K % 32)) - 1
+    q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+    whole = xr.PackedCodes(torch.from_numpy(big.view(np.int32)).cuda(), None, K)
+    for lo in (1, 2, 3):
+        view = whole.rows(lo, lo + R)
+        assert view.bits.data_ptr() == whole.bits.data_ptr() + lo * W * 4          # a view, not a copy
+        d, i = xr.hamming_topk(q, view, k, 5)
+        wd, wi = co.topk(qb, big[lo:lo + R], K + 1, k, 5)
+        assert np.array_equal(i.cpu().numpy(), wi), (lo, Q, R, K, k)
+        assert np.array_equal(d.cpu().numpy().view(np.uint16), wd)
+
+
 @pytest.mark.parametrize("Q,R,K,k", [(5, 50001, 128, 10), (16, 33333, 128, 100), (17, 70001, 256, 100), (33, 40007, 256, 5), (70, 25013, 256, 100),
                                      (20, 30011, 512, 50), (40, 9999, 512, 100), (5, 15, 256, 3), (64, 1_200_003, 256, 100), (12, 900_001, 128, 20)])
 def test_topk_matrix_core_filter(xr, Q, R, K, k):

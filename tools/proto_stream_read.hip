@@ -1,5 +1,5 @@
 // What a read-only pass over a gallery of 256-bit codes can reach from HBM (no Infinity Cache help: `ngal` galleries of 320 MB in
-// rotation, 1.28 GB in all), by load form.  The top-k filter (csrc/xmh_topk.hip, k_topk_filter<8, 2, 1, 1>) is variant "rec": one lane
+// rotation, 1.28 GB in all), by load form.  The top-k filter of rounds 1-4 (k_topk_filter<8, 2, 1, 1>, removed in round 5) is variant "rec": one lane
 // per item, two 16-byte loads 32 bytes apart between neighbouring lanes.  Every variant computes the same thing -- the Hamming
 // distance of each item to one query, a count of the items under a threshold -- so the loads cannot be dropped and the integer work
 // is the filter's.
@@ -172,7 +172,6 @@ int main(int argc, char** argv) {
         };
         for (int grid : {512, 1024, 2048}) {
             runlib("LIB k_topk_filter_seq<8,4,1>", k_topk_filter_seq<8, 4, 1>, grid);
-            runlib("LIB k_topk_filter<8,2,1,1>", k_topk_filter<8, 2, 1, 1>, grid);
         }
         // the same bytes as 64-bit and 32-bit codes (4 x / 8 x the items; thresholds low enough for a few hundred candidates)
         const int64_t R8 = R;
@@ -193,9 +192,7 @@ int main(int argc, char** argv) {
         };
         for (int grid : {512, 1024}) {
             runshort("LIB k_topk_filter_short<2,4,1>", k_topk_filter_short<2, 4, 1>, grid, R8 * 4, (uint32_t)(getenv("LIB_THR2") ? atoi(getenv("LIB_THR2")) : 12));
-            runshort("LIB k_topk_filter<2,8,1,1>", k_topk_filter<2, 8, 1, 1>, grid, R8 * 4, (uint32_t)(getenv("LIB_THR2") ? atoi(getenv("LIB_THR2")) : 12));
             runshort("LIB k_topk_filter_short<1,4,1>", k_topk_filter_short<1, 4, 1>, grid, R8 * 8, 3u);
-            runshort("LIB k_topk_filter<1,8,1,1>", k_topk_filter<1, 8, 1, 1>, grid, R8 * 8, 3u);
             runshort("LIB k_topk_filter_short<2,4,8>", k_topk_filter_short<2, 4, 8>, grid, R8 * 4, 12u);
             runshort("LIB k_topk_filter_short<1,4,8>", k_topk_filter_short<1, 4, 8>, grid, R8 * 8, 3u);
         }
