@@ -285,11 +285,15 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
                                                           uint16_t* __restrict__ part_d, int32_t* __restrict__ part_i,
                                                           const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (gate && *gate == 0) return;                       // fast path already produced the exact answer
     constexpr int TILE = kThreads * IPT;
     const int lane = lane_id(), w = wave_id();
     const int q0 = blockIdx.y * kQG;
     const int nq = (Q - q0 < kQG) ? Q - q0 : kQG;
+    if (gate) {                                           // round 5: one flag per query -- a group whose queries all got their exact lists
+        int any = 0;                                      // from the fast path returns, the others recompute (the merge takes only the
+        for (int q = 0; q < nq; ++q) any |= gate[q0 + q]; // failed queries' lists: a failure costs its group's share, not the whole call)
+        if (!any) return;
+    }
     init_state(smem, L);
     Shared sh = shared_of(smem, L);
 
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_merge(const uint16_t* __restr
                                                          uint16_t* __restrict__ out_d, int32_t* __restrict__ out_i,
                                                          const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (gate && *gate == 0) return;
+    if (gate && gate[blockIdx.x] == 0) return;            // this query's list came out of the fast path
     constexpr int TILE = kThreads * IPT;
     const int lane = lane_id(), w = wave_id();
     const int q = blockIdx.x;
@@ -467,7 +471,7 @@ struct FastWs {
     uint32_t* hist;            // [Q][nb]  sample histogram
     uint32_t* t_est;           // [Q]
     uint32_t* cnt;             // [Q]      candidates appended
-    int* fail;                 // [1]
+    int* fail;                 // [Q]: the fast path could not give this query its exact list
     unsigned long long* cand;  // [Q][kCandCap]
 };
 
@@ -580,13 +584,13 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
     const int lane = lane_id();
     for (int q = wave_id(); q < Q; q += kWaves) {
         const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane);
-        if (lane == 0) t_est[q] = (uint32_t)t;
+        if (lane == 0) {
+            t_est[q] = (uint32_t)t;
+            fail[q] = 0;
+        }
         if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
     }
-    if (threadIdx.x == 0) {
-        *fail = 0;
-        __hip_atomic_store(&ctl->sample_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(&ctl->sample_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // many queries: one wave per query after the sample launch; also resets the per-call state (candidate counts, fail flag)
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, i
     const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane);
     if (lane == 0) {
         t_est[q] = (uint32_t)t;
-        if (q == 0) *fail = 0;
+        fail[q] = 0;
     }
     if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
 }
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     for (int s_ = 0; s_ < kSub; ++s_) mine_n = s_ == sub ? nsub[s_] : mine_n;
     const uint32_t want = (uint32_t)((int64_t)k < R ? (int64_t)k : R);
     if (over || n < want) {                                     // a sub-list overflowed (its counter ran on) or too few candidates
-        if (threadIdx.x == 0) atomicOr(fail, 1);
+        if (threadIdx.x == 0) fail[q] = 1;
         return;
     }
     const int kk = (int)want;                                   // number of real results (<= k)
@@ -1126,7 +1130,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
     __syncthreads();
     const int ng = sc[5];
     if (ng > 1024) {                                           // thousands of equal distances inside one index bin: leave it to
-        if (threadIdx.x == 0) atomicOr(fail, 1);               // the robust path
+        if (threadIdx.x == 0) fail[q] = 1;                     // the robust path
         return;
     }
     for (int p = threadIdx.x; p < ng; p += kThreads) {         // rank inside the last bin (usually a handful of keys)
@@ -1198,7 +1202,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->off_hist = take((size_t)Q * (K + 1) * 4);
     p->off_test = take((size_t)Q * 4);
     p->off_cnt = take((size_t)Q * kSub * kCntStride * 4);
-    p->off_fail = take(256);
+    p->off_fail = take((size_t)Q * 4);
     p->off_cand = take((size_t)Q * kCandCap * 8);
     p->ws_bytes = o;
     return XMH_OK;
@@ -1280,7 +1284,11 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         const int nb = K + 1;
         int sblocks = kSampleBlocks;
         int64_t stride = R / sblocks;
-        int per_block = kSamplePerBlock;
+        // short codes: the sample grows with the gallery (2.6 % of it up to 80 M rows): at a fixed 262 144 rows the safety margin of the pick (+8
+        // sampled hits) asked for 8 / fraction = 1 200 estimated candidates at 40 M rows, one bucket too far for short codes, where a
+        // bucket more is 4-5 x the candidates and overflows the list (40 M x 32 bit, Q = 16: the robust path in most calls)
+        // (codes of 128 bits and more have fine buckets and keep the fixed sample: at 256 bit, Q = 64 the larger one cost 6 % of the call)
+        int per_block = kSamplePerBlock * (p.W >= 4 ? 1 : (int)(R / 10000000 < 1 ? 1 : (R / 10000000 > 8 ? 8 : R / 10000000)));
         bool exact = false;
         if (stride <= per_block) {                      // small gallery: the "sample" is the whole gallery
             sblocks = (int)xmh::ceil_div(R, per_block);
