@@ -1254,6 +1254,30 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("K", [64, 256])
+def test_topk_robust_path_for_the_failed_queries_only(xr, K):
+    """Round 5: the fast path's fail flag is per query.  Twelve queries in two groups of eight; query 0 equals a code that the gallery
+    holds 20 000 times -- 20 000 candidates at distance 0, its list overflows and the select raises ITS flag; in a second gallery the
+    same happens to query 11.  The robust kernels recompute group 0 (resp. group 1) only, the merge replaces the failed query's list
+    only, and every list of the call equals the oracle's."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(41 + K)
+    W = K // 32
+    R, Q, k = 300_001, 12, 100
+    rb = rng.integers(0, 2**32, size=(R, W), dtype=np.uint32)
+    qb = rng.integers(0, 2**32, size=(Q, W), dtype=np.uint32)
+    for failing in (0, 11):
+        g = rb.copy()
+        g[rng.choice(R, size=20_000, replace=False)] = qb[failing]
+        q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+        r = xr.PackedCodes(torch.from_numpy(g.view(np.int32)).cuda(), None, K)
+        d, i = xr.hamming_topk(q, r, k, 3)
+        wd, wi = co.topk(qb, g, K + 1, k, 3)
+        assert np.array_equal(i.cpu().numpy(), wi), (K, failing)
+        assert np.array_equal(d.cpu().numpy().view(np.uint16), wd)
+        assert (wd[failing] == 0).all() and (wd[(failing + 5) % Q] > 0).all()
+
+
 @pytest.mark.parametrize("Q,R,K,k", [(1, 100_003, 64, 10), (2, 64_001, 64, 100), (3, 50_001, 32, 7), (4, 77_777, 32, 100), (5, 33_333, 64, 50),
                                      (8, 41_001, 16, 100), (9, 200_003, 64, 9), (17, 60_001, 32, 100), (1, 1_000_001, 32, 100), (1, 3, 64, 2),
                                      (6, 1023, 24, 5), (2, 4097, 64, 100)])
