@@ -470,6 +470,7 @@ constexpr int kFoldPickQ = 16;        // up to this many queries the last sample
 struct FastWs {
     uint32_t* hist;            // [Q][nb]  sample histogram
     uint32_t* t_est;           // [Q]
+    uint32_t* bound;           // [Q]      index bound of the threshold bucket (index_bound)
     uint32_t* cnt;             // [Q]      candidates appended
     int* fail;                 // [Q]: the fast path could not give this query its exact list
     unsigned long long* cand;  // [Q][kCandCap]
@@ -487,11 +488,14 @@ __device__ __forceinline__ int dist_words(const Rec<W>& r, const uint32_t* __res
 // 64 consecutive buckets, wave prefix sum, first lane over the target wins (a thread per query walking the buckets one
 // dependent load at a time took 13 us -- a quarter of the Q=1 filter pass).  The row is left ZEROED for the next call on this
 // workspace.  COHERENT: the counts were added by other blocks of the SAME launch (agent-scope loads).
+// below / at (round 5): the sampled count strictly below the bucket taken and the count in it (0 / 0 if the target was never reached).
 template <bool COHERENT>
-__device__ __forceinline__ int pick_row(uint32_t* __restrict__ row, int nb, uint32_t target, int lane) {
+__device__ __forceinline__ int pick_row(uint32_t* __restrict__ row, int nb, uint32_t target, int lane, uint32_t* below, uint32_t* at) {
     uint32_t carry = 0;
     int t = nb - 1;
     bool found = false;
+    *below = 0u;
+    *at = 0u;
     for (int base = 0; base < nb; base += 512) {                    // 8 segments of 64 buckets per round, their loads issued together
         uint32_t v[8];
 #pragma unroll
@@ -517,13 +521,34 @@ __device__ __forceinline__ int pick_row(uint32_t* __restrict__ row, int nb, uint
             }
             const unsigned long long over = __ballot(d0 + lane < nb && carry + s >= target);
             if (over) {
-                t = d0 + __ffsll((long long)over) - 1;
+                const int win = __ffsll((long long)over) - 1;
+                t = d0 + win;
                 found = true;
+                *at = (uint32_t)__shfl((int)v[j], win, 64);
+                *below = carry + (uint32_t)__shfl((int)s, win, 64) - *at;
             }
             carry += __shfl(s, 63, 64);
         }
     }
     return t;
+}
+
+// Round 5: an INDEX BOUND for the threshold bucket.  Candidates = every item below the threshold t plus the items AT t whose index is
+// below bound[q].  Exact for any bound: a non-candidate has d > t, or d == t with an index not below the bound -- it follows every
+// candidate in (distance, index) order, so whenever the list holds k keys the k smallest of them are the k smallest of the gallery (the
+// select checks the count as before).  The bound only decides how often that holds: it is set from the sample so that the bucket's
+// share below it covers what the buckets under t are expected to leave open, with 3-sigma / 2-sigma lower bounds on both sampled
+// counts and a factor 2.  Fine buckets (128 bits and more) get bound = R, i.e. nothing changes; for coarse codes on large galleries --
+// 16 bit over 40 M rows: 610 items at distance 0, 10 400 within 1 -- the list no longer overflows when the pick goes one bucket further.
+struct PickParams { float inv_frac; uint32_t k, R; int exact; };
+__device__ __forceinline__ uint32_t index_bound(uint32_t below, uint32_t at, PickParams pp) {
+    if (pp.exact || at == 0u) return pp.R;                        // exact counts (small gallery) or no estimate: no bound
+    const float b = (float)below, a = (float)at;
+    const float below_lb = fmaxf(0.0f, b - 3.0f * sqrtf(b)) * pp.inv_frac;       // items strictly below t, at least
+    const float need = fmaxf((float)pp.k - below_lb, 0.0f) + 8.0f;                 // wanted from the bucket t
+    const float at_lb = fmaxf(1.0f, a - 2.0f * sqrtf(a)) * pp.inv_frac;          // items in the bucket t, at least
+    const float rows = 2.0f * need * (float)pp.R / at_lb;
+    return rows >= (float)pp.R ? pp.R : (uint32_t)rows;
 }
 
 // Control words at the head of the fast-path workspace.  Contract (xmh_topk_ws_init / xmh_hamming_topk_prepared): zero on entry,
@@ -542,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
                                                           int Q, int64_t R, int nb, int64_t stride, int per_block,
                                                           uint32_t* __restrict__ hist, int fold, uint32_t target,
                                                           TopkCtl* __restrict__ ctl, uint32_t* __restrict__ t_est,
-                                                          uint32_t* __restrict__ cnt, int* __restrict__ fail) {
+                                                          uint32_t* __restrict__ cnt, int* __restrict__ fail, PickParams pp, uint32_t* __restrict__ bound) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];     // [qg][nb]
     __shared__ int last;
     constexpr int QG = 16;
@@ -583,9 +608,11 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
     if (!last) return;
     const int lane = lane_id();
     for (int q = wave_id(); q < Q; q += kWaves) {
-        const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane);
+        uint32_t below, at;
+        const int t = pick_row<true>(hist + (int64_t)q * nb, nb, target, lane, &below, &at);
         if (lane == 0) {
             t_est[q] = (uint32_t)t;
+            bound[q] = index_bound(below, at, pp);
             fail[q] = 0;
         }
         if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
@@ -595,12 +622,15 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
 
 // many queries: one wave per query after the sample launch; also resets the per-call state (candidate counts, fail flag)
 __global__ __launch_bounds__(64) void k_topk_pick(uint32_t* __restrict__ hist, int Q, int nb, uint32_t target,
-                                                  uint32_t* __restrict__ t_est, uint32_t* __restrict__ cnt, int* __restrict__ fail) {
+                                                  uint32_t* __restrict__ t_est, uint32_t* __restrict__ cnt, int* __restrict__ fail, PickParams pp,
+                                                  uint32_t* __restrict__ bound) {
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= Q) return;
-    const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane);
+    uint32_t below, at;
+    const int t = pick_row<false>(hist + (int64_t)q * nb, nb, target, lane, &below, &at);
     if (lane == 0) {
         t_est[q] = (uint32_t)t;
+        bound[q] = index_bound(below, at, pp);
         fail[q] = 0;
     }
     if (lane < kSub) cnt[((int64_t)q * kSub + lane) * kCntStride] = 0u;
@@ -684,7 +714,7 @@ __device__ __forceinline__ int join_pieces(int h) {
 
 template <int W, int NLD, int QN>
 __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
-                                                              int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                              int Q, int64_t R, const uint32_t* __restrict__ t_est, const uint32_t* __restrict__ bound,
                                                               uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     static_assert(W % 4 == 0 && W <= 64, "whole 16-byte pieces, at most 16 lanes per item");
     constexpr int LPI = W / 4;                              // lanes (pieces) per item
@@ -698,11 +728,13 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
     const topk_u4* __restrict__ g = reinterpret_cast<const topk_u4*>(rbits);
     topk_u4 qw[QN];
     int thr[QN];
+    int bnd[QN];                                            // items at the threshold count only below this index (index_bound; R < 2^31)
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
         const int qq = q0 + q < Q ? q0 + q : Q - 1;            // surplus slots repeat the last query and are ignored below
         qw[q] = *reinterpret_cast<const topk_u4*>(qbits + (int64_t)qq * W + 4 * part);
         thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+        bnd[q] = (int)bound[qq];
     }
     auto piece_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
     auto load_tile = [&](topk_u4 (&dst)[NLD], int64_t tile) {
@@ -731,13 +763,15 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
         if (tn < ntiles) load_tile(nxt, tn);
         int dd[QN][NLD];
         bool hit_any = false;
+        const int first_item = (int)((tile * TILE) >> LOGL);  // tiles are in index order: past the bound the threshold bucket no longer counts
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
+            const int te = thr[q] - (first_item >= bnd[q] ? 1 : 0);       // uniform
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int h = __popc(cur[j].x ^ qw[q].x) + __popc(cur[j].y ^ qw[q].y) + __popc(cur[j].z ^ qw[q].z) + __popc(cur[j].w ^ qw[q].w);
                 dd[q][j] = join_pieces<LPI>(h);
-                hit_any |= dd[q][j] <= thr[q];              // every lane of the item sees it; pieces past the end are sorted out below
+                hit_any |= dd[q][j] <= te;                  // every lane of the item sees it; pieces past the end are sorted out below
             }
         }
         if (__ballot(hit_any)) {                            // uncommon
@@ -746,7 +780,8 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int64_t pc = piece_of(tile, j);
-                    stage_candidate(part == 0 && pc < npieces && dd[q][j] <= thr[q], (uint32_t)(pc >> LOGL), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
+                    const bool in = dd[q][j] < thr[q] || (dd[q][j] == thr[q] && (int)(pc >> LOGL) < bnd[q]);
+                    stage_candidate(part == 0 && pc < npieces && in, (uint32_t)(pc >> LOGL), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -769,7 +804,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
 // below it; the pieces at either end that are not whole are loaded word by word.
 template <int W, int NLD, int QN>
 __global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
-                                                                int Q, int64_t R, const uint32_t* __restrict__ t_est,
+                                                                int Q, int64_t R, const uint32_t* __restrict__ t_est, const uint32_t* __restrict__ bound,
                                                                 uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     static_assert(W == 1 || W == 2, "4 or 2 items per 16-byte piece");
     constexpr int IPP = 4 / W;
@@ -783,12 +818,14 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* 
     const int64_t ntiles = (npieces + TILE - 1) / TILE;
     uint32_t qw[QN][W];
     int thr[QN];
+    int bnd[QN];                                            // items at the threshold count only below this index (index_bound; R < 2^31)
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
         const int qq = q0 + q < Q ? q0 + q : Q - 1;            // surplus slots repeat the last query and never hit
 #pragma unroll
         for (int x = 0; x < W; ++x) qw[q][x] = qbits[(int64_t)qq * W + x];
         thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+        bnd[q] = (int)bound[qq];
     }
     auto piece_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
     auto load_tile = [&](topk_u4 (&dst)[NLD], int64_t tile) {
@@ -825,8 +862,10 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* 
         if (tn < ntiles) load_tile(nxt, tn);
         bool hit_any = false;
         unsigned qhit = 0;
+        const int first_item = (int)((tile * TILE * 4 - mis) / W);   // (negative in the first tile of a view that starts inside a piece: below any bound)
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
+            const int te = thr[q] - (first_item >= bnd[q] ? 1 : 0);  // uniform: past the bound the threshold bucket no longer counts
             int m = 0x7fffffff;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
@@ -837,7 +876,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* 
                     m = min(m, min(dist_of(cur[j], 0, q), dist_of(cur[j], 1, q)));
                 }
             }
-            const bool h = m <= thr[q];                     // zero words of a ragged end may vote: sorted out below
+            const bool h = m <= te;                         // zero words of a ragged end may vote: sorted out below
             hit_any |= h;
             qhit |= (__ballot(h) != 0ull ? 1u : 0u) << q;
         }
@@ -852,7 +891,8 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_short(const uint32_t* 
                     for (int s = 0; s < IPP; ++s) {
                         const int64_t wi = w0 + s * W;
                         const int d = dist_of(cur[j], s, q);
-                        stage_candidate(wi >= 0 && wi < R * W && d <= thr[q], (uint32_t)(wi / W), (uint32_t)d, q, mine_stage, mine_n, q0, cnt, cand);
+                        const bool in = d < thr[q] || (d == thr[q] && (int)(wi / W) < bnd[q]);
+                        stage_candidate(wi >= 0 && wi < R * W && in, (uint32_t)(wi / W), (uint32_t)d, q, mine_stage, mine_n, q0, cnt, cand);
                     }
                 }
             }
@@ -1157,7 +1197,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
 struct TopkPlan {
     int W, ipt, tile, nblocks, tiles_per_block, nqg;
     Layout L, Lm;
-    size_t robust_bytes, off_ctl, off_hist, off_test, off_cnt, off_fail, off_cand;
+    size_t robust_bytes, off_ctl, off_hist, off_test, off_bound, off_cnt, off_fail, off_cand;
     size_t ws_bytes;
 };
 
@@ -1201,6 +1241,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->off_ctl = take(256);                           // ctl, hist, t_est, cnt, fail are contiguous: one memset clears them
     p->off_hist = take((size_t)Q * (K + 1) * 4);
     p->off_test = take((size_t)Q * 4);
+    p->off_bound = take((size_t)Q * 4);
     p->off_cnt = take((size_t)Q * kSub * kCntStride * 4);
     p->off_fail = take((size_t)Q * 4);
     p->off_cand = take((size_t)Q * kCandCap * 8);
@@ -1269,6 +1310,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
     FastWs f;
     f.hist = reinterpret_cast<uint32_t*>(wsb + p.off_hist);
     f.t_est = reinterpret_cast<uint32_t*>(wsb + p.off_test);
+    f.bound = reinterpret_cast<uint32_t*>(wsb + p.off_bound);
     f.cnt = reinterpret_cast<uint32_t*>(wsb + p.off_cnt);
     f.fail = reinterpret_cast<int*>(wsb + p.off_fail);
     f.cand = reinterpret_cast<unsigned long long*>(wsb + p.off_cand);
@@ -1298,12 +1340,13 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         const double frac = exact ? 1.0 : (double)((int64_t)sblocks * per_block) / (double)R;
         const uint32_t target = exact ? (uint32_t)((int64_t)k < R ? (int64_t)k : R) : (uint32_t)(2.0 * k * frac + 8.0);
         const size_t slds = (size_t)16 * nb * 4;
+        const PickParams pp{(float)(1.0 / frac), (uint32_t)k, (uint32_t)R, exact ? 1 : 0};
 #define XMH_FAST(WW)                                                                                                       \
         {                                                                                                                  \
             hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096)), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
-                               per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail);                         \
+                               per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);            \
             if (!fold_pick)                                                                                                \
-                hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail); \
+                hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail, pp, f.bound); \
             const FilterChoice fc_ = topk_filter_choice(WW, Q);      /* one decision for the launch and for xmh_topk_describe */        \
             const int qn = fc_.qn;                                                                                         \
             bool on_mfma = false;                                                                                          \
@@ -1333,7 +1376,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     if (fb_ > ft_) fb_ = ft_;                                                                              \
                     xmh::ProfScope prof("topk_filter", st);                                                                \
                     auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
-                                                                     (const uint32_t*)f.t_est, f.cnt, f.cand); };           \
+                                                                     (const uint32_t*)f.t_est, (const uint32_t*)f.bound, f.cnt, f.cand); }; \
                     if (qn == 1) gos_(k_topk_filter_seq<WW, kSeqLoads, 1>);                                                 \
                     if (qn == 2) gos_(k_topk_filter_seq<WW, kSeqLoads, 2>);                                                 \
                     if (qn == 4) gos_(k_topk_filter_seq<WW, kSeqLoads, 4>);                                                 \
@@ -1348,7 +1391,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                 if (fb_ > ft_) fb_ = ft_;                                                                                  \
                 xmh::ProfScope prof("topk_filter", st);                                                                    \
                 auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
-                                                                 (const uint32_t*)f.t_est, f.cnt, f.cand); };               \
+                                                                 (const uint32_t*)f.t_est, (const uint32_t*)f.bound, f.cnt, f.cand); }; \
                 if (qn == 1) gos_(k_topk_filter_short<WW, kSeqLoads, 1>);                                                   \
                 if (qn == 2) gos_(k_topk_filter_short<WW, kSeqLoads, 2>);                                                   \
                 if (qn == 4) gos_(k_topk_filter_short<WW, kSeqLoads, 4>);                                                   \

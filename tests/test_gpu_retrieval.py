@@ -1254,6 +1254,30 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("Q,R,K,k", [(1, 3_000_000, 16, 100), (5, 2_000_001, 16, 37), (3, 4_000_000, 24, 100), (9, 1_500_000, 32, 1000), (2, 6_000_000, 8, 10)])
+def test_topk_index_bound_on_coarse_codes(xr, Q, R, K, k):
+    """Round 5: on coarse codes the threshold bucket holds thousands of ties and only its first rows are wanted; the pick hands the
+    filters an index bound for that bucket (index_bound: estimated from the sampled density, exact for ANY value because every
+    non-candidate follows every candidate in (distance, index) order).  Galleries above the sampling size so that the bound is an
+    estimate: iid codes, and a gallery SORTED by code (the density of the bucket in the first rows is nothing like the average: the
+    bound is too small or too large and the select's count check / the robust path have to hold the result)."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(Q + R + K + k)
+    W = 1
+    mask = (1 << K) - 1
+    qb = (rng.integers(0, 2**32, size=(Q, W), dtype=np.uint32) & mask).astype(np.uint32)
+    for kind in ("iid", "sorted"):
+        rb = (rng.integers(0, 2**32, size=(R, W), dtype=np.uint32) & mask).astype(np.uint32)
+        if kind == "sorted":
+            rb = np.sort(rb, axis=0)
+        q = xr.PackedCodes(torch.from_numpy(qb.view(np.int32)).cuda(), None, K)
+        r = xr.PackedCodes(torch.from_numpy(rb.view(np.int32)).cuda(), None, K)
+        d, i = xr.hamming_topk(q, r, k, 11)
+        wd, wi = co.topk(qb, rb, K + 1, k, 11)
+        assert np.array_equal(i.cpu().numpy(), wi), (kind, Q, R, K, k)
+        assert np.array_equal(d.cpu().numpy().view(np.uint16), wd)
+
+
 @pytest.mark.parametrize("K", [64, 256])
 def test_topk_robust_path_for_the_failed_queries_only(xr, K):
     """Round 5: the fast path's fail flag is per query.  Twelve queries in two groups of eight; query 0 equals a code that the gallery

@@ -152,15 +152,16 @@ int main(int argc, char** argv) {
     printf("%d galleries of %.0f MB in rotation, %d launches each variant (time includes the launch gap)\n", ngal, bytes / 1e6, iters);
 #ifdef WITH_LIB
     {
-        uint32_t* t_est; uint32_t* cnt; unsigned long long* cand;
-        CK(hipMalloc(&t_est, 64)); CK(hipMalloc(&cnt, 4096)); CK(hipMalloc(&cand, (size_t)kCandCap * 8 * 2));
+        uint32_t* t_est; uint32_t* bnd; uint32_t* cnt; unsigned long long* cand;
+        CK(hipMalloc(&t_est, 64)); CK(hipMalloc(&bnd, 64)); CK(hipMemset(bnd, 0x7f, 64));      // index bound = none (0x7f7f7f7f rows)
+        CK(hipMalloc(&cnt, 4096)); CK(hipMalloc(&cand, (size_t)kCandCap * 8 * 2));
         const uint32_t th = (uint32_t)(getenv("LIB_THR") ? atoi(getenv("LIB_THR")) : thr);
         CK(hipMemcpy(t_est, &th, 4, hipMemcpyHostToDevice));
         auto runlib = [&](const char* name, auto kern, int grid) {
-            for (int i = 0; i < 2 * ngal; ++i) { CK(hipMemsetAsync(cnt, 0, 4096, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, R, (const uint32_t*)t_est, cnt, cand); }
+            for (int i = 0; i < 2 * ngal; ++i) { CK(hipMemsetAsync(cnt, 0, 4096, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, R, (const uint32_t*)t_est, (const uint32_t*)bnd, cnt, cand); }
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
-            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, R, (const uint32_t*)t_est, cnt, cand);
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, R, (const uint32_t*)t_est, (const uint32_t*)bnd, cnt, cand);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms = 0;
@@ -177,10 +178,10 @@ int main(int argc, char** argv) {
         const int64_t R8 = R;
         auto runshort = [&](const char* name, auto kern, int grid, int64_t Rs, uint32_t ths) {
             CK(hipMemcpy(t_est, &ths, 4, hipMemcpyHostToDevice));
-            for (int i = 0; i < 2 * ngal; ++i) { CK(hipMemsetAsync(cnt, 0, 4096, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, cnt, cand); }
+            for (int i = 0; i < 2 * ngal; ++i) { CK(hipMemsetAsync(cnt, 0, 4096, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, (const uint32_t*)bnd, cnt, cand); }
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
-            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, cnt, cand);
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint32_t*)dq, (const uint32_t*)gal[i % ngal], 1, Rs, (const uint32_t*)t_est, (const uint32_t*)bnd, cnt, cand);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms = 0;
