@@ -435,6 +435,9 @@ def main():
             out["roofline_hbm_regime"] = bench_topk.measure(Q=1)
             out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
             out["roofline_hbm_regime_q64"] = bench_topk.measure(Q=64)
+            # the same 320 MB as the reference's own code lengths: 40 M x 64 bit and 80 M x 32 bit (k_topk_filter_short), robust path timing left out
+            out["roofline_hbm_regime_64bit"] = bench_topk.measure(R=40_000_000, K=64, Q=1, robust=False)
+            out["roofline_hbm_regime_32bit"] = bench_topk.measure(R=80_000_000, K=32, Q=1, robust=False)
             out["topk_structured_codes"] = bench_topk.measure_structured()
         except Exception as exc:                                           # keep the headline line alive
             out["roofline_hbm_regime"] = {"error": repr(exc)}

@@ -44,7 +44,8 @@ def _short(s, n):
 def _summary(out):
     """numbers only, short keys: the other legs of the run"""
     s = {}
-    for name, key in (("topk_q1", "roofline_hbm_regime"), ("topk_q8", "roofline_hbm_regime_q8"), ("topk_q64", "roofline_hbm_regime_q64")):
+    for name, key in (("topk_q1", "roofline_hbm_regime"), ("topk_q8", "roofline_hbm_regime_q8"), ("topk_q64", "roofline_hbm_regime_q64"),
+                      ("topk_q1_64bit", "roofline_hbm_regime_64bit"), ("topk_q1_32bit", "roofline_hbm_regime_32bit")):
         if key in out:
             s[name] = _pick(out[key], ("frac", "achieved", "whole_call_GBps", "whole_call_ms", "error"))
     cd = out.get("topk_infinity_cache_defeated", {})

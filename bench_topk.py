@@ -76,7 +76,7 @@ def _codes(kind, R, K, Q, seed=1814):
     return side(Q), rep
 
 
-def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
+def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid", robust=True):
     from xmh import retrieval as X
     from xmh._lib import lib
     W = (K + 31) // 32
@@ -111,6 +111,8 @@ def measure(R=10_000_000, K=256, Q=8, k=100, iters=20, warmup=3, kind="iid"):
     alg = R * W * 4 + Q * W * 4 + Q * 4                 # gallery read once + queries + thresholds
     # the robust path alone (what a call costs when a candidate list overflows or the sample misjudges): XMH_TOPK_ROBUST_ONLY
     # makes the library skip the fast path; same call, same outputs
+    if not robust:
+        return _result(alg, t, t_call, launches, R, K, Q, k, kind)
     os.environ["XMH_TOPK_ROBUST_ONLY"] = "1"
     try:
         for _ in range(2):
