@@ -1254,6 +1254,40 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("K", [16, 64, 100, 128, 256])
+def test_materialised_outputs_on_odd_shapes_and_unaligned_output_pointers(xr, K):
+    """Round 5: the float32 outputs of calc_hammingDist / calc_label_sim are written in 128-byte-aligned runs whose columns slide with
+    each row's start (xmh_dist.hip: k_dist_f32 / k_label_sim_f32; items staged in LDS with 32 extra columns).  Every column of every
+    row must still be written exactly once and nothing outside the matrix: row lengths around the 32-column and 1024-column steps, a
+    single column, and output pointers 1, 2, 3 and 7 floats into a buffer (guard values before and after the matrix)."""
+    from oracle import retrieval as orc
+    from xmh._lib import check, current_stream, lib, ptr
+    g = torch.Generator().manual_seed(K)
+    C = 70
+    for Q, R in ((1, 1), (3, 31), (2, 33), (33, 1023), (5, 1025), (34, 2049), (7, 4100)):
+        qB = torch.randn(Q, K, generator=g).sign(); rB = torch.randn(R, K, generator=g).sign()
+        qB[qB == 0] = 1; rB[rB == 0] = 1
+        qL = (torch.rand(Q, C, generator=g) < 0.1).long(); rL = (torch.rand(R, C, generator=g) < 0.1).long()
+        q, r = xr.pack_sign(qB.cuda()), xr.pack_sign(rB.cuda())
+        q, r = xr.PackedCodes(q.bits, None, K), xr.PackedCodes(r.bits, None, K)
+        ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
+        want_d = orc.hamming_dist(qB, rB)
+        want_s = (qL.float() @ rL.float().t() > 0).float()
+        for off in (0, 1, 2, 3, 7):
+            for what in ("dist", "sim"):
+                buf = torch.full((Q * R + 64,), -7.0, dtype=torch.float32, device="cuda")
+                out = buf[off + 16: off + 16 + Q * R]
+                if what == "dist":
+                    check(lib.xmh_hamming_dist(ptr(q.bits), None, ptr(r.bits), None, Q, R, K, ptr(out), None, current_stream()), "xmh_hamming_dist")
+                    want = want_d
+                else:
+                    check(lib.xmh_label_sim(ptr(ql), ptr(rl), Q, R, C, ptr(out), current_stream()), "xmh_label_sim")
+                    want = want_s
+                got = buf.cpu()
+                assert torch.equal(got[off + 16: off + 16 + Q * R].view(Q, R), want), (what, Q, R, K, off)
+                assert (got[:off + 16] == -7.0).all() and (got[off + 16 + Q * R:] == -7.0).all(), (what, Q, R, K, off)
+
+
 @pytest.mark.parametrize("Q,R,K,k", [(1, 3_000_000, 16, 100), (5, 2_000_001, 16, 37), (3, 4_000_000, 24, 100), (9, 1_500_000, 32, 1000), (2, 6_000_000, 8, 10)])
 def test_topk_index_bound_on_coarse_codes(xr, Q, R, K, k):
     """Round 5: on coarse codes the threshold bucket holds thousands of ties and only its first rows are wanted; the pick hands the
