@@ -459,6 +459,32 @@ def main():
         out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
                                      "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
     if rank == 0 and world == 1 and not use_dist and not args.no_extra_configs:
+        # SURVEY 8 rows a-1 / a-5 as matrices (calc_hammingDist / calc_label_sim, 2000 x R floats): write-bound, against torch's fill_
+        try:
+            qs, qls = R.PackedCodes(q.bits[:2000].contiguous(), None, K), ql[:2000].contiguous()
+            rs = R.PackedCodes(r.bits, None, K)
+
+            def _t(fn):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 5 * 1e-3
+            nbytes = 2000 * Rn * 4
+            scratch = torch.empty(2000, Rn, dtype=torch.float32, device="cuda")
+            out["materialised_outputs"] = {"workload": "calc_hammingDist / calc_label_sim as float32 [2000, %d] matrices (%d-bit codes, %d classes)" % (Rn, K, C),
+                                           "hamming_dist_GBps": nbytes / _t(lambda: R.hamming_dist(qs, rs)) / 1e9,
+                                           "label_sim_GBps": nbytes / _t(lambda: R.label_sim(qls, rl, C)) / 1e9,
+                                           "torch_fill_GBps": nbytes / _t(lambda: scratch.fill_(1.0)) / 1e9}
+            del scratch
+        except Exception as exc:
+            out["materialised_outputs"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
         for name, leg in RL.EXTRA_LEGS.items():
             try:
                 out[name] = RL.extra_scan_leg(**leg)

@@ -70,6 +70,8 @@ def _summary(out):
                        ("topk_q5000_10M", "topk_q5000_10M_256bit")):
         if isinstance(out.get(key), dict):
             s[short] = _pick(out[key], ("ms_per_step", "whole_call_ms", "pairs_per_s", "pairs_per_s_whole_call", "traffic_per_step", "error"))
+    if isinstance(out.get("materialised_outputs"), dict):
+        s["materialised_outputs"] = _pick(out["materialised_outputs"], ("hamming_dist_GBps", "label_sim_GBps", "torch_fill_GBps"))
     if isinstance(out.get("boundary_inclusive"), dict):
         s["boundary_inclusive"] = _pick(out["boundary_inclusive"], ("ms_per_call", "pairs_per_s"))
     if isinstance(out.get("strong_scaling"), dict):
