@@ -40,6 +40,74 @@ __global__ __launch_bounds__(kBlock) void k_pack_sign(const float* __restrict__ 
     }
 }
 
+// Round 5: the slot-per-lane kernels above read 4 bytes per lane (256 bytes per wave instruction) and divide a 64-bit index per element:
+// 4 M x 64 float codes went in at 1.6 TB/s, 0.75 at 16 bits (tools/bench_pack.py).  When the code length is a multiple of 32 the codes are
+// one flat stream of n*K floats -> n*K bits with no padding: a lane loads 16 bytes (four columns, non-temporal) and holds their four
+// sign bits as a nibble; three DPP steps (row_shl 1, 2, 4) gather the eight nibbles of a word into the lane that leads them, which
+// stores it.  Same words, same zero plane, same flags.  (A first form took one ballot per component and let lanes 0..7 weave the bytes:
+// 3.1-3.3 TB/s, bound by its ~150 instructions per KB.)
+typedef float pack_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t gather8(uint32_t nib) {     // lane 8 k ends with the nibbles of lanes 8 k .. 8 k + 7, lowest first
+    uint32_t x = nib | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xf, 0xf, true) << 4;     // row_shl:1: the next lane's
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xf, 0xf, true) << 8;                      // row_shl:2
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true) << 16;                     // row_shl:4
+    return x;
+}
+
+template <bool POW2>
+__global__ __launch_bounds__(kBlock) void k_pack_sign_flat(const pack_f4* __restrict__ codes4, int64_t nwords, int W, int wshift,
+                                                           const int64_t* __restrict__ row_index, uint32_t* __restrict__ bits,
+                                                           uint32_t* __restrict__ zero, int32_t* __restrict__ flags) {
+    const int64_t total4 = nwords * 8;                       // 16-byte pieces
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i - lane < total4; i += (int64_t)gridDim.x * kBlock) {
+        const bool in = i < total4;
+        pack_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (in) v = __builtin_nontemporal_load(codes4 + i);
+        uint32_t np = 0, nz = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            np |= (v[j] > 0.0f ? 1u : 0u) << j;
+            nz |= (v[j] == 0.0f ? 1u : 0u) << j;
+            bad |= (in && v[j] == 0.0f ? 1 : 0) | (v[j] != 0.0f && fabsf(v[j]) != 1.0f ? 2 : 0);      // (2: incl. NaN)
+        }
+        const uint32_t wp = gather8(np), wz = gather8(nz);
+        if ((lane & 7) == 0 && in) {                         // i % 8 == 0: this lane leads a word
+            const int64_t wi = i >> 3;
+            int64_t dst = wi;
+            if (row_index) {
+                const int64_t row = POW2 ? wi >> wshift : wi / W;
+                dst = row_index[row] * W + (POW2 ? (wi & (W - 1)) : wi % W);
+            }
+            bits[dst] = wp;
+            if (zero) zero[dst] = wz;
+        }
+    }
+    if (flags) {
+        const int any = (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
+        if (any && lane == 0) atomicOr(flags, any);
+    }
+}
+
+// unpack, four columns per lane as one 16-byte non-temporal store (K % 4 == 0: the four share a row and a word)
+__global__ __launch_bounds__(kBlock) void k_unpack_flat(const uint32_t* __restrict__ bits, const uint32_t* __restrict__ zero,
+                                                        int64_t n, int K, int W, pack_f4* __restrict__ out4) {
+    const int64_t total4 = n * (int64_t)K / 4;
+    const int k4 = K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = i / k4;
+        const int col = (int)(i % k4) * 4;
+        const uint32_t b = bits[row * W + col / 32] >> (col & 31);
+        const uint32_t z = zero ? zero[row * W + col / 32] >> (col & 31) : 0u;
+        pack_f4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (z >> j & 1u) ? 0.0f : ((b >> j & 1u) ? 1.0f : -1.0f);
+        __builtin_nontemporal_store(v, out4 + i);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_pack_pair(const float2* __restrict__ probs, int64_t n, int K, int W,
                                                       const int64_t* __restrict__ row_index,
                                                       uint32_t* __restrict__ bits) {
@@ -103,8 +171,20 @@ extern "C" int xmh_pack_sign(const float* codes, int64_t n, int K, const int64_t
     if (n == 0) return XMH_OK;
     if (!codes || !bits) return xmh::fail(XMH_EINVAL, "xmh_pack_sign: null pointer");
     const int W = (K + 31) / 32;
-    hipLaunchKernelGGL(k_pack_sign, dim3(grid_for(n * W * 32)), dim3(kBlock), 0, xmh::as_stream(stream), codes, n, K, W,
-                       row_index, bits, zero, flags);
+    if (K % 32 == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0)
+    {
+        int wshift = 0;
+        while ((1 << wshift) < W) ++wshift;
+        if ((1 << wshift) == W)
+            hipLaunchKernelGGL(k_pack_sign_flat<true>, dim3(grid_for(n * W * 8)), dim3(kBlock), 0, xmh::as_stream(stream),
+                               reinterpret_cast<const pack_f4*>(codes), n * W, W, wshift, row_index, bits, zero, flags);
+        else
+            hipLaunchKernelGGL(k_pack_sign_flat<false>, dim3(grid_for(n * W * 8)), dim3(kBlock), 0, xmh::as_stream(stream),
+                               reinterpret_cast<const pack_f4*>(codes), n * W, W, 0, row_index, bits, zero, flags);
+    }
+    else
+        hipLaunchKernelGGL(k_pack_sign, dim3(grid_for(n * W * 32)), dim3(kBlock), 0, xmh::as_stream(stream), codes, n, K, W,
+                           row_index, bits, zero, flags);
     XMH_LAUNCH_CHECK("xmh_pack_sign");
     return XMH_OK;
 }
@@ -127,7 +207,11 @@ extern "C" int xmh_unpack_pm1(const uint32_t* bits, const uint32_t* zero, int64_
     if (n == 0) return XMH_OK;
     if (!bits || !out) return xmh::fail(XMH_EINVAL, "xmh_unpack_pm1: null pointer");
     const int W = (K + 31) / 32;
-    hipLaunchKernelGGL(k_unpack, dim3(grid_for(n * K)), dim3(kBlock), 0, xmh::as_stream(stream), bits, zero, n, K, W, out);
+    if (K % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+        hipLaunchKernelGGL(k_unpack_flat, dim3(grid_for(n * K / 4)), dim3(kBlock), 0, xmh::as_stream(stream), bits, zero, n, K, W,
+                           reinterpret_cast<pack_f4*>(out));
+    else
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for(n * K)), dim3(kBlock), 0, xmh::as_stream(stream), bits, zero, n, K, W, out);
     XMH_LAUNCH_CHECK("xmh_unpack_pm1");
     return XMH_OK;
 }

@@ -96,14 +96,15 @@ def empty_packed(n: int, K: int, device, with_zero: bool = False) -> PackedCodes
 
 
 def pack_sign(codes: torch.Tensor, out: Optional[PackedCodes] = None, row_index: Optional[torch.Tensor] = None,
-              flags: Optional[torch.Tensor] = None) -> PackedCodes:
+              flags: Optional[torch.Tensor] = None, defer: bool = False) -> PackedCodes:
     """sign-quantise + pack float codes [n, K] (BaseTrainer.make_hash_code + the row scatter of get_code).
 
     Stand-alone (``out is None``): returns a fresh PackedCodes; one 4-byte D2H read of the value flags
     decides whether the zero plane is kept (``sign(0) = 0`` seen) and records ``.flags`` (bit1 = some
     element was not in {-1,0,+1}, i.e. the input was not yet quantised -- harmless here, sign is applied).
     Scatter mode (``out``/``row_index``): rows land in ``out`` at ``row_index``; ``flags`` (int32 [1] device
-    tensor) accumulates the value flags without any sync."""
+    tensor) accumulates the value flags without any sync.  ``defer=True`` (stand-alone, with ``flags``): no read
+    either -- the zero plane stays and the caller settles several packs with ONE read (``settle_flags``)."""
     _require_cuda(codes, row_index, flags)
     codes = codes.contiguous().float()
     n, K = codes.shape
@@ -117,10 +118,26 @@ def pack_sign(codes: torch.Tensor, out: Optional[PackedCodes] = None, row_index:
     fl = torch.zeros(1, dtype=torch.int32, device=codes.device) if flags is None else flags
     check(lib.xmh_pack_sign(ptr(codes), n, K, ptr(row_index), ptr(res.bits), ptr(res.zero), ptr(fl), current_stream()),
           "xmh_pack_sign")
+    if defer:
+        if flags is None:
+            raise ValueError("pack_sign(defer=True) needs the caller's flags tensor")
+        return res
     res.flags = int(fl.item())
     if not (res.flags & 1):
         res.zero = None
     return res
+
+
+def settle_flags(flags: torch.Tensor, *packed: PackedCodes) -> int:
+    """ONE 4-byte D2H read for several deferred packs that accumulated into the same flags word: every code set takes the OR of the
+    value flags (a zero seen in any of them keeps all the zero planes -- an all-live plane changes no result -- and any unquantised
+    value sends the caller down its float path, which is what the per-set flags decided too)."""
+    f = int(flags.item())
+    for p in packed:
+        p.flags = f
+        if not (f & 1):
+            p.zero = None
+    return f
 
 
 def pack_pair_argmax(probs: torch.Tensor, out: Optional[PackedCodes] = None,
@@ -226,14 +243,26 @@ class RankingScan:
     """The two-pass fused scan for one (query set, gallery shard): owns the workspace and exposes the
     pieces the sharded driver needs (histogram totals, AP partial sums)."""
 
-    def __init__(self, q: PackedCodes, qlab: torch.Tensor, r: PackedCodes, rlab: torch.Tensor, Cn: int):
+    def __init__(self, q: PackedCodes, qlab: torch.Tensor, r: PackedCodes, rlab: torch.Tensor, Cn: int, workspace=None):
+        """``workspace``: a (plan, buffer) pair of an earlier RankingScan of the SAME shape, ternary-ness and device (``.workspace``) to
+        run in instead of allocating one -- a caller that evaluates the same shape again and again (valid(): four calls per epoch) skips
+        the allocation; use it from one stream at a time."""
         _require_cuda(q.bits, r.bits, qlab, rlab)
         if q.K != r.K:
             raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
         q, r = widened(q), widened(r)
         self.q, self.r, self.qlab, self.rlab, self.C = q, r, qlab.contiguous(), rlab.contiguous(), Cn
         self.qz, self.rz = _both_planes(q, r)
-        self.plan, self.ws = _plan_and_workspace(q.n, r.n, q.K, self.qz is not None, q.bits.device)
+        if workspace is not None:
+            self.plan, self.ws = workspace
+            if self.ws.device != q.bits.device or self.ws.numel() < int(lib.xmh_scan_ws_bytes_nocache(q.n, r.n, q.K, 1 if self.qz is not None else 0)):
+                raise ValueError("RankingScan: the workspace handed in does not fit this shape")
+        else:
+            self.plan, self.ws = _plan_and_workspace(q.n, r.n, q.K, self.qz is not None, q.bits.device)
+
+    @property
+    def workspace(self):
+        return self.plan, self.ws
 
     def _common(self):
         return (ptr(self.q.bits), ptr(self.qz), ptr(self.qlab), ptr(self.r.bits), ptr(self.rz), ptr(self.rlab),
@@ -362,11 +391,12 @@ def shard_offsets(hist_gathered: torch.Tensor, rank: int):
 
 
 def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch.Tensor, Cn: int,
-                 k: Optional[int] = None) -> torch.Tensor:
-    """mAP of one query set against one (unsharded) gallery; float64 [1] on the device."""
-    scan = RankingScan(q, qlab, r, rlab, Cn)
+                 k: Optional[int] = None, workspace=None, return_scan: bool = False):
+    """mAP of one query set against one (unsharded) gallery; float64 [1] on the device (``workspace``: see RankingScan)."""
+    scan = RankingScan(q, qlab, r, rlab, Cn, workspace=workspace)
     scan.histograms(want_totals=False)
-    return scan.map_all(k)[0]
+    m = scan.map_all(k)[0]
+    return (m, scan) if return_scan else m
 
 
 class TopkWorkspace:
