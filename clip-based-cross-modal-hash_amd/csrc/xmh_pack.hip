@@ -55,6 +55,46 @@ __device__ __forceinline__ uint32_t gather8(uint32_t nib) {     // lane 8 k ends
     return x;
 }
 
+// The reference's default code length, 16 bits (and 8): one word per ROW with 16 (8) live bits, i.e. four (two) 16-byte pieces per word and
+// nothing else changes: the stream is still flat, the upper bits of the word are padding (0 in the sign plane, 1 = dead in the zero plane).
+template <int PPW>
+__global__ __launch_bounds__(kBlock) void k_pack_sign_short(const pack_f4* __restrict__ codes4, int64_t n, const int64_t* __restrict__ row_index,
+                                                            uint32_t* __restrict__ bits, uint32_t* __restrict__ zero, int32_t* __restrict__ flags) {
+    static_assert(PPW == 4 || PPW == 2, "16- or 8-bit codes");
+    const int64_t total4 = n * PPW;
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i - lane < total4; i += (int64_t)gridDim.x * kBlock) {
+        const bool in = i < total4;
+        pack_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (in) v = __builtin_nontemporal_load(codes4 + i);
+        uint32_t np = 0, nz = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            np |= (v[j] > 0.0f ? 1u : 0u) << j;
+            nz |= (v[j] == 0.0f ? 1u : 0u) << j;
+            bad |= (in && v[j] == 0.0f ? 1 : 0) | (v[j] != 0.0f && fabsf(v[j]) != 1.0f ? 2 : 0);
+        }
+        uint32_t wp = np | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)np, 0x101, 0xf, 0xf, true) << 4;
+        uint32_t wz = nz | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nz, 0x101, 0xf, 0xf, true) << 4;
+        if (PPW == 4) {
+            wp |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wp, 0x102, 0xf, 0xf, true) << 8;
+            wz |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wz, 0x102, 0xf, 0xf, true) << 8;
+        }
+        if ((lane & (PPW - 1)) == 0 && in) {
+            const int64_t row = i / PPW;
+            const int64_t dst = row_index ? row_index[row] : row;
+            constexpr uint32_t live = PPW == 4 ? 0xffffu : 0xffu;
+            bits[dst] = wp & live;
+            if (zero) zero[dst] = (wz & live) | ~live;       // padding counts as "zero" (dead bit), like the slot kernel
+        }
+    }
+    if (flags) {
+        const int any = (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
+        if (any && lane == 0) atomicOr(flags, any);
+    }
+}
+
 template <bool POW2>
 __global__ __launch_bounds__(kBlock) void k_pack_sign_flat(const pack_f4* __restrict__ codes4, int64_t nwords, int W, int wshift,
                                                            const int64_t* __restrict__ row_index, uint32_t* __restrict__ bits,
@@ -171,7 +211,11 @@ extern "C" int xmh_pack_sign(const float* codes, int64_t n, int K, const int64_t
     if (n == 0) return XMH_OK;
     if (!codes || !bits) return xmh::fail(XMH_EINVAL, "xmh_pack_sign: null pointer");
     const int W = (K + 31) / 32;
-    if (K % 32 == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0)
+    if ((K == 16 || K == 8) && (reinterpret_cast<uintptr_t>(codes) & 15) == 0) {
+        const pack_f4* c4 = reinterpret_cast<const pack_f4*>(codes);
+        if (K == 16) hipLaunchKernelGGL(k_pack_sign_short<4>, dim3(grid_for(n * 4)), dim3(kBlock), 0, xmh::as_stream(stream), c4, n, row_index, bits, zero, flags);
+        else hipLaunchKernelGGL(k_pack_sign_short<2>, dim3(grid_for(n * 2)), dim3(kBlock), 0, xmh::as_stream(stream), c4, n, row_index, bits, zero, flags);
+    } else if (K % 32 == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0)
     {
         int wshift = 0;
         while ((1 << wshift) < W) ++wshift;

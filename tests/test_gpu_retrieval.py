@@ -1254,6 +1254,57 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("K", [8, 16, 24, 32, 64, 96, 100, 128, 256])
+def test_pack_sign_and_unpack_every_kernel_form(xr, K):
+    """Round 5: pack_sign has a flat 16-byte form for code lengths of whole words (k_pack_sign_flat: four sign bits per lane, DPP nibble
+    gather), one for 16- / 8-bit codes (k_pack_sign_short: one word per row) and the slot-per-lane form for everything else and for
+    inputs that are not 16-byte aligned; unpack has a 16-byte form (K % 4 == 0).  Same words, same zero plane (padding = dead), same
+    flags, same scatter: against numpy, with zeros, unquantised values and NaN, odd row counts, scattered rows and a misaligned view."""
+    rng = np.random.default_rng(K)
+    W = (K + 31) // 32
+    for n in (1, 7, 64, 1000, 4099):
+        x = rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=(n, K))
+        for variant in ("pm1", "zeros", "other"):
+            y = x.copy()
+            if variant == "zeros":
+                y[rng.integers(0, n, size=max(1, n // 5)), rng.integers(0, K, size=max(1, n // 5))] = 0.0
+            if variant == "other":
+                y[rng.integers(0, n), rng.integers(0, K)] = 0.37
+                y[rng.integers(0, n), rng.integers(0, K)] = np.nan
+            want_bits = np.zeros((n, W), dtype=np.uint32)
+            want_zero = np.zeros((n, W), dtype=np.uint32)
+            for c in range(W * 32):
+                if c < K:
+                    want_bits[:, c // 32] |= (y[:, c] > 0).astype(np.uint32) << np.uint32(c % 32)
+                    want_zero[:, c // 32] |= (y[:, c] == 0).astype(np.uint32) << np.uint32(c % 32)
+                else:
+                    want_zero[:, c // 32] |= np.uint32(1) << np.uint32(c % 32)
+            want_flags = (1 if (y == 0).any() else 0) | (2 if ((y != 0) & (np.abs(y) != 1)).any() else 0)
+            for view in ("aligned", "misaligned"):
+                buf = torch.zeros(n * K + 8, dtype=torch.float32, device="cuda")
+                off = 0 if view == "aligned" else 1
+                t = buf[off: off + n * K].view(n, K)
+                t.copy_(torch.from_numpy(y))
+                p = xr.pack_sign(t)
+                assert p.flags == want_flags, (K, n, variant, view)
+                assert np.array_equal(p.bits.cpu().numpy().view(np.uint32), want_bits), (K, n, variant, view)
+                if want_flags & 1:
+                    assert np.array_equal(p.zero.cpu().numpy().view(np.uint32), want_zero), (K, n, variant, view)
+                else:
+                    assert p.zero is None
+                # scatter mode: rows land at row_index
+                perm = torch.from_numpy(rng.permutation(n + 3)[:n].astype(np.int64)).cuda()
+                out = xr.empty_packed(n + 3, K, "cuda", with_zero=True)
+                fl = torch.zeros(1, dtype=torch.int32, device="cuda")
+                xr.pack_sign(t, out=out, row_index=perm, flags=fl)
+                assert int(fl.item()) == want_flags
+                assert np.array_equal(out.bits[perm].cpu().numpy().view(np.uint32), want_bits)
+                assert np.array_equal(out.zero[perm].cpu().numpy().view(np.uint32), want_zero)
+            if variant != "other":
+                q = xr.pack_sign(torch.from_numpy(y).cuda())
+                assert np.array_equal(q.unpack().cpu().numpy(), np.sign(y)), (K, n, variant)
+
+
 @pytest.mark.parametrize("K", [16, 64, 100, 128, 256])
 def test_materialised_outputs_on_odd_shapes_and_unaligned_output_pointers(xr, K):
     """Round 5: the float32 outputs of calc_hammingDist / calc_label_sim are written in 128-byte-aligned runs whose columns slide with
