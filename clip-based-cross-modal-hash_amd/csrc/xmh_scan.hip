@@ -1308,13 +1308,16 @@ int dispatch_shape(int W, int LW, F&& f) {
     XMH_CASE(2, 1) XMH_CASE(2, 2) XMH_CASE(2, 3) XMH_CASE(2, 4)
     XMH_CASE(4, 1) XMH_CASE(4, 2) XMH_CASE(4, 3) XMH_CASE(4, 4)
     XMH_CASE(8, 1) XMH_CASE(8, 2) XMH_CASE(8, 3) XMH_CASE(8, 4)
+    if constexpr (!TERN) {                                 // 129 ... 256 classes (IAPR TC-12 has 255) as EIGHT label words: binary codes up to 256 bits,
+        XMH_CASE(1, 8) XMH_CASE(2, 8) XMH_CASE(4, 8) XMH_CASE(8, 8)      // the VALU kernels; callers with 5 ... 7 words pad to 8 (Python: RankingScan does)
+    }
     if constexpr (!TERN) {                                 // long binary codes
         XMH_CASE(16, 1) XMH_CASE(16, 2) XMH_CASE(16, 3) XMH_CASE(16, 4)
         XMH_CASE(32, 1) XMH_CASE(32, 2) XMH_CASE(32, 3) XMH_CASE(32, 4)
         XMH_CASE(64, 1) XMH_CASE(64, 2) XMH_CASE(64, 3) XMH_CASE(64, 4)
     }
 #undef XMH_CASE
-    return xmh::fail(XMH_ENOTSUP, "scan: unsupported shape W=%d code words (K in {<=32,64,128,256}, binary also 512,1024,2048), Lw=%d label words (C<=128)%s",
+    return xmh::fail(XMH_ENOTSUP, "scan: unsupported shape W=%d code words (K in {<=32,64,128,256}, binary also 512,1024,2048), Lw=%d label words (C<=128; binary codes up to 256 bits also exactly 8 words: 129..256 classes)%s",
                      W, LW, TERN ? ", ternary" : "");
 }
 

@@ -251,6 +251,12 @@ class RankingScan:
         if q.K != r.K:
             raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
         q, r = widened(q), widened(r)
+        if 4 < qlab.shape[1] <= 8 and qlab.shape[1] == rlab.shape[1]:
+            # 129 ... 256 classes (IAPR TC-12: 255): the library's instances take exactly eight label words -- absent classes are zero bits
+            pad = 8 - qlab.shape[1]
+            if pad:
+                qlab, rlab = torch.nn.functional.pad(qlab, (0, pad)), torch.nn.functional.pad(rlab, (0, pad))
+            Cn = 256
         self.q, self.r, self.qlab, self.rlab, self.C = q, r, qlab.contiguous(), rlab.contiguous(), Cn
         self.qz, self.rz = _both_planes(q, r)
         if workspace is not None:

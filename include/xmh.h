@@ -130,6 +130,9 @@ int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary, char* out
 
 /* pass 1.  hist_all / hist_rel: [Q][nbuckets] u32 totals over this shard (either may be NULL).
  * qzero / rzero NULL => binary codes.
+ * Labels: [n][ceil(C / 32)] u32 masks.  C <= 128 (1..4 words) on every path; binary codes up to 256 bits also take exactly EIGHT words
+ * (C in 225..256): a caller with 129..224 classes pads its masks to eight words with zero bits and passes C = 256 (Python:
+ * RankingScan does).  More classes: XMH_ENOTSUP.
  * Also leaves in the workspace what a single-shard pass 2 needs from the totals (per-bucket rank offsets, the relevant count
  * of every query), so that xmh_hamming_ap / xmh_hamming_map with NULL offsets launch pass 2 and the reduction only. */
 int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab,

@@ -1254,6 +1254,25 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("C", [129, 160, 200, 255, 256])
+@pytest.mark.parametrize("K", [16, 64, 128, 256])
+def test_map_with_more_than_128_classes(xr, K, C):
+    """Round 5: 129 ... 256 classes (IAPR TC-12 has 255) run as eight label words on the VALU kernels (the Python layer pads 5 ... 7 words
+    to 8); the drop-in calc_map_k, the scan object and the top-k-capped form against the oracle."""
+    from oracle import retrieval as orc
+    from xmh.common import calc_utils as cu
+    g = torch.Generator().manual_seed(K + C)
+    Q, R = 37, 2500
+    qB = torch.randn(Q, K, generator=g).sign(); rB = torch.randn(R, K, generator=g).sign()
+    qB[qB == 0] = 1; rB[rB == 0] = 1
+    qL = (torch.rand(Q, C, generator=g) < 0.02).long(); rL = (torch.rand(R, C, generator=g) < 0.02).long()
+    qL[:, C - 1] = 1; rL[::7, C - 1] = 1                          # the last class matters: it sits in the last label word
+    for k in (None, 50):
+        want = float(orc.map_k(qB, rB, qL, rL, k))
+        got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), k))
+        assert abs(got - want) < 2e-6, (K, C, k, got, want)
+
+
 @pytest.mark.parametrize("K", [8, 16, 24, 32, 64, 96, 100, 128, 256])
 def test_pack_sign_and_unpack_every_kernel_form(xr, K):
     """Round 5: pack_sign has a flat 16-byte form for code lengths of whole words (k_pack_sign_flat: four sign bits per lane, DPP nibble
