@@ -497,6 +497,7 @@ def main():
             out["encode"] = bench_encode.measure()
             if not args.no_extra_configs:
                 out["encode_mith"] = bench_encode.measure_mith()
+                out["encode_mith_b400"] = bench_encode.measure_mith(batch=400, steps=5)      # the runner's fused evaluation batches (encode_fuse = 4)
         except Exception as exc:
             out["encode"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not use_dist and not args.no_encode and not args.no_extra_configs:

@@ -61,6 +61,8 @@ def _summary(out):
         s["encode"] = _pick(e, ("images_per_s_f32", "captions_per_s_f32", "images_per_s_f16", "gemm_tflops_f32", "gemm_tflops_f16", "error"))
         if isinstance(e.get("fused_batches"), dict):
             s["encode_b400"] = _pick(e["fused_batches"], ("images_per_s_f32", "images_per_s_f16", "gemm_tflops_f32", "gemm_tflops_f16"))
+    if isinstance(out.get("encode_mith_b400"), dict):
+        s["encode_mith_b400"] = _pick(out["encode_mith_b400"], ("images_per_s", "captions_per_s", "error"))
     if isinstance(out.get("encode_mith"), dict):
         s["encode_mith"] = _pick(out["encode_mith"], ("images_per_s", "captions_per_s", "images_per_s_f32", "captions_per_s_f32", "error"))
     if isinstance(out.get("cpu_baseline_encode"), dict):
