@@ -56,6 +56,9 @@ def _codes(kind, R, K, Q, seed=1814):
     if kind == "iid":
         rb = torch.randint(-2**31, 2**31 - 1, (R, W), dtype=torch.int32, device="cuda", generator=g)
         qb = torch.randint(-2**31, 2**31 - 1, (Q, W), dtype=torch.int32, device="cuda", generator=g)
+        if K % 32:                                           # the contract of packed codes: bits beyond K are zero
+            rb[:, -1] &= (1 << (K % 32)) - 1
+            qb[:, -1] &= (1 << (K % 32)) - 1
         return X.PackedCodes(qb, None, K), X.PackedCodes(rb, None, K)
     C, p = 80, 0.04
     Wm = torch.randn(C, K, device="cuda", generator=g)
