@@ -65,6 +65,7 @@ def _pack_codes(B: torch.Tensor) -> R.PackedCodes:
 
 _label_cache = {}            # (data_ptr, version, shape, dtype, device) -> (packed masks, the label tensor itself)
 _scan_ws = threading.local()  # .entry = (shape key, (plan, workspace buffer)) of this thread's last calc_map_k
+_KEEP_WS_BYTES = 2 << 30     # workspaces up to 2 GiB are kept between calls (0.6 GB at the COCO shape)
 
 
 def release_scan_workspace() -> None:
@@ -129,7 +130,10 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
             key = (q.n, r.n, q.K, q.zero is not None or r.zero is not None, str(gq.device), torch.cuda.current_stream(gq.device).cuda_stream)
             hit = _scan_ws.__dict__.get("entry")
             res, scan = R.map_k_packed(q, r, ql, rl, C, k, workspace=hit[1] if hit is not None and hit[0] == key else None, return_scan=True)
-            _scan_ws.entry = (key, scan.workspace)
+            if scan.ws.numel() <= _KEEP_WS_BYTES:
+                _scan_ws.entry = (key, scan.workspace)
+            else:                                        # a 10 M-row gallery's pair cache is tens of GB: not something to sit on between calls
+                release_scan_workspace()
         else:
             from .. import dense
             res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), ql, rl, C, k)
