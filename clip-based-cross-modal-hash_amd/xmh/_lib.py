@@ -93,6 +93,8 @@ PROTOTYPES = {
     "xmh_hamming_map_sharded": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, i32, i32, i64, vp, vp, vp, vp]),
     "xmh_shard_slice_offsets": (i32, [vp, i32, i32, i32, vp, vp]),
     "xmh_hamming_map_sharded_offsets": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, sz, vp, i32, i64, vp, vp, vp, vp]),
+    "xmh_calc_map_k_ws_bytes": (sz, [i64, i64, i32, i32]),
+    "xmh_calc_map_k": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, vp, sz, C.POINTER(C.c_double), C.POINTER(i32), vp]),
     "xmh_map_finalize": (i32, [vp, vp, i64, vp, vp]),
     "xmh_shard_offsets": (i32, [vp, i32, i32, i64, i32, vp, vp, vp, vp]),
     "xmh_gemm_nt_f32": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, i32, vp]),

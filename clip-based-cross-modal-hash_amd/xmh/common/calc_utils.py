@@ -87,6 +87,41 @@ def _packed_labels(L: torch.Tensor) -> torch.Tensor:
     return hit[0]
 
 
+def _calc_map_k_one_call(gq: torch.Tensor, gr: torch.Tensor, ql: torch.Tensor, rl: torch.Tensor, C: int, k):
+    """xmh_calc_map_k: pack + both passes + the scalar back in one call of the C ABI (round 5: the composed path spent 140 us of host work
+    around a 360 us scan).  None when the shape needs the composed path or the codes are not quantised."""
+    import ctypes
+    from .._lib import current_stream, lib, ptr
+    if gq.dtype != torch.float32 or gr.dtype != torch.float32 or gq.dim() != 2 or gr.dim() != 2 or gq.shape[1] != gr.shape[1]:
+        return None
+    gq, gr = gq.contiguous(), gr.contiguous()
+    Q, Rn, K = gq.shape[0], gr.shape[0], gq.shape[1]
+    if (K + 31) // 32 not in (1, 2, 4, 8, 16, 32, 64) or ql.shape[1] != (C + 31) // 32 or not (ql.shape[1] <= 4 or ql.shape[1] == 8):
+        return None
+    need = int(lib.xmh_calc_map_k_ws_bytes(Q, Rn, K, C))
+    if need == 0:
+        return None
+    key = ("fused", Q, Rn, K, C, str(gq.device), torch.cuda.current_stream(gq.device).cuda_stream)
+    hit = _scan_ws.__dict__.get("entry")
+    if hit is not None and hit[0] == key:
+        ws = hit[1]
+    else:
+        release_scan_workspace()
+        free, _ = torch.cuda.mem_get_info(gq.device)
+        free += torch.cuda.memory_reserved(gq.device) - torch.cuda.memory_allocated(gq.device)
+        if need > 0.9 * free:
+            return None                                  # the composed path knows how to run without the pair cache
+        ws = torch.empty(need, dtype=torch.uint8, device=gq.device)
+    m, fl = ctypes.c_double(float("nan")), ctypes.c_int32(0)
+    rc = lib.xmh_calc_map_k(ptr(gq), ptr(gr), ptr(ql), ptr(rl), Q, Rn, K, C, 0 if k is None else int(k), ptr(ws), need,
+                            ctypes.byref(m), ctypes.byref(fl), current_stream())
+    if need <= _KEEP_WS_BYTES:
+        _scan_ws.entry = (key, ws)
+    if rc != 0 or (fl.value & 2):
+        return None                                      # not supported in this form / unquantised codes: the composed path reports or handles it
+    return torch.tensor(m.value, dtype=torch.float32)
+
+
 def _is_quantised(*packed: R.PackedCodes) -> bool:
     return not any(p.flags & 2 for p in packed)
 
@@ -118,12 +153,16 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
     if num_query == 1:
         raise IndexError("calc_map_k needs more than one query (reference squeezes the query axis, calc_utils.py:72)")
     with _on_device_of(qB, rB, query_L, retrieval_L):
-        # both code matrices are packed before the ONE read of their value flags (round 5: two stand-alone packs were two syncs)
         gq, gr = _to_gpu(qB), _to_gpu(rB)
+        ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]
+        fused = _calc_map_k_one_call(gq, gr, ql, rl, C, k)
+        if fused is not None:
+            return fused
+        # (code lengths that need widening, 129 ... 224 classes, unquantised values: the composed path below)
+        # both code matrices are packed before the ONE read of their value flags (round 5: two stand-alone packs were two syncs)
         fl = torch.zeros(1, dtype=torch.int32, device=gq.device)
         q, r = R.pack_sign(gq, flags=fl, defer=True), R.pack_sign(gr, flags=fl, defer=True)
         R.settle_flags(fl, q, r)
-        ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]
         if _is_quantised(q, r):
             # valid() evaluates the same shape four times per epoch (runners/base.py:312-315): the scan workspace of the last shape is
             # kept (release_scan_workspace() drops it; it is per thread, and used on the caller's current stream)

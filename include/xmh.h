@@ -160,6 +160,18 @@ int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t*
 int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
                     const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                     size_t ws_bytes, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream);
+/* calc_map_k (reference common/calc_utils.py:58-92) in ONE call, on the operands the reference's callers hold
+ * (runners/base.py:259-264: float code matrices on the device): qB [Q][K] / rB [R][K] float32 codes (-1 / 0 / +1), qlab / rlab packed
+ * label masks (xmh_pack_labels: the label matrices are the same for every call of an evaluation, pack them once), k <= 0 = all.
+ * Packs both code matrices into the workspace, reads their value flags (first synchronisation), runs both passes with the binary or --
+ * an exact zero among the codes -- the ternary kernels, and copies the mAP to *map_host (second synchronisation: the reference
+ * returns a host scalar too).  *flags_host: bit 0 = an exact zero was seen, bit 1 = a value outside {-1, 0, +1}: then NOTHING is
+ * evaluated (the codes are not quantised: common/calc_utils.py would rank the float inner products) and *map_host is left alone.
+ * K must be a code length the kernels take as it is (<= 32, 64, 128, 256, 512, 1024, 2048 bits); C as for xmh_hamming_hist.
+ * The same kernels and the same bits as pack + xmh_hamming_hist + xmh_hamming_map. */
+size_t xmh_calc_map_k_ws_bytes(int64_t Q, int64_t R, int K, int C);
+int xmh_calc_map_k(const float* qB, const float* rB, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C,
+                   int64_t k, void* ws, size_t ws_bytes, double* map_host, int32_t* flags_host, xmh_stream_t stream);
 /* mean over queries of ap_sum/cap -> map_out[0] (f64, device).  A query with cap == 0 makes the result
  * NaN, as torch.mean of an empty tensor does in the reference (common/calc_utils.py:87-89). */
 int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream);

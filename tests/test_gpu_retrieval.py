@@ -1254,6 +1254,49 @@ def test_topk_per_piece_filter(xr, Q, R, K, k):
         _topk_check(xr, Q, R, K, k, seed=Q + K + 1, dup=True)
 
 
+@pytest.mark.parametrize("K", [16, 32, 64, 128, 256, 512])
+def test_calc_map_k_in_one_call_of_the_c_abi(xr, K):
+    """xmh_calc_map_k (round 5): float codes + packed label masks in, the mAP on the host out -- what a binding of the reference's
+    common/calc_utils.py:58-92 would bind.  Against the oracle: binary codes, codes with exact zeros (ternary kernels; up to 256 bits),
+    a cap k, and unquantised values (flag bit 1: nothing evaluated)."""
+    import ctypes
+    from oracle import retrieval as orc
+    from xmh._lib import check, current_stream, lib, ptr
+    g = torch.Generator().manual_seed(K)
+    Q, R, C = 41, 3000, 37
+    qB = torch.randn(Q, K, generator=g).sign(); rB = torch.randn(R, K, generator=g).sign()
+    qB[qB == 0] = 1; rB[rB == 0] = 1
+    qL = (torch.rand(Q, C, generator=g) < 0.1).long(); rL = (torch.rand(R, C, generator=g) < 0.1).long()
+    qL[:, 0] = 1; rL[::5, 0] = 1
+    ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
+    need = int(lib.xmh_calc_map_k_ws_bytes(Q, R, K, C))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+
+    def call(q, r, k):
+        m, fl = ctypes.c_double(-1.0), ctypes.c_int32(-1)
+        qd, rd = q.cuda().contiguous(), r.cuda().contiguous()
+        check(lib.xmh_calc_map_k(ptr(qd), ptr(rd), ptr(ql), ptr(rl), Q, R, K, C, 0 if k is None else k, ptr(ws), need, ctypes.byref(m),
+                                 ctypes.byref(fl), current_stream()), "xmh_calc_map_k")
+        return m.value, fl.value
+
+    for k in (None, 25):
+        got, fl = call(qB, rB, k)
+        assert fl == 0 and abs(got - float(orc.map_k(qB, rB, qL, rL, k))) < 2e-6, (K, k)
+    if K <= 256:
+        qz, rz = qB.clone(), rB.clone()
+        qz[3, 5] = 0.0; rz[::17, K // 2] = 0.0
+        got, fl = call(qz, rz, None)
+        assert fl == 1 and abs(got - float(orc.map_k(qz, rz, qL, rL, None))) < 2e-6, K
+    ru = rB.clone(); ru[7, 1] = 0.4
+    got, fl = call(qB, ru, None)
+    assert fl & 2 and got == -1.0                                   # not quantised: nothing written
+    # a workspace one byte short is refused
+    m, f2 = ctypes.c_double(0.0), ctypes.c_int32(0)
+    assert lib.xmh_calc_map_k(ptr(qB.cuda()), ptr(rB.cuda()), ptr(ql), ptr(rl), Q, R, K, C, 0, ptr(ws), need - 1, ctypes.byref(m), ctypes.byref(f2),
+                              current_stream()) != 0
+
+
 @pytest.mark.parametrize("C", [129, 160, 200, 255, 256])
 @pytest.mark.parametrize("K", [16, 64, 128, 256])
 def test_map_with_more_than_128_classes(xr, K, C):
