@@ -430,17 +430,21 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_hbm_regime:
+        import bench_topk
+        # one try per leg: a failure (e.g. no room for 80 M rows) must not overwrite a leg already measured
+        for key, kw in (("roofline_hbm_regime", dict(Q=1)), ("roofline_hbm_regime_q8", dict(Q=8)), ("roofline_hbm_regime_q64", dict(Q=64)),
+                        # the same 320 MB as the reference's own code lengths: 40 M x 64 bit and 80 M x 32 bit (k_topk_filter_short), robust path timing left out
+                        ("roofline_hbm_regime_64bit", dict(R=40_000_000, K=64, Q=1, robust=False)),
+                        ("roofline_hbm_regime_32bit", dict(R=80_000_000, K=32, Q=1, robust=False))):
+            try:
+                out[key] = bench_topk.measure(**kw)
+            except Exception as exc:                                       # keep the headline line alive
+                out[key] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
         try:
-            import bench_topk
-            out["roofline_hbm_regime"] = bench_topk.measure(Q=1)
-            out["roofline_hbm_regime_q8"] = bench_topk.measure(Q=8)
-            out["roofline_hbm_regime_q64"] = bench_topk.measure(Q=64)
-            # the same 320 MB as the reference's own code lengths: 40 M x 64 bit and 80 M x 32 bit (k_topk_filter_short), robust path timing left out
-            out["roofline_hbm_regime_64bit"] = bench_topk.measure(R=40_000_000, K=64, Q=1, robust=False)
-            out["roofline_hbm_regime_32bit"] = bench_topk.measure(R=80_000_000, K=32, Q=1, robust=False)
             out["topk_structured_codes"] = bench_topk.measure_structured()
-        except Exception as exc:                                           # keep the headline line alive
-            out["roofline_hbm_regime"] = {"error": repr(exc)}
+        except Exception as exc:
+            out["topk_structured_codes"] = {"error": repr(exc)}
         for key, fn in (("topk_q5000_10M_256bit", bench_topk.measure_many_queries), ("topk_infinity_cache_defeated", bench_topk.measure_cache_defeat)):
             try:
                 out[key] = fn()

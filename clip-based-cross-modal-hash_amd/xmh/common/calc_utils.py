@@ -96,14 +96,19 @@ def _calc_map_k_one_call(gq: torch.Tensor, gr: torch.Tensor, ql: torch.Tensor, r
         return None
     gq, gr = gq.contiguous(), gr.contiguous()
     Q, Rn, K = gq.shape[0], gr.shape[0], gq.shape[1]
-    if (K + 31) // 32 not in (1, 2, 4, 8, 16, 32, 64) or ql.shape[1] != (C + 31) // 32 or not (ql.shape[1] <= 4 or ql.shape[1] == 8):
+    Lw = (C + 31) // 32
+    if (K + 31) // 32 not in (1, 2, 4, 8, 16, 32, 64) or not (Lw <= 4 or Lw == 8):
         return None
+    # the C ABI takes raw pointers: every extent it will read is checked here (mismatches make the reference's mm raise, :72)
+    if tuple(ql.shape) != (Q, Lw) or tuple(rl.shape) != (Rn, Lw) or not ql.is_contiguous() or not rl.is_contiguous():
+        raise ValueError("calc_map_k: labels %s / %s do not match %d queries, %d gallery rows, %d classes"
+                         % (tuple(ql.shape), tuple(rl.shape), Q, Rn, C))
     need = int(lib.xmh_calc_map_k_ws_bytes(Q, Rn, K, C))
     if need == 0:
         return None
     key = ("fused", Q, Rn, K, C, str(gq.device), torch.cuda.current_stream(gq.device).cuda_stream)
     hit = _scan_ws.__dict__.get("entry")
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[1].numel() >= need:    # (the plan size follows per-call switches: a kept buffer must still fit)
         ws = hit[1]
     else:
         release_scan_workspace()
@@ -113,9 +118,9 @@ def _calc_map_k_one_call(gq: torch.Tensor, gr: torch.Tensor, ql: torch.Tensor, r
             return None                                  # the composed path knows how to run without the pair cache
         ws = torch.empty(need, dtype=torch.uint8, device=gq.device)
     m, fl = ctypes.c_double(float("nan")), ctypes.c_int32(0)
-    rc = lib.xmh_calc_map_k(ptr(gq), ptr(gr), ptr(ql), ptr(rl), Q, Rn, K, C, 0 if k is None else int(k), ptr(ws), need,
+    rc = lib.xmh_calc_map_k(ptr(gq), ptr(gr), ptr(ql), ptr(rl), Q, Rn, K, C, 0 if k is None else int(k), ptr(ws), ws.numel(),
                             ctypes.byref(m), ctypes.byref(fl), current_stream())
-    if need <= _KEEP_WS_BYTES:
+    if ws.numel() <= _KEEP_WS_BYTES:
         _scan_ws.entry = (key, ws)
     if rc != 0 or (fl.value & 2):
         return None                                      # not supported in this form / unquantised codes: the composed path reports or handles it
@@ -152,6 +157,15 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
     num_query = query_L.shape[0]
     if num_query == 1:
         raise IndexError("calc_map_k needs more than one query (reference squeezes the query axis, calc_utils.py:72)")
+    if k is not None:
+        k = int(k)
+        if k == 0:                                       # reference: totals = 0 -> mean of an empty tensor per query (:81-89) -> nan
+            return torch.tensor(float("nan"), dtype=torch.float32)
+        if k < 0:                                        # reference: count / tindex of different lengths -> RuntimeError (:85-89)
+            raise ValueError("calc_map_k: k must be positive or None (got %d)" % k)
+    if query_L.shape[0] != qB.shape[0] or retrieval_L.shape[0] != rB.shape[0] or query_L.shape[1] != retrieval_L.shape[1]:
+        raise ValueError("calc_map_k: %d / %d code rows against %d / %d label rows, %d / %d classes"
+                         % (qB.shape[0], rB.shape[0], query_L.shape[0], retrieval_L.shape[0], query_L.shape[1], retrieval_L.shape[1]))
     with _on_device_of(qB, rB, query_L, retrieval_L):
         gq, gr = _to_gpu(qB), _to_gpu(rB)
         ql, rl, C = _packed_labels(query_L), _packed_labels(retrieval_L), query_L.shape[1]

@@ -12,7 +12,7 @@ reference.  Two independent formulations of mAP are kept on purpose:
   against each other.
 
 Pinned by ``tests/golden/calc_utils_*.npz`` (generated from the imported
-reference by ``oracle/make_golden.py``).
+reference by ``oracle/make_golden_retrieval.py``).
 """
 from __future__ import annotations
 
