@@ -278,9 +278,26 @@ __device__ __forceinline__ void load_rec(Rec<W>& r, const uint32_t* __restrict__
 }
 
 // ---- streaming kernel -----------------------------------------------------------------------------
-template <int W, int IPT>
-__global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __restrict__ qbits,
-                                                          const uint32_t* __restrict__ rbits, int Q, int64_t R, int k,
+// TERN (round 6): codes with exact zeros (sign(0) = 0, reference runners/base.py:407-410) carry a second plane (bit set <=> element is 0,
+// padding bits set); the distance is in HALF units, 2 d = K - q.r = #(positions where either side is 0) + 2 #(both live and different)
+// in [0, 2K] (nb = 2K + 1 buckets), `pad` = 32 W - K removes the padding bits from the first count.
+template <int W>
+__device__ __forceinline__ int dist2_words(const uint32_t (&rb)[W], const uint32_t (&rz)[W], const uint32_t* __restrict__ qb,
+                                           const uint32_t* __restrict__ qz, int pad) {
+    int dead = 0, diff = 0;
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        const uint32_t z = rz[x] | qz[x];
+        dead += __popc(z);
+        diff += __popc((rb[x] ^ qb[x]) & ~z);
+    }
+    return dead - pad + 2 * diff;
+}
+
+template <int W, int IPT, bool TERN>
+__global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qzero,
+                                                          const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rzero,
+                                                          int pad, int Q, int64_t R, int k,
                                                           Layout L, int tiles_per_block, int nblocks,
                                                           uint16_t* __restrict__ part_d, int32_t* __restrict__ part_i,
                                                           const int* __restrict__ gate) {
@@ -304,11 +321,13 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
     auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)w * (64 * IPT) + j * 64 + lane; };
 
     Rec<W> cur[IPT], nxt[IPT];
+    Rec<W> curz[TERN ? IPT : 1], nxtz[TERN ? IPT : 1];
     if (tile0 < tile1) {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const int64_t it = item_of(tile0, j);
             load_rec<W>(cur[j], rbits, it, it < R);
+            if constexpr (TERN) load_rec<W>(curz[j], rzero, it, it < R);
         }
     }
     for (int64_t tile = tile0; tile < tile1; ++tile) {
@@ -318,6 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
             for (int j = 0; j < IPT; ++j) {
                 const int64_t it = item_of(tile + 1, j);
                 load_rec<W>(nxt[j], rbits, it, it < R);
+                if constexpr (TERN) load_rec<W>(nxtz[j], rzero, it, it < R);
             }
         }
         int d[kQG][IPT];
@@ -334,8 +354,11 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
                     int acc = 0;
+                    if constexpr (TERN) acc = dist2_words<W>(cur[j].w, curz[j].w, qw, qzero + (int64_t)(q0 + q) * W, pad);
+                    else {
 #pragma unroll
-                    for (int x = 0; x < W; ++x) acc += __popc(cur[j].w[x] ^ qw[x]);
+                        for (int x = 0; x < W; ++x) acc += __popc(cur[j].w[x] ^ qw[x]);
+                    }
                     d[q][j] = ((int64_t)item[j] < R && item[j] >= 0) ? acc : (int)kInf;
                     any |= d[q][j] < t_run;
                 }
@@ -355,7 +378,10 @@ __global__ __launch_bounds__(kThreads) void k_topk_stream(const uint32_t* __rest
         }
         if (more) {
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) cur[j] = nxt[j];
+            for (int j = 0; j < IPT; ++j) {
+                cur[j] = nxt[j];
+                if constexpr (TERN) curz[j] = nxtz[j];
+            }
         }
     }
     __syncthreads();
@@ -562,8 +588,9 @@ struct TopkCtl {
 // sample histogram: block b reads kSamplePerBlock consecutive rows starting at b*stride (whole gallery if small).
 // FOLD (few queries): the block that finishes last (ticket) also picks the thresholds and resets the per-call state, so the
 // call needs neither a memset nor a pick launch.
-template <int W>
-__global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+template <int W, bool TERN>
+__global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qzero,
+                                                          const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rzero, int pad,
                                                           int Q, int64_t R, int nb, int64_t stride, int per_block,
                                                           uint32_t* __restrict__ hist, int fold, uint32_t target,
                                                           TopkCtl* __restrict__ ctl, uint32_t* __restrict__ t_est,
@@ -581,15 +608,22 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
         constexpr int NB = W <= 8 ? 4 : (W <= 16 ? 2 : 1);          // records in flight per thread (one dependent miss per record otherwise)
         for (int64_t it0 = lo + threadIdx.x; it0 < hi; it0 += (int64_t)NB * kThreads) {
             Rec<W> r[NB];
+            Rec<W> rz[TERN ? NB : 1];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int64_t it = it0 + (int64_t)j * kThreads;
                 load_rec<W>(r[j], rbits, it < hi ? it : lo, true);
+                if constexpr (TERN) load_rec<W>(rz[j], rzero, it < hi ? it : lo, true);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (it0 + (int64_t)j * kThreads < hi)
-                    for (int q = 0; q < nq; ++q) atomicAdd(&sh[q * nb + dist_words<W>(r[j], qbits + (int64_t)(q0 + q) * W)], 1u);
+                    for (int q = 0; q < nq; ++q) {
+                        int d;
+                        if constexpr (TERN) d = dist2_words<W>(r[j].w, rz[j].w, qbits + (int64_t)(q0 + q) * W, qzero + (int64_t)(q0 + q) * W, pad);
+                        else d = dist_words<W>(r[j], qbits + (int64_t)(q0 + q) * W);
+                        atomicAdd(&sh[q * nb + d], 1u);
+                    }
             }
         }
         __syncthreads();
@@ -712,8 +746,9 @@ __device__ __forceinline__ int join_pieces(int h) {
     return h;
 }
 
-template <int W, int NLD, int QN>
-__global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ rbits,
+template <int W, int NLD, int QN, bool TERN>
+__global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qzero,
+                                                              const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rzero, int pad,
                                                               int Q, int64_t R, const uint32_t* __restrict__ t_est, const uint32_t* __restrict__ bound,
                                                               uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     static_assert(W % 4 == 0 && W <= 64, "whole 16-byte pieces, at most 16 lanes per item");
@@ -721,31 +756,39 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
     constexpr int LOGL = LPI == 1 ? 0 : (LPI == 2 ? 1 : (LPI == 4 ? 2 : (LPI == 8 ? 3 : 4)));
     static_assert((1 << LOGL) == LPI, "a power of two");
     constexpr int TILE = kThreads * NLD;                    // pieces per tile
+    constexpr int NZ = TERN ? NLD : 1, QZ = TERN ? QN : 1;
     const int part = threadIdx.x & (LPI - 1);
     const int q0 = blockIdx.y * QN;
     const int64_t npieces = R * LPI;
     const int64_t nfull = npieces / TILE, ntiles = (npieces + TILE - 1) / TILE;
     const topk_u4* __restrict__ g = reinterpret_cast<const topk_u4*>(rbits);
-    topk_u4 qw[QN];
+    const topk_u4* __restrict__ gz = reinterpret_cast<const topk_u4*>(rzero);    // TERN: the zero plane, read piece for piece like the bits
+    topk_u4 qw[QN], qz[QZ];
     int thr[QN];
     int bnd[QN];                                            // items at the threshold count only below this index (index_bound; R < 2^31)
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
         const int qq = q0 + q < Q ? q0 + q : Q - 1;            // surplus slots repeat the last query and are ignored below
         qw[q] = *reinterpret_cast<const topk_u4*>(qbits + (int64_t)qq * W + 4 * part);
+        if constexpr (TERN) qz[q] = *reinterpret_cast<const topk_u4*>(qzero + (int64_t)qq * W + 4 * part);
         thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
         bnd[q] = (int)bound[qq];
+        if constexpr (TERN) thr[q] = q0 + q < Q ? thr[q] + pad : -1;     // the joined sums below still hold the padding bits: compare there
     }
     auto piece_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
-    auto load_tile = [&](topk_u4 (&dst)[NLD], int64_t tile) {
+    auto load_tile = [&](topk_u4 (&dst)[NLD], topk_u4 (&dstz)[NZ], int64_t tile) {
         if (tile < nfull) {                                 // uniform: whole tiles load without a bounds check
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) dst[j] = __builtin_nontemporal_load(g + piece_of(tile, j));
+            for (int j = 0; j < NLD; ++j) {
+                dst[j] = __builtin_nontemporal_load(g + piece_of(tile, j));
+                if constexpr (TERN) dstz[j] = __builtin_nontemporal_load(gz + piece_of(tile, j));
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int64_t pc = piece_of(tile, j);
                 dst[j] = pc < npieces ? __builtin_nontemporal_load(g + pc) : topk_u4{0u, 0u, 0u, 0u};
+                if constexpr (TERN) dstz[j] = pc < npieces ? __builtin_nontemporal_load(gz + pc) : topk_u4{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -755,12 +798,12 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
     uint32_t* mine_n = stage_n + wave_id();
     if (lane_id() == 0) *mine_n = 0;
     __builtin_amdgcn_wave_barrier();
-    topk_u4 cur[NLD], nxt[NLD];
+    topk_u4 cur[NLD], nxt[NLD], curz[NZ], nxtz[NZ];
     int64_t tile = blockIdx.x;
-    if (tile < ntiles) load_tile(cur, tile);
+    if (tile < ntiles) load_tile(cur, curz, tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const int64_t tn = tile + gridDim.x;
-        if (tn < ntiles) load_tile(nxt, tn);
+        if (tn < ntiles) load_tile(nxt, nxtz, tn);
         int dd[QN][NLD];
         bool hit_any = false;
         const int first_item = (int)((tile * TILE) >> LOGL);  // tiles are in index order: past the bound the threshold bucket no longer counts
@@ -769,7 +812,14 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
             const int te = thr[q] - (first_item >= bnd[q] ? 1 : 0);       // uniform
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
-                const int h = __popc(cur[j].x ^ qw[q].x) + __popc(cur[j].y ^ qw[q].y) + __popc(cur[j].z ^ qw[q].z) + __popc(cur[j].w ^ qw[q].w);
+                int h;
+                if constexpr (TERN) {                       // half units: positions dead on either side + 2 x (live and different)
+                    const topk_u4 z = curz[j] | qz[q];
+                    const topk_u4 x = (cur[j] ^ qw[q]) & ~z;
+                    h = __popc(z.x) + __popc(z.y) + __popc(z.z) + __popc(z.w) + 2 * (__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w));
+                } else {
+                    h = __popc(cur[j].x ^ qw[q].x) + __popc(cur[j].y ^ qw[q].y) + __popc(cur[j].z ^ qw[q].z) + __popc(cur[j].w ^ qw[q].w);
+                }
                 dd[q][j] = join_pieces<LPI>(h);
                 hit_any |= dd[q][j] <= te;                  // every lane of the item sees it; pieces past the end are sorted out below
             }
@@ -781,7 +831,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
                 for (int j = 0; j < NLD; ++j) {
                     const int64_t pc = piece_of(tile, j);
                     const bool in = dd[q][j] < thr[q] || (dd[q][j] == thr[q] && (int)(pc >> LOGL) < bnd[q]);
-                    stage_candidate(part == 0 && pc < npieces && in, (uint32_t)(pc >> LOGL), (uint32_t)dd[q][j], q, mine_stage, mine_n, q0, cnt, cand);
+                    stage_candidate(part == 0 && pc < npieces && in, (uint32_t)(pc >> LOGL), (uint32_t)(dd[q][j] - (TERN ? pad : 0)), q, mine_stage, mine_n, q0, cnt, cand);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -789,7 +839,73 @@ __global__ __launch_bounds__(kThreads) void k_topk_filter_seq(const uint32_t* __
         }
         if (tn < ntiles) {
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) cur[j] = nxt[j];
+            for (int j = 0; j < NLD; ++j) {
+                cur[j] = nxt[j];
+                if constexpr (TERN) curz[j] = nxtz[j];
+            }
+        }
+    }
+    flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+}
+
+// ---- ternary codes of 32 / 64 bits (W = 1, 2): one lane per item, NLD items per lane and tile, both planes (round 6) -----------------
+// MITH / DSPH quantise with sign_() and can emit exact zeros (reference runners/base.py:407-410, runners/MITH/runner.py:125-131); such
+// code sets are rare and short, so this filter keeps the simple form: 4- / 8-byte loads from either plane, queries in scalar registers.
+template <int W, int NLD, int QN>
+__global__ __launch_bounds__(kThreads) void k_topk_filter_item_tern(const uint32_t* __restrict__ qbits, const uint32_t* __restrict__ qzero,
+                                                                    const uint32_t* __restrict__ rbits, const uint32_t* __restrict__ rzero, int pad,
+                                                                    int Q, int64_t R, const uint32_t* __restrict__ t_est, const uint32_t* __restrict__ bound,
+                                                                    uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    constexpr int TILE = kThreads * NLD;                    // items per tile
+    const int q0 = blockIdx.y * QN;
+    const int64_t ntiles = (R + TILE - 1) / TILE;
+    int thr[QN], bnd[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int qq = q0 + q < Q ? q0 + q : Q - 1;
+        thr[q] = q0 + q < Q ? (int)t_est[qq] : -1;
+        bnd[q] = (int)bound[qq];
+    }
+    __shared__ uint2 stage_all[kThreads / 64][kStageV];
+    __shared__ uint32_t stage_n[kThreads / 64];
+    uint2* mine_stage = stage_all[wave_id()];
+    uint32_t* mine_n = stage_n + wave_id();
+    if (lane_id() == 0) *mine_n = 0;
+    __builtin_amdgcn_wave_barrier();
+    auto item_of = [&](int64_t tile, int j) -> int64_t { return tile * TILE + (int64_t)j * kThreads + threadIdx.x; };
+    Rec<W> cur[NLD], curz[NLD], nxt[NLD], nxtz[NLD];
+    auto load_tile = [&](Rec<W> (&b)[NLD], Rec<W> (&z)[NLD], int64_t tile) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int64_t it = item_of(tile, j);
+            load_rec<W>(b[j], rbits, it, it < R);
+            load_rec<W>(z[j], rzero, it, it < R);
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(cur, curz, tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) load_tile(nxt, nxtz, tn);
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int qq = q0 + q < Q ? q0 + q : Q - 1;    // uniform: scalar loads
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int64_t it = item_of(tile, j);
+                const int d = dist2_words<W>(cur[j].w, curz[j].w, qbits + (int64_t)qq * W, qzero + (int64_t)qq * W, pad);
+                const bool in = it < R && (d < thr[q] || (d == thr[q] && (int)it < bnd[q]));
+                if (__ballot(in)) stage_candidate(in, (uint32_t)it, (uint32_t)d, q, mine_stage, mine_n, q0, cnt, cand);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (__builtin_amdgcn_readfirstlane((int)*mine_n) >= 64) flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
+        if (tn < ntiles) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                cur[j] = nxt[j];
+                curz[j] = nxtz[j];
+            }
         }
     }
     flush_staged(mine_stage, mine_n, kStageV, q0, cnt, cand);
@@ -1195,7 +1311,7 @@ __global__ __launch_bounds__(kThreads) void k_topk_select(const unsigned long lo
 }
 
 struct TopkPlan {
-    int W, ipt, tile, nblocks, tiles_per_block, nqg;
+    int W, ipt, tile, nblocks, tiles_per_block, nqg, nb;
     Layout L, Lm;
     size_t robust_bytes, off_ctl, off_hist, off_test, off_bound, off_cnt, off_fail, off_cand;
     size_t ws_bytes;
@@ -1203,7 +1319,7 @@ struct TopkPlan {
 
 int ipt_for(int W) { return W >= 16 ? 1 : (W >= 8 ? 4 : 8); }      // long codes: one 64..256-byte record per thread and tile
 
-int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
+int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p, bool tern = false) {
     if (Q <= 0 || R <= 0 || K <= 0) return xmh::fail(XMH_EINVAL, "topk: bad shape Q=%lld R=%lld K=%d", (long long)Q, (long long)R, K);
     if (k <= 0 || k > 1024) return xmh::fail(XMH_EINVAL, "topk: k=%d out of range (1..1024)", k);
     if (R >= (1ll << 31) - 65536) return xmh::fail(XMH_ENOTSUP, "topk: shard of %lld rows (max 2^31-1)", (long long)R);
@@ -1213,10 +1329,12 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->W = W;
     p->ipt = ipt_for(W);
     p->tile = kThreads * p->ipt;
-    p->L.nb = K + 1;
+    const int nb = tern ? 2 * K + 1 : K + 1;               // ternary codes: half-unit distances 0 ... 2K
+    p->nb = nb;
+    p->L.nb = nb;
     p->L.nq = kQG;
     p->L.cap = k + p->tile + 64;
-    if (p->L.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d needs %zu B of LDS (max 163840)", k, K, p->L.bytes());
+    if (p->L.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d%s needs %zu B of LDS (max 163840)", k, K, tern ? " (ternary)" : "", p->L.bytes());
     if ((p->L.cap + kThreads - 1) / kThreads > 24) return xmh::fail(XMH_ENOTSUP, "topk: candidate buffer too large for the compaction segment");
     const int64_t ntiles = xmh::ceil_div(R, p->tile);
     int bpc = (int)((160 * 1024) / p->L.bytes());
@@ -1227,7 +1345,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
     p->tiles_per_block = (int)xmh::ceil_div(ntiles, nblocks);
     p->nblocks = (int)xmh::ceil_div(ntiles, p->tiles_per_block);
     p->nqg = (int)xmh::ceil_div(Q, kQG);
-    p->Lm.nb = K + 1;
+    p->Lm.nb = nb;
     p->Lm.nq = 3;
     p->Lm.cap = k + kThreads * 4 + 64;
     if (p->Lm.bytes() > 160 * 1024) return xmh::fail(XMH_ENOTSUP, "topk: k=%d, K=%d needs %zu B of LDS in the merge (max 163840)", k, K, p->Lm.bytes());
@@ -1239,7 +1357,7 @@ int plan_topk(int64_t Q, int64_t R, int K, int k, TopkPlan* p) {
         return at;
     };
     p->off_ctl = take(256);                           // ctl, hist, t_est, cnt, fail are contiguous: one memset clears them
-    p->off_hist = take((size_t)Q * (K + 1) * 4);
+    p->off_hist = take((size_t)Q * nb * 4);
     p->off_test = take((size_t)Q * 4);
     p->off_bound = take((size_t)Q * 4);
     p->off_cnt = take((size_t)Q * kSub * kCntStride * 4);
@@ -1296,11 +1414,41 @@ FilterChoice topk_filter_choice(int W, int64_t Q) {
     return c;
 }
 
-int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes,
-              uint16_t* dist, int32_t* idx, xmh_stream_t stream, bool prepared) {
+// the ternary fast path's streaming pass: per-piece filter with both planes (128 bits and more), per-item for 32 / 64 bits
+template <int WW>
+void launch_filter_tern(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero, int pad, int64_t Q, int64_t R,
+                        const FastWs& f, hipStream_t st) {
+    const int qn = Q >= 5 ? 8 : (Q >= 3 ? 4 : (Q >= 2 ? 2 : 1));
+    const unsigned gy = (unsigned)xmh::ceil_div(Q, qn);
+    int64_t fb = (int64_t)xmh::device_cu_count() * 2;
+    xmh::ProfScope prof("topk_filter", st);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)fb, gy), dim3(kThreads), 0, st, qbits, qzero, rbits, rzero, pad, (int)Q, R,
+                                                  (const uint32_t*)f.t_est, (const uint32_t*)f.bound, f.cnt, f.cand); };
+    if constexpr (WW % 4 == 0) {
+        const int64_t ft = xmh::ceil_div(R * (WW / 4), (int64_t)kThreads * kSeqLoads);
+        if (fb > ft) fb = ft;
+        if (qn == 1) go(k_topk_filter_seq<WW, kSeqLoads, 1, true>);
+        if (qn == 2) go(k_topk_filter_seq<WW, kSeqLoads, 2, true>);
+        if (qn == 4) go(k_topk_filter_seq<WW, kSeqLoads, 4, true>);
+        if (qn == 8) go(k_topk_filter_seq<WW, kSeqLoads, 8, true>);
+    } else {
+        const int64_t ft = xmh::ceil_div(R, (int64_t)kThreads * kSeqLoads);
+        if (fb > ft) fb = ft;
+        if (qn == 1) go(k_topk_filter_item_tern<WW, kSeqLoads, 1>);
+        if (qn == 2) go(k_topk_filter_item_tern<WW, kSeqLoads, 2>);
+        if (qn == 4) go(k_topk_filter_item_tern<WW, kSeqLoads, 4>);
+        if (qn == 8) go(k_topk_filter_item_tern<WW, kSeqLoads, 8>);
+    }
+}
+
+int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero, int64_t Q, int64_t R, int K, int k,
+              int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream, bool prepared) {
+    if ((qzero == nullptr) != (rzero == nullptr)) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk: zero planes for both sides or neither");
+    const bool tern = qzero != nullptr;
     TopkPlan p;
-    int rc = plan_topk(Q, R, K, k, &p);
+    int rc = plan_topk(Q, R, K, k, &p, tern);
     if (rc) return rc;
+    const int pad = 32 * p.W - K;                         // padding bits: set in both zero planes, taken out of the half-unit distance
     if (!qbits || !rbits || !ws || !dist || !idx) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk: null pointer");
     if (ws_bytes < p.ws_bytes) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
     int32_t* part_i = static_cast<int32_t*>(ws);
@@ -1323,7 +1471,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         // a prepared workspace needs no memset launch.
         if (!prepared) XMH_HIP(hipMemsetAsync(wsb + p.off_ctl, 0, p.off_cand - p.off_ctl, st));
         const int fold_pick = Q <= kFoldPickQ;            // few queries: the last sample block picks the thresholds itself
-        const int nb = K + 1;
+        const int nb = p.nb;
         int sblocks = kSampleBlocks;
         int64_t stride = R / sblocks;
         // short codes: the sample grows with the gallery (2.6 % of it up to 80 M rows): at a fixed 262 144 rows the safety margin of the pick (+8
@@ -1343,10 +1491,19 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         const PickParams pp{(float)(1.0 / frac), (uint32_t)k, (uint32_t)R, exact ? 1 : 0};
 #define XMH_FAST(WW)                                                                                                       \
         {                                                                                                                  \
-            hipLaunchKernelGGL((k_topk_sample<WW>), dim3(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096)), dim3(kThreads), slds, st, qbits, rbits, (int)Q, R, nb, stride, \
-                               per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);            \
+            const dim3 sgrid_(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096));       \
+            if (tern)                                                                                                      \
+                hipLaunchKernelGGL((k_topk_sample<WW, true>), sgrid_, dim3(kThreads), slds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, nb, stride, \
+                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
+            else                                                                                                           \
+                hipLaunchKernelGGL((k_topk_sample<WW, false>), sgrid_, dim3(kThreads), slds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, nb, stride, \
+                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail, pp, f.bound); \
+            if (tern) {                                           /* both planes: the per-piece / per-item ternary filters */      \
+                launch_filter_tern<WW>(qbits, qzero, rbits, rzero, pad, Q, R, f, st);                                      \
+                break;                                                                                                     \
+            }                                                                                                              \
             const FilterChoice fc_ = topk_filter_choice(WW, Q);      /* one decision for the launch and for xmh_topk_describe */        \
             const int qn = fc_.qn;                                                                                         \
             bool on_mfma = false;                                                                                          \
@@ -1375,12 +1532,12 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
                     const int64_t ft_ = xmh::ceil_div(R * (WW / 4), (int64_t)kThreads * kSeqLoads);                        \
                     if (fb_ > ft_) fb_ = ft_;                                                                              \
                     xmh::ProfScope prof("topk_filter", st);                                                                \
-                    auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, rbits, (int)Q, R, \
+                    auto gos_ = [&](auto kern_) { hipLaunchKernelGGL(kern_, dim3((unsigned)fb_, gy_), dim3(kThreads), 0, st, qbits, qzero, rbits, rzero, 0, (int)Q, R, \
                                                                      (const uint32_t*)f.t_est, (const uint32_t*)f.bound, f.cnt, f.cand); }; \
-                    if (qn == 1) gos_(k_topk_filter_seq<WW, kSeqLoads, 1>);                                                 \
-                    if (qn == 2) gos_(k_topk_filter_seq<WW, kSeqLoads, 2>);                                                 \
-                    if (qn == 4) gos_(k_topk_filter_seq<WW, kSeqLoads, 4>);                                                 \
-                    if (qn == 8) gos_(k_topk_filter_seq<WW, kSeqLoads, 8>);                                                 \
+                    if (qn == 1) gos_(k_topk_filter_seq<WW, kSeqLoads, 1, false>);                                          \
+                    if (qn == 2) gos_(k_topk_filter_seq<WW, kSeqLoads, 2, false>);                                          \
+                    if (qn == 4) gos_(k_topk_filter_seq<WW, kSeqLoads, 4, false>);                                          \
+                    if (qn == 8) gos_(k_topk_filter_seq<WW, kSeqLoads, 8, false>);                                          \
                 }                                                                                                          \
             }                                                                                                              \
             if constexpr (WW < 4) {                                 /* 32- and 64-bit codes: several items per 16 bytes */          \
@@ -1412,11 +1569,11 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
         XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
         {
             auto kern = k_topk_select;
-            const size_t sel_lds = (size_t)kCandCap * 8 + 1024 * 8 + (size_t)(K + 1 > 2048 ? K + 1 : 2048) * 4 + 64;
+            const size_t sel_lds = (size_t)kCandCap * 8 + 1024 * 8 + (size_t)(p.nb > 2048 ? p.nb : 2048) * 4 + 64;
             rc = raise_lds(kern, sel_lds, "xmh_hamming_topk select");
             if (rc) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)Q), dim3(kThreads), sel_lds, st, (const unsigned long long*)f.cand,
-                               (const uint32_t*)f.cnt, R, k, K + 1, base_index, dist, idx, f.fail);
+                               (const uint32_t*)f.cnt, R, k, p.nb, base_index, dist, idx, f.fail);
         }
         XMH_LAUNCH_CHECK("xmh_hamming_topk select");
         gate = f.fail;                                   // the robust kernels below run only if a query failed
@@ -1425,11 +1582,14 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
     const size_t lds = p.L.bytes();
 #define XMH_TOPK_LAUNCH(WW, II)                                                                                        \
     {                                                                                                                  \
-        auto kern = k_topk_stream<WW, II>;                                                                             \
-        rc = raise_lds(kern, lds, "xmh_hamming_topk");                                                                 \
+        auto go_ = [&](auto kern) -> int {                                                                             \
+            if (const int rc_ = raise_lds(kern, lds, "xmh_hamming_topk")) return rc_;                                   \
+            hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, k, p.L, p.tiles_per_block, \
+                               p.nblocks, part_d, part_i, gate);                                                       \
+            return XMH_OK;                                                                                             \
+        };                                                                                                             \
+        rc = tern ? go_(k_topk_stream<WW, II, true>) : go_(k_topk_stream<WW, II, false>);                              \
         if (rc) return rc;                                                                                             \
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, qbits, rbits, (int)Q, R, k, p.L, p.tiles_per_block,    \
-                           p.nblocks, part_d, part_i, gate);                                                           \
     }
     switch (p.W) {
         case 1: XMH_TOPK_LAUNCH(1, 8) break;
@@ -1456,12 +1616,35 @@ int topk_call(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
 
 extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws,
                                 size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
-    return topk_call(qbits, rbits, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, false);
+    return topk_call(qbits, nullptr, rbits, nullptr, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, false);
 }
 
 extern "C" int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index,
                                          void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
-    return topk_call(qbits, rbits, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, true);
+    return topk_call(qbits, nullptr, rbits, nullptr, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, true);
+}
+
+// ---- ternary codes (round 6): the same call with the zero planes; distances come back in HALF units (2 d = K - q.r, 0 ... 2K) ----
+extern "C" size_t xmh_topk_ternary_ws_bytes(int64_t Q, int64_t R, int K, int k) {
+    TopkPlan p;
+    if (plan_topk(Q, R, K, k, &p, true) != XMH_OK) return 0;
+    return p.ws_bytes;
+}
+
+extern "C" int xmh_topk_ternary_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_bytes, xmh_stream_t stream) {
+    TopkPlan p;
+    if (const int rc = plan_topk(Q, R, K, k, &p, true)) return rc;
+    if (!ws) return xmh::fail(XMH_EINVAL, "xmh_topk_ternary_ws_init: null workspace");
+    if (ws_bytes < p.ws_bytes) return xmh::fail(XMH_EINVAL, "xmh_topk_ternary_ws_init: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+    XMH_HIP(hipMemsetAsync(static_cast<char*>(ws) + p.off_ctl, 0, p.off_cand - p.off_ctl, xmh::as_stream(stream)));
+    return XMH_OK;
+}
+
+extern "C" int xmh_hamming_topk_ternary(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero, int64_t Q,
+                                        int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes, int prepared, uint16_t* dist2,
+                                        int32_t* idx, xmh_stream_t stream) {
+    if (!qzero || !rzero) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk_ternary: needs both zero planes (binary codes: xmh_hamming_topk)");
+    return topk_call(qbits, qzero, rbits, rzero, Q, R, K, k, base_index, ws, ws_bytes, dist2, idx, stream, prepared != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------

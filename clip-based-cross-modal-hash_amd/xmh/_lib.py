@@ -138,6 +138,9 @@ PROTOTYPES = {
     "xmh_hamming_topk": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
     "xmh_topk_ws_init": (i32, [i64, i64, i32, i32, vp, sz, vp]),
     "xmh_hamming_topk_prepared": (i32, [vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp]),
+    "xmh_topk_ternary_ws_bytes": (sz, [i64, i64, i32, i32]),
+    "xmh_topk_ternary_ws_init": (i32, [i64, i64, i32, i32, vp, sz, vp]),
+    "xmh_hamming_topk_ternary": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, vp, sz, i32, vp, vp, vp]),
     "xmh_topk_describe": (i32, [i64, i64, i32, i32, C.c_char_p, sz]),
     "xmh_topk_record_bytes": (sz, [i64, i32]),
     "xmh_topk_merge_host": (i32, [vp, i32, i64, i32, vp, vp]),

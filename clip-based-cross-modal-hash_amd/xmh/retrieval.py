@@ -408,15 +408,26 @@ def map_k_packed(q: PackedCodes, r: PackedCodes, qlab: torch.Tensor, rlab: torch
 class TopkWorkspace:
     """A prepared top-k workspace for one (Q, R, K, k) shape on one device: initialised once (xmh_topk_ws_init), then every call
     through it leaves its control words clean for the next one -- a query loop over a fixed gallery pays no memset launch.
-    Use it from one stream at a time."""
+    Use it from one stream at a time.  ``ternary``: for code sets with zero planes (2K + 1 half-unit buckets)."""
 
-    def __init__(self, Q: int, R: int, K: int, k: int, device):
+    def __init__(self, Q: int, R: int, K: int, k: int, device, ternary: bool = False):
         self.shape = (int(Q), int(R), int(K), int(k))
-        self.bytes = lib.xmh_topk_ws_bytes(*self.shape)
+        self.ternary = bool(ternary)
+        ws_bytes, ws_init = ((lib.xmh_topk_ternary_ws_bytes, lib.xmh_topk_ternary_ws_init) if self.ternary
+                             else (lib.xmh_topk_ws_bytes, lib.xmh_topk_ws_init))
+        self.bytes = ws_bytes(*self.shape)
         if self.bytes == 0:
-            check(lib.xmh_hamming_topk(None, None, Q, R, K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
+            _topk_shape_error(self.shape, self.ternary)
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
-        check(lib.xmh_topk_ws_init(*self.shape, ptr(self.buf), self.bytes, current_stream()), "xmh_topk_ws_init")
+        check(ws_init(*self.shape, ptr(self.buf), self.bytes, current_stream()), "xmh_topk_ws_init")
+
+
+def _topk_shape_error(shape, ternary: bool):
+    """a shape the planner refuses: make the library say why"""
+    Q, R, K, k = shape
+    if ternary:
+        check(lib.xmh_hamming_topk_ternary(None, None, None, None, Q, R, K, k, 0, None, 0, 0, None, None, None), "xmh_hamming_topk_ternary")
+    check(lib.xmh_hamming_topk(None, None, Q, R, K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
 
 
 def _topk_out(out, Q: int, k: int, dev):
@@ -429,34 +440,62 @@ def _topk_out(out, Q: int, k: int, dev):
     return dist, idx
 
 
-def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, workspace: Optional[TopkWorkspace] = None, out=None):
+def topk_ws_key(q: PackedCodes, r: PackedCodes, k: int, ternary: Optional[bool] = None):
+    """(Q, R, K as the kernels see it, k, ternary) -- the shape a TopkWorkspace must have been prepared for"""
+    tern = q.zero is not None or r.zero is not None or bool(ternary)
+    return (q.n, r.n, widened(q).K, int(k), tern)
+
+
+def hamming_topk(q: PackedCodes, r: PackedCodes, k: int, base_index: int = 0, workspace: Optional[TopkWorkspace] = None, out=None,
+                 ternary: Optional[bool] = None):
     """Exact top-k of every query over this gallery shard under (distance, index) order.
     Returns (dist int16-storage [Q,k] (uint16 bit pattern, 0xFFFF = unused slot), idx int32 [Q,k] global
     indices = base_index + row, -1 = unused slot when the shard has fewer than k rows).
+    Ternary code sets (a zero plane on either side: sign_() left an exact 0, reference runners/base.py:407-410) are ranked by the
+    reference's 0.5 * (K - q.r); ``dist`` then holds HALF units (K - q.r, 0 ... 2K) -- ``q.ternary or r.ternary`` tells which.
+    ``ternary=True`` asks for half units although neither side has a zero plane (a rank of a sharded call whose shard happens to hold
+    no zero while another rank's does: the lists must merge in one unit).
     ``workspace``: a TopkWorkspace of this shape (see there); without one a scratch workspace is allocated and cleared per call.
     ``out``: (dist, idx) contiguous device tensors of those shapes and dtypes to write into (the sharded driver passes views of the
     record it all-gathers)."""
     _require_cuda(q.bits, r.bits)
     if q.K != r.K:
         raise ValueError("code lengths differ: %d vs %d" % (q.K, r.K))
-    if q.zero is not None or r.zero is not None:
-        raise NotImplementedError("top-k over ternary codes is not supported; quantise without zeros")
+    K_true = q.K
+    qz, rz = _both_planes(q, r)
+    if qz is None and ternary:
+        qz, rz = zero_plane_or_default(q), zero_plane_or_default(r)
+    if qz is not None and ternary is False:
+        raise ValueError("hamming_topk: ternary=False for code sets with a zero plane")
+    tern = qz is not None
+    if tern:
+        q, r = PackedCodes(q.bits, qz, q.K, q.flags), PackedCodes(r.bits, rz, r.K, r.flags)
     q, r = widened(q), widened(r)
     Q, R = q.n, r.n
     dev = q.bits.device
+    shape = (Q, R, q.K, int(k))
     if workspace is not None:
-        if workspace.shape != (Q, R, q.K, int(k)) or workspace.buf.device != dev:
-            raise ValueError("top-k workspace was prepared for %r on %s, call is %r on %s"
-                             % (workspace.shape, workspace.buf.device, (Q, R, q.K, int(k)), dev))
-        dist, idx = _topk_out(out, Q, k, dev)
-        check(lib.xmh_hamming_topk_prepared(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(workspace.buf), workspace.bytes,
-                                            ptr(dist), ptr(idx), current_stream()), "xmh_hamming_topk_prepared")
-        return dist, idx
-    need = lib.xmh_topk_ws_bytes(Q, R, q.K, k)
-    if need == 0:
-        check(lib.xmh_hamming_topk(None, None, Q, R, q.K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
-    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if workspace.shape != shape or workspace.buf.device != dev or workspace.ternary != tern:
+            raise ValueError("top-k workspace was prepared for %r%s on %s, call is %r%s on %s"
+                             % (workspace.shape, " ternary" if workspace.ternary else "", workspace.buf.device, shape, " ternary" if tern else "", dev))
+        ws, need, prepared = workspace.buf, workspace.bytes, 1
+    else:
+        need = (lib.xmh_topk_ternary_ws_bytes if tern else lib.xmh_topk_ws_bytes)(*shape)
+        if need == 0:
+            _topk_shape_error(shape, tern)
+        ws, prepared = torch.empty(need, dtype=torch.uint8, device=dev), 0
     dist, idx = _topk_out(out, Q, k, dev)
-    check(lib.xmh_hamming_topk(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(ws), need, ptr(dist), ptr(idx),
-                               current_stream()), "xmh_hamming_topk")
+    if tern:
+        check(lib.xmh_hamming_topk_ternary(ptr(q.bits), ptr(q.zero), ptr(r.bits), ptr(r.zero), Q, R, q.K, k, base_index, ptr(ws), need, prepared,
+                                           ptr(dist), ptr(idx), current_stream()), "xmh_hamming_topk_ternary")
+        if q.K != K_true:
+            # codes widened to the next kernel word count: the extra words are "zero on both sides" and add the same constant to every
+            # half-unit distance (the ranking is untouched); taken out again, unused slots (0xFFFF) stay
+            dist.sub_(torch.where(dist == -1, 0, q.K - K_true).to(torch.int16))
+    elif prepared:
+        check(lib.xmh_hamming_topk_prepared(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(ws), need,
+                                            ptr(dist), ptr(idx), current_stream()), "xmh_hamming_topk_prepared")
+    else:
+        check(lib.xmh_hamming_topk(ptr(q.bits), ptr(r.bits), Q, R, q.K, k, base_index, ptr(ws), need, ptr(dist), ptr(idx),
+                                   current_stream()), "xmh_hamming_topk")
     return dist, idx

@@ -371,13 +371,16 @@ def merge_topk_records(gathered: torch.Tensor, world: int, nq: int, k: int):
     return d, i
 
 
-def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
+def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None, ternary: Optional[bool] = None):
     """north_star retrieval mode over a sharded gallery: exact top-k of every query on this rank's shard (global indices
     = base_index + row) written straight into this rank's record, ONE all-gather of the records ([Q, k] indices + distances,
     6 bytes per entry), one pinned device-to-host copy, k-way merge on the host (xmh_topk_merge_host).  Returns
     (dist int32 [Q,k], idx int32 [Q,k]) CPU tensors, identical on every rank; unused slots (fewer than k rows in all)
     carry distance 0xFFFF and idx -1.  ``topk_fn(q, r_shard, k, base_index) -> (dist, idx)`` defaults to the HIP op; a rank
-    without gallery rows contributes empty lists."""
+    without gallery rows contributes empty lists.
+    Ternary code sets (sign_() left an exact 0 somewhere, reference runners/base.py:407-410) are ranked in half units (K - q.r) and
+    EVERY rank must use that unit: ``ternary=None`` agrees on it with one 4-byte all-reduce (MAX of "my query set or my shard has a
+    zero plane"), ``True`` / ``False`` is the caller's word (e.g. from reduce_flags over the quantiser's value flags) and costs nothing."""
     from ._lib import lib
     world = dist.get_world_size(group)
     n_rows = r_shard.n if hasattr(r_shard, "n") else len(r_shard)
@@ -389,16 +392,24 @@ def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None):
     mine = out[dist.get_rank(group)]
     i_view = mine[: nq * k * 4].view(torch.int32).view(nq, k)
     d_view = mine[nq * k * 4: nq * k * 6].view(torch.int16).view(nq, k)
+    if hip and ternary is None:
+        ternary = getattr(q, "zero", None) is not None or getattr(r_shard, "zero", None) is not None
+        if world > 1:
+            t = torch.tensor([1 if ternary else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            ternary = bool(int(t.item()))
     if n_rows == 0:
         mine.fill_(0xFF)                                                     # distance 0xFFFF, index -1 = unused slots
     elif hip:
         from . import retrieval as R
         # a query loop over one gallery shard calls with the same shape every time: keep the prepared workspace of the last shape
         # (cleared once, left clean by every call) instead of allocating and clearing a scratch one per call
-        shape = (nq, n_rows, q.K, int(k), dev, torch.cuda.current_stream(dev).cuda_stream)
-        ws = _prepared_topk_workspace(shape, lambda: R.TopkWorkspace(nq, n_rows, q.K, int(k), dev))
+        # (code sets with zero planes -- sign_() left an exact 0 -- rank in half units: every rank must agree on that, see reduce_flags)
+        key = R.topk_ws_key(q, r_shard, k, ternary)
+        shape = key + (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _prepared_topk_workspace(shape, lambda: R.TopkWorkspace(key[0], key[1], key[2], key[3], dev, ternary=key[4]))
         try:
-            R.hamming_topk(q, r_shard, k, base_index, workspace=ws, out=(d_view, i_view))
+            R.hamming_topk(q, r_shard, k, base_index, workspace=ws, out=(d_view, i_view), ternary=ternary)
         except Exception:
             _topk_local.__dict__.pop("entry", None)                          # its control words may be dirty: the next call prepares a fresh one
             raise

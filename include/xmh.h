@@ -223,6 +223,18 @@ int xmh_topk_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_byt
 int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k,
                               int64_t base_index, void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx,
                               xmh_stream_t stream);
+/* Ternary codes (round 6).  BaseTrainer.make_hash_code is an in-place sign_() (reference runners/base.py:407-410): an activation of
+ * exactly 0 stays 0, and MITH sums two saturating tanh terms before it (runners/MITH/runner.py:125-131), so the code sets of the
+ * MITH / DSPH configs can hold -1 / 0 / +1.  Same call with the zero planes of both sides (bit set <=> the element is 0, padding
+ * bits set: what xmh_pack_sign writes); the order is the same canonical (distance, index) order over the reference's
+ * 0.5 * (K - q.r) (common/calc_utils.py:51-56), and dist2[Q][k] holds that distance in HALF units (K - q.r, 0 ... 2K; 0xFFFF =
+ * unused slot) since it is a multiple of 1/2.  Workspace: xmh_topk_ternary_ws_bytes; `prepared` != 0: the workspace went through
+ * xmh_topk_ternary_ws_init (or an earlier call) and needs no memset. */
+size_t xmh_topk_ternary_ws_bytes(int64_t Q, int64_t R, int K, int k);
+int xmh_topk_ternary_ws_init(int64_t Q, int64_t R, int K, int k, void* ws, size_t ws_bytes, xmh_stream_t stream);
+int xmh_hamming_topk_ternary(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero,
+                             int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes, int prepared,
+                             uint16_t* dist2, int32_t* idx, xmh_stream_t stream);
 /* Diagnostics for the measurement harness: writes "filter=<kernel instance>" -- the streaming kernel the fast path of
  * xmh_hamming_topk launches for this shape, spelled as rocprofv3 prints it (the counterpart of xmh_scan_describe).  out_bytes >= 64. */
 int xmh_topk_describe(int64_t Q, int64_t R, int K, int k, char* out, size_t out_bytes);

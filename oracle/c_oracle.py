@@ -65,3 +65,14 @@ def topk(qbits, rbits, nb, k, base_index=0):
     _lib.orc_topk(_ptr(qbits), _ptr(rbits), C.c_int64(Q), C.c_int64(rbits.shape[0]), qbits.shape[1], nb, k,
                   C.c_int64(base_index), _ptr(d), _ptr(i))
     return d, i
+
+
+def topk_ternary(qbits, qzero, rbits, rzero, K, k, base_index=0):
+    """top-k of ternary codes (bits + zero planes, padding bits set in the zero planes); distances in half units K - q.r"""
+    qbits, qzero, rbits, rzero = map(_u32, (qbits, qzero, rbits, rzero))
+    Q = qbits.shape[0]
+    d = np.empty((Q, k), dtype=np.uint16)
+    i = np.empty((Q, k), dtype=np.int32)
+    _lib.orc_topk_ternary(_ptr(qbits), _ptr(qzero), _ptr(rbits), _ptr(rzero), C.c_int64(Q), C.c_int64(rbits.shape[0]), qbits.shape[1],
+                          int(K), int(k), C.c_int64(base_index), _ptr(d), _ptr(i))
+    return d, i

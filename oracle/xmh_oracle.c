@@ -10,6 +10,8 @@
  *                    ranking by (distance, gallery index) == torch.sort(stable=True) (:77), the first
  *                    min(n_rel,k) relevant ranks (:81,:86-88), sum of ordinal/rank (:89).
  *   orc_topk         exact per-query top-k under the same order (north_star retrieval mode).
+ *   orc_topk_ternary the same for codes in {-1, 0, +1} (BaseTrainer.make_hash_code is sign_(), runners/base.py:407-410, sign(0) = 0):
+ *                    calc_hammingDist's 0.5 * (K - q.r) (:51-56) in half units, K - q.r = #(either side 0) + 2 #(both live, different).
  * Pinned through tests/test_oracle_c.py against oracle/retrieval.py, which is pinned against the
  * golden vectors generated from the reference.
  */
@@ -127,6 +129,42 @@ void orc_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R
             }
         }
         free(hist);
+        free(start);
+    }
+}
+
+/* ternary codes: bits (1 <=> element > 0) and zero planes (1 <=> element == 0; padding bits of the last word set on both sides).
+ * dist2 = K - q.r in 0 ... 2K (half units of the reference's distance); order (dist2, index). */
+static inline int dist2_of(const uint32_t* qb, const uint32_t* qz, const uint32_t* rb, const uint32_t* rz, int W, int K) {
+    int dead = 0, diff = 0;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t z = qz[w] | rz[w];
+        dead += __builtin_popcount(z);
+        diff += __builtin_popcount((qb[w] ^ rb[w]) & ~z);
+    }
+    return dead - (32 * W - K) + 2 * diff;
+}
+
+void orc_topk_ternary(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero, int64_t Q, int64_t R, int W,
+                      int K, int k, int64_t base_index, uint16_t* dist2, int32_t* idx) {
+    const int nb = 2 * K + 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < Q; ++q) {
+        uint32_t* start = (uint32_t*)calloc(nb + 1, sizeof(uint32_t));
+        for (int64_t r = 0; r < R; ++r) start[dist2_of(qbits + q * W, qzero + q * W, rbits + r * W, rzero + r * W, W, K) + 1]++;
+        for (int d = 0; d < nb; ++d) start[d + 1] += start[d];
+        for (int i = 0; i < k; ++i) {
+            dist2[q * k + i] = 0xFFFF;
+            idx[q * k + i] = -1;
+        }
+        for (int64_t r = 0; r < R; ++r) {
+            const int d = dist2_of(qbits + q * W, qzero + q * W, rbits + r * W, rzero + r * W, W, K);
+            const uint32_t pos = start[d]++;
+            if (pos < (uint32_t)k) {
+                dist2[q * k + pos] = (uint16_t)d;
+                idx[q * k + pos] = (int32_t)(base_index + r);
+            }
+        }
         free(start);
     }
 }
