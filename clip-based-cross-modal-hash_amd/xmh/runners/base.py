@@ -368,6 +368,35 @@ class BaseTrainer:
         maps = (self._map(q_img, r_txt, k), self._map(q_txt, r_img, k), self._map(q_img, r_img, k), self._map(q_txt, r_txt, k))
         return maps, (q_img, q_txt, r_img, r_txt)
 
+    def retrieve_topk(self, k: int, tasks=("i2t", "t2i")):
+        """north_star retrieval mode on the runner: encode both sets like valid() (get_code x 2, reference :309-310), then the exact
+        k nearest gallery items of every query under (distance, gallery index) order instead of the mAP -- per rank on its gallery shard,
+        the lists merged on the host (sharded.topk_sharded).  Returns {task: (dist float32 [Q, k], idx int32 [Q, k])} CPU tensors,
+        identical on every rank: ``dist`` are the reference's calc_hammingDist values 0.5 * (K - q.r) (common/calc_utils.py:51-56;
+        halves appear when sign_() left an exact 0 in a code, :407-410), unused slots (fewer than k gallery rows) hold inf / -1.
+        Tasks: i2t / t2i / i2i / t2t as in valid()."""
+        self._qlab = self._rlab = None
+        q_img, q_txt = self.encode_shard(self.query_loader, self.query_num)
+        r_img, r_txt = self.encode_shard(self.retrieval_loader, self.retrieval_num)
+        q_img, q_txt = self._gather_packed(q_img, self.query_num), self._gather_packed(q_txt, self.query_num)
+        pairs = {"i2t": (q_img, r_txt), "t2i": (q_txt, r_img), "i2i": (q_img, r_img), "t2t": (q_txt, r_txt)}
+        lo, _ = self._shard(self.retrieval_num)
+        # one unit for every rank and task: encode_streams reduced the quantiser's value flags over the ranks already
+        tern = any(p.zero is not None for p in (q_img, q_txt, r_img, r_txt))
+        out = {}
+        for task in tasks:
+            q, r = pairs[task]
+            if self.distributed:
+                d, i = sharded.topk_sharded(q, r, int(k), lo, ternary=tern)
+            else:
+                d, i = R.hamming_topk(q, r, int(k), 0, ternary=tern)
+                d, i = d.cpu().to(torch.int32) & 0xFFFF, i.cpu()
+            unused = i < 0
+            d = d.to(torch.float32) * (0.5 if tern else 1.0)
+            d[unused] = float("inf")
+            out[task] = (d, i)
+        return out
+
     def _is_writer(self):
         return not self.distributed or self.rank == 0
 

@@ -480,3 +480,46 @@ def test_twdh_reproduces_reference_class_on_shipped_matrices(tmp_path):
         line = [ln for ln in lines if ln.startswith(">>>>>> [0/1], " + tag)][-1]
         assert _mask_numbers(line) == _mask_numbers(str(g["TwDH_%s_log_line" % name]))
     assert sorted(os.listdir(os.path.join(str(tmp_path), "mat_files"))) == [str(f) for f in g["TwDH_files"]]
+
+
+def test_mith_runner_topk_mode_with_a_forced_exact_zero(tmp_path):
+    """VERDICT r5 missing 1: MITH quantises sign(cls_hash + tokens_hash) (reference runners/MITH/runner.py:125-131, base.py:407-410): an
+    activation of exactly 0 stays 0.  Force one in a query row and one in a gallery row: retrieve_topk() must return, for every query, the
+    stable sort of the reference's calc_hammingDist on the -1/0/+1 codes the runner itself produced (half-integer distances included)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from oracle import retrieval as orc
+    from xmh.common.register import registry
+    cfg = make_cfg(tmp_path, "MITH", "MITHTrainer", 64, layers=1)
+    trainer = registry.get_runner_class("MITHTrainer").from_config(cfg=cfg, autorun=False)
+    inner = trainer.generate_hash
+
+    def with_zeros(image, text, key_padding_mask=None):
+        ih, th = inner(image, text, key_padding_mask)
+        ih, th = ih.clone(), th.clone()
+        ih[0, 3] = 0.0                                       # first row of every forward: query 0 / gallery rows 0, 128, ...
+        th[0, 7] = 0.0
+        th[1, 7] = 0.0
+        return ih, th
+    trainer.generate_hash = with_zeros
+    q_img, q_txt = trainer.get_code(trainer.query_loader, trainer.query_num)
+    r_img, r_txt = trainer.get_code(trainer.retrieval_loader, trainer.retrieval_num)
+    assert (q_img == 0).any() and (r_txt == 0).any() and set(np.unique(r_img.cpu().numpy())) <= {-1.0, 0.0, 1.0}
+    got = trainer.retrieve_topk(20, tasks=("i2t", "t2i", "i2i", "t2t"))
+    halves = False
+    for task, (q, r) in {"i2t": (q_img, r_txt), "t2i": (q_txt, r_img), "i2i": (q_img, r_img), "t2t": (q_txt, r_txt)}.items():
+        val, order = torch.sort(orc.hamming_dist(q.cpu(), r.cpu()), dim=1, stable=True)       # restates calc_hammingDist, :51-56
+        d, i = got[task]
+        assert torch.equal(i.long(), order[:, :20]), task
+        assert torch.equal(d, val[:, :20]), task
+        halves |= bool((d * 2 % 2 == 1).any())
+    assert halves                                            # a half-integer distance made it into a list: the ternary kernels ran
+    # and the mAP path on the same ternary code sets (the scan's zero planes), against the oracle's stable-order calc_map_k port
+    maps = trainer.valid(0, k=None)
+    want = orc.map_k(q_img.cpu(), r_txt.cpu(), trainer.query_labels, trainer.retrieval_labels, None, stable=True)
+    assert abs(maps[0] - float(want)) < 1e-6
+    # k larger than the gallery: unused slots
+    d, i = trainer.retrieve_topk(300, tasks=("i2t",))["i2t"]
+    assert (i[:, 230:] == -1).all() and torch.isinf(d[:, 230:]).all() and (i[:, :230] >= 0).all()
