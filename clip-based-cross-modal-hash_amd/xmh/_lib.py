@@ -129,7 +129,9 @@ PROTOTYPES = {
     "xmh_row_l2normalize": (i32, [vp, i64, i32, vp, vp, vp]),
     "xmh_pairwise_l2_from_gram": (i32, [vp, vp, vp, i64, i64, vp]),
     "xmh_affine_inplace": (i32, [vp, i64, C.c_float, C.c_float, vp]),
-    "xmh_float_rank_ap": (i32, [vp, vp, vp, i64, i64, i32, i64, vp, vp, vp]),
+    "xmh_gemm_f32_sort_ws_bytes": (sz, [i64, i64]),
+    "xmh_gemm_f32_sort_map": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i64, vp, sz, vp, vp, vp, vp]),
+    "xmh_float_sort_ap": (i32, [vp, vp, vp, i64, i64, i32, i64, vp, sz, vp, vp, vp]),
     "xmh_pair_similarity_loss": (i32, [vp, vp, i64, i32, vp, i32, i32, C.c_float, C.c_float, vp, vp]),
     "xmh_quant_loss": (i32, [vp, i64, vp, vp]),
     "xmh_pair_similarity_loss_grad": (i32, [vp, vp, i64, i32, vp, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp, i32, vp]),

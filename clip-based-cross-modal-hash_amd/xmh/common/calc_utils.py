@@ -173,11 +173,24 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
         if fused is not None:
             return fused
         # (code lengths that need widening, 129 ... 224 classes, unquantised values: the composed path below)
-        # both code matrices are packed before the ONE read of their value flags (round 5: two stand-alone packs were two syncs)
-        fl = torch.zeros(1, dtype=torch.int32, device=gq.device)
-        q, r = R.pack_sign(gq, flags=fl, defer=True), R.pack_sign(gr, flags=fl, defer=True)
-        R.settle_flags(fl, q, r)
-        if _is_quantised(q, r):
+        K = gq.shape[1]
+        # what the bit-packed kernels have no instance for goes down the reference's own route -- float GEMM + one sort per query
+        # (xmh_gemm_f32_sort_map): the drop-in returns a number wherever the reference does
+        why = None
+        if K > 2048:
+            why = "codes of %d bits (the bit-packed scan stops at 2048)" % K
+        elif ql.shape[1] > 8:
+            why = "%d classes (the bit-packed scan stops at 256)" % C
+        if why is None:
+            # both code matrices are packed before the ONE read of their value flags (round 5: two stand-alone packs were two syncs)
+            fl = torch.zeros(1, dtype=torch.int32, device=gq.device)
+            q, r = R.pack_sign(gq, flags=fl, defer=True), R.pack_sign(gr, flags=fl, defer=True)
+            R.settle_flags(fl, q, r)
+            if not _is_quantised(q, r):
+                why = "codes contain values outside {-1,0,+1}"
+            elif q.zero is not None and K > 256:
+                why = "ternary codes (an exact 0 among the values) of %d bits (the bit-packed scan takes zero planes up to 256)" % K
+        if why is None:
             # valid() evaluates the same shape four times per epoch (runners/base.py:312-315): the scan workspace of the last shape is
             # kept (release_scan_workspace() drops it; it is per thread, and used on the caller's current stream)
             key = (q.n, r.n, q.K, q.zero is not None or r.zero is not None, str(gq.device), torch.cuda.current_stream(gq.device).cuda_stream)
@@ -189,7 +202,8 @@ def calc_map_k(qB, rB, query_L, retrieval_L, k=None) -> torch.Tensor:
                 release_scan_workspace()
         else:
             from .. import dense
-            res = dense.map_k_float(_to_gpu(qB).float(), _to_gpu(rB).float(), ql, rl, C, k)
+            release_scan_workspace()                     # the float path's tile wants the room
+            res = dense.map_k_float(gq.float(), gr.float(), ql, rl, C, k, why=why)
         return res.to(torch.float32).cpu().reshape(())
 
 

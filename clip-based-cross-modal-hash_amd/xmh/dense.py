@@ -43,30 +43,48 @@ def hamming_dist_float(B1: torch.Tensor, B2: torch.Tensor) -> torch.Tensor:
     return g
 
 
-_FLOAT_TILE_BYTES = 1 << 30        # the [q-tile, R] fp32 distance block of the float path stays under 1 GiB
-
-
-def map_k_float(qB, rB, qlab, rlab, C: int, k: Optional[int]) -> torch.Tensor:
-    """calc_map_k on un-quantised float "codes": distances by exact-fp32 GEMM, ranks by comparison counting.  The queries are
-    tiled so that at most 1 GiB of distances exists at a time (Q=5000 x R=117k would be 2.3 GB at once); the ranking itself
-    is O(nrel * R) per query -- this is the slow path, and the caller is told so once."""
+def map_k_float(qB, rB, qlab, rlab, C: int, k: Optional[int], why: Optional[str] = None) -> torch.Tensor:
+    """calc_map_k the way the reference computes it (common/calc_utils.py:72-89) for code sets the bit-packed scan has no kernel for:
+    un-quantised float "codes" (UMoED-style tanh outputs), ternary codes above 256 bits, more than 2048 bits, more than 256 classes.
+    xmh_gemm_f32_sort_map: exact-fp32 GEMM distances, one stable radix sort per query row, one AP pass -- query tiles of at most 1.5 GB
+    (20 bytes per pair) inside the C call.  ``qlab`` / ``rlab``: packed label masks of any word count."""
     global _warned_float
     if not _warned_float:
         import warnings
-        warnings.warn("xmh: codes contain values outside {-1,0,+1}: using the float ranking path (GEMM + comparison counting), "
-                      "orders of magnitude slower than the bit-packed scan; quantise the codes (make_hash_code) to avoid it")
+        warnings.warn("xmh: %s: using the float ranking path (fp32 GEMM + one radix sort per query), slower than the bit-packed scan"
+                      % (why or "codes contain values outside {-1,0,+1}"))
         _warned_float = True
     qB, rB = qB.contiguous(), rB.contiguous()
-    Q, Rn = qB.shape[0], rB.shape[0]
-    ap = torch.empty(Q, dtype=torch.float64, device=qB.device)
-    cap = torch.empty(Q, dtype=torch.int32, device=qB.device)
-    tile = max(1, min(Q, _FLOAT_TILE_BYTES // (4 * max(Rn, 1))))
-    for lo in range(0, Q, tile):
-        hi = min(Q, lo + tile)
-        d = hamming_dist_float(qB[lo:hi], rB)
-        check(lib.xmh_float_rank_ap(ptr(d), ptr(qlab[lo:hi]), ptr(rlab), hi - lo, Rn, C, 0 if k is None else int(k), ptr(ap[lo:hi]),
-                                    ptr(cap[lo:hi]), current_stream()), "xmh_float_rank_ap")
-    return R.map_finalize(ap, cap)
+    qlab, rlab = qlab.contiguous(), rlab.contiguous()
+    Q, Rn, K = qB.shape[0], rB.shape[0], qB.shape[1]
+    if rB.shape[1] != K or qlab.shape[0] != Q or rlab.shape[0] != Rn or qlab.shape[1] != rlab.shape[1] or qlab.shape[1] != (C + 31) // 32:
+        raise ValueError("map_k_float: shapes %s %s / labels %s %s do not fit %d classes"
+                         % (tuple(qB.shape), tuple(rB.shape), tuple(qlab.shape), tuple(rlab.shape), C))
+    dev = qB.device
+    ap = torch.empty(Q, dtype=torch.float64, device=dev)
+    cap = torch.empty(Q, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    need = int(lib.xmh_gemm_f32_sort_ws_bytes(Q, Rn))
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    need = max(min(need, int(0.8 * free)), 20 * Rn + 4096)       # a smaller workspace is a smaller query tile, not an error
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib.xmh_gemm_f32_sort_map(ptr(qB), ptr(rB), ptr(qlab), ptr(rlab), Q, Rn, K, C, 0 if k is None else int(k), ptr(ws), need,
+                                    ptr(ap), ptr(cap), ptr(out), current_stream()), "xmh_gemm_f32_sort_map")
+    return out
+
+
+def float_sort_ap(dist: torch.Tensor, qlab: torch.Tensor, rlab: torch.Tensor, C: int, k: Optional[int] = None):
+    """the ranking half of map_k_float on a distance matrix the caller holds (float32 [Q, R], any values): stable ascending sort per
+    row, sum(ordinal / rank) over the first min(n_rel, k) relevant items -> (ap_sum float64 [Q], cap int32 [Q])."""
+    dist, qlab, rlab = dist.contiguous(), qlab.contiguous(), rlab.contiguous()
+    Q, Rn = dist.shape
+    ap = torch.empty(Q, dtype=torch.float64, device=dist.device)
+    cap = torch.empty(Q, dtype=torch.int32, device=dist.device)
+    ws = torch.empty(16 * Q * Rn + 2048, dtype=torch.uint8, device=dist.device)
+    check(lib.xmh_float_sort_ap(ptr(dist), ptr(qlab), ptr(rlab), Q, Rn, C, 0 if k is None else int(k), ptr(ws), ws.numel(), ptr(ap), ptr(cap),
+                                current_stream()), "xmh_float_sort_ap")
+    return ap, cap
 
 
 _warned_float = False

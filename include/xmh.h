@@ -479,10 +479,23 @@ int xmh_pairwise_l2_from_gram(float* gram_inout, const float* sqnorm_a, const fl
                               xmh_stream_t stream);
 /* in place: x = alpha * x + beta   (0.5 * (K - q.r) on float codes, calc_hammingDist :51-56) */
 int xmh_affine_inplace(float* x, int64_t n, float alpha, float beta, xmh_stream_t stream);
-/* calc_map_k ranking for FLOAT distances dist[Q][R] under (distance, index) order; same outputs as xmh_hamming_ap.
- * Direct counting, O(R * n_rel) per query: the small-set fallback for non-binary "codes". */
-int xmh_float_rank_ap(const float* dist, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C,
-                      int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream);
+/* calc_map_k on FLOAT "codes" (values outside {-1, 0, +1}: UMoED-style raw tanh outputs, reference runners/UMoED/runner.py:162-186) the
+ * way the reference computes it (common/calc_utils.py:72-89): distances 0.5 * (K - qB . rB^T) by exact-fp32 GEMM (:51-56), ONE stable
+ * sort per query (:76-77; a segmented LSD radix sort, ties in gallery-index order = torch.sort(stable=True)), the first min(n_rel, k)
+ * relevant ranks (:81-89).  SURVEY 8(b)'s xmh_gemm_f32_sort_map.  qB [Q][K], rB [R][K] fp32 row-major, packed label masks as
+ * xmh_pack_labels writes them; k <= 0: mAP@all.  Outputs like xmh_hamming_ap (ap_sum[Q] f64, cap[Q] i32) and, when map_out is not
+ * NULL, the mean over the queries like xmh_map_finalize.  Also the route of every code set the bit-packed kernels have no instance for
+ * (ternary codes above 256 bits, more than 2048 bits, more than 256 classes): the drop-in never refuses what the reference evaluates.
+ * Workspace: xmh_gemm_f32_sort_ws_bytes(Q, R) (a query tile of at most 1.5 GB: 20 bytes per pair); any size from one row
+ * (20 R + 1280 bytes) up is accepted and sets the tile.  R < 2^31. */
+size_t xmh_gemm_f32_sort_ws_bytes(int64_t Q, int64_t R);
+int xmh_gemm_f32_sort_map(const float* qB, const float* rB, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R,
+                          int K, int C, int64_t k, void* ws, size_t ws_bytes, double* ap_sum, int32_t* cap, double* map_out,
+                          xmh_stream_t stream);
+/* The ranking half alone, for a distance matrix the caller holds: dist[Q][R] any floats, same order, same outputs.
+ * Workspace: 16 Q R + 1280 bytes. */
+int xmh_float_sort_ap(const float* dist, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C, int64_t k,
+                      void* ws, size_t ws_bytes, double* ap_sum, int32_t* cap, xmh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss of the DCMHT objective: forward, and its gradient with respect to the two code matrices (what

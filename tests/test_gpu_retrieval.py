@@ -1728,3 +1728,123 @@ def test_topk_sharded_ternary_merge_equals_global(xr):
     md, mi = sharded.merge_topk(torch.stack(ds), torch.stack(is_), k)
     wd, wi = xr.hamming_topk(q, whole, k)
     assert torch.equal(mi, wi.cpu()) and torch.equal(md, (wd.cpu().int() & 0xFFFF))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the float route = the reference's own (GEMM + ONE stable sort per query), and the drop-in never refuses a shape
+# ------------------------------------------------------------------------------------------------
+def _ap_from_distances(dist, rel, k=None):
+    """reference calc_utils.py:76-89 on a given distance matrix with torch.sort(stable=True): per-query sum(ordinal / rank), cap"""
+    order = torch.sort(dist, dim=1, stable=True).indices
+    sums, caps = [], []
+    for i in range(dist.shape[0]):
+        hits = rel[i][order[i]]
+        n = int(hits.sum()) if k is None else min(int(hits.sum()), k)
+        rank = torch.nonzero(hits)[:n].squeeze(-1).to(torch.float32) + 1.0
+        sums.append(float((torch.arange(1, n + 1, dtype=torch.float32) / rank).to(torch.float64).sum()))
+        caps.append(n)
+    return np.array(sums), np.array(caps)
+
+
+@pytest.mark.parametrize("Q,R,C", [(3, 1, 5), (4, 63, 21), (5, 64, 80), (7, 1000, 33), (3, 70001, 24), (33, 5000, 300)])
+def test_float_sort_ranking_is_torch_stable_sort(xr, Q, R, C):
+    """xmh_float_sort_ap (segmented LSD radix sort + AP pass) on distance matrices full of ties, negative values and signed zeros:
+    the same sums as torch.sort(stable=True) of the same matrix, for k in {None, 1, 10}"""
+    from xmh import dense
+    gen = torch.Generator().manual_seed(Q * 1000 + R)
+    dist = (torch.randn(Q, R, generator=gen) * 3).mul(4).round().div(4)                # quarter steps: thousands of ties per row
+    dist[:, ::7] = 0.0
+    dist[:, 3::11] = -0.0
+    dist[0, :] = 5.0                                                                    # one row: a single bucket, pure index order
+    if R > 100:
+        dist[1, :] = torch.randn(R, generator=gen) * 1e-30                             # tiny magnitudes, both signs
+        dist[2, :50] = float("inf")
+    qL = (torch.rand(Q, C, generator=gen) < 0.1).to(torch.int64)
+    rL = (torch.rand(R, C, generator=gen) < 0.1).to(torch.int64)
+    qL[:, 0] = 1
+    rL[::3, 0] = 1
+    rel = (qL.float() @ rL.float().t()) > 0
+    ql, rl = xr.pack_labels(qL.cuda()), xr.pack_labels(rL.cuda())
+    for k in (None, 1, 10):
+        ap, cap = dense.float_sort_ap(dist.cuda(), ql, rl, C, k)
+        want, wcap = _ap_from_distances(dist, rel, k)
+        assert np.array_equal(cap.cpu().numpy(), wcap)
+        assert np.allclose(ap.cpu().numpy(), want, rtol=1e-9, atol=1e-12), (k, np.abs(ap.cpu().numpy() - want).max())
+
+
+def test_calc_map_k_on_umoed_style_float_codes_at_scale(cu):
+    """tanh "codes" (reference runners/UMoED/runner.py:162-186 hands calc_map_k un-quantised values) at
+    Q 500 x R 117 218 x 64: under 50 ms per call, and equal to the oracle's calc_map_k port on a query subsample."""
+    import time
+    orc = _orc()
+    gen = torch.Generator().manual_seed(42)
+    Q, R, K, C = 500, 117218, 64, 80
+    qL = (torch.rand(Q, C, generator=gen) < 0.04).to(torch.int64)
+    rL = (torch.rand(R, C, generator=gen) < 0.04).to(torch.int64)
+    qL[:, 0] = 1
+    rL[::5, 0] = 1
+    W = torch.randn(C, K, generator=gen)
+    qB = torch.tanh(qL.float() @ W + 0.8 * torch.randn(Q, K, generator=gen))
+    rB = torch.tanh(rL.float() @ W + 0.8 * torch.randn(R, K, generator=gen))
+    dq, dr, dql, drl = qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()
+    with pytest.warns(UserWarning):
+        import xmh.dense as dense
+        dense._warned_float = False
+        got = float(cu.calc_map_k(dq, dr, dql, drl))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        cu.calc_map_k(dq, dr, dql, drl)
+    dt = (time.perf_counter() - t0) / 3
+    assert dt < 0.050, dt
+    sub = slice(0, 24)
+    got_sub = float(cu.calc_map_k(dq[sub], dr, dql[sub], drl))
+    want_sub = float(orc.map_k(qB[sub], rB, qL[sub], rL, stable=True))
+    assert abs(got_sub - want_sub) < 1e-5, (got_sub, want_sub)            # fp32 GEMM rounding (CPU sgemm vs v_mfma_f32) may swap near-ties
+    assert 0.0 < got < 1.0
+    got50 = float(cu.calc_map_k(dq[sub], dr, dql[sub], drl, 50))
+    assert abs(got50 - float(orc.map_k(qB[sub], rB, qL[sub], rL, 50, stable=True))) < 1e-4
+
+
+@pytest.mark.parametrize("case", ["ternary_512", "bits_4096", "classes_300", "ternary_2048_classes_300"])
+def test_drop_in_never_refuses_what_the_reference_evaluates(cu, case):
+    """ternary codes above 256 bits, codes above 2048 bits, more than 256 classes: calc_map_k (reference common/calc_utils.py:58-92 has no
+    such limits) returns the oracle's value through the float route instead of raising"""
+    import xmh.dense as dense
+    orc = _orc()
+    gen = torch.Generator().manual_seed(len(case))
+    K = {"ternary_512": 512, "bits_4096": 4096, "classes_300": 64, "ternary_2048_classes_300": 2048}[case]
+    C = 300 if "classes_300" in case else 24
+    Q, R = 21, 1500
+    qB = _ternary_codes(Q, K, gen) if "ternary" in case else torch.randn(Q, K, generator=gen).sign()
+    rB = _ternary_codes(R, K, gen) if "ternary" in case else torch.randn(R, K, generator=gen).sign()
+    qL = (torch.rand(Q, C, generator=gen) < 0.05).to(torch.int64)
+    rL = (torch.rand(R, C, generator=gen) < 0.05).to(torch.int64)
+    qL[:, C - 1] = 1
+    rL[::4, C - 1] = 1
+    dense._warned_float = False
+    with pytest.warns(UserWarning, match="float ranking path"):
+        got = cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())
+    assert got.device.type == "cpu" and got.dtype == torch.float32 and got.dim() == 0
+    assert abs(float(got) - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL
+    got7 = cu.calc_map_k(qB, rB, qL, rL, 7)                                    # host tensors in, like the reference's callers
+    assert abs(float(got7) - float(orc.map_k(qB, rB, qL, rL, 7, stable=True))) < MAP_TOL
+
+
+def test_calc_map_k_argument_checks(cu):
+    """k = 0 is the reference's nan (mean of an empty tensor, :81-89) on every path, k < 0 raises, mismatched label shapes
+    raise instead of reaching the C ABI as raw pointers"""
+    gen = torch.Generator().manual_seed(3)
+    qB, rB = torch.randn(9, 64, generator=gen).sign().cuda(), torch.randn(700, 64, generator=gen).sign().cuda()
+    qL = torch.ones(9, 24, dtype=torch.int64).cuda()
+    rL = torch.ones(700, 24, dtype=torch.int64).cuda()
+    for K in (64, 96):                                                          # the one-call ABI and the composed path
+        assert torch.isnan(cu.calc_map_k(qB[:, :K] if K == 64 else torch.cat([qB, qB[:, :32]], 1), rB if K == 64 else torch.cat([rB, rB[:, :32]], 1), qL, rL, 0))
+        with pytest.raises(ValueError):
+            cu.calc_map_k(qB, rB, qL, rL, -3)
+    with pytest.raises(ValueError):
+        cu.calc_map_k(qB, rB, qL[:5], rL)
+    with pytest.raises(ValueError):
+        cu.calc_map_k(qB, rB, qL, rL[:, :20])
+    with pytest.raises(ValueError):
+        cu.calc_map_k(qB, rB[:600], qL, rL)
