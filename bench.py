@@ -28,6 +28,7 @@ import socket
 import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd")):
@@ -310,7 +311,9 @@ def strong_legs(args, world, rank, barrier):
         steps = 20
         dt, res = timed(tstep, barrier, steps, True)
         legs["Q%d" % Qn] = {"pairs_per_s": Qn * Rt * steps / dt, "ms_per_call": dt / steps * 1e3,
-                            "gallery_GBps": Rt * W * 4 * steps / dt / 1e9, "first_hit": [int(res[0][0, 0]), int(res[1][0, 0])]}
+                            "gallery_GBps": Rt * W * 4 * steps / dt / 1e9, "first_hit": [int(res[0][0, 0]), int(res[1][0, 0])],
+                            # digest of the merged (distance, index) lists: a test re-derives it from ONE top-k over all shards
+                            "lists_crc32": zlib.crc32(res[0].numpy().tobytes() + res[1].numpy().tobytes())}
     out["configs4_topk_10M_256bit"] = {"workload": "exact top-%d over R=%d x %d-bit IN TOTAL (%d shards of ~%d rows): shard top-k, "
                                                    "all-gather of [Q,k] lists, host merge" % (k, Rt, K, world, n_loc),
                                        "scaling": "strong", "legs": legs}

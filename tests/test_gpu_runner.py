@@ -523,3 +523,130 @@ def test_mith_runner_topk_mode_with_a_forced_exact_zero(tmp_path):
     # k larger than the gallery: unused slots
     d, i = trainer.retrieve_topk(300, tasks=("i2t",))["i2t"]
     assert (i[:, 230:] == -1).all() and torch.isinf(d[:, 230:]).all() and (i[:, :230] >= 0).all()
+
+
+def test_bench_eight_ranks_sharing_the_gpu():
+    """the driver's N = 8 command line (`bench.py --gpus 8`) END TO END without an 8-GPU node: eight ranks on cuda:0
+    over gloo (--share-gpu).  The weak-scaling headline's mAP must equal ONE scan over all eight shards, configs[2]'s strong-scaling
+    mAP one scan over the whole NUS-WIDE-shaped gallery, and configs[4]'s merged top-100 lists (Q = 1, 8, 64) the lists of ONE top-k
+    over all 10 M rows (digest of the (distance, index) arrays)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world, Q, Rn = 8, 296, 9000
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--share-gpu", "--steps", "2", "--warmup", "1", "--settle", "0", "--Q", str(Q),
+           "--R", str(Rn), "--no-cpu-baseline", "--no-hbm-regime", "--no-encode"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XMH_BENCH_CHILD")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["value"] > 0
+    detail = json.load(open(os.path.join(root, "gpurun_out", "bench_detail.json")))
+    assert detail["rccl_ranks"] == world and "share-gpu" in detail["launcher"]
+    strong = detail["strong_scaling"]
+    assert "error" not in strong, strong
+    spec = importlib.util.spec_from_file_location("xmh_bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from xmh import retrieval as R
+    from xmh import sharded
+
+    def one_scan(qB, qL, rB, rL, C):
+        whole = R.RankingScan(R.pack_sign(qB.cuda()), R.pack_labels(qL.cuda()), R.pack_sign(rB.cuda()), R.pack_labels(rL.cuda()), C)
+        whole.histograms(False)
+        return float(whole.map_all(None)[0].item())
+    # weak-scaling headline: the same synthetic shards in one process, one scan
+    qB, qL, _, _ = bench.synth(Q, 8, 64, 80, seed=1814, p=0.04)
+    shards = [bench.synth(8, Rn, 64, 80, seed=1814 + 1 + rank, p=0.04)[2:] for rank in range(world)]
+    want = one_scan(qB, qL, torch.cat([s_[0] for s_ in shards]), torch.cat([s_[1] for s_ in shards]), 80)
+    assert abs(detail["mAP"] - want) < 1e-9, (detail["mAP"], want)
+    # configs[2], strong scaling: Q 5000 x R 188 000 in total
+    b = sharded.shard_bounds(188000, world)
+    qB, qL, _, _ = bench.synth(5000, 8, 64, 21, seed=2814, p=0.1)
+    shards = [bench.synth(8, b[rank + 1] - b[rank], 64, 21, seed=2815 + rank, p=0.1)[2:] for rank in range(world)]
+    want = one_scan(qB, qL, torch.cat([s_[0] for s_ in shards]), torch.cat([s_[1] for s_ in shards]), 21)
+    assert abs(strong["configs2_nuswide_map"]["mAP"] - want) < 1e-9, (strong["configs2_nuswide_map"]["mAP"], want)
+    # configs[4], strong scaling: top-100 over 10 M x 256 bit in total, merged lists vs ONE top-k over all rows
+    b = sharded.shard_bounds(10_000_000, world)
+    g = torch.Generator(device="cuda")
+    parts = []
+    for rank in range(world):
+        g.manual_seed(4814 + rank)
+        parts.append(torch.randint(-2**31, 2**31 - 1, (b[rank + 1] - b[rank], 8), dtype=torch.int32, device="cuda", generator=g))
+    g.manual_seed(4813)
+    qall = torch.randint(-2**31, 2**31 - 1, (64, 8), dtype=torch.int32, device="cuda", generator=g)
+    gallery = R.PackedCodes(torch.cat(parts), None, 256)
+    for Qn in (1, 8, 64):
+        d, i = R.hamming_topk(R.PackedCodes(qall[:Qn].contiguous(), None, 256), gallery, 100)
+        d, i = (d.cpu().to(torch.int32) & 0xFFFF), i.cpu()
+        leg = strong["configs4_topk_10M_256bit"]["legs"]["Q%d" % Qn]
+        assert leg["lists_crc32"] == zlib.crc32(d.numpy().tobytes() + i.numpy().tobytes()), Qn
+        assert leg["first_hit"] == [int(d[0, 0]), int(i[0, 0])]
+
+
+def _runner_topk_two_rank_worker(rank, world, port, tmp):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "clip-based-cross-modal-hash_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import pathlib
+    import torch.distributed as dist
+    import xmh.models  # noqa: F401
+    import xmh.runners  # noqa: F401
+    from xmh.common.register import registry
+    cfg = make_cfg(pathlib.Path(tmp), "MITH", "MITHTrainer", 64, layers=1)
+    cfg.run.distributed_addr, cfg.run.distributed_port, cfg.run.share_gpu = "127.0.0.1", port, True
+    cfg.run.save_dir = cfg.run.log_dir = os.path.join(tmp, "dist")
+    try:
+        shard = registry.get_runner_class("MITHTrainer").from_config(rank, world, True, cfg, None, autorun=False)
+        inner = shard.generate_hash
+
+        def with_zero(image, text, key_padding_mask=None):          # rank 1 only: its shard alone holds exact zeros
+            ih, th = inner(image, text, key_padding_mask)
+            if rank == 1:
+                ih, th = ih.clone(), th.clone()
+                ih[0, 5] = 0.0
+                th[0, 9] = 0.0
+            return ih, th
+        shard.generate_hash = with_zero
+        got = shard.retrieve_topk(15)
+        torch.save({k: (d, i) for k, (d, i) in got.items()}, os.path.join(tmp, "lists%d.pt" % rank))
+        q_img, q_txt = shard.get_code(shard.query_loader, shard.query_num)
+        r_img, r_txt = shard.get_code(shard.retrieval_loader, shard.retrieval_num)
+        torch.save((q_img.cpu(), q_txt.cpu(), r_img.cpu(), r_txt.cpu()), os.path.join(tmp, "codes%d.pt" % rank))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_runner_topk_two_ranks_sharing_the_gpu_with_zeros_on_one_rank(tmp_path):
+    """retrieve_topk() sharded (north_star: rank r holds its shard's codes, query codes all-gathered, partial lists merged on the host)
+    with world = 2 on the one GPU, and exact zeros in rank 1's rows only: both ranks must rank in half units (the reduced value flags)
+    and return the same lists = the stable sort of the reference's distance over the whole code sets."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import retrieval as orc
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mp.spawn(_runner_topk_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    lists = [torch.load(os.path.join(str(tmp_path), "lists%d.pt" % r)) for r in range(2)]
+    q_img, q_txt, r_img, r_txt = torch.load(os.path.join(str(tmp_path), "codes0.pt"))
+    assert (r_img == 0).any() or (q_img == 0).any()
+    for task, (q, r) in {"i2t": (q_img, r_txt), "t2i": (q_txt, r_img)}.items():
+        val, order = torch.sort(orc.hamming_dist(q, r), dim=1, stable=True)
+        for rank in range(2):
+            d, i = lists[rank][task]
+            assert torch.equal(i.long(), order[:, :15]), (task, rank)
+            assert torch.equal(d, val[:, :15]), (task, rank)

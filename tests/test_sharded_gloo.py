@@ -238,6 +238,22 @@ def test_bench_self_launches_n_ranks_dry_run():
     assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["ranks_in_group"] == 1
 
 
+@pytest.mark.timeout(600)
+def test_bench_self_launches_eight_ranks_dry_run():
+    """the driver's N = 8 command line with --dry-run: launcher, rendezvous of eight ranks and one step's collectives over gloo"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], env=env, capture_output=True, text=True, timeout=580)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 8 and d["ranks_in_group"] == 8
+
+
 def test_topk_merge_host_equals_the_torch_merge():
     """xmh_topk_merge_host (k-way merge in C on the gathered records) against sharded.merge_topk (argsort of 64-bit keys), bit for
     bit: ties across shards, lists shorter than k (index -1 padding), shards without rows, fewer rows than k in all."""
