@@ -55,6 +55,17 @@ struct ProfScope {
     hipStream_t st;
 };
 
+// roctx range around a phase of the path (tower forward, head, pack, pass 1, pass 2, top-k phases, ...): shows up in a
+// `rocprofv3 --marker-trace` timeline.  Off unless xmh_prof_enable(2 or 3): then librocprofiler-sdk-roctx.so (or libroctx64.so) is
+// looked up with dlopen -- libxmh.so itself does not link it -- and every scope is one push / pop pair; off = one branch.
+struct RangeScope {
+    explicit RangeScope(const char* name);
+    ~RangeScope();
+    void end();                                            // close the range before the scope does
+    bool on;
+};
+#define XMH_RANGE(name) ::xmh::RangeScope xmh_range_scope_(name)
+
 }  // namespace xmh
 
 // Tuning switches (tile rules, query-group shapes, A/B toggles of tools/) exist only in a library built with -DXMH_EXPERIMENTS; the shipped

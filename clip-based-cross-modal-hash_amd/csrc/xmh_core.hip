@@ -1,6 +1,7 @@
 // libxmh core: version, thread-local error string, device queries.
 #include "xmh_common.h"
 
+#include <dlfcn.h>
 #include <string.h>
 
 #include <mutex>
@@ -80,6 +81,40 @@ static void prof_collect(ProfSlot& s) {
     s.pending = false;
 }
 
+// ---- roctx ranges (rocprofv3 --marker-trace) -------------------------------------------------------
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+static bool g_range_on = false;
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+
+static bool roctx_lookup() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* so : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(so, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+            g_roctx_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+            if (g_roctx_push && g_roctx_pop) return;
+            g_roctx_push = nullptr;
+            g_roctx_pop = nullptr;
+        }
+    });
+    return g_roctx_push != nullptr;
+}
+
+RangeScope::RangeScope(const char* name) : on(g_range_on) {
+    if (on) g_roctx_push(name);
+}
+
+RangeScope::~RangeScope() { end(); }
+
+void RangeScope::end() {
+    if (on) g_roctx_pop();
+    on = false;
+}
+
 ProfScope::ProfScope(const char* name, hipStream_t stream) : slot(-1), st(stream) {
     if (!g_prof_on) return;
     slot = prof_slot(name);
@@ -105,7 +140,9 @@ ProfScope::~ProfScope() {
 }  // namespace xmh
 
 extern "C" int xmh_prof_enable(int on) {
-    xmh::g_prof_on = on != 0;
+    if ((on & 2) && !xmh::roctx_lookup()) return xmh::fail(XMH_ENOTSUP, "xmh_prof_enable: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) on the loader path");
+    xmh::g_range_on = (on & 2) != 0;
+    xmh::g_prof_on = (on & 1) != 0;
     for (int i = 0; i < xmh::g_prof_n; ++i) {
         xmh::prof_collect(xmh::g_prof[i]);
         xmh::g_prof[i].total_ms = 0.0;
@@ -126,6 +163,17 @@ extern "C" int xmh_prof_read(const char* name, double* avg_ms, int64_t* launches
     }
     *launches = 0;
     *avg_ms = 0.0;
+    return XMH_OK;
+}
+
+extern "C" int xmh_range_push(const char* name) {
+    if (!name) return xmh::fail(XMH_EINVAL, "xmh_range_push: null name");
+    if (xmh::g_range_on) xmh::g_roctx_push(name);
+    return XMH_OK;
+}
+
+extern "C" int xmh_range_pop(void) {
+    if (xmh::g_range_on) xmh::g_roctx_pop();
     return XMH_OK;
 }
 

@@ -245,6 +245,7 @@ extern "C" size_t xmh_gemm_f32_sort_ws_bytes(int64_t Q, int64_t R) {
 extern "C" int xmh_gemm_f32_sort_map(const float* qB, const float* rB, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int K,
                                      int C, int64_t k, void* ws, size_t ws_bytes, double* ap_sum, int32_t* cap, double* map_out,
                                      xmh_stream_t stream) {
+    XMH_RANGE("xmh_gemm_f32_sort_map");
     if (Q <= 0 || R <= 0 || K <= 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_gemm_f32_sort_map: bad shape Q=%lld R=%lld K=%d C=%d", (long long)Q, (long long)R, K, C);
     if (R >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_gemm_f32_sort_map: %lld gallery rows (the payload keeps 31 index bits)", (long long)R);
     if (!qB || !rB || !qlab || !rlab || !ws || !ap_sum || !cap) return xmh::fail(XMH_EINVAL, "xmh_gemm_f32_sort_map: null pointer");
@@ -274,6 +275,7 @@ extern "C" int xmh_gemm_f32_sort_map(const float* qB, const float* rB, const uin
 // the same ranking for a distance matrix the caller already holds (dist[Q][R], any float values): ws = Q * R * 16 bytes + 1 KB
 extern "C" int xmh_float_sort_ap(const float* dist, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C, int64_t k, void* ws,
                                  size_t ws_bytes, double* ap_sum, int32_t* cap, xmh_stream_t stream) {
+    XMH_RANGE("xmh_float_sort_ap");
     if (Q <= 0 || R <= 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_float_sort_ap: bad shape");
     if (R >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_float_sort_ap: %lld gallery rows (the payload keeps 31 index bits)", (long long)R);
     if (!dist || !qlab || !rlab || !ws || !ap_sum || !cap) return xmh::fail(XMH_EINVAL, "xmh_float_sort_ap: null pointer");

@@ -289,6 +289,7 @@ void launch_dist(int W, hipStream_t st, const uint32_t* qb, const uint32_t* qz, 
 
 extern "C" int xmh_hamming_dist(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero,
                                 int64_t Q, int64_t R, int K, float* out_f32, uint16_t* out_u16, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_dist");
     if (Q < 0 || R < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_hamming_dist: bad shape");
     if (Q == 0 || R == 0) return XMH_OK;
     if (!qbits || !rbits) return xmh::fail(XMH_EINVAL, "xmh_hamming_dist: null pointer");
@@ -307,6 +308,7 @@ extern "C" int xmh_hamming_dist(const uint32_t* qbits, const uint32_t* qzero, co
 
 extern "C" int xmh_label_sim(const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int C, float* out,
                              xmh_stream_t stream) {
+    XMH_RANGE("xmh_label_sim");
     if (Q < 0 || R < 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_label_sim: bad shape");
     if (Q == 0 || R == 0) return XMH_OK;
     if (!qlab || !rlab || !out) return xmh::fail(XMH_EINVAL, "xmh_label_sim: null pointer");

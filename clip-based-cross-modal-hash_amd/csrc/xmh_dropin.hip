@@ -46,6 +46,7 @@ extern "C" size_t xmh_calc_map_k_ws_bytes(int64_t Q, int64_t R, int K, int C) {
 
 extern "C" int xmh_calc_map_k(const float* qB, const float* rB, const uint32_t* qlab, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C,
                               int64_t k, void* ws, size_t ws_bytes, double* map_host, int32_t* flags_host, xmh_stream_t stream) {
+    XMH_RANGE("xmh_calc_map_k");
     DropinLayout L;
     if (const int rc = dropin_layout(Q, R, K, C, &L)) return rc;
     if (!qB || !rB || !qlab || !rlab || !ws || !map_host || !flags_host) return xmh::fail(XMH_EINVAL, "xmh_calc_map_k: null pointer");

@@ -331,6 +331,7 @@ extern "C" size_t xmh_clip_workspace_bytes(int64_t B, int L, int width, int conv
 extern "C" int xmh_clip_blocks_forward(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
                                        int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
                                        size_t workspace_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_clip_blocks_forward");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!blocks || !x || !workspace || layers < 0 || heads <= 0 || width % heads) return xmh::fail(-22, "xmh_clip_blocks_forward: bad arguments");
@@ -349,6 +350,7 @@ extern "C" size_t xmh_clip_saved_bytes(int64_t B, int L, int width, int layers) 
 extern "C" int xmh_clip_blocks_forward_saved(const xmh_clip_block* blocks, int layers, int width, int heads, float* x, int64_t B, int L,
                                              int causal, const uint8_t* key_padding_mask, int precision, void* workspace,
                                              size_t workspace_bytes, float* saved, size_t saved_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_clip_blocks_forward_saved");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!blocks || !x || !workspace || !saved || layers < 0 || heads <= 0 || width % heads)
@@ -365,6 +367,7 @@ extern "C" int xmh_clip_blocks_forward_saved(const xmh_clip_block* blocks, int l
 
 extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image, int64_t B, int precision, float* out_cls,
                                    float* out_tokens, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_vit_b32_forward (image tower)");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!w || !image || !workspace || (!out_cls && !out_tokens)) return xmh::fail(-22, "xmh_vit_b32_forward: bad arguments");
@@ -407,6 +410,7 @@ extern "C" int xmh_vit_b32_forward(const xmh_vit_weights* w, const float* image,
 extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
                                 int precision, float* out_eos, float* out_tokens, int32_t* eos_index, void* workspace,
                                 size_t workspace_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_text_forward (text tower)");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!w || !ids || !workspace || (!out_eos && !out_tokens)) return xmh::fail(-22, "xmh_text_forward: bad arguments");
@@ -440,6 +444,7 @@ extern "C" int xmh_text_forward(const xmh_text_weights* w, const int64_t* ids, c
 // row-wise; in the attention kernel the keys behind a row are masked either way), so out_eos is bit-identical to the padded call.
 extern "C" int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t* ids, const int32_t* row_offsets, int64_t total_rows, int64_t B,
                                        int L, int precision, float* out_eos, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_text_forward_packed (text tower)");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!w || !ids || !row_offsets || !workspace || !out_eos) return xmh::fail(-22, "xmh_text_forward_packed: bad arguments");
@@ -473,6 +478,7 @@ extern "C" int xmh_text_forward_packed(const xmh_text_weights* w, const int64_t*
 extern "C" int xmh_text_forward_packed_dev(const xmh_text_weights* w, const int64_t* ids, const uint8_t* key_padding_mask, int64_t B, int L,
                                            int precision, float* out_eos, float* out_tokens, void* workspace, size_t workspace_bytes,
                                            xmh_stream_t stream) {
+    XMH_RANGE("xmh_text_forward_packed_dev (text tower)");
     if (int rc = check_precision(precision)) return rc;
     if (precision == kPrecExact) return xmh::fail(-95, "xmh_text_forward_packed_dev: parity or fast mode only");
     if (B == 0) return 0;
@@ -549,6 +555,7 @@ extern "C" size_t xmh_head_workspace_bytes(int64_t B, int E, int precision) {
 
 extern "C" int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t B, int precision, float* probs, uint32_t* bits,
                               const int64_t* row_index, void* workspace, size_t workspace_bytes, xmh_stream_t stream) {
+    XMH_RANGE("xmh_head_dcmht");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!h || !emb || !workspace || (!probs && !bits)) return xmh::fail(-22, "xmh_head_dcmht: bad arguments");
@@ -577,6 +584,7 @@ extern "C" int xmh_head_dcmht(const xmh_dcmht_head* h, const float* emb, int64_t
 extern "C" int xmh_head_dsph(const xmh_linear* fc, const float* emb, int64_t B, int precision, float* out, uint32_t* bits,
                              uint32_t* zero, int32_t* flags, const int64_t* row_index, void* workspace, size_t workspace_bytes,
                              xmh_stream_t stream) {
+    XMH_RANGE("xmh_head_dsph");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!fc || !emb || (!out && !bits)) return xmh::fail(-22, "xmh_head_dsph: bad arguments");
@@ -665,6 +673,7 @@ extern "C" size_t xmh_head_mith_workspace_bytes(int64_t B, int L, int width, int
 extern "C" int xmh_head_mith(const xmh_mith_head* h, const float* cls, const float* tokens, const uint8_t* token_mask, int64_t B, int L,
                              int precision, float* cls_hash, float* tokens_hash, void* workspace, size_t workspace_bytes,
                              xmh_stream_t stream) {
+    XMH_RANGE("xmh_head_mith");
     if (int rc = check_precision(precision)) return rc;
     if (B == 0) return 0;
     if (!h || !cls || !tokens || !cls_hash || !tokens_hash || !workspace || L <= 0) return xmh::fail(-22, "xmh_head_mith: bad arguments");

@@ -179,6 +179,7 @@ __global__ void k_set_double(double* p, double v0, double v1, int n) {
 
 extern "C" int xmh_pair_similarity_loss(const float* a, const float* b, int64_t B, int D, const uint32_t* lab, int C, int cosine,
                                         float max_value, float threshold, double* out2, xmh_stream_t stream) {
+    XMH_RANGE("xmh_pair_similarity_loss");
     if (B <= 0 || D <= 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss: bad shape B=%lld D=%d C=%d", (long long)B, D, C);
     if (!a || !b || !lab || !out2) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss: null pointer");
     if (D > 12288) return xmh::fail(XMH_ENOTSUP, "xmh_pair_similarity_loss: D=%d > 12288 (one row must fit LDS)", D);
@@ -192,6 +193,7 @@ extern "C" int xmh_pair_similarity_loss(const float* a, const float* b, int64_t 
 }
 
 extern "C" int xmh_quant_loss(const float* code, int64_t n, double* out, xmh_stream_t stream) {
+    XMH_RANGE("xmh_quant_loss");
     if (n <= 0) return xmh::fail(XMH_EINVAL, "xmh_quant_loss: empty input");
     if (!code || !out) return xmh::fail(XMH_EINVAL, "xmh_quant_loss: null pointer");
     hipStream_t st = xmh::as_stream(stream);
@@ -206,6 +208,7 @@ extern "C" int xmh_quant_loss(const float* code, int64_t n, double* out, xmh_str
 extern "C" int xmh_pair_similarity_loss_grad(const float* a, const float* b, int64_t B, int D, const uint32_t* lab, int C, int cosine,
                                              float max_value, float threshold, float scale, const float* upstream, float* grad_a,
                                              int accumulate, xmh_stream_t stream) {
+    XMH_RANGE("xmh_pair_similarity_loss_grad");
     if (B <= 0 || D <= 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss_grad: bad shape B=%lld D=%d C=%d", (long long)B, D, C);
     if (!a || !b || !lab || !grad_a) return xmh::fail(XMH_EINVAL, "xmh_pair_similarity_loss_grad: null pointer");
     if (B >= (1ll << 31)) return xmh::fail(XMH_ENOTSUP, "xmh_pair_similarity_loss_grad: B too large");
@@ -220,6 +223,7 @@ extern "C" int xmh_pair_similarity_loss_grad(const float* a, const float* b, int
 
 extern "C" int xmh_quant_loss_grad(const float* code, int64_t n, float scale, const float* upstream, float* grad, int accumulate,
                                    xmh_stream_t stream) {
+    XMH_RANGE("xmh_quant_loss_grad");
     if (n <= 0) return xmh::fail(XMH_EINVAL, "xmh_quant_loss_grad: empty input");
     if (!code || !grad) return xmh::fail(XMH_EINVAL, "xmh_quant_loss_grad: null pointer");
     hipStream_t st = xmh::as_stream(stream);

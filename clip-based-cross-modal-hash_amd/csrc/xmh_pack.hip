@@ -207,6 +207,7 @@ inline int grid_for(int64_t work) {
 
 extern "C" int xmh_pack_sign(const float* codes, int64_t n, int K, const int64_t* row_index, uint32_t* bits,
                              uint32_t* zero, int32_t* flags, xmh_stream_t stream) {
+    XMH_RANGE("xmh_pack_sign");
     if (n < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_pack_sign: bad shape n=%lld K=%d", (long long)n, K);
     if (n == 0) return XMH_OK;
     if (!codes || !bits) return xmh::fail(XMH_EINVAL, "xmh_pack_sign: null pointer");
@@ -235,6 +236,7 @@ extern "C" int xmh_pack_sign(const float* codes, int64_t n, int K, const int64_t
 
 extern "C" int xmh_pack_pair_argmax(const float* probs, int64_t n, int K, const int64_t* row_index, uint32_t* bits,
                                     xmh_stream_t stream) {
+    XMH_RANGE("xmh_pack_pair_argmax");
     if (n < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_pack_pair_argmax: bad shape n=%lld K=%d", (long long)n, K);
     if (n == 0) return XMH_OK;
     if (!probs || !bits) return xmh::fail(XMH_EINVAL, "xmh_pack_pair_argmax: null pointer");
@@ -247,6 +249,7 @@ extern "C" int xmh_pack_pair_argmax(const float* probs, int64_t n, int K, const 
 
 extern "C" int xmh_unpack_pm1(const uint32_t* bits, const uint32_t* zero, int64_t n, int K, float* out,
                               xmh_stream_t stream) {
+    XMH_RANGE("xmh_unpack_pm1");
     if (n < 0 || K <= 0) return xmh::fail(XMH_EINVAL, "xmh_unpack_pm1: bad shape n=%lld K=%d", (long long)n, K);
     if (n == 0) return XMH_OK;
     if (!bits || !out) return xmh::fail(XMH_EINVAL, "xmh_unpack_pm1: null pointer");
@@ -261,6 +264,7 @@ extern "C" int xmh_unpack_pm1(const uint32_t* bits, const uint32_t* zero, int64_
 }
 
 extern "C" int xmh_pack_labels(const void* labels, int dt, int64_t n, int C, uint32_t* lab, xmh_stream_t stream) {
+    XMH_RANGE("xmh_pack_labels");
     if (n < 0 || C <= 0) return xmh::fail(XMH_EINVAL, "xmh_pack_labels: bad shape n=%lld C=%d", (long long)n, C);
     if (n == 0) return XMH_OK;
     if (!labels || !lab) return xmh::fail(XMH_EINVAL, "xmh_pack_labels: null pointer");

@@ -97,6 +97,7 @@ extern "C" int xmh_image_preprocess_u8(const uint8_t* images, int64_t B, int H, 
                                        const int32_t* bounds_h, const int32_t* kk_h, int ksize_h,
                                        const float* mean3_host, const float* std3_host, uint8_t* tmp, uint8_t* resized_u8,
                                        float* out_chw, xmh_stream_t stream) {
+    XMH_RANGE("xmh_image_preprocess_u8");
     if (B < 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return xmh::fail(XMH_EINVAL, "xmh_image_preprocess_u8: bad shape");
     if (B == 0) return XMH_OK;
     if (!images || (!resized_u8 && !out_chw)) return xmh::fail(XMH_EINVAL, "xmh_image_preprocess_u8: null pointer");

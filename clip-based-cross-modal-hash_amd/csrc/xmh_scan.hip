@@ -1510,6 +1510,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
                                 const uint32_t* rbits, const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R,
                                 int K, int C, void* ws, size_t ws_bytes, uint32_t* hist_all, uint32_t* hist_rel,
                                 xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_hist (pass 1)");
     const bool tern = qzero != nullptr;
     xmh_scan_plan p;
     int rc = make_plan(Q, R, K, tern, &p);
@@ -1781,6 +1782,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
                               const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                               size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
                               const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_ap (pass 2)");
     return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, base_all, base_rel, nrel_total, k, ap_sum, cap,
                            nullptr, stream);
 }
@@ -1788,6 +1790,7 @@ extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, cons
 extern "C" int xmh_hamming_map(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
                                const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                                size_t ws_bytes, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_map (pass 2 + mean)");
     if (!map_out) return xmh::fail(XMH_EINVAL, "xmh_hamming_map: null output");
     return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_out,
                            stream);
@@ -1805,6 +1808,7 @@ extern "C" int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qz
                                        const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                                        size_t ws_bytes, const uint32_t* hist_gathered, int world, int rank, int64_t k, double* ap_sum,
                                        int32_t* cap, double* map_partial, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_map_sharded (pass 2)");
     if (!hist_gathered || !map_partial) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded: null pointer");
     if (world <= 0 || rank < 0 || rank >= world) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded: bad world=%d rank=%d", world, rank);
     return hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws, ws_bytes, nullptr, nullptr, nullptr, k, ap_sum, cap, map_partial,
@@ -1812,6 +1816,7 @@ extern "C" int xmh_hamming_map_sharded(const uint32_t* qbits, const uint32_t* qz
 }
 
 extern "C" int xmh_shard_slice_offsets(const uint32_t* totals_slices, int world, int nbuckets, int slice, uint32_t* offsets_out, xmh_stream_t stream) {
+    XMH_RANGE("xmh_shard_slice_offsets");
     if (!totals_slices || !offsets_out) return xmh::fail(XMH_EINVAL, "xmh_shard_slice_offsets: null pointer");
     if (world <= 0 || nbuckets <= 0 || slice <= 0) return xmh::fail(XMH_EINVAL, "xmh_shard_slice_offsets: bad arguments (world=%d nb=%d slice=%d)", world, nbuckets, slice);
     hipLaunchKernelGGL(k_shard_slice_offsets, dim3((unsigned)xmh::ceil_div(slice, 64)), dim3(256), 0, xmh::as_stream(stream),
@@ -1824,6 +1829,7 @@ extern "C" int xmh_hamming_map_sharded_offsets(const uint32_t* qbits, const uint
                                                const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                                                size_t ws_bytes, const uint32_t* offsets, int world, int64_t k, double* ap_sum, int32_t* cap,
                                                double* map_partial, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_map_sharded_offsets (pass 2)");
     if (!offsets || !map_partial) return xmh::fail(XMH_EINVAL, "xmh_hamming_map_sharded_offsets: null pointer");
     xmh_scan_plan p;
     const int rc = make_plan(Q, R, K, qzero != nullptr, &p);
@@ -1834,6 +1840,7 @@ extern "C" int xmh_hamming_map_sharded_offsets(const uint32_t* qbits, const uint
 }
 
 extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_t Q, double* map_out, xmh_stream_t stream) {
+    XMH_RANGE("xmh_map_finalize");
     if (!ap_sum || !cap || !map_out || Q <= 0) return xmh::fail(XMH_EINVAL, "xmh_map_finalize: bad arguments");
     hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, xmh::as_stream(stream), ap_sum, cap, Q, map_out);
     XMH_LAUNCH_CHECK("xmh_map_finalize");
@@ -1842,6 +1849,7 @@ extern "C" int xmh_map_finalize(const double* ap_sum, const int32_t* cap, int64_
 
 extern "C" int xmh_shard_offsets(const uint32_t* hist_gathered, int world, int rank, int64_t Q, int nbuckets, uint32_t* base_all,
                                  uint32_t* base_rel, uint32_t* nrel_total, xmh_stream_t stream) {
+    XMH_RANGE("xmh_shard_offsets");
     if (!hist_gathered || !base_all || !base_rel || !nrel_total) return xmh::fail(XMH_EINVAL, "xmh_shard_offsets: null pointer");
     if (world <= 0 || rank < 0 || rank >= world || Q <= 0 || nbuckets <= 0 || Q >= (1ll << 24))
         return xmh::fail(XMH_EINVAL, "xmh_shard_offsets: bad arguments (world=%d rank=%d Q=%lld nb=%d)", world, rank, (long long)Q, nbuckets);

@@ -1492,6 +1492,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
 #define XMH_FAST(WW)                                                                                                       \
         {                                                                                                                  \
             const dim3 sgrid_(sblocks, fold_pick ? 1u : (unsigned)(xmh::ceil_div(Q, 16) < 4096 ? xmh::ceil_div(Q, 16) : 4096));       \
+            xmh::RangeScope rs_("topk: sample + threshold pick");                                                         \
             if (tern)                                                                                                      \
                 hipLaunchKernelGGL((k_topk_sample<WW, true>), sgrid_, dim3(kThreads), slds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, nb, stride, \
                                    per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
@@ -1500,6 +1501,8 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
                                    per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail, pp, f.bound); \
+            rs_.end();                                                                                                     \
+            XMH_RANGE("topk: streaming filter");                                                                           \
             if (tern) {                                           /* both planes: the per-piece / per-item ternary filters */      \
                 launch_filter_tern<WW>(qbits, qzero, rbits, rzero, pad, Q, R, f, st);                                      \
                 break;                                                                                                     \
@@ -1568,6 +1571,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
 #undef XMH_FAST
         XMH_LAUNCH_CHECK("xmh_hamming_topk fast path");
         {
+            XMH_RANGE("topk: select");
             auto kern = k_topk_select;
             const size_t sel_lds = (size_t)kCandCap * 8 + 1024 * 8 + (size_t)(p.nb > 2048 ? p.nb : 2048) * 4 + 64;
             rc = raise_lds(kern, sel_lds, "xmh_hamming_topk select");
@@ -1578,6 +1582,7 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
         XMH_LAUNCH_CHECK("xmh_hamming_topk select");
         gate = f.fail;                                   // the robust kernels below run only if a query failed
     }
+    XMH_RANGE("topk: robust path (gated on the fail flags)");
     const dim3 grid(p.nblocks, p.nqg);
     const size_t lds = p.L.bytes();
 #define XMH_TOPK_LAUNCH(WW, II)                                                                                        \
@@ -1616,11 +1621,13 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
 
 extern "C" int xmh_hamming_topk(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index, void* ws,
                                 size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_topk");
     return topk_call(qbits, nullptr, rbits, nullptr, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, false);
 }
 
 extern "C" int xmh_hamming_topk_prepared(const uint32_t* qbits, const uint32_t* rbits, int64_t Q, int64_t R, int K, int k, int64_t base_index,
                                          void* ws, size_t ws_bytes, uint16_t* dist, int32_t* idx, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_topk_prepared");
     return topk_call(qbits, nullptr, rbits, nullptr, Q, R, K, k, base_index, ws, ws_bytes, dist, idx, stream, true);
 }
 
@@ -1643,6 +1650,7 @@ extern "C" int xmh_topk_ternary_ws_init(int64_t Q, int64_t R, int K, int k, void
 extern "C" int xmh_hamming_topk_ternary(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbits, const uint32_t* rzero, int64_t Q,
                                         int64_t R, int K, int k, int64_t base_index, void* ws, size_t ws_bytes, int prepared, uint16_t* dist2,
                                         int32_t* idx, xmh_stream_t stream) {
+    XMH_RANGE("xmh_hamming_topk_ternary");
     if (!qzero || !rzero) return xmh::fail(XMH_EINVAL, "xmh_hamming_topk_ternary: needs both zero planes (binary codes: xmh_hamming_topk)");
     return topk_call(qbits, qzero, rbits, rzero, Q, R, K, k, base_index, ws, ws_bytes, dist2, idx, stream, prepared != 0);
 }
@@ -1670,6 +1678,7 @@ extern "C" size_t xmh_topk_record_bytes(int64_t Q, int k) {
 }
 
 extern "C" int xmh_topk_merge_host(const void* gathered_host, int world, int64_t Q, int k, int32_t* dist_out, int32_t* idx_out) {
+    XMH_RANGE("xmh_topk_merge_host");
     if (world <= 0 || world > 4096 || Q < 0 || k <= 0) return xmh::fail(XMH_EINVAL, "xmh_topk_merge_host: bad shape world=%d Q=%lld k=%d", world, (long long)Q, k);
     if (Q == 0) return XMH_OK;
     if (!gathered_host || !dist_out || !idx_out) return xmh::fail(XMH_EINVAL, "xmh_topk_merge_host: null pointer");

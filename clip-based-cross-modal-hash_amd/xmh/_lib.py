@@ -74,6 +74,8 @@ PROTOTYPES = {
     "xmh_version": (i32, []),
     "xmh_last_error": (C.c_char_p, []),
     "xmh_prof_enable": (i32, [i32]),
+    "xmh_range_push": (i32, [C.c_char_p]),
+    "xmh_range_pop": (i32, []),
     "xmh_prof_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
     "xmh_pack_sign": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "xmh_pack_pair_argmax": (i32, [vp, i64, i32, vp, vp, vp]),
@@ -177,8 +179,26 @@ def current_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def prof_enable(on: bool = True) -> None:
+def prof_enable(on=True) -> None:
+    """True / 1: HIP events around the dominant kernels (prof_read); 2: roctx ranges around every phase of the path (a
+    `rocprofv3 --marker-trace` timeline gets phase markers); 3: both; False / 0: off."""
     check(lib.xmh_prof_enable(int(on)), "xmh_prof_enable")
+
+
+class prof_range:
+    """roctx range from the host layer (collectives of the sharded evaluation, the encode loop): ``with prof_range("name"):``.
+    A no-op -- two foreign calls that return at once -- while ranges are off (prof_enable(2))."""
+
+    def __init__(self, name: str):
+        self.name = name.encode()
+
+    def __enter__(self):
+        lib.xmh_range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        lib.xmh_range_pop()
+        return False
 
 
 def prof_read(name: str):

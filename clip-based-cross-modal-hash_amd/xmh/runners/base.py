@@ -24,6 +24,7 @@ import torch
 from torch import distributed as dist
 from torch.utils.data import DataLoader, Sampler
 
+from .. import _lib
 from .. import retrieval as R
 from .. import sharded
 from .. import towers
@@ -275,9 +276,12 @@ class BaseTrainer:
             pending.clear()
             if isinstance(image, list) or image.dtype == torch.uint8:     # raw RGB bytes: the eval transform runs on the GPU
                 image = self._image_transform()(image)       # (dataset/transformer_dataset.py:38-42, Pillow-exact)
-            for name, (image_hash, text_hash) in self.generate_hashes(image, text, kpm).items():
-                self.pack_hash_code(image_hash, bufs[name][0], rows, flags)
-                self.pack_hash_code(text_hash, bufs[name][1], rows, flags)
+            with _lib.prof_range("encode: towers + heads (%d rows)" % rows.shape[0]):
+                hashes = self.generate_hashes(image, text, kpm)
+            with _lib.prof_range("encode: quantise + pack"):
+                for name, (image_hash, text_hash) in hashes.items():
+                    self.pack_hash_code(image_hash, bufs[name][0], rows, flags)
+                    self.pack_hash_code(text_hash, bufs[name][1], rows, flags)
 
         # Host-to-device copies go on their own HIP stream: with pinned loader batches (pin_memory=True) the copy of the next
         # group overlaps the forward of the current one (60 MB of fp32 pixels per 100 images is 2-3 ms of PCIe time against a

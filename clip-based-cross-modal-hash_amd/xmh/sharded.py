@@ -109,6 +109,13 @@ def slice_offsets_reference(totals_slices: torch.Tensor) -> torch.Tensor:
     return torch.cat([rows, last], dim=1).to(torch.int32).contiguous()
 
 
+def _range(name: str):
+    """roctx range around a collective (xmh_range_push / _pop; a no-op unless _lib.prof_enable(2)): the exchange steps show up between
+    the pass-1 and pass-2 ranges of a `rocprofv3 --marker-trace` timeline"""
+    from ._lib import prof_range
+    return prof_range(name)
+
+
 def all_gather_rows(t: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
     """all_gather of row-ragged tensors (rank i contributes counts[i] rows) -> concatenated rows."""
     world = dist.get_world_size(group)
@@ -116,7 +123,8 @@ def all_gather_rows(t: torch.Tensor, counts: Sequence[int], group=None) -> torch
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    with _range("collective: all_gather rows (packed codes)"):
+        dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
@@ -207,22 +215,27 @@ def map_k_sharded(ops, k: Optional[int] = None, group=None, map_only: bool = Fal
             S = qpad // world
             send = t.view(nb, world, S, 2).permute(1, 0, 2, 3).contiguous()      # [world (slice owner), nb, S, 2]
             recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send, group=group)      # [world (shard), nb, S, 2]: every shard's columns of MY slice
+            with _range("collective: all_to_all totals-table query slices"):
+                dist.all_to_all_single(recv, send, group=group)  # [world (shard), nb, S, 2]: every shard's columns of MY slice
             offs = ops.slice_offsets(recv)                       # [world (shard), nb + 1, S, 2]
             back = torch.empty_like(offs)
-            dist.all_to_all_single(back, offs, group=group)      # [world (slice owner), nb + 1, S, 2]: MY rows for every slice
+            with _range("collective: all_to_all offset rows"):
+                dist.all_to_all_single(back, offs, group=group)  # [world (slice owner), nb + 1, S, 2]: MY rows for every slice
             m = ops.map_partial_offsets(k, back)                 # scatter, pass 2, this shard's share of the mean
-            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+            with _range("collective: all_reduce mAP [1] f64"):
+                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
             return m, None, None
         if exchange == "alltoall":
             raise ValueError("map_k_sharded: the all-to-all exchange needs qpad %% world == 0 (qpad=%d, world=%d)" % (qpad, world))
         g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
-            _all_gather_stacked(g, t, group=group)                # [world, nb, qpad, 2]
-        else:
-            dist.all_gather(list(g.unbind(0)), t, group=group)
+        with _range("collective: all_gather totals tables"):
+            if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
+                _all_gather_stacked(g, t, group=group)            # [world, nb, qpad, 2]
+            else:
+                dist.all_gather(list(g.unbind(0)), t, group=group)
         m = ops.map_partial(k, g, rank)                          # offsets, pass 2, this shard's share of the mean
-        dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)    # [1] f64
+        with _range("collective: all_reduce mAP [1] f64"):
+            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)    # [1] f64
         return m, None, None
     ha, hr = ops.histograms()                                    # pass 1 on the local shard
     g = _gather_hist_pair(ha, hr, group)                         # [world, 2, Q, nb]
@@ -417,10 +430,12 @@ def topk_sharded(q, r_shard, k: int, base_index: int, group=None, topk_fn=None, 
         d, i = topk_fn(q, r_shard, k, base_index)
         d_view.copy_(d.to(torch.int16) if d.dtype != torch.int16 else d)
         i_view.copy_(i.to(torch.int32))
-    if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
-        # in place (NCCL / RCCL semantics: the input may be the rank's own slot of the output): rank r's record is already at out[r]
-        assert mine.data_ptr() == out.data_ptr() + dist.get_rank(group) * rec and mine.is_contiguous()
-        _all_gather_stacked(out, mine, group=group)
-    else:
-        dist.all_gather(list(out.unbind(0)), mine.clone(), group=group)
-    return merge_topk_records(out, world, nq, k)
+    with _range("collective: all_gather top-k records"):
+        if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
+            # in place (NCCL / RCCL semantics: the input may be the rank's own slot of the output): rank r's record is already at out[r]
+            assert mine.data_ptr() == out.data_ptr() + dist.get_rank(group) * rec and mine.is_contiguous()
+            _all_gather_stacked(out, mine, group=group)
+        else:
+            dist.all_gather(list(out.unbind(0)), mine.clone(), group=group)
+    with _range("top-k: D2H + host merge"):
+        return merge_topk_records(out, world, nq, k)

@@ -49,6 +49,14 @@ const char* xmh_last_error(void);
  * on the last recorded event of that name and returns the mean launch duration since xmh_prof_enable(1). */
 int xmh_prof_enable(int on);
 int xmh_prof_read(const char* name_host, double* avg_ms_host, int64_t* launches_host);
+/* roctx ranges (SURVEY 5 "Build adds"; round 6).  `on` of xmh_prof_enable is a bit set: 1 = the HIP events above, 2 = roctx ranges
+ * around every phase of the path -- tower forward, head, pack, pass 1, pass 2, the top-k phases, the float route --, so that a
+ * `rocprofv3 --marker-trace --kernel-trace` timeline of valid() (reference runners/base.py:307-357) carries phase markers.  The roctx
+ * library (librocprofiler-sdk-roctx.so, else libroctx64.so) is looked up with dlopen when bit 2 is first asked for (XMH_ENOTSUP if
+ * absent); libxmh.so does not link it.  xmh_range_push / _pop: the same ranges for the host layer above the C ABI (the collectives of
+ * the sharded evaluation, the encode loop); no-ops while ranges are off. */
+int xmh_range_push(const char* name_host);
+int xmh_range_pop(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantisers (a-6).

@@ -650,3 +650,57 @@ def test_runner_topk_two_ranks_sharing_the_gpu_with_zeros_on_one_rank(tmp_path):
             d, i = lists[rank][task]
             assert torch.equal(i.long(), order[:, :15]), (task, rank)
             assert torch.equal(d, val[:, :15]), (task, rank)
+
+
+def test_roctx_ranges_mark_the_phases_of_valid(tmp_path):
+    """VERDICT r5 missing 5 / SURVEY 5 "Build adds": with xmh_prof_enable(2) every phase of valid() pushes a roctx range (tower forward,
+    head, pack, pass 1, pass 2, top-k phases).  The roctx library is interposed by a recorder: LD_PRELOAD of a tiny shared object that
+    logs roctxRangePushA / roctxRangePop, built here with gcc."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "fake_roctx.c"
+    src.write_text(textwrap.dedent('''
+        #include <stdio.h>
+        #include <stdlib.h>
+        static FILE* f;
+        static int depth;
+        static void open_log(void) { if (!f) f = fopen(getenv("XMH_ROCTX_LOG"), "a"); }
+        int roctxRangePushA(const char* m) { open_log(); fprintf(f, "%d push %s\\n", depth, m); fflush(f); return depth++; }
+        int roctxRangePop(void) { open_log(); --depth; fprintf(f, "%d pop\\n", depth); fflush(f); return depth; }
+    '''))
+    so = tmp_path / "librocprofiler-sdk-roctx.so.1"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    log = tmp_path / "roctx.log"
+    code = textwrap.dedent('''
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import pathlib, torch
+        from test_gpu_runner import make_cfg
+        import xmh.models, xmh.runners
+        from xmh import _lib
+        from xmh.common.register import registry
+        t = registry.get_runner_class("MITHTrainer").from_config(cfg=make_cfg(pathlib.Path(%r), "MITH", "MITHTrainer", 64, layers=1), autorun=False)
+        t.valid(0, k=None)                                  # warm: nothing logged while ranges are off
+        _lib.prof_enable(2)
+        t.valid(1, k=None)
+        t.retrieve_topk(5, tasks=("i2t",))
+        _lib.prof_enable(0)
+        t.valid(2, k=None)
+    ''') % (root, os.path.join(root, "clip-based-cross-modal-hash_amd"), os.path.join(root, "tests"), str(tmp_path / "run"))
+    env = dict(os.environ, XMH_ROCTX_LOG=str(log), LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = log.read_text().splitlines()
+    pushes = [ln.split(" push ", 1)[1] for ln in lines if " push " in ln]
+    assert len(pushes) == sum(" pop" in ln for ln in lines) and lines[-1] == "0 pop"       # balanced, closed
+    for must in ("encode: towers + heads", "xmh_vit_b32_forward (image tower)", "xmh_text_forward", "xmh_head_mith", "encode: quantise + pack",
+                 "xmh_pack_sign", "xmh_hamming_hist (pass 1)", "xmh_hamming_map (pass 2 + mean)", "topk: sample + threshold pick",
+                 "topk: streaming filter", "topk: select"):
+        assert any(p.startswith(must) for p in pushes), (must, sorted(set(pushes)))
+    # nesting: the tower entry points sit inside the runner's encode range
+    depth_of = {ln.split(" push ", 1)[1]: int(ln.split(" ", 1)[0]) for ln in lines if " push " in ln}
+    assert depth_of["xmh_head_mith"] >= 1
