@@ -1,0 +1,418 @@
+// Round 6 prototype: where does k_gemm_g16's time go once the main loop is as it is, and what do a register epilogue and a persistent
+// tile loop return?  A/B in one process on the same random operands (ViT-B/32 Linear shapes, fast = one activation plane, parity = two):
+//   MODE 0  the shipped structure: one tile per block, accumulators -> the wave's LDS region -> 16-byte row pieces -> C
+//   MODE 1  one tile per block, REGISTER epilogue: the MFMA operands swapped (D = W_frag x A_frag^T), so a lane holds 4 CONSECUTIVE
+//           COLUMNS of one row of C -- bias / activation / residual / stores work on the accumulators where they are, no LDS round trip
+//   MODE 2  persistent blocks (grid = blocks per CU x CUs, tiles b, b + G, ...): the first k tile of the next output tile is staged under
+//           the last k step of this one, register epilogue after the k loop
+//   MODE 3  persistent + DEFERRED epilogue: the finished accumulators move to a second register set and are stored two fragments per k
+//           step of the NEXT tile's loop -- the C stores of a block no longer arrive as one burst while its matrix pipe idles
+//   MODE 4  MODE 1 without the stores (what the store costs)
+// OUT16: the result goes out as one fp16 plane (what c_fc hands to c_proj in fast mode) instead of fp32 C.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/proto_gemm_persist.hip -o /tmp/pg && /tmp/pg
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <utility>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct GArgs {
+    const _Float16 *A0, *A1;     // A0 = lo plane (or the only one), A1 = hi
+    const _Float16* W;
+    const float* bias;
+    const float* residual;       // may alias C
+    float* C;
+    _Float16* O;                 // fp16 plane out (OUT16)
+    int64_t lda, ldw, ldc, ldo;
+    int M, N, K, gelu;
+};
+
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x)); }
+
+__device__ __forceinline__ void tile_of_id(int nbm, int nbn, int b, int& tm, int& tn) {
+    const int nwg = nbm * nbn;
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    tn = id / nbm;
+    tm = id % nbm;
+    constexpr int kGroupM = 8;
+    const int id2 = tn * nbm + tm;
+    const int per = kGroupM * nbn;
+    const int grp = id2 / per, rem = id2 % per;
+    const int gm0 = grp * kGroupM;
+    const int gsz = nbm - gm0 < kGroupM ? nbm - gm0 : kGroupM;
+    tm = gm0 + rem % gsz;
+    tn = rem / gsz;
+}
+
+template <int BK>
+__device__ __forceinline__ int chunk_swz(int r) {
+    constexpr int CH = BK / 8, RPB = 16 / CH;
+    return (BK == 32 ? -(r / RPB) : r / RPB) & (CH - 1);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int MINB, int MODE, bool OUT16>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void k_gemm(GArgs g) {
+    constexpr int NWAVE = WM * WN;
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr int CH = BK / 8, RPP = 64 / CH;
+    constexpr int ROWB = BK * 2;
+    constexpr int PA = TBM / RPP, PW = TBN / RPP;
+    constexpr int NPIECE = NA * PA + PW;
+    static_assert(NPIECE % NWAVE == 0, "pieces per wave");
+    constexpr int PPW = NPIECE / NWAVE;
+    constexpr int BUFB = NPIECE * 1024;
+    constexpr int MF = 2 * MI, NF = 2 * NJ;
+    constexpr bool PERSIST = MODE == 2 || MODE == 3;
+    constexpr bool SWAP = MODE != 0;                                // register epilogue: a lane holds 4 consecutive columns
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nbm = (g.M + TBM - 1) / TBM, nbn = (g.N + TBN - 1) / TBN;
+    const int ntiles = nbm * nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / WN) * 32 * MI, wn = (wave % WN) * 32 * NJ;
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int swz = chunk_swz<BK>(r16);
+    const int nk = g.K / BK;
+
+    const _Float16* src[PPW];
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = j * NWAVE + wave;
+            const int prow = lane / CH;
+            int r;
+            const _Float16* base;
+            if (p < NA * PA) {
+                r = (p % PA) * RPP + prow;
+                const int rg = m0 + r < g.M ? m0 + r : g.M - 1;
+                base = (p / PA == 0 ? g.A0 : g.A1) + (int64_t)rg * g.lda;
+            } else {
+                const int q = p - NA * PA;
+                r = q * RPP + prow;
+                const int rg = n0 + r < g.N ? n0 + r : g.N - 1;
+                base = g.W + (int64_t)rg * g.ldw;
+            }
+            src[j] = base + ((lane % CH) ^ chunk_swz<BK>(r)) * 8;
+        }
+    };
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = j * NWAVE + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BUFB + p * 1024), 16, 0, 0);
+        }
+    };
+    // register epilogue of ONE 16 x 16 fragment: lane = row r16, columns 4 kc .. 4 kc + 3
+    const float* __restrict__ resid = g.residual;
+    float* __restrict__ cout = g.C;
+    auto emit = [&](const f32x4& v, int row, int col) {
+        if (row >= g.M || col >= g.N) return;
+        const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+        float x0 = v[0] + bv.x, x1 = v[1] + bv.y, x2 = v[2] + bv.z, x3 = v[3] + bv.w;
+        if (g.gelu) { x0 = quick_gelu(x0); x1 = quick_gelu(x1); x2 = quick_gelu(x2); x3 = quick_gelu(x3); }
+        if (resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(resid + (int64_t)row * g.ldc + col);
+            x0 += rr.x; x1 += rr.y; x2 += rr.z; x3 += rr.w;
+        }
+        if (MODE == 4) { asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3)); return; }
+        if (OUT16) {
+            f16x4 h;
+            h[0] = (_Float16)x0; h[1] = (_Float16)x1; h[2] = (_Float16)x2; h[3] = (_Float16)x3;
+            *reinterpret_cast<f16x4*>(g.O + (int64_t)row * g.ldo + col) = h;
+        } else {
+            *reinterpret_cast<float4*>(cout + (int64_t)row * g.ldc + col) = make_float4(x0, x1, x2, x3);
+        }
+    };
+
+    f32x4 acc[MF][NF];
+    f32x4 prev[MODE == 3 ? MF : 1][MODE == 3 ? NF : 1];
+    int prev_m0 = 0, prev_n0 = 0;
+    bool have_prev = false;
+    int step = 0;                                                   // k steps done by this block: picks the LDS buffer
+    constexpr int FPS = 2;                                          // MODE 3: fragments of the previous tile stored per k step
+    constexpr int SPF = 1;                                          // stores per fragment
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int tm, tn;
+    tile_of_id(nbm, nbn, t, tm, tn);
+    set_src(tm * TBM, tn * TBN);
+    stage(0, 0);
+    bool stores_behind_stage = false;
+    for (;;) {
+        const int m0 = tm * TBM, n0 = tn * TBN;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+        const int tnext = PERSIST ? t + (int)gridDim.x : ntiles;
+        int tm2 = 0, tn2 = 0;
+        // one k step; DS >= 0: the step also stores fragments FPS * DS .. of the previous tile (compile-time indices: the fragments stay
+        // in registers; a run-time index cost 40 registers of selects and the second block per CU)
+        auto kstep = [&](int kt, auto ds_tag) {
+            constexpr int DS = decltype(ds_tag)::value;
+            const int buf = step & 1;
+            ++step;
+            if (MODE == 3 && stores_behind_stage) wait_vm<FPS * SPF>();      // the stage of this tile has landed; the stores issued behind it may still fly
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+            else if (tnext < ntiles) {                              // persistent: the first k tile of the next output tile under this step
+                tile_of_id(nbm, nbn, tnext, tm2, tn2);
+                set_src(tm2 * TBM, tn2 * TBN);
+                stage(buf ^ 1, 0);
+            }
+            stores_behind_stage = false;
+            if constexpr (MODE == 3 && DS >= 0) {
+                if (have_prev) {
+#pragma unroll
+                    for (int f = 0; f < FPS; ++f) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int fi = DS * FPS + f;
+                        emit(prev[fi / NF][fi % NF], prev_m0 + wm + 16 * (fi / NF) + r16, prev_n0 + wn + 16 * (fi % NF) + 4 * kc);
+                    }
+                    stores_behind_stage = true;
+                }
+            }
+            const char* bA = lds + buf * BUFB;
+            const char* bW = bA + NA * PA * 1024;
+#pragma unroll
+            for (int s = 0; s < BK / 32; ++s) {
+                const int coff = ((4 * s + kc) ^ swz) * 16;
+                f16x8 b[NF], a[MF], ah[NA == 2 ? MF : 1];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) b[j] = *reinterpret_cast<const f16x8*>(bW + (wn + j * 16 + r16) * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const f16x8*>(bA + (wm + i * 16 + r16) * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (NA == 2) {
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) ah[i] = *reinterpret_cast<const f16x8*>(bA + PA * 1024 + (wm + i * 16 + r16) * ROWB + coff);
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], ah[i], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        constexpr int NDEF = MODE == 3 ? MF * NF / FPS : 0;         // the first NDEF k steps carry the previous tile's stores (nk >= NDEF)
+        int kt = 0;
+        if constexpr (MODE == 3) {
+            [&]<int... U>(std::integer_sequence<int, U...>) { (kstep(U, std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, NDEF>{});
+            kt = NDEF;
+        }
+        for (; kt < nk; ++kt) kstep(kt, std::integral_constant<int, -1>{});
+        if (MODE == 0) {
+            // the shipped epilogue: C layout (lane = column r16, rows 4 kc + e) -> the wave's LDS region -> 16-byte row pieces
+            constexpr int TW = 32 * NJ, RS = TW + 4, LPR = TW / 4, NIT = 32 * LPR / 64;
+            __builtin_amdgcn_s_barrier();
+            float* reg = reinterpret_cast<float*>(lds + wave * (32 * RS * 4));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) reg[(i2 * 16 + 4 * kc + e) * RS + j * 16 + r16] = acc[2 * i + i2][j][e];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int f = it * 64 + lane;
+                    const int r = f / LPR, col = n0 + wn + (f % LPR) * 4;
+                    const float4 v4 = *reinterpret_cast<const float4*>(reg + r * RS + (f % LPR) * 4);
+                    const f32x4 v = {v4.x, v4.y, v4.z, v4.w};
+                    emit(v, m0 + wm + i * 32 + r, col);
+                }
+            }
+        } else if (MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) prev[i][j] = acc[i][j];
+            prev_m0 = m0;
+            prev_n0 = n0;
+            have_prev = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) emit(acc[i][j], m0 + wm + 16 * i + r16, n0 + wn + 16 * j + 4 * kc);
+        }
+        if (tnext >= ntiles) break;
+        t = tnext;
+        tm = tm2;
+        tn = tn2;
+    }
+    if (MODE == 3 && have_prev) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) emit(prev[i][j], prev_m0 + wm + 16 * i + r16, prev_n0 + wn + 16 * j + 4 * kc);
+    }
+}
+
+__global__ void k_fill(_Float16* p, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed * 0x9E3779B9u;
+        x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+        p[i] = (_Float16)(((float)(x & 0xFFFF) / 65536.0f - 0.5f) * scale);
+    }
+}
+__global__ void k_fillf(float* p, int64_t n, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed * 0x9E3779B9u;
+        x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
+        p[i] = ((float)(x & 0xFFFF) / 65536.0f - 0.5f);
+    }
+}
+
+template <int WM, int WN, int MI, int NJ, int NA, int BK, int MINB, int MODE, bool OUT16>
+float run(GArgs g, int iters, std::vector<float>* out, const char* tag) {
+    constexpr int TBM = 32 * MI * WM, TBN = 32 * NJ * WN;
+    constexpr size_t stage_b = (size_t)2 * (NA * TBM + TBN) * BK * 2, epi_b = (size_t)WM * WN * 32 * (32 * NJ + 4) * 4;
+    const size_t ldsb = (MODE == 0 && epi_b > stage_b) ? epi_b : stage_b;
+    auto kern = k_gemm<WM, WN, MI, NJ, NA, BK, MINB, MODE, OUT16>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int ntiles = ((g.M + TBM - 1) / TBM) * ((g.N + TBN - 1) / TBN);
+    int grid = ntiles;
+    if (MODE == 2 || MODE == 3) {
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WM * WN, ldsb));
+        grid = occ * 256;
+        if (grid > ntiles) grid = ntiles;
+        grid = (grid / 8) * 8 ? (grid / 8) * 8 : grid;              // whole XCD rounds: tile b, b + G stay on one XCD
+    }
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), ldsb, 0, g);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), ldsb, 0, g);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    if (out) {
+        out->resize((size_t)64 * g.N);
+        if (OUT16) {
+            std::vector<_Float16> h((size_t)64 * g.N);
+            CK(hipMemcpy(h.data(), g.O + (int64_t)(g.M - 64) * g.ldo, h.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < h.size(); ++i) (*out)[i] = (float)h[i];
+        } else CK(hipMemcpy(out->data(), g.C + (int64_t)(g.M - 64) * g.ldc, out->size() * 4, hipMemcpyDeviceToHost));
+    }
+    printf("  %-44s grid %5d  %8.1f us  %7.0f TF\n", tag, grid, ms * 1e3, 2.0 * g.M * g.N * g.K / (ms * 1e-3) / 1e12);
+    return ms;
+}
+
+static void compare(const std::vector<float>& a, const std::vector<float>& b, const char* what) {
+    double worst = 0;
+    size_t diff = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (a[i] != b[i]) ++diff;
+        const double d = fabs((double)a[i] - (double)b[i]);
+        if (d > worst) worst = d;
+    }
+    printf("    %s: %zu of %zu values differ, max |diff| %.3g\n", what, diff, a.size(), worst);
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 30;
+    struct Shape { const char* name; int M, N, K; bool resid, gelu; };
+    const Shape shapes[] = {{"vit qkv", 5000, 2304, 768, false, false}, {"vit out", 5000, 768, 768, true, false}, {"vit c_fc", 5000, 3072, 768, false, true},
+                            {"vit c_proj", 5000, 768, 3072, true, false}, {"vit qkv", 20000, 2304, 768, false, false}, {"vit out", 20000, 768, 768, true, false},
+                            {"vit c_fc", 20000, 3072, 768, false, true}, {"vit c_proj", 20000, 768, 3072, true, false}};
+    for (const Shape& s : shapes) {
+        const int M = s.M, N = s.N, K = s.K;
+        _Float16 *A0, *A1, *W, *O;
+        float *C, *bias;
+        CK(hipMalloc(&A0, (size_t)M * K * 2)); CK(hipMalloc(&A1, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));
+        CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&O, (size_t)M * N * 2)); CK(hipMalloc(&bias, (size_t)N * 4));
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, A1, (int64_t)M * K, 1u, 1.0f);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, A0, (int64_t)M * K, 2u, 0.0005f);
+        hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, W, (int64_t)N * K, 3u, 0.1f);
+        hipLaunchKernelGGL(k_fillf, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 4u);
+        printf("%s  M=%d N=%d K=%d%s%s\n", s.name, M, N, K, s.resid ? "  (+= residual)" : "", s.gelu ? "  (QuickGELU)" : "");
+        std::vector<float> r0, r1, r2, r3;
+        auto reset = [&] { hipLaunchKernelGGL(k_fillf, dim3(1024), dim3(256), 0, 0, C, (int64_t)M * N, 9u); CK(hipDeviceSynchronize()); };
+        // ---- fast mode: one plane, 128 x 128 as 8 waves of 32 x 64, BK 64, two blocks per CU (the shipped rule) ----
+        {
+            GArgs g{A1, A1, W, bias, nullptr, C, O, K, K, N, N, M, N, K, s.gelu ? 1 : 0};
+            // the residual form reads what it overwrites (x += ...): timing only -- the values drift over the iterations, so the
+            // bit comparison runs without the residual
+            printf(" fast (1 plane), fp32 C out\n");
+            run<4, 2, 1, 2, 1, 64, 2, 0, false>(g, iters, &r0, "shipped: LDS epilogue");
+            run<4, 2, 1, 2, 1, 64, 2, 1, false>(g, iters, &r1, "register epilogue");
+            run<4, 2, 1, 2, 1, 64, 2, 2, false>(g, iters, &r2, "persistent, register epilogue");
+            run<4, 2, 1, 2, 1, 64, 4, 3, false>(g, iters, &r3, "persistent, deferred epilogue");
+            run<4, 2, 1, 2, 1, 64, 2, 4, false>(g, iters, nullptr, "no stores");
+            compare(r0, r1, "register vs LDS epilogue");
+            compare(r0, r2, "persistent vs shipped");
+            compare(r0, r3, "deferred vs shipped");
+            if (s.resid) {
+                g.residual = C;
+                printf(" fast, x += ... (residual = C)\n");
+                run<4, 2, 1, 2, 1, 64, 2, 0, false>(g, iters, nullptr, "shipped: LDS epilogue");
+                run<4, 2, 1, 2, 1, 64, 2, 1, false>(g, iters, nullptr, "register epilogue");
+                run<4, 2, 1, 2, 1, 64, 4, 3, false>(g, iters, nullptr, "persistent, deferred epilogue");
+                g.residual = nullptr;
+            } else {
+                printf(" fast, fp16 plane out\n");
+                run<4, 2, 1, 2, 1, 64, 2, 1, true>(g, iters, &r1, "register epilogue");
+                run<4, 2, 1, 2, 1, 64, 4, 3, true>(g, iters, &r3, "persistent, deferred epilogue");
+                compare(r1, r3, "deferred vs one tile per block");
+            }
+        }
+        // ---- parity mode: two activation planes, 128 x 128 of 4 waves, BK 32, three blocks per CU (the shipped rule), and 128 x 256 of 8 ----
+        {
+            GArgs g{A0, A1, W, bias, nullptr, C, O, K, K, N, N, M, N, K, s.gelu ? 1 : 0};
+            printf(" parity (2 planes), fp32 C out, 128 x 128 / 4 waves / BK 32 / 3 blocks per CU\n");
+            run<2, 2, 2, 2, 2, 32, 3, 0, false>(g, iters, &r0, "shipped: LDS epilogue");
+            run<2, 2, 2, 2, 2, 32, 3, 1, false>(g, iters, &r1, "register epilogue");
+            run<2, 2, 2, 2, 2, 32, 3, 2, false>(g, iters, &r2, "persistent, register epilogue");
+            run<2, 2, 2, 2, 2, 32, 2, 3, false>(g, iters, &r3, "persistent, deferred epilogue (2 per CU)");
+            run<2, 2, 2, 2, 2, 32, 3, 4, false>(g, iters, nullptr, "no stores");
+            compare(r0, r1, "register vs LDS epilogue");
+            compare(r0, r3, "deferred vs shipped");
+            printf(" parity, 128 x 256 / 8 waves / BK 32 / 1 block per CU\n");
+            run<2, 4, 2, 2, 2, 32, 1, 0, false>(g, iters, &r0, "shipped: LDS epilogue");
+            run<2, 4, 2, 2, 2, 32, 1, 1, false>(g, iters, &r1, "register epilogue");
+            run<2, 4, 2, 2, 2, 32, 1, 3, false>(g, iters, &r3, "persistent, deferred epilogue");
+            run<2, 4, 2, 2, 2, 32, 1, 4, false>(g, iters, nullptr, "no stores");
+            compare(r0, r3, "deferred vs shipped");
+            if (s.resid) {
+                g.residual = C;
+                printf(" parity, x += ... (residual = C), 128 x 128\n");
+                run<2, 2, 2, 2, 2, 32, 3, 0, false>(g, iters, nullptr, "shipped: LDS epilogue");
+                run<2, 2, 2, 2, 2, 32, 3, 1, false>(g, iters, nullptr, "register epilogue");
+                run<2, 2, 2, 2, 2, 32, 2, 3, false>(g, iters, nullptr, "persistent, deferred epilogue (2 per CU)");
+            }
+        }
+        (void)reset;
+        CK(hipFree(A0)); CK(hipFree(A1)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(O)); CK(hipFree(bias));
+    }
+    return 0;
+}
