@@ -35,6 +35,8 @@
 // wave at K=64, C=80.  The relevance test is one v_and_or_b32 per label word + one v_min_u32 (inline asm: hipcc does
 // not form them).  Algorithmic HBM bytes per launch: R*(4W+4Lw) + Q*(4W+4Lw) (+ the bucket tables in the workspace).
 #include "xmh_common.h"
+#include <atomic>
+#include <math.h>
 #include <mutex>
 #include <string.h>
 #include <vector>
@@ -730,6 +732,87 @@ __global__ __launch_bounds__(64) void k_probe_lane_order(uint32_t* __restrict__ 
     if (lane == 0) *ok_out = all_ok ? 1u : 0u;
 }
 
+// The same question AT PASS 2'S GEOMETRY AND UNDER LOAD (round 6): one wave per block with k_scan_ap_c's counter
+// array -- 65 bucket rows x 16 queries x 8 bytes, row stride 128 bytes, lane = slot * 16 + query --, five such waves per SIMD like
+// the product launch, eight returning 64-bit adds {1, -relevant} in flight before a counted wait, and every fifth block an MFMA loop
+// instead, so that probing waves share their SIMDs with matrix waves as pass 2 shares the chip with nothing less busy.  A few
+// hundred million adds in all -- the size of the headline evaluation -- in a fraction of a millisecond, once per device and process.
+// The check needs no model of the counters' history: the lanes of one instruction that hit the same cell must have been served in
+// ascending slot order, i.e. a lane's return = the lowest such lane's return + {lower lanes of the cell, - relevant lower lanes}; a
+// shadow array (one plain LDS update per cell and instruction) must equal the counters at the end.  `fault` (XMH_SCAN_PROBE_FAULT,
+// the test hook) makes the expectation that of a device serving the lanes in DESCENDING order, which no device does: the probe then
+// fails exactly as it would on hardware with another order.
+constexpr int kProbeRows = 65, kProbeRounds = 96;
+__global__ __launch_bounds__(64) void k_probe_lane_order_load(uint32_t* __restrict__ bad_out, int fault, float* __restrict__ sink) {
+    __shared__ unsigned long long cnt[kProbeRows * 16];
+    __shared__ unsigned long long shadow[kProbeRows * 16];
+    const int lane = threadIdx.x;
+    if (blockIdx.x % 5 == 4) {                                   // a matrix wave beside the probing ones
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+        v8h x, y;
+        for (int i = 0; i < 8; ++i) { x[i] = (_Float16)(0.001f * (float)(lane + i)); y[i] = (_Float16)(0.002f * (float)(lane ^ i)); }
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < kProbeRounds * 24; ++it) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, acc, 0, 0, 0);
+        if (acc[0] == 12345.678f) sink[lane] = acc[1];           // (never: keeps the loop)
+        return;
+    }
+    const int ql = lane & 15, slot = lane >> 4;
+    for (int e = lane; e < kProbeRows * 16; e += 64) {
+        cnt[e] = (unsigned long long)(0x4b000000u + 3u * e) | ((unsigned long long)(0x4b7fffffu - 5u * e) << 32);      // float-bit counters as pass 2 starts them
+        shadow[e] = cnt[e];
+    }
+    __syncthreads();
+    const uint32_t cntbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)cnt + ql * 8;
+    uint32_t bad = 0;
+    uint32_t h = 0x9E3779B9u * (blockIdx.x + 1) + 0x85ebca6bu * (uint32_t)lane;
+    for (int round = 0; round < kProbeRounds; ++round) {
+        uint32_t d[8], m[8];
+        unsigned long long old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+            // few distinct rows per instruction: the four slots of a query collide often, in every pattern
+            d[u] = ((uint32_t)(round * 8 + u) * 7u + ((h >> 9) % 3u) * 11u) % (uint32_t)kProbeRows;
+            m[u] = (h & 0x70u) ? 0u : ~0u;                        // about one lane in eight "relevant"
+            const uint32_t addr = cntbase + d[u] * 128u;
+            const unsigned long long inc = 1ull | ((unsigned long long)m[u] << 32);
+            asm volatile("ds_add_rtn_u64 %0, %1, %2" : "=v"(old[u]) : "v"(addr), "v"(inc) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // the other three slots of this query, same instruction
+            uint32_t before = 0, before_rel = 0, group = 0, group_rel = 0;
+            unsigned long long first = old[u];
+            int first_slot = slot;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int src = s2 * 16 + ql;
+                const uint32_t d2 = (uint32_t)__shfl((int)d[u], src, 64), m2 = (uint32_t)__shfl((int)m[u], src, 64);
+                const unsigned long long o2 = ((unsigned long long)(uint32_t)__shfl((int)(old[u] >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)old[u], src, 64);
+                if (d2 != d[u]) continue;
+                ++group;
+                group_rel += m2 & 1u;
+                const bool lower = fault ? s2 > slot : s2 < slot;     // the order this device is expected to serve the lanes in
+                if (lower) { ++before; before_rel += m2 & 1u; }
+                const bool firster = fault ? s2 > first_slot : s2 < first_slot;
+                if (firster) { first = o2; first_slot = s2; }
+            }
+            const uint32_t want_lo = (uint32_t)first + before, want_hi = (uint32_t)(first >> 32) - before_rel;
+            if ((uint32_t)old[u] != want_lo || (uint32_t)(old[u] >> 32) != want_hi) bad = 1;
+            if (first_slot == slot) {                             // one lane per cell and instruction keeps the books
+                const unsigned long long sv = shadow[d[u] * 16 + ql];
+                shadow[d[u] * 16 + ql] = (unsigned long long)((uint32_t)sv + group) | ((unsigned long long)((uint32_t)(sv >> 32) - group_rel) << 32);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < kProbeRows * 16; e += 64)
+        if (cnt[e] != shadow[e]) bad = 1;
+    if (__any(bad != 0) && lane == 0) atomicOr(bad_out, 1u);
+}
+
 // sharded evaluation: the all-gathered per-shard bucket histograms hist_g[world][2][Q][nb] (plane 0 = all
 // items, plane 1 = relevant) -> the rank offsets pass 2 starts from on shard `rank`:
 //   base[q][d] = (# items in buckets < d on ANY shard) + (# items in bucket d on shards < rank);  nrel[q] = all relevant.
@@ -1184,22 +1267,40 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
 
 // 1 if same-address returning LDS adds of one instruction come back in ascending lane order on this device (probed once
 // per process with a 1-wave kernel and one blocking copy), 0 otherwise or when XMH_SCAN_MASKED is set
+static thread_local bool g_force_masked = false;      // xmh_scan_verify: the re-derivation runs the kernels that do not rely on the lane order
 int lane_order_ok(hipStream_t st) {
     static int cached[64];
     static bool have[64];
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (g_force_masked) return 0;
     if (getenv("XMH_SCAN_MASKED") != nullptr) return 0;           // read per call: the self-check test runs both paths in one process
+    std::lock_guard<std::mutex> lock(mu);
     if (have[dev]) return cached[dev];
     int ok = 0;
     {
+        // per DEVICE (not per process: a process may drive several), two probes: one wave alone, every counter geometry; then pass 2's own
+        // geometry under load beside matrix waves (k_probe_lane_order_load).  Both must hold.
+        const char* fe = getenv("XMH_SCAN_PROBE_FAULT");          // test hook, read once per device: expect an order no device serves
+        const int fault = fe && atoi(fe) != 0;
         uint32_t* flag = nullptr;
-        if (hipMalloc(&flag, 4) == hipSuccess) {
-            uint32_t h = 0;
-            hipLaunchKernelGGL(k_probe_lane_order, dim3(1), dim3(64), 0, st, flag);
-            if (hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) ok = h == 1u;
-            (void)hipFree(flag);
+        float* sink = nullptr;
+        if (hipMalloc(&flag, 8) == hipSuccess && hipMalloc(&sink, 256) == hipSuccess) {
+            uint32_t h[2] = {0, 1};
+            int cus = xmh::device_cu_count();
+            if (hipMemsetAsync(flag, 0, 8, st) == hipSuccess) {
+                hipLaunchKernelGGL(k_probe_lane_order, dim3(1), dim3(64), 0, st, flag);
+                hipLaunchKernelGGL(k_probe_lane_order_load, dim3((unsigned)(cus * 25)), dim3(64), 0, st, flag + 1, fault, sink);
+                if (hipGetLastError() == hipSuccess && hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                    ok = h[0] == 1u && h[1] == 0u;
+            }
         }
+        if (flag) (void)hipFree(flag);
+        if (sink) (void)hipFree(sink);
+        if (!ok)
+            fprintf(stderr, "xmh: the lane-order probe FAILED on device %d%s: same-address returning LDS adds are not served in lane order here; "
+                            "pass 2 runs the masked kernels (about 2x slower, same results).\n", dev, fault ? " (XMH_SCAN_PROBE_FAULT set: forced)" : "");
     }
     cached[dev] = ok;
     have[dev] = true;
@@ -1580,11 +1681,72 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
 }
 
 namespace {
+// ---- xmh_scan_verify: re-derive an evaluation with the kernels that do not rely on the lane order (round 6) ----------------------------
+// Debug mode, off by default.  While on, every UNSHARDED xmh_hamming_ap / xmh_hamming_map call is followed by a second evaluation of the
+// same inputs in a scratch workspace with the masked VALU kernels (no returning-atomic lane order, no hand-scheduled MFMA statement),
+// and the per-query AP sums and divisors are compared on the host: divisors bit for bit, sums to float rounding (the two families chunk
+// the gallery differently, so pass 2's per-chunk fp32 partial sums add in another order; a wrong rank moves a sum by >= 1 / R relative).
+// Synchronises the stream -- a diagnostic for a new device / compiler, not something to leave on.
+static std::atomic<int> g_verify{0};
+static thread_local bool g_in_verify = false;
+constexpr int XMH_EVERIFY_CODE = -74;                 // EBADMSG: the two derivations disagree
+
 int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
                     const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
                     size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
                     const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream,
-                    const uint32_t* hist_g = nullptr, int world = 0, int rank = 0) {
+                    const uint32_t* hist_g = nullptr, int world = 0, int rank = 0);
+
+int verify_against_masked(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rzero,
+                          const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, int64_t k, const double* ap_sum, const int32_t* cap,
+                          xmh_stream_t stream) {
+    hipStream_t st = xmh::as_stream(stream);
+    std::vector<double> a1((size_t)Q), a0((size_t)Q);
+    std::vector<int32_t> c1((size_t)Q), c0((size_t)Q);
+    XMH_HIP(hipMemcpyAsync(a1.data(), ap_sum, (size_t)Q * 8, hipMemcpyDeviceToHost, st));
+    XMH_HIP(hipMemcpyAsync(c1.data(), cap, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+    XMH_HIP(hipStreamSynchronize(st));
+    struct Restore {
+        int r2; bool fm;
+        ~Restore() { g_r2_force = r2; g_force_masked = fm; g_in_verify = false; }
+    } restore{g_r2_force, g_force_masked};
+    g_in_verify = true;
+    g_force_masked = true;
+    g_r2_force = 0;                                       // VALU pass 1 too
+    xmh_scan_plan p;
+    if (const int rc = xmh_scan_plan_make(Q, R, K, qzero != nullptr, &p)) return rc;
+    const size_t small = xmh_scan_ws_bytes_nocache(Q, R, K, qzero != nullptr);      // without a pair cache: the re-derivation evaluates the pairs from the codes
+    DevBuf ws2, ap2, cap2;
+    if (small == 0 || !ws2.alloc(small) || !ap2.alloc((size_t)Q * 8) || !cap2.alloc((size_t)Q * 4))
+        return xmh::fail(XMH_ENOMEM, "xmh_scan_verify: no room for the second evaluation (%zu bytes)", small);
+    if (const int rc = xmh_hamming_hist(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws2.p, small, nullptr, nullptr, stream)) return rc;
+    if (const int rc = hamming_ap_impl(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, ws2.p, small, nullptr, nullptr, nullptr, k, ap2.as<double>(),
+                                       cap2.as<int32_t>(), nullptr, stream))
+        return rc;
+    XMH_HIP(hipMemcpyAsync(a0.data(), ap2.p, (size_t)Q * 8, hipMemcpyDeviceToHost, st));
+    XMH_HIP(hipMemcpyAsync(c0.data(), cap2.p, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+    XMH_HIP(hipStreamSynchronize(st));
+    if (const char* fe = getenv("XMH_SCAN_VERIFY_FAULT")) {   // test hook: pretend the fast derivation got one query wrong
+        const int64_t at = atoll(fe) % Q;
+        a1[(size_t)at] *= 1.0 + 1e-3;
+    }
+    int64_t bad = -1, nbad = 0;
+    for (int64_t i = 0; i < Q; ++i) {
+        const bool same = c1[(size_t)i] == c0[(size_t)i] && fabs(a1[(size_t)i] - a0[(size_t)i]) <= 4e-6 * fabs(a0[(size_t)i]) + 1e-9;
+        if (!same) { if (bad < 0) bad = i; ++nbad; }
+    }
+    if (nbad)
+        return xmh::fail(XMH_EVERIFY_CODE, "xmh_scan_verify: %lld of %lld queries differ between the lane-order kernels and the masked re-derivation "
+                         "(first: query %lld, AP sum %.9g vs %.9g, divisor %d vs %d)", (long long)nbad, (long long)Q, (long long)bad, a1[(size_t)bad], a0[(size_t)bad],
+                         c1[(size_t)bad], c0[(size_t)bad]);
+    return XMH_OK;
+}
+
+int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
+                    const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,
+                    size_t ws_bytes, const uint32_t* base_all, const uint32_t* base_rel,
+                    const uint32_t* nrel_total, int64_t k, double* ap_sum, int32_t* cap, double* map_out, xmh_stream_t stream,
+                    const uint32_t* hist_g, int world, int rank) {
     const bool tern = qzero != nullptr;
     xmh_scan_plan p;
     int rc = make_plan(Q, R, K, tern, &p);
@@ -1765,18 +1927,25 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         hipLaunchKernelGGL(k_ap_reduce_map, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, (const uint32_t*)cap_ws, kcap,
                            cap, ap_sum, reinterpret_cast<double*>(base + L.gate + 256), nrel_max + 1, map_out);
         XMH_LAUNCH_CHECK("xmh_hamming_map reduce+finalize");
-        return XMH_OK;
+    } else {
+        hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum,
+                           sharded ? (const uint32_t*)nullptr : (const uint32_t*)cap_ws, kcap, cap);
+        XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
+        if (map_out) {
+            hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);
+            XMH_LAUNCH_CHECK("xmh_hamming_map finalize");
+        }
     }
-    hipLaunchKernelGGL(k_ap_reduce, dim3(nred), dim3(256), 0, st, ap_part, (int)Q, (int)p.qpad, (int)p.nchunk, ap_sum,
-                       sharded ? (const uint32_t*)nullptr : (const uint32_t*)cap_ws, kcap, cap);
-    XMH_LAUNCH_CHECK("xmh_hamming_ap reduce");
-    if (map_out) {
-        hipLaunchKernelGGL(k_map_finalize, dim3(1), dim3(256), 0, st, (const double*)ap_sum, (const int32_t*)cap, Q, map_out);
-        XMH_LAUNCH_CHECK("xmh_hamming_map finalize");
-    }
+    if (g_verify.load(std::memory_order_relaxed) && !g_in_verify && !sharded)
+        return verify_against_masked(qbits, qzero, qlab, rbits, rzero, rlab, Q, R, K, C, k, ap_sum, cap, stream);
     return XMH_OK;
 }
 }  // namespace
+
+extern "C" int xmh_scan_verify(int on) {
+    g_verify.store(on != 0 ? 1 : 0, std::memory_order_relaxed);
+    return XMH_OK;
+}
 
 extern "C" int xmh_hamming_ap(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* qlab, const uint32_t* rbits,
                               const uint32_t* rzero, const uint32_t* rlab, int64_t Q, int64_t R, int K, int C, void* ws,

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "xmh_prof_enable": (i32, [i32]),
     "xmh_range_push": (i32, [C.c_char_p]),
     "xmh_range_pop": (i32, []),
+    "xmh_scan_verify": (i32, [i32]),
     "xmh_prof_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
     "xmh_pack_sign": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "xmh_pack_pair_argmax": (i32, [vp, i64, i32, vp, vp, vp]),
@@ -183,6 +184,12 @@ def prof_enable(on=True) -> None:
     """True / 1: HIP events around the dominant kernels (prof_read); 2: roctx ranges around every phase of the path (a
     `rocprofv3 --marker-trace` timeline gets phase markers); 3: both; False / 0: off."""
     check(lib.xmh_prof_enable(int(on)), "xmh_prof_enable")
+
+
+def scan_verify(on: bool = True) -> None:
+    """debug mode: every unsharded ranking call is re-derived with the masked VALU kernels and compared (xmh_scan_verify); a
+    disagreement raises RuntimeError from the call.  About 3x the cost of an evaluation plus a stream synchronisation."""
+    check(lib.xmh_scan_verify(int(bool(on))), "xmh_scan_verify")
 
 
 class prof_range:

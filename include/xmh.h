@@ -57,6 +57,14 @@ int xmh_prof_read(const char* name_host, double* avg_ms_host, int64_t* launches_
  * the sharded evaluation, the encode loop); no-ops while ranges are off. */
 int xmh_range_push(const char* name_host);
 int xmh_range_pop(void);
+/* Debug mode for a new device / compiler (round 6).  The fast ranking kernels rely on two things no ISA document promises: same-address
+ * lanes of one returning LDS add are served in lane order (probed per device: one wave alone, then pass 2's geometry under load beside
+ * matrix waves), and hand-kept hazards around inline MFMA statements (a self-check scan per device).  While xmh_scan_verify(1) is on,
+ * every UNSHARDED xmh_hamming_ap / xmh_hamming_map / xmh_calc_map_k is followed by a second derivation of the same evaluation with the
+ * masked VALU kernels, which rely on neither; divisors must agree bit for bit and the per-query AP sums to float rounding, else the
+ * call returns -74 with the first differing query in xmh_last_error().  Costs about three evaluations and a stream synchronisation
+ * per call. */
+int xmh_scan_verify(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantisers (a-6).

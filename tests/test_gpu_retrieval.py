@@ -1848,3 +1848,82 @@ def test_calc_map_k_argument_checks(cu):
         cu.calc_map_k(qB, rB, qL, rL[:, :20])
     with pytest.raises(ValueError):
         cu.calc_map_k(qB, rB[:600], qL, rL)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the lane-order assumption, hardened
+# ------------------------------------------------------------------------------------------------
+_PROBE_CHILD = r'''
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import bench
+from xmh.common import calc_utils as cu
+qB, qL, rB, rL = bench.synth(5000, 117218, 64, 80, seed=1814, p=0.04)
+dq, dr, dql, drl = qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()
+full = float(cu.calc_map_k(dq, dr, dql, drl))
+sub = float(cu.calc_map_k(dq[:48], dr, dql[:48], drl))
+k50 = float(cu.calc_map_k(dq[:48], dr, dql[:48], drl, 50))
+print(json.dumps({"full": full, "sub": sub, "k50": k50}))
+'''
+
+
+def test_lane_order_probe_forced_to_fail_engages_the_fallback_at_full_shape():
+    """XMH_SCAN_PROBE_FAULT makes the per-device probe (one wave alone + pass 2's geometry under load beside matrix waves) expect an order
+    the hardware does not serve: it must fail, say so, and the whole configs[1] evaluation (Q 5000 x R 117 218 x 64 bit) must then run on
+    the masked kernels with the same result -- against the unforced run and against the oracle on a query subsample."""
+    import json
+    import subprocess
+    import sys
+    code = _PROBE_CHILD % (ROOT, os.path.join(ROOT, "clip-based-cross-modal-hash_amd"))
+    runs = {}
+    for fault in ("0", "1"):
+        env = dict(os.environ, XMH_SCAN_PROBE_FAULT=fault)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[fault] = (json.loads(r.stdout.strip().splitlines()[-1]), r.stderr)
+    assert "lane-order probe FAILED" not in runs["0"][1]                       # the real probe holds on this device, at load
+    assert "lane-order probe FAILED" in runs["1"][1] and "forced" in runs["1"][1]
+    for key in ("full", "sub", "k50"):
+        assert abs(runs["0"][0][key] - runs["1"][0][key]) < 2e-7, (key, runs["0"][0], runs["1"][0])
+    sys.path.insert(0, ROOT)
+    import bench
+    qB, qL, rB, rL = bench.synth(5000, 117218, 64, 80, seed=1814, p=0.04)
+    want = float(_orc().map_k(qB[:48], rB, qL[:48], rL, stable=True))
+    assert abs(runs["1"][0]["sub"] - want) < MAP_TOL and abs(runs["0"][0]["sub"] - want) < MAP_TOL
+
+
+@pytest.mark.parametrize("K", [16, 64, 128, 256])
+def test_scan_verify_mode_rederives_every_evaluation(cu, K, monkeypatch):
+    """xmh_scan_verify(1): each unsharded evaluation is derived a second time by the masked VALU kernels and compared on the host; a
+    planted disagreement (XMH_SCAN_VERIFY_FAULT = the query to spoil) surfaces as an error from the call"""
+    from xmh import _lib
+    orc = _orc()
+    qB, rB, qL, rL = _synth(300, 20000, K, 80, seed=40 + K)
+    want = float(orc.map_k(qB[:40], rB, qL[:40], rL, stable=True))
+    _lib.scan_verify(True)
+    try:
+        assert abs(float(cu.calc_map_k(qB[:40].cuda(), rB.cuda(), qL[:40].cuda(), rL.cuda())) - want) < MAP_TOL
+        float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), 100))
+        monkeypatch.setenv("XMH_SCAN_VERIFY_FAULT", "7")
+        with pytest.raises(RuntimeError, match="xmh_scan_verify"):
+            cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda())
+        monkeypatch.delenv("XMH_SCAN_VERIFY_FAULT")
+        float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))
+    finally:
+        _lib.scan_verify(False)
+
+
+def test_scan_verify_mode_at_the_headline_shape(cu):
+    import sys
+    from xmh import _lib
+    sys.path.insert(0, ROOT)
+    import bench
+    qB, qL, rB, rL = bench.synth(5000, 117218, 64, 80, seed=1814, p=0.04)
+    dq, dr, dql, drl = qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()
+    plain = float(cu.calc_map_k(dq, dr, dql, drl))
+    _lib.scan_verify(True)
+    try:
+        assert float(cu.calc_map_k(dq, dr, dql, drl)) == plain                 # the verified call returns the fast derivation's value
+    finally:
+        _lib.scan_verify(False)
