@@ -1541,7 +1541,8 @@ def test_float_similarities_and_float_code_fallback(cu):
 @pytest.mark.parametrize("K", [512, 2048, 96])
 def test_long_and_odd_code_lengths_distance(xr, cu, K):
     """TwDH-style long codes (up to 2048 bits) and a non-power-of-two word count go through the generic
-    distance kernel; the ranking scan reports what it does not support instead of failing silently."""
+    distance kernel; what the bit-packed scan has no kernel for (4096 bits) is evaluated on the float route (round 6: the drop-in never
+    refuses what the reference evaluates), while the scan's own C entry still reports the limit."""
     orc = _orc()
     gen = torch.Generator().manual_seed(K)
     qB, rB = torch.randn(9, K, generator=gen).sign(), torch.randn(301, K, generator=gen).sign()
@@ -1566,8 +1567,11 @@ def test_long_and_odd_code_lengths_distance(xr, cu, K):
         order = np.argsort(full * 1000 + np.arange(301)[None, :], axis=1, kind="stable")[:, :10]
         assert np.array_equal(i.cpu().numpy(), order) and np.array_equal(d.cpu().numpy().view(np.uint16), np.take_along_axis(full, order, 1).astype(np.uint16))
     qB4, rB4 = torch.randn(9, 4096, generator=gen).sign(), torch.randn(40, 4096, generator=gen).sign()
+    L4 = torch.ones(40, 3, dtype=torch.int64)
+    got = cu.calc_map_k(qB4.cuda(), rB4.cuda(), L.cuda(), L4.cuda())
+    assert abs(float(got) - float(orc.map_k(qB4, rB4, L, L4, stable=True))) < MAP_TOL
     with pytest.raises(RuntimeError, match="at most 2048"):
-        cu.calc_map_k(qB4.cuda(), rB4.cuda(), L.cuda(), torch.ones(40, 3, dtype=torch.int64).cuda())
+        xr.scan_plan(9, 40, 4096, False)
 
 
 @pytest.mark.parametrize("Q,R,K,C", [(21, 3000, 512, 24), (9, 2500, 1024, 80), (12, 4100, 2048, 21)])
