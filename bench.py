@@ -448,6 +448,11 @@ def main():
             out["topk_structured_codes"] = bench_topk.measure_structured()
         except Exception as exc:
             out["topk_structured_codes"] = {"error": repr(exc)}
+        try:
+            out["topk_ternary"] = bench_topk.measure_ternary()
+        except Exception as exc:
+            out["topk_ternary"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
         for key, fn in (("topk_q5000_10M_256bit", bench_topk.measure_many_queries), ("topk_infinity_cache_defeated", bench_topk.measure_cache_defeat)):
             try:
                 out[key] = fn()
@@ -466,6 +471,28 @@ def main():
         out["boundary_inclusive"] = {"what": "xmh.common.calc_utils.calc_map_k on host fp32 codes / int64 labels (PCIe H2D + pack + scan + D2H)",
                                      "ms_per_call": t_host * 1e3, "pairs_per_s": Q * Rn / t_host, "mAP": float(m_host)}
     if rank == 0 and world == 1 and not use_dist and not args.no_extra_configs:
+        # round 6: calc_map_k on un-quantised float "codes" (UMoED-style tanh outputs, reference runners/UMoED/runner.py:162-186) -- the
+        # reference's own route, fp32 GEMM + one stable sort per query (xmh_gemm_f32_sort_map), Q 500 x R at the COCO shape
+        try:
+            from xmh.common import calc_utils as cu2
+            import xmh.dense as dense2
+            dense2._warned_float = True
+            gq = torch.Generator().manual_seed(5)
+            fq, fr = torch.tanh(torch.randn(500, K, generator=gq)).cuda(), torch.tanh(torch.randn(Rn, K, generator=gq)).cuda()
+            fql, frl = qL[:500].cuda(), rL.cuda()
+            cu2.calc_map_k(fq, fr, fql, frl)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                mf = cu2.calc_map_k(fq, fr, fql, frl)
+            tf = (time.perf_counter() - t0) / 3
+            out["float_route"] = {"workload": "calc_map_k on tanh float codes, Q=500 x R=%d x %d: fp32 GEMM + segmented radix sort per query + AP pass" % (Rn, K),
+                                  "ms_per_call": tf * 1e3, "pairs_per_s": 500 * Rn / tf, "mAP": float(mf)}
+            del fq, fr
+            cu2.release_scan_workspace()
+        except Exception as exc:
+            out["float_route"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
         # SURVEY 8 rows a-1 / a-5 as matrices (calc_hammingDist / calc_label_sim, 2000 x R floats): write-bound, against torch's fill_
         try:
             qs, qls = R.PackedCodes(q.bits[:2000].contiguous(), None, K), ql[:2000].contiguous()

@@ -48,6 +48,10 @@ def _summary(out):
                       ("topk_q1_64bit", "roofline_hbm_regime_64bit"), ("topk_q1_32bit", "roofline_hbm_regime_32bit")):
         if key in out:
             s[name] = _pick(out[key], ("frac", "achieved", "whole_call_GBps", "whole_call_ms", "error"))
+    if isinstance(out.get("topk_ternary"), dict):
+        s["topk_q1_ternary"] = _pick(out["topk_ternary"], ("whole_call_ms", "whole_call_GBps", "filter_GBps", "error"))
+    if isinstance(out.get("float_route"), dict):
+        s["float_map_q500"] = _pick(out["float_route"], ("ms_per_call", "pairs_per_s", "error"))
     cd = out.get("topk_infinity_cache_defeated", {})
     for qn in ("Q1", "Q8", "Q64"):
         legs = cd.get(qn) if isinstance(cd, dict) else None
@@ -58,9 +62,11 @@ def _summary(out):
         s["valid_e2e"] = _pick(out["valid_e2e"], ("valid_seconds", "encode_seconds", "retrieve_seconds", "error"))
     e = out.get("encode")
     if isinstance(e, dict):
-        s["encode"] = _pick(e, ("images_per_s_f32", "captions_per_s_f32", "images_per_s_f16", "gemm_tflops_f32", "gemm_tflops_f16", "error"))
+        s["encode"] = _pick(e, ("images_per_s_f32", "captions_per_s_f32", "images_per_s_f16", "images_gemm_tflops_f32", "images_gemm_tflops_f16",
+                                "gemm_frac_of_fp16_peak_f32", "gemm_frac_of_fp16_peak_f16", "error"))
         if isinstance(e.get("fused_batches"), dict):
-            s["encode_b400"] = _pick(e["fused_batches"], ("images_per_s_f32", "images_per_s_f16", "gemm_tflops_f32", "gemm_tflops_f16"))
+            s["encode_b400"] = _pick(e["fused_batches"], ("images_per_s_f32", "images_per_s_f16", "images_gemm_tflops_f32", "images_gemm_tflops_f16",
+                                                          "gemm_frac_of_fp16_peak_f32", "gemm_frac_of_fp16_peak_f16"))
     if isinstance(out.get("encode_mith_b400"), dict):
         s["encode_mith_b400"] = _pick(out["encode_mith_b400"], ("images_per_s", "captions_per_s", "error"))
     if isinstance(out.get("encode_mith"), dict):

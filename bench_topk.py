@@ -159,6 +159,53 @@ def _robust_launches(filter_launches):
         return None
 
 
+def measure_ternary(R=10_000_000, K=256, Q=1, k=100, iters=20, p_zero=0.02):
+    """round 6: the same call over TERNARY codes (sign_() left exact zeros: reference runners/base.py:407-410) -- two planes per item, so
+    twice the bytes (640 MB); distances in half units.  Checked against the binary call on the zero-free subset property: every list is
+    ascending in (distance, index) with indices in range."""
+    from xmh import _lib
+    from xmh import retrieval as X
+    W = (K + 31) // 32
+    g = torch.Generator(device="cuda").manual_seed(1815)
+    q, r = _codes("iid", R, K, Q)
+    def plane(n):
+        z = torch.zeros(n, W, dtype=torch.int32, device="cuda")
+        for b in range(2):                                   # a few zero bits per word: AND of random words thins them out
+            m = torch.randint(-2**31, 2**31 - 1, (n, W), dtype=torch.int32, device="cuda", generator=g)
+            for _ in range(5):
+                m &= torch.randint(-2**31, 2**31 - 1, (n, W), dtype=torch.int32, device="cuda", generator=g)
+            z |= m
+        return z
+    qz, rz = plane(Q), plane(R)
+    qt = X.PackedCodes(q.bits & ~qz, qz, K)                  # a zero element has its sign bit clear
+    rt = X.PackedCodes(r.bits & ~rz, rz, K)
+    ws = X.TopkWorkspace(Q, R, K, k, "cuda", ternary=True)
+    for _ in range(3):
+        d, i = X.hamming_topk(qt, rt, k, workspace=ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        d, i = X.hamming_topk(qt, rt, k, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    t_call = e0.elapsed_time(e1) / iters * 1e-3
+    _lib.prof_enable(True)
+    for _ in range(iters):
+        X.hamming_topk(qt, rt, k, workspace=ws)
+    torch.cuda.synchronize()
+    t, launches = _lib.prof_read("topk_filter")
+    _lib.prof_enable(False)
+    t *= 1e-3
+    dd = d.to(torch.int32) & 0xFFFF
+    key = (dd.to(torch.int64) << 32) | i.to(torch.int64)
+    ok = bool((key[:, 1:] > key[:, :-1]).all()) and bool((i >= 0).all()) and bool((i < R).all())
+    alg = 2 * R * W * 4 + 2 * Q * W * 4
+    return {"workload": "exact top-%d of Q=%d over R=%d x %d-bit TERNARY codes (bits + zero planes: %d MB), half-unit distances" % (k, Q, R, K, alg // 10**6),
+            "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9, "filter_ms": t * 1e3, "filter_GBps": alg / t / 1e9,
+            "filter_frac_of_8TBps": alg / t / 1e9 / HBM_PEAK_GBS, "lists_sorted_distinct_in_range": ok, "zero_fraction": float((rz[:4096] != 0).float().mean())}
+
+
 def measure_structured(R=10_000_000, K=256, k=100):
     """the sampled threshold is ideal on i.i.d. codes -- the same call on label-correlated codes and on a
     duplicate-heavy gallery (lists overflow -> the robust path recomputes), Q = 1 and 8."""
