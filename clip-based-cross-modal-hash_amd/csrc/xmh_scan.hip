@@ -1600,6 +1600,9 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
                      S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");
         }
         const int S = cached ? cache_slots(Wc) : S8;
+        if (cache && apc_on && K > 128 && K <= 256 && !tern && R <= kFloatBitsMaxItems)      // round 6: float-bit counters on two-byte entries
+            snprintf(p2, sizeof(p2), "%sk_scan_ap_c<false, 16, false>", a32);
+        else
         snprintf(p2, sizeof(p2), "%sk_scan_ap_s<%d, %d, %s, %s, %d, false, false, %d, %s>", a32, Wc, cached ? 1 : LW, tern ? "true" : "false", cached ? "false" : "true", S,
                  S == 64 ? waves_for(Wc, tern) : 1, cached ? "true" : "false");     // (uncached kernels: the capped form serves both)
     }
@@ -1827,7 +1830,8 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         auto go = [&](auto kc) {
             const int r3 = raise_lds(kc, lds, "xmh_hamming_ap");
             if (r3) return r3;
-            hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap, wrapped);
+            hipLaunchKernelGGL(kc, grid, dim3(64), lds, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part, fb_gate, kcap, wrapped,
+                               (const uint32_t*)nullptr, 0);
             return (int)XMH_OK;
         };
         rc = half ? (capped ? go(k_scan_ap_c<true, 8, true>) : go(k_scan_ap_c<false, 8, true>)) : (capped ? go(k_scan_ap_c<true, 8>) : go(k_scan_ap_c<false, 8>));
@@ -1903,6 +1907,27 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
             }
         });
     };
+    // Round 6: 129..256-bit binary codes (two-byte entries).  Where the shard is too large or too relevant for packed 32-bit counters --
+    // configs[4]: a shard of 1.25 M rows, 150 k relevant items per query -- the 64-bit pass 2 was the integer-counter k_scan_ap_s (15 VALU
+    // instructions per pair); the float-bit counters of k_scan_ap_c (9) read the same entries 8 slots x 8 queries wide.  Unsharded calls.
+    const bool apc16 = cache_bytes && apc_on && K > 128 && K <= 256 && !tern && !masked && !sharded && R <= kFloatBitsMaxItems;
+    if (apc16) {
+        ScanArgs as = a;
+        as.nqt = a.nqt * 8;
+        as.pair_cache = reinterpret_cast<uint4*>(base + L.pair_cache);
+        const size_t lds16 = (size_t)p.nbuckets * 8 * 8;
+        xmh::ProfScope prof("scan_ap", st);
+        auto go16 = [&](auto kc) {
+            const int r3 = raise_lds(kc, lds16, "xmh_hamming_ap");
+            if (r3) return r3;
+            hipLaunchKernelGGL(kc, dim3((unsigned)(scan_grid(p) * 8)), dim3(64), lds16, st, as, below, (const uint2*)dpre, (const uint32_t*)cap_ws, ap_part,
+                               (const uint32_t*)nullptr, kcap, (const uint32_t*)nullptr, (const uint32_t*)nrel_max, rank_bits);
+            return (int)XMH_OK;
+        };
+        rc = capped ? go16(k_scan_ap_c<true, 16>) : go16(k_scan_ap_c<false, 16>);
+        if (rc) return rc;
+        XMH_LAUNCH_CHECK("xmh_hamming_ap (float-bit counters, two-byte entries)");
+    }
     if ((apc || apr2) && !fb_gate && !byte128) {
         // k_scan_ap_c / k_scan_ap_r2 alone takes the call
     } else {
@@ -1918,9 +1943,11 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap packed");
     }
-    rc = launch_width(T0{});
-    if (rc) return rc;
-    XMH_LAUNCH_CHECK("xmh_hamming_ap");
+    if (!apc16) {                                                   // (k_scan_ap_c<., 16> above is the 64-bit pass 2 of that shape)
+        rc = launch_width(T0{});
+        if (rc) return rc;
+        XMH_LAUNCH_CHECK("xmh_hamming_ap");
+    }
     }
     const unsigned nred = (unsigned)xmh::ceil_div(Q, 64);
     if (map_out && nred <= 4096) {                                   // reduce + mean in one launch (last-ticket block finalises)

@@ -842,7 +842,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_r2w(MfmaArgs a, uint32_t*
 template <bool CAPPED, int EB, bool HALF = false>
 __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
-                                                  const uint32_t* __restrict__ items_total, uint32_t kcap, const uint32_t* __restrict__ skip_if = nullptr) {
+                                                  const uint32_t* __restrict__ items_total, uint32_t kcap, const uint32_t* __restrict__ skip_if = nullptr,
+                                                  const uint32_t* __restrict__ nrel_max = nullptr, int rank_bits = 0) {
     static_assert(!HALF || EB == 8, "the 8 x 8 geometry on one-byte entries");
     constexpr int QW = HALF ? 8 : 128 / EB, LOG_QW = QW == 16 ? 4 : 3, S = 64 / QW, EPW = HALF ? 2 : 32 / EB;      // queries per tile, slots, entries a lane takes from a cache word
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [nb][QW] 64-bit counters
@@ -850,6 +851,9 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     if (!map_block(a, chunk_id, qtile)) return;                      // a.nqt counts QW-query tiles here
     if (items_total && (int64_t)*items_total > kFloatBitsMaxItems) return;      // sharded call: the integer-counter kernel takes it
     if (skip_if && *skip_if != 0u) return;                           // a distance wrapped in the one-byte cache of 65..128-bit codes: see k_scan_hist_m
+    // two-byte entries (129..256 bits, round 6): the packed 32-bit k_scan_ap_s is launched beside this kernel and takes the call when the
+    // shard's ranks and relevant counts fit its counters (the same test, on the same device word, as in k_scan_ap_s)
+    if (nrel_max && rank_bits > 0 && (uint64_t)(*nrel_max) + 2 < (1ull << (32 - rank_bits))) return;
     const int lane = threadIdx.x & 63;
     const int ql = lane & (QW - 1), slot = lane >> LOG_QW;
     const int q0 = qtile * QW, q = q0 + ql;

@@ -1931,3 +1931,25 @@ def test_scan_verify_mode_at_the_headline_shape(cu):
         assert float(cu.calc_map_k(dq, dr, dql, drl)) == plain                 # the verified call returns the fast derivation's value
     finally:
         _lib.scan_verify(False)
+
+
+@pytest.mark.parametrize("K", [160, 256])
+def test_scan_256_bit_pass2_on_float_bit_counters(xr, cu, K, monkeypatch):
+    """round 6: 129..256-bit codes whose shard does not fit packed 32-bit counters run pass 2 on k_scan_ap_c<., 16> (float-bit counters on
+    the two-byte pair cache) instead of the integer-counter k_scan_ap_s.  XMH_SCAN_PACK32=0 forces the 64-bit width at a test-sized shape;
+    dense relevance, duplicate-heavy gallery (lanes collide), k in {None, 37}."""
+    import ctypes
+    from xmh import _lib
+    orc = _orc()
+    qB, rB, qL, rL = _synth(70, 21000, K, 24, seed=K, p=0.3)
+    rB[9000:] = rB[torch.randint(0, 11, (12000,), generator=torch.Generator().manual_seed(K))]
+    monkeypatch.setenv("XMH_SCAN_PACK32", "0")
+    buf = ctypes.create_string_buffer(512)
+    _lib.check(_lib.lib.xmh_scan_describe(70, 21000, 256, 24, 0, buf, 512), "xmh_scan_describe")
+    assert b"k_scan_ap_c<false, 16, false>" in buf.value, buf.value
+    for kk in (None, 37):
+        got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda(), kk))
+        assert abs(got - float(orc.map_k(qB, rB, qL, rL, kk, stable=True))) < MAP_TOL
+    monkeypatch.delenv("XMH_SCAN_PACK32")
+    got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))            # default: the device word picks the packed kernel here
+    assert abs(got - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL

@@ -133,6 +133,6 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(h, sums, 16, hipMemcpyDeviceToHost));
     printf("histogram checksum %llu, reference %llu: %s\n", h[0], h[1], h[0] == h[1] ? "equal" : "DIFFERENT");
 #endif
-    timed("pass 2 (k_scan_ap_c)", [&]() { hipLaunchKernelGGL(k2, grid2, dim3(64), lds2, 0, s, (const uint2*)below, (const uint2*)dpre, (const uint32_t*)nullptr, ap_part, (const uint32_t*)nullptr, 0xffffffffu, (const uint32_t*)nullptr); });
+    timed("pass 2 (k_scan_ap_c)", [&]() { hipLaunchKernelGGL(k2, grid2, dim3(64), lds2, 0, s, (const uint2*)below, (const uint2*)dpre, (const uint32_t*)nullptr, ap_part, (const uint32_t*)nullptr, 0xffffffffu, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0); });
     return 0;
 }
