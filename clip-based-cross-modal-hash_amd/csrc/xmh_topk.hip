@@ -594,10 +594,10 @@ __global__ __launch_bounds__(kThreads) void k_topk_sample(const uint32_t* __rest
                                                           int Q, int64_t R, int nb, int64_t stride, int per_block,
                                                           uint32_t* __restrict__ hist, int fold, uint32_t target,
                                                           TopkCtl* __restrict__ ctl, uint32_t* __restrict__ t_est,
-                                                          uint32_t* __restrict__ cnt, int* __restrict__ fail, PickParams pp, uint32_t* __restrict__ bound) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];     // [qg][nb]
+                                                          uint32_t* __restrict__ cnt, int* __restrict__ fail, PickParams pp, uint32_t* __restrict__ bound,
+                                                          const int QG) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];     // [QG][nb]: QG = 16 queries per round unless the histograms of long ternary codes (2K + 1 buckets) leave room for fewer
     __shared__ int last;
-    constexpr int QG = 16;
     const int64_t lo = (int64_t)blockIdx.x * stride;
     const int64_t hi = (lo + per_block < R) ? lo + per_block : R;
     // many queries (no fold): the groups of 16 queries are spread over blockIdx.y -- 64 queries in one block were 52 us of a 200 us call
@@ -1487,7 +1487,8 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
         }
         const double frac = exact ? 1.0 : (double)((int64_t)sblocks * per_block) / (double)R;
         const uint32_t target = exact ? (uint32_t)((int64_t)k < R ? (int64_t)k : R) : (uint32_t)(2.0 * k * frac + 8.0);
-        const size_t slds = (size_t)16 * nb * 4;
+        const int sqg = nb <= 2049 ? 16 : (32768 / nb > 0 ? 32768 / nb : 1);      // 128 KB of histograms per sample block at most (ternary 1024 / 2048 bits)
+        const size_t slds = (size_t)sqg * nb * 4;
         const PickParams pp{(float)(1.0 / frac), (uint32_t)k, (uint32_t)R, exact ? 1 : 0};
 #define XMH_FAST(WW)                                                                                                       \
         {                                                                                                                  \
@@ -1495,10 +1496,10 @@ int topk_call(const uint32_t* qbits, const uint32_t* qzero, const uint32_t* rbit
             xmh::RangeScope rs_("topk: sample + threshold pick");                                                         \
             if (tern)                                                                                                      \
                 hipLaunchKernelGGL((k_topk_sample<WW, true>), sgrid_, dim3(kThreads), slds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, nb, stride, \
-                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
+                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound, sqg);   \
             else                                                                                                           \
                 hipLaunchKernelGGL((k_topk_sample<WW, false>), sgrid_, dim3(kThreads), slds, st, qbits, qzero, rbits, rzero, pad, (int)Q, R, nb, stride, \
-                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound);        \
+                                   per_block, f.hist, fold_pick, target, ctl, f.t_est, f.cnt, f.fail, pp, f.bound, sqg);   \
             if (!fold_pick)                                                                                                \
                 hipLaunchKernelGGL(k_topk_pick, dim3((unsigned)Q), dim3(64), 0, st, f.hist, (int)Q, nb, target, f.t_est, f.cnt, f.fail, pp, f.bound); \
             rs_.end();                                                                                                     \

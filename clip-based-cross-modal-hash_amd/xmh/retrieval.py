@@ -425,8 +425,8 @@ class TopkWorkspace:
 def _topk_shape_error(shape, ternary: bool):
     """a shape the planner refuses: make the library say why"""
     Q, R, K, k = shape
-    if ternary:
-        check(lib.xmh_hamming_topk_ternary(None, None, None, None, Q, R, K, k, 0, None, 0, 0, None, None, None), "xmh_hamming_topk_ternary")
+    if ternary:                                          # (the planner speaks first: the null workspace is never reached)
+        check(lib.xmh_topk_ternary_ws_init(Q, R, K, k, None, 0, None), "xmh_hamming_topk_ternary")
     check(lib.xmh_hamming_topk(None, None, Q, R, K, k, 0, None, 0, None, None, None), "xmh_hamming_topk")
 
 

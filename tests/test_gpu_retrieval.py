@@ -1668,6 +1668,9 @@ def test_topk_ternary_odd_lengths_heavy_ties_and_one_sided_zeros(xr):
     _topk_ternary_check(xr, 1, 1, 32, 1, seed=8, p_zero=0.5)
     _topk_ternary_check(xr, 5, 30000, 512, 20, seed=9)                      # TwDH lengths
     _topk_ternary_check(xr, 2, 9000, 1024, 7, seed=10)
+    _topk_ternary_check(xr, 3, 7000, 2048, 9, seed=11)                      # 4097 buckets: the sample keeps 7 queries' histograms per round
+    _topk_ternary_check(xr, 17, 5000, 2048, 20, seed=12)                    # ... and without the folded pick (more than 16 queries)
+    _topk_ternary_check(xr, 33, 6000, 1024, 100, seed=13)
 
 
 def test_topk_ternary_fuzz(xr):

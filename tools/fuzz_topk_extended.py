@@ -44,7 +44,11 @@ for case in range(n):
             rz = rz[rng.integers(0, int(rng.integers(1, 9)), size=R)]
         qb, rb = qb & ~qz, rb & ~rz                                             # a zero element has its sign bit clear
         t = lambda a: torch.from_numpy(a.view(np.int32)).cuda()
-        d, i = xr.hamming_topk(xr.PackedCodes(t(qb), t(qz), K), xr.PackedCodes(t(rb), t(rz), K), k, base)
+        try:
+            d, i = xr.hamming_topk(xr.PackedCodes(t(qb), t(qz), K), xr.PackedCodes(t(rb), t(rz), K), k, base)
+        except Exception as exc:                                                # 4097 buckets x 8 queries + k = 1000 candidates: beyond one block's LDS, said so
+            assert "LDS" in str(exc) and K >= 1024, exc
+            continue
         wd, wi = co.topk_ternary(qb, qz, rb, rz, K, k, base)
         if not (np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy().view(np.uint16), wd)):
             bad += 1
