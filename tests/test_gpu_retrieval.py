@@ -1568,6 +1568,7 @@ def test_long_and_odd_code_lengths_distance(xr, cu, K):
         assert np.array_equal(i.cpu().numpy(), order) and np.array_equal(d.cpu().numpy().view(np.uint16), np.take_along_axis(full, order, 1).astype(np.uint16))
     qB4, rB4 = torch.randn(9, 4096, generator=gen).sign(), torch.randn(40, 4096, generator=gen).sign()
     L4 = torch.ones(40, 3, dtype=torch.int64)
+    assert torch.equal(cu.calc_hammingDist(qB4.cuda(), rB4.cuda()).cpu(), orc.hamming_dist(qB4, rB4))       # 128 code words: the generic distance kernel
     got = cu.calc_map_k(qB4.cuda(), rB4.cuda(), L.cuda(), L4.cuda())
     assert abs(float(got) - float(orc.map_k(qB4, rB4, L, L4, stable=True))) < MAP_TOL
     with pytest.raises(RuntimeError, match="at most 2048"):
@@ -1811,6 +1812,15 @@ def test_calc_map_k_on_umoed_style_float_codes_at_scale(cu):
     assert 0.0 < got < 1.0
     got50 = float(cu.calc_map_k(dq[sub], dr, dql[sub], drl, 50))
     assert abs(got50 - float(orc.map_k(qB[sub], rB, qL[sub], rL, 50, stable=True))) < 1e-4
+    # a code length that is no multiple of 4 floats (unaligned rows: the GEMM's general path), small set, exact against the oracle
+    gen = torch.Generator().manual_seed(7)
+    fq, fr = torch.tanh(torch.randn(19, 33, generator=gen) * 2), torch.tanh(torch.randn(777, 33, generator=gen) * 2)
+    fqL, frL = (torch.rand(19, 9, generator=gen) < 0.3).long(), (torch.rand(777, 9, generator=gen) < 0.3).long()
+    fqL[:, 0] = 1
+    frL[::5, 0] = 1
+    for kk in (None, 13):
+        got33 = float(cu.calc_map_k(fq.cuda(), fr.cuda(), fqL.cuda(), frL.cuda(), kk))
+        assert abs(got33 - float(orc.map_k(fq, fr, fqL, frL, kk, stable=True))) < 1e-5
 
 
 @pytest.mark.parametrize("case", ["ternary_512", "bits_4096", "classes_300", "ternary_2048_classes_300"])
