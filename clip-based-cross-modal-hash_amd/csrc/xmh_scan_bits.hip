@@ -22,6 +22,10 @@
 #include "xmh_common.h"
 #include "xmh_scan_bits.h"
 
+#ifndef XMH_HIST_B_GI
+#define XMH_HIST_B_GI 2
+#endif
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -121,28 +125,48 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     for (int i = 0; i < nbat; ++i) {
         if (i + 1 < nbat) load(nxt, i + 1);
         uint32_t cw[4], cw2[4];
+        // Round 6: the groups of 16 items go through the matrix pipe GI at a time, their chains interleaved MFMA by MFMA.  With 66 KB of
+        // counters per block the kernel runs two waves per SIMD, and one group's chain (four dependent MFMAs + two for the labels) left
+        // the pipe waiting on its own results; independent chains of the other groups fill those slots.
+        constexpr int GI = XMH_HIST_B_GI;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4i am[NMC], al[2];
+        for (int g0 = 0; g0 < 4; g0 += GI) {
+            v4i am[GI][NMC], al[GI][2];
 #pragma unroll
-            for (int v = 0; v < LWC; ++v) word_to_bytes(cur[g][v], am[2 * v], am[2 * v + 1]);
-            word_to_bytes(cur[g][LWC], al[0], al[1]);
-            v4i acc = {cinit, cinit, cinit, cinit};
+            for (int u = 0; u < GI; ++u) {
 #pragma unroll
-            for (int m = 0; m < NMC; ++m) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[m], bq[m], acc, 0, 0, 0);
-            v4i lab = {0x10000, 0x10000, 0x10000, 0x10000};
-#pragma unroll
-            for (int m = 0; m < 2; ++m) lab = __builtin_amdgcn_mfma_i32_16x16x64_i8(al[m], bl[m], lab, 0, 0, 0);
-            uint32_t e[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t inc = min((uint32_t)lab[j], 0x10001u);                       // all << 16 | relevant
-                asm volatile("ds_add_u32 %0, %1" ::"v"(acc[j]), "v"(inc) : "memory");
-                if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[j] - lanebase) >> 5);          // entry: distance << 1 | relevant (16 bits)
+                for (int v = 0; v < LWC; ++v) word_to_bytes(cur[g0 + u][v], am[u][2 * v], am[u][2 * v + 1]);
+                word_to_bytes(cur[g0 + u][LWC], al[u][0], al[u][1]);
             }
-            if (CACHE) {                                             // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
-                cw[g] = e[0] | (e[2] << 16);
-                cw2[g] = e[1] | (e[3] << 16);
+            v4i acc[GI], lab[GI];
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                acc[u] = v4i{cinit, cinit, cinit, cinit};
+                lab[u] = v4i{0x10000, 0x10000, 0x10000, 0x10000};
+            }
+#pragma unroll
+            for (int m = 0; m < NMC; ++m) {
+#pragma unroll
+                for (int u = 0; u < GI; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[u][m], bq[m], acc[u], 0, 0, 0);
+                if (m < 2) {
+#pragma unroll
+                    for (int u = 0; u < GI; ++u) lab[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al[u][m], bl[m], lab[u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GI; ++u) {
+                const int g = g0 + u;
+                uint32_t e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t inc = min((uint32_t)lab[u][j], 0x10001u);                    // all << 16 | relevant
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(acc[u][j]), "v"(inc) : "memory");
+                    if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[u][j] - lanebase) >> 5);       // entry: distance << 1 | relevant (16 bits)
+                }
+                if (CACHE) {                                         // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
+                    cw[g] = e[0] | (e[2] << 16);
+                    cw2[g] = e[1] | (e[3] << 16);
+                }
             }
         }
         if (CACHE) {
