@@ -1131,7 +1131,11 @@ inline bool r2w_shape(int K, bool ternary) { return !ternary && K > 64 && K <= 1
 // k_scan_hist_b (xmh_scan_bits.hip, round 3): 129..256-bit binary codes build their MFMA operands from the packed bits in registers;
 // counters in the (all << 16 | relevant) form of k_scan_hist_r2.  Compiler-scheduled intrinsics: no hand-kept hazard, no self-check.
 inline bool bits_shape(int K, bool ternary) { return !ternary && K > 128 && K <= 256 && mfma_env_on() && g_r2_force != 0; }
-inline bool mfma_shape(int K, bool ternary) { return r2_shape(K, ternary) || r2w_shape(K, ternary) || bits_shape(K, ternary); }
+// Round 6: TERNARY codes of at most 128 bits on the same kernel (k_scan_hist_b<., ., ., TERN>): the operand is the 2K-bit pair of planes
+// [+1 | -1], 2K + 1 bucket rows, two-byte cache entries -- so pass 2 is that of the 129..256-bit binary codes.  Before: the VALU kernels
+// (one exact 0.0 among the code elements cost 2.7 x the binary evaluation).
+inline bool tbits_shape(int K, bool ternary) { return ternary && K <= 128 && mfma_env_on() && g_r2_force != 0; }
+inline bool mfma_shape(int K, bool ternary) { return r2_shape(K, ternary) || r2w_shape(K, ternary) || bits_shape(K, ternary) || tbits_shape(K, ternary); }
 // k_scan_ap_r2 (round 5): pass 2 evaluates the pairs again on the MFMA from the packed words instead of reading a pair cache (binary codes
 // of at most 64 bits whose pass 1 is k_scan_hist_r2).  Measured at Q 5000 x R 117 218 x 64 bit: pass 1 without the cache stores 0.157 ->
 // 0.128 ms, pass 2 0.173 (k_scan_ap_c on the cache) -> 0.262 ms, step 0.361 -> 0.416 ms -- so it is the pass 2 of evaluations that HAVE no
@@ -1168,9 +1172,10 @@ inline bool ap_c_on() {                                  // XMH_SCAN_AP_C=0: the
 }
 size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     const long long cap_mb = cache_cap_mb();
-    if (ternary || K > 256 || cap_mb <= 0 || (K <= 32 && !r2_shape(K, ternary))) return 0;
+    const bool tb = tbits_shape(K, ternary);                        // ternary on the MFMA: two-byte entries, 8 slots (as 129..256-bit binary codes)
+    if ((ternary && !tb) || K > 256 || cap_mb <= 0 || (!tb && K <= 32 && !r2_shape(K, ternary))) return 0;
     if (r2_shape(K, ternary) && ap_r2_mode() == 1) return 0;        // k_scan_ap_r2 evaluates the pairs itself
-    const int S = K <= 64 ? 4 : 8;                                 // slots of the kernels that use it: 64 / S queries per wave
+    const int S = tb ? 8 : (K <= 64 ? 4 : 8);                      // slots of the kernels that use it: 64 / S queries per wave
     const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
 }
@@ -1499,7 +1504,16 @@ int hist_r2w_t(const MfmaArgs& a, const xmh_scan_plan& p, char* base, const WsLa
 }
 
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
-              const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+              const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st,
+              const uint32_t* qzero = nullptr, const uint32_t* rzero = nullptr) {
+    if (qzero) {                                                     // tbits_shape: ternary codes, K <= 128
+        XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words of the call
+        xmh::ScanBitsArgs a{rbits, rlab, qbits, qlab, (int)Q, (int)R, K, W, LW, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)),
+                            (int)p.nbuckets, (int)p.qpad};
+        a.rzero = rzero;
+        a.qzero = qzero;
+        return xmh::launch_scan_hist_bits(a, K <= 64 ? 2 : 4, chunk_hist, cache, st);
+    }
     if (bits_shape(K, false)) {
         XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words of the call
         const xmh::ScanBitsArgs a{rbits, rlab, qbits, qlab, (int)Q, (int)R, K, W, LW, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)),
@@ -1576,7 +1590,8 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const R2Geom g = r2_geom(K);
     if (use_mfma && r2w_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
     else if (use_mfma && r2_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
-    else if (use_mfma) snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %s>", kMfmaWaves, cache ? "true" : "false");
+    else if (use_mfma && tbits_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s, true>", K <= 64 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
+    else if (use_mfma) snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %s, false>", kMfmaWaves, cache ? "true" : "false");
     else {
         const bool cached = cache && !tern && Wc <= 8;
         const int S = cached ? cache_slots(Wc) : S4;
@@ -1586,7 +1601,11 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const bool packable = packed_rank_bits(K, R) > 0;                 // exactly what hamming_ap_impl launches for an unsharded evaluation
     const bool apc_on = ap_c_on();
     const bool byte128 = cache && use_mfma && r2w_shape(K, tern);     // one-byte entries of 65..128-bit codes
-    if (cache && !tern && K <= 128 && apc_on && (byte128 || (K <= 64 && !packable)) && R <= kFloatBitsMaxItems) {
+    const bool tb = tern && cache && use_mfma && tbits_shape(K, tern);  // ternary on the MFMA: the cached pass 2 of the 129..256-bit binary codes
+    if (tb) {
+        snprintf(p2, sizeof(p2), "%s%s", packable ? "k_scan_ap_s<8, 1, false, false, 8, true, false, 1, true>|" : "",
+                 apc_on && R <= kFloatBitsMaxItems ? "k_scan_ap_c<false, 16, false>" : "k_scan_ap_s<8, 1, false, false, 8, false, false, 1, true>");
+    } else if (cache && !tern && K <= 128 && apc_on && (byte128 || (K <= 64 && !packable)) && R <= kFloatBitsMaxItems) {
         snprintf(p2, sizeof(p2), "k_scan_ap_c<false, 8, %s>", byte128 ? "true" : "false");     // all three template arguments: the name a profile prints
     } else if (use_mfma && !cache && r2_shape(K, tern) && ap_r2_mode() != 0 && !packable && R <= kFloatBitsMaxItems) {
         snprintf(p2, sizeof(p2), "k_scan_ap_r2<%d, %d, %d, false>", NML, kAp2Waves, kAp2Groups);
@@ -1636,7 +1655,7 @@ extern "C" int xmh_hamming_hist(const uint32_t* qbits, const uint32_t* qzero, co
     if (!use_mfma) XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));   // (the MFMA path clears them in its first launch)
     if (use_mfma) {
         rc = mfma_hist(qbits, qlab, rbits, rlab, Q, R, K, W, LW, p, base, L, chunk_hist,
-                       cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st);
+                       cache_bytes ? reinterpret_cast<uint4*>(base + L.pair_cache) : nullptr, st, qzero, rzero);
         if (rc) return rc;
     }
     auto launch = [&](auto tern_c) {
@@ -1859,6 +1878,9 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         if (rc) return rc;
         XMH_LAUNCH_CHECK("xmh_hamming_ap (MFMA from the packed words)");
     }
+    // tb: ternary codes whose pass 1 ran on the MFMA (same predicate as in xmh_hamming_hist) and left two-byte entries: the cached pass-2
+    // kernels read nothing but the entries and the tables, so the BINARY 256-bit instances serve (the bucket count comes from the plan)
+    const bool tb = tern && cache_bytes && mfma_plan && LW <= 4 && !masked && tbits_shape(K, tern);
     // behind k_scan_ap_c on one-byte entries of 65..128-bit codes only the 64-bit stand-in is launched (always valid; it runs once in a blue moon)
     const int rb = (byte128 && apc) ? 0 : rank_bits;
     // both counter widths are launched; the device word nrel_max (written by k_scan_dpre) lets exactly one of them run
@@ -1867,7 +1889,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
         constexpr bool CP = decltype(cap_c)::value;
         constexpr bool P32 = decltype(p32_c)::value;
         constexpr bool MK = decltype(masked_c)::value;
-        return dispatch_shape<T>(W, LW, [&](auto w, auto l) {
+        return dispatch_shape<T>(tb ? 8 : W, LW, [&](auto w, auto l) {
             constexpr int WW = decltype(w)::value, LL = decltype(l)::value;
             if constexpr (P32 && MK) return xmh::fail(XMH_ENOTSUP, "xmh_hamming_ap: the masked fallback runs 64-bit counters only");      // (never launched: rank_bits is 0 when masked)
             else {
@@ -1910,7 +1932,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     // Round 6: 129..256-bit binary codes (two-byte entries).  Where the shard is too large or too relevant for packed 32-bit counters --
     // configs[4]: a shard of 1.25 M rows, 150 k relevant items per query -- the 64-bit pass 2 was the integer-counter k_scan_ap_s (15 VALU
     // instructions per pair); the float-bit counters of k_scan_ap_c (9) read the same entries 8 slots x 8 queries wide.  Unsharded calls.
-    const bool apc16 = cache_bytes && apc_on && K > 128 && K <= 256 && !tern && !masked && !sharded && R <= kFloatBitsMaxItems;
+    const bool apc16 = cache_bytes && apc_on && ((K > 128 && K <= 256 && !tern) || tb) && !masked && !sharded && R <= kFloatBitsMaxItems;
     if (apc16) {
         ScanArgs as = a;
         as.nqt = a.nqt * 8;
@@ -1935,7 +1957,7 @@ int hamming_ap_impl(const uint32_t* qbits, const uint32_t* qzero, const uint32_t
     using T0 = std::false_type;
     auto launch_width = [&](auto p32_c) {
         auto by_mask = [&](auto tern_c, auto cap_c) { return masked ? launch(tern_c, cap_c, p32_c, T1{}) : launch(tern_c, cap_c, p32_c, T0{}); };
-        if (tern) return capped ? by_mask(T1{}, T1{}) : by_mask(T1{}, T0{});
+        if (tern && !tb) return capped ? by_mask(T1{}, T1{}) : by_mask(T1{}, T0{});
         return capped ? by_mask(T0{}, T1{}) : by_mask(T0{}, T0{});
     };
     if (rb) {

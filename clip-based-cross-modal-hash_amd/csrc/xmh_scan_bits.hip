@@ -53,9 +53,17 @@ __device__ __forceinline__ void word_to_weights(uint32_t w, int on, int off, v4i
     }
 }
 
-template <int NMC, int NW, bool CACHE>
+// TERN (round 6): codes in {-1, 0, +1} (sign_() left exact zeros: reference runners/base.py:407-410).  The i8 dot product takes them as
+// they are: the item operand is the 2K-bit pair of planes [pos | neg] (pos = bits & ~zero: element is +1; neg = ~bits & ~zero: element is
+// -1), built from the two packed planes as the lane loads them; the query weights are -q on the pos half and +q on the neg half, so the
+// chain started at (bucket-0 counter) + 64 K ends at the counter of K - q.r -- the reference's distance in half units, 0 ... 2K (2K + 1
+// bucket rows).  A lane's quarter of the operand lies wholly in one half (quarters 0, 1: pos; 2, 3: neg), so the planes cost the lane two
+// loads and two ANDs per word instead of one load.  K <= 64 runs as NMC = 2 (a 128-bit operand), K <= 128 as NMC = 4.  Entries of the
+// pair cache: 2 (K - q.r) | relevant in 16 bits, the layout of the 129 ... 256-bit binary codes: pass 2 reads them with the same kernels.
+template <int NMC, int NW, bool CACHE, bool TERN>
 __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
     constexpr int LWC = NMC / 2;                                    // code words per lane (a quarter of the padded code)
+    constexpr int WH = TERN ? NMC : 2 * NMC;                        // words of one plane half of the operand (TERN: 2 WH words in all)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters
     const int b = blockIdx.x;
     const int qtile = (b >> 3) % a.nqt, chunk_id = (b & 7) + 8 * ((b >> 3) / a.nqt);        // as mfma_map_block (xmh_scan.hip)
@@ -71,13 +79,27 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     // B operands: this lane is column ql (its query) and k quarter `slot`
     v4i bq[NMC], bl[2];
     int pc = 0;
-    if (valid)
+    const bool negq = TERN && slot * LWC >= WH;                      // TERN: this lane's quarter lies in the neg half of the operand
+    if (TERN) pc = a.K;                                              // the chain starts at the row of K - 0
+    else if (valid)
         for (int w = 0; w < a.W; ++w) pc += __popc(a.qbits[(int64_t)q * a.W + w]);
 #pragma unroll
     for (int v = 0; v < LWC; ++v) {
-        const int wi = slot * LWC + v;
-        const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
-        word_to_weights(w, -1, valid && wi < a.W ? 1 : 0, bq[2 * v], bq[2 * v + 1]);      // no such word: zero weights, whatever the item lane loads
+        if constexpr (TERN) {
+            const int wi = (slot * LWC + v) % WH;                    // word of the plane
+            const bool have = valid && wi < a.W;
+            const uint32_t b = have ? a.qbits[(int64_t)q * a.W + wi] : 0u, z = have ? a.qzero[(int64_t)q * a.W + wi] : 0xffffffffu;
+            const uint32_t qpos = b & ~z, qneg = ~b & ~z;            // (padding bits are set in the zero plane: neither)
+            v4i p0, p1, n0, n1;
+            word_to_weights(qpos, negq ? 1 : -1, 0, p0, p1);         // -q on the pos half, +q on the neg half
+            word_to_weights(qneg, negq ? -1 : 1, 0, n0, n1);
+            bq[2 * v] = p0 | n0;                                     // disjoint bytes
+            bq[2 * v + 1] = p1 | n1;
+        } else {
+            const int wi = slot * LWC + v;
+            const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
+            word_to_weights(w, -1, valid && wi < a.W ? 1 : 0, bq[2 * v], bq[2 * v + 1]);      // no such word: zero weights, whatever the item lane loads
+        }
     }
     word_to_weights(valid && slot < a.LW ? a.qlab[(int64_t)q * a.LW + slot] : 0u, 1, 0, bl[0], bl[1]);
     const int lanebase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4;     // this lane's bucket-0 counter
@@ -95,7 +117,12 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     // a zero word with off = 0 for the labels; for the code see wq below), so what is loaded in its place counts for nothing
     int wic[LWC];
 #pragma unroll
-    for (int v = 0; v < LWC; ++v) wic[v] = slot * LWC + v < a.W ? slot * LWC + v : a.W - 1;
+    for (int v = 0; v < LWC; ++v) {
+        const int wi = TERN ? (slot * LWC + v) % WH : slot * LWC + v;
+        wic[v] = wi < a.W ? wi : a.W - 1;
+    }
+    // TERN: bits and zero plane -> this lane's half of the operand
+    auto plane = [&](uint32_t b, uint32_t z) -> uint32_t { return (negq ? ~b : b) & ~z; };
     const int wil = slot < a.LW ? slot : (a.LW > 0 ? a.LW - 1 : 0);
     auto load = [&](uint32_t (&dst)[4][LWC + 1], int i) {
         const int64_t first = lo + (int64_t)i * 64;
@@ -105,7 +132,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int v = 0; v < LWC; ++v) dst[g][v] = pc[g * 16 * a.W + wic[v]];
+                for (int v = 0; v < LWC; ++v) {
+                    if constexpr (TERN) dst[g][v] = plane(pc[g * 16 * a.W + wic[v]], a.rzero[(first + rowitem + g * 16) * a.W + wic[v]]);
+                    else dst[g][v] = pc[g * 16 * a.W + wic[v]];
+                }
                 dst[g][LWC] = pl[g * 16 * a.LW];
             }
         } else {
@@ -115,7 +145,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
                 const int64_t it = item < hi ? item : hi - 1;
                 const uint32_t ok = item < hi ? 0xffffffffu : 0u;    // beyond the chunk: all-zero code, no labels (corrected below)
 #pragma unroll
-                for (int v = 0; v < LWC; ++v) dst[g][v] = a.rbits[it * a.W + wic[v]] & ok;
+                for (int v = 0; v < LWC; ++v) {
+                    if constexpr (TERN) dst[g][v] = plane(a.rbits[it * a.W + wic[v]], a.rzero[it * a.W + wic[v]]) & ok;      // beyond the chunk: both halves empty
+                    else dst[g][v] = a.rbits[it * a.W + wic[v]] & ok;
+                }
                 dst[g][LWC] = a.rlab[it * a.LW + wil] & ok;
             }
         }
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
                 for (int v = 0; v <= LWC; ++v) cur[g][v] = nxt[g][v];
         }
     }
-    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query), never relevant
+    // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query) (TERN: empty planes, K - 0), never relevant
     const int npad = nbat * 64 - (int)(hi - lo);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (npad > 0 && slot == 0 && valid) cnt[pc * 16 + ql] -= (uint32_t)npad << 16;
@@ -196,17 +229,17 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
 }
 
-template <int NMC, int NW>
+template <int NMC, int NW, bool TERN>
 int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
     const size_t lds = (size_t)NW * a.nb * 16 * 4;
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(a.nchunk, 8)));
     xmh::ProfScope prof("scan_hist", st);
     if (cache) {
-        auto kern = k_scan_hist_b<NMC, NW, true>;
+        auto kern = k_scan_hist_b<NMC, NW, true, TERN>;
         if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
     } else {
-        auto kern = k_scan_hist_b<NMC, NW, false>;
+        auto kern = k_scan_hist_b<NMC, NW, false, TERN>;
         if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
     }
@@ -218,7 +251,13 @@ int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hip
 namespace xmh {
 
 int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
-    if (nmc == 4) return launch_t<4, kScanBitsWaves>(a, chunk_hist, cache, st);
+    if (a.rzero) {
+        if (!a.qzero) return fail(XMH_EINVAL, "xmh_hamming_hist: zero planes of both sides or neither");
+        if (nmc == 2 && a.K <= 64) return launch_t<2, kScanBitsWaves, true>(a, chunk_hist, cache, st);
+        if (nmc == 4 && a.K <= 128) return launch_t<4, kScanBitsWaves, true>(a, chunk_hist, cache, st);
+        return fail(XMH_ENOTSUP, "xmh_hamming_hist: no ternary k_scan_hist_b instance for %d code tiles at K=%d", nmc, a.K);
+    }
+    if (nmc == 4) return launch_t<4, kScanBitsWaves, false>(a, chunk_hist, cache, st);
     return fail(XMH_ENOTSUP, "xmh_hamming_hist: no k_scan_hist_b instance for %d code tiles", nmc);
 }
 

@@ -23,6 +23,12 @@ for case in range(n):
     qB, rB = torch.randn(Q, K, generator=gen).sign(), torch.randn(R, K, generator=gen).sign()
     if case % 4 == 0 and R > 8:
         rB = rB[torch.randint(0, int(rng.integers(1, 12)), (R,), generator=gen)]          # heavy ties
+    if case % 5 == 3:                                          # round 6: exact zeros (ternary kernels; up to 128 bits on the MFMA)
+        pz = float(rng.choice([0.0005, 0.02, 0.3]))
+        rB[torch.rand(rB.shape, generator=gen) < pz] = 0.0
+        if case % 10 == 3:
+            qB[torch.rand(qB.shape, generator=gen) < pz] = 0.0
+        rB[0, 0] = 0.0
     qL, rL = (torch.rand(Q, C, generator=gen) < p).long(), (torch.rand(R, C, generator=gen) < p).long()
     qL[:, 0] = 1
     rL[0, 0] = 1
