@@ -398,7 +398,9 @@ int main(int argc, char** argv) {
             compare(r0, r1, "register vs LDS epilogue");
             compare(r0, r3, "deferred vs shipped");
             printf(" parity, 128 x 256 / 8 waves / BK 32 / 1 block per CU\n");
+            run<2, 4, 2, 2, 2, 64, 1, 0, false>(g, iters, &r1, "BK 64 (128 KB of staging), LDS epilogue");
             run<2, 4, 2, 2, 2, 32, 1, 0, false>(g, iters, &r0, "shipped: LDS epilogue");
+            compare(r0, r1, "BK 64 vs BK 32");
             run<2, 4, 2, 2, 2, 32, 1, 1, false>(g, iters, &r1, "register epilogue");
             run<2, 4, 2, 2, 2, 32, 1, 3, false>(g, iters, &r3, "persistent, deferred epilogue");
             run<2, 4, 2, 2, 2, 32, 1, 4, false>(g, iters, nullptr, "no stores");
