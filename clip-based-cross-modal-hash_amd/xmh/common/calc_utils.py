@@ -73,6 +73,20 @@ def release_scan_workspace() -> None:
     _scan_ws.__dict__.pop("entry", None)
 
 
+def set_workspace_keep_bytes(nbytes: int) -> int:
+    """how large a scan workspace calc_map_k may keep alive between calls (per thread; default 2 GiB; 0 = keep nothing: every call
+    allocates and frees its own, +0.1 ms at the COCO shape).  Returns the previous limit.  The reference keeps nothing on the device
+    between calls; this is the one piece of device memory the drop-in holds on to, so it has a knob."""
+    global _KEEP_WS_BYTES
+    old, _KEEP_WS_BYTES = _KEEP_WS_BYTES, max(0, int(nbytes))
+    kept = _scan_ws.__dict__.get("entry")
+    if kept is not None:
+        buf = kept[1][1] if isinstance(kept[1], tuple) else kept[1]          # composed path keeps (plan, buffer), the one-call path the buffer
+        if buf.numel() > _KEEP_WS_BYTES:
+            release_scan_workspace()
+    return old
+
+
 def _packed_labels(L: torch.Tensor) -> torch.Tensor:
     """bit-packed label masks on the GPU.  valid() calls calc_map_k four times with the same two label matrices
     (runners/base.py:312-315), usually int64 on the CPU: they are moved and packed once.  The entry keeps a reference to the

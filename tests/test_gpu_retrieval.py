@@ -1966,3 +1966,27 @@ def test_scan_256_bit_pass2_on_float_bit_counters(xr, cu, K, monkeypatch):
     monkeypatch.delenv("XMH_SCAN_PACK32")
     got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))            # default: the device word picks the packed kernel here
     assert abs(got - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL
+
+
+def test_calc_map_k_workspace_keep_knob(cu):
+    """the one piece of device memory the drop-in holds between calls has a knob"""
+    gen = torch.Generator().manual_seed(2)
+    qB, rB = torch.randn(40, 64, generator=gen).sign().cuda(), torch.randn(3000, 64, generator=gen).sign().cuda()
+    qL, rL = torch.ones(40, 8, dtype=torch.int64).cuda(), torch.ones(3000, 8, dtype=torch.int64).cuda()
+    a = float(cu.calc_map_k(qB, rB, qL, rL))
+    assert cu._scan_ws.__dict__.get("entry") is not None
+    old = cu.set_workspace_keep_bytes(0)
+    try:
+        assert cu._scan_ws.__dict__.get("entry") is None
+        assert float(cu.calc_map_k(qB, rB, qL, rL)) == a and cu._scan_ws.__dict__.get("entry") is None
+        q96 = torch.cat([qB, qB[:, :32]], 1)
+        r96 = torch.cat([rB, rB[:, :32]], 1)
+        cu.calc_map_k(q96, r96, qL, rL)                         # the composed path (three code words)
+        assert cu._scan_ws.__dict__.get("entry") is None
+    finally:
+        cu.set_workspace_keep_bytes(old)
+    cu.calc_map_k(q96, r96, qL, rL)
+    assert cu._scan_ws.__dict__.get("entry") is not None
+    cu.set_workspace_keep_bytes(1)
+    assert cu._scan_ws.__dict__.get("entry") is None
+    cu.set_workspace_keep_bytes(old)
