@@ -98,7 +98,7 @@ def compact(out):
         cfg = dict(line["config"])
         cfg.pop("collectives_in_step", None) if len(json.dumps(cfg)) > 600 else None
         line["config"] = cfg
-    for k in ("mAP", "settle_steps", "rccl_ranks", "gpu_over_cpu", "dry_run", "ranks_in_group", "backend", "exchange_ms"):
+    for k in ("mAP", "settle_steps", "rccl_ranks", "gpu_over_cpu", "dry_run", "ranks_in_group", "backend", "exchange_ms", "build"):
         if k in out:
             line[k] = out[k]
     if isinstance(out.get("roofline"), dict):

@@ -179,4 +179,9 @@ extern "C" int xmh_range_pop(void) {
 
 extern "C" int xmh_version(void) { return 100; }
 
+#ifndef XMH_BUILD_ID
+#define XMH_BUILD_ID "unknown"
+#endif
+extern "C" const char* xmh_build_id(void) { return XMH_BUILD_ID; }
+
 extern "C" const char* xmh_last_error(void) { return xmh::g_err; }

@@ -72,6 +72,7 @@ class MithHead(C.Structure):                   # xmh_mith_head
 # name -> (restype, argtypes); mirrors include/xmh.h one to one
 PROTOTYPES = {
     "xmh_version": (i32, []),
+    "xmh_build_id": (C.c_char_p, []),
     "xmh_last_error": (C.c_char_p, []),
     "xmh_prof_enable": (i32, [i32]),
     "xmh_range_push": (i32, [C.c_char_p]),

@@ -53,3 +53,14 @@ def test_the_binding_brings_torch_in_before_the_library():
             "assert 'torch' in sys.modules and L.lib.xmh_version() >= 100; print('ok')") % os.path.join(ROOT, "clip-based-cross-modal-hash_amd")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-500:]
+
+
+def test_the_in_tree_library_is_a_build_of_the_sources_beside_it():
+    """libxmh.so carries the sha256 of the sources it was compiled from (xmh_build_id): a stale in-tree library -- a source edited and
+    the library not rebuilt -- fails here instead of travelling to the GPU box"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    info = bench.build_info()
+    assert info["lib_is_a_build_of_these_sources"], info
+    assert len(info["build_id"]) == 16
