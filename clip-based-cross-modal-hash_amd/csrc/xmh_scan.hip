@@ -1131,10 +1131,11 @@ inline bool r2w_shape(int K, bool ternary) { return !ternary && K > 64 && K <= 1
 // k_scan_hist_b (xmh_scan_bits.hip, round 3): 129..256-bit binary codes build their MFMA operands from the packed bits in registers;
 // counters in the (all << 16 | relevant) form of k_scan_hist_r2.  Compiler-scheduled intrinsics: no hand-kept hazard, no self-check.
 inline bool bits_shape(int K, bool ternary) { return !ternary && K > 128 && K <= 256 && mfma_env_on() && g_r2_force != 0; }
-// Round 6: TERNARY codes of at most 128 bits on the same kernel (k_scan_hist_b<., ., ., TERN>): the operand is the 2K-bit pair of planes
+// Round 6: TERNARY codes (up to 256 bits: every length the zero planes exist for) on the same kernel (k_scan_hist_b<., ., ., TERN>): the operand is the 2K-bit pair of planes
 // [+1 | -1], 2K + 1 bucket rows, two-byte cache entries -- so pass 2 is that of the 129..256-bit binary codes.  Before: the VALU kernels
 // (one exact 0.0 among the code elements cost 2.7 x the binary evaluation).
-inline bool tbits_shape(int K, bool ternary) { return ternary && K <= 128 && mfma_env_on() && g_r2_force != 0; }
+inline bool tbits_shape(int K, bool ternary) { return ternary && K <= 256 && mfma_env_on() && g_r2_force != 0; }
+inline int tbits_tiles(int K) { return K <= 64 ? 2 : (K <= 128 ? 4 : 8); }      // 64-bit tiles of the 2K-bit operand
 inline bool mfma_shape(int K, bool ternary) { return r2_shape(K, ternary) || r2w_shape(K, ternary) || bits_shape(K, ternary) || tbits_shape(K, ternary); }
 // k_scan_ap_r2 (round 5): pass 2 evaluates the pairs again on the MFMA from the packed words instead of reading a pair cache (binary codes
 // of at most 64 bits whose pass 1 is k_scan_hist_r2).  Measured at Q 5000 x R 117 218 x 64 bit: pass 1 without the cache stores 0.157 ->
@@ -1506,13 +1507,13 @@ int hist_r2w_t(const MfmaArgs& a, const xmh_scan_plan& p, char* base, const WsLa
 int mfma_hist(const uint32_t* qbits, const uint32_t* qlab, const uint32_t* rbits, const uint32_t* rlab, int64_t Q, int64_t R, int K, int W, int LW,
               const xmh_scan_plan& p, char* base, const WsLayout& L, uint32_t* chunk_hist, uint4* cache, hipStream_t st,
               const uint32_t* qzero = nullptr, const uint32_t* rzero = nullptr) {
-    if (qzero) {                                                     // tbits_shape: ternary codes, K <= 128
+    if (qzero) {                                                     // tbits_shape: ternary codes, K <= 256
         XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words of the call
         xmh::ScanBitsArgs a{rbits, rlab, qbits, qlab, (int)Q, (int)R, K, W, LW, (int)p.chunk, (int)p.nchunk, (int)(p.qpad / (16 * kMfmaWaves)),
                             (int)p.nbuckets, (int)p.qpad};
         a.rzero = rzero;
         a.qzero = qzero;
-        return xmh::launch_scan_hist_bits(a, K <= 64 ? 2 : 4, chunk_hist, cache, st);
+        return xmh::launch_scan_hist_bits(a, tbits_tiles(K), chunk_hist, cache, st);
     }
     if (bits_shape(K, false)) {
         XMH_HIP(hipMemsetAsync(base + L.tick, 0, L.gate + 256 - L.tick, st));       // the control words of the call
@@ -1590,7 +1591,7 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const R2Geom g = r2_geom(K);
     if (use_mfma && r2w_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
     else if (use_mfma && r2_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
-    else if (use_mfma && tbits_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s, true>", K <= 64 ? 2 : 4, kMfmaWaves, cache ? "true" : "false");
+    else if (use_mfma && tbits_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s, true>", tbits_tiles(K), kMfmaWaves, cache ? "true" : "false");
     else if (use_mfma) snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %s, false>", kMfmaWaves, cache ? "true" : "false");
     else {
         const bool cached = cache && !tern && Wc <= 8;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void word_to_weights(uint32_t w, int on, int off, v4i
 // -1), built from the two packed planes as the lane loads them; the query weights are -q on the pos half and +q on the neg half, so the
 // chain started at (bucket-0 counter) + 64 K ends at the counter of K - q.r -- the reference's distance in half units, 0 ... 2K (2K + 1
 // bucket rows).  A lane's quarter of the operand lies wholly in one half (quarters 0, 1: pos; 2, 3: neg), so the planes cost the lane two
-// loads and two ANDs per word instead of one load.  K <= 64 runs as NMC = 2 (a 128-bit operand), K <= 128 as NMC = 4.  Entries of the
+// loads and two ANDs per word instead of one load.  K <= 64 runs as NMC = 2 (a 128-bit operand), K <= 128 as NMC = 4, K <= 256 as NMC = 8.  Entries of the
 // pair cache: 2 (K - q.r) | relevant in 16 bits, the layout of the 129 ... 256-bit binary codes: pass 2 reads them with the same kernels.
 template <int NMC, int NW, bool CACHE, bool TERN>
 __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
@@ -255,6 +255,7 @@ int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, 
         if (!a.qzero) return fail(XMH_EINVAL, "xmh_hamming_hist: zero planes of both sides or neither");
         if (nmc == 2 && a.K <= 64) return launch_t<2, kScanBitsWaves, true>(a, chunk_hist, cache, st);
         if (nmc == 4 && a.K <= 128) return launch_t<4, kScanBitsWaves, true>(a, chunk_hist, cache, st);
+        if (nmc == 8 && a.K <= 256) return launch_t<8, kScanBitsWaves, true>(a, chunk_hist, cache, st);      // 513 bucket rows: 131 KB of counters, one block per CU
         return fail(XMH_ENOTSUP, "xmh_hamming_hist: no ternary k_scan_hist_b instance for %d code tiles at K=%d", nmc, a.K);
     }
     if (nmc == 4) return launch_t<4, kScanBitsWaves, false>(a, chunk_hist, cache, st);

@@ -20,7 +20,7 @@ def t(fn, n=20):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-for K in (16, 64, 128):
+for K in [int(a) for a in sys.argv[1:]] or (16, 64, 128):
     qB, qL, rB, rL = bench.synth(5000, 117218, K, 80, seed=1814, p=0.04)
     ql, rl = R.pack_labels(qL.cuda()), R.pack_labels(rL.cuda())
     out = {}
