@@ -1990,3 +1990,41 @@ def test_calc_map_k_workspace_keep_knob(cu):
     cu.set_workspace_keep_bytes(1)
     assert cu._scan_ws.__dict__.get("entry") is None
     cu.set_workspace_keep_bytes(old)
+
+
+@pytest.mark.parametrize("K", [16, 64, 128, 256])
+def test_sharded_scan_of_ternary_codes(xr, K):
+    """round 6: ternary codes run pass 1 on the matrix cores and the cached pass 2 of the 256-bit binary codes -- also per shard.  Three
+    contiguous shards of very different sizes, duplicate-heavy gallery: explicit offsets (ap_sums), the totals-table form (map_sharded)
+    and the all-to-all form (map_sharded_offsets) against the unsharded scan and the oracle."""
+    from xmh import sharded
+    orc = _orc()
+    gen = torch.Generator().manual_seed(300 + K)
+    Q, R, C, k = 130, 9000, 24, 37
+    qB, rB = _ternary_codes(Q, K, gen, 0.05), _ternary_codes(40, K, gen, 0.05)[torch.randint(0, 40, (R,), generator=gen)]
+    rB[: R // 3] = _ternary_codes(R // 3, K, gen, 0.2)
+    qL = (torch.rand(Q, C, generator=gen) < 0.15).to(torch.int64)
+    rL = (torch.rand(R, C, generator=gen) < 0.15).to(torch.int64)
+    qL[:, 0] = 1
+    rL[::3, 0] = 1
+    q, ql = xr.pack_sign(qB.cuda()), xr.pack_labels(qL.cuda())
+    r, rl = xr.pack_sign(rB.cuda()), xr.pack_labels(rL.cuda())
+    assert q.zero is not None and r.zero is not None
+    for kk in (None, k):
+        want = float(orc.map_k(qB, rB, qL, rL, kk, stable=True))
+        whole = xr.RankingScan(q, ql, r, rl, C)
+        whole.histograms(False)
+        ap_ref, cap_ref = whole.ap_sums(kk)
+        assert abs(float((ap_ref / cap_ref.double()).mean()) - want) < MAP_TOL
+        bounds = [0, 700, 6100, R]
+        ops = [sharded.HipShardOps(q, ql, r.rows(bounds[s], bounds[s + 1]), rl[bounds[s]:bounds[s + 1]].contiguous(), C) for s in range(3)]
+        gathered = torch.stack([torch.stack(o.histograms()) for o in ops]).contiguous()
+        ap = torch.zeros(Q, dtype=torch.float64, device="cuda")
+        for s, o in enumerate(ops):
+            part, cap = o.ap_sums(kk, *o.offsets(gathered, s))
+            assert torch.equal(cap, cap_ref)
+            ap += part
+        assert torch.allclose(ap, ap_ref, rtol=1e-6, atol=1e-9)
+        tg = torch.stack([o.totals() for o in ops]).contiguous()
+        got = sum(float(o.map_partial(kk, tg, s)) for s, o in enumerate(ops))
+        assert abs(got - want) < MAP_TOL
