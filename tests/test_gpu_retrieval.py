@@ -1931,6 +1931,25 @@ def test_scan_verify_mode_rederives_every_evaluation(cu, K, monkeypatch):
         _lib.scan_verify(False)
 
 
+def test_scan_verify_mode_on_ternary_codes(cu):
+    """the re-derivation of a ternary evaluation: matrix-core pass 1 + cached pass 2 against the masked VALU ternary kernels"""
+    from xmh import _lib
+    orc = _orc()
+    gen = torch.Generator().manual_seed(77)
+    for K in (64, 256):
+        qB, rB = _ternary_codes(90, K, gen, 0.1), _ternary_codes(15000, K, gen, 0.1)
+        qL = (torch.rand(90, 24, generator=gen) < 0.1).to(torch.int64)
+        rL = (torch.rand(15000, 24, generator=gen) < 0.1).to(torch.int64)
+        qL[:, 0] = 1
+        rL[::3, 0] = 1
+        _lib.scan_verify(True)
+        try:
+            got = float(cu.calc_map_k(qB.cuda(), rB.cuda(), qL.cuda(), rL.cuda()))
+        finally:
+            _lib.scan_verify(False)
+        assert abs(got - float(orc.map_k(qB, rB, qL, rL, stable=True))) < MAP_TOL
+
+
 def test_scan_verify_mode_at_the_headline_shape(cu):
     import sys
     from xmh import _lib
