@@ -500,12 +500,15 @@ def main():
             fql, frl = qL[:500].cuda(), rL.cuda()
             cu2.calc_map_k(fq, fr, fql, frl)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            tfs = []
+            for _ in range(7):                                  # median: one call in a few dozen pays a hipMalloc of the 1.2 GB sort workspace
+                t0 = time.perf_counter()
                 mf = cu2.calc_map_k(fq, fr, fql, frl)
-            tf = (time.perf_counter() - t0) / 3
+                tfs.append(time.perf_counter() - t0)
+            tf = sorted(tfs)[len(tfs) // 2]
             out["float_route"] = {"workload": "calc_map_k on tanh float codes, Q=500 x R=%d x %d: fp32 GEMM + segmented radix sort per query + AP pass" % (Rn, K),
-                                  "ms_per_call": tf * 1e3, "pairs_per_s": 500 * Rn / tf, "mAP": float(mf)}
+                                  "ms_per_call": tf * 1e3, "ms_per_call_max": max(tfs) * 1e3, "timing": "median of 7 calls",
+                                  "pairs_per_s": 500 * Rn / tf, "mAP": float(mf)}
             del fq, fr
             cu2.release_scan_workspace()
         except Exception as exc:
