@@ -1591,8 +1591,16 @@ extern "C" int xmh_scan_describe(int64_t Q, int64_t R, int K, int C, int ternary
     const R2Geom g = r2_geom(K);
     if (use_mfma && r2w_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2w<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
     else if (use_mfma && r2_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_r2<%d, %d, %d, %s>", NML, g.nw, g.nq, cache ? "true" : "false");
-    else if (use_mfma && tbits_shape(K, tern)) snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %s, true>", tbits_tiles(K), kMfmaWaves, cache ? "true" : "false");
-    else if (use_mfma) snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %s, false>", kMfmaWaves, cache ? "true" : "false");
+    else if (use_mfma && tbits_shape(K, tern)) {
+        int nsh, nqt;
+        xmh::scan_hist_bits_shape(tbits_tiles(K), true, &nsh, &nqt);
+        snprintf(p1, sizeof(p1), "k_scan_hist_b<%d, %d, %d, %d, %s, true>", tbits_tiles(K), kMfmaWaves, nsh, nqt, cache ? "true" : "false");
+    }
+    else if (use_mfma) {
+        int nsh, nqt;
+        xmh::scan_hist_bits_shape(4, false, &nsh, &nqt);
+        snprintf(p1, sizeof(p1), "k_scan_hist_b<4, %d, %d, %d, %s, false>", kMfmaWaves, nsh, nqt, cache ? "true" : "false");
+    }
     else {
         const bool cached = cache && !tern && Wc <= 8;
         const int S = cached ? cache_slots(Wc) : S4;

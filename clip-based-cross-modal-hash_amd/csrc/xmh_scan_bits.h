@@ -20,6 +20,8 @@ struct ScanBitsArgs {
 // nmc = code tiles of 64 bits (2: up to 128 bits, 4: up to 256); counters come out as (all << 16 | relevant) per (chunk, bucket, query).
 // Ternary codes (a.rzero != null): K <= 64 with nmc = 2, K <= 128 with nmc = 4, K <= 256 with nmc = 8 -- the operand is the 2K-bit pair of planes
 // [element is +1 | element is -1], the distance K - q.r in half units (2K + 1 bucket rows).
+// (waves per counter table, query tiles per wave) of the instance launch_scan_hist_bits picks; for xmh_scan_describe
+void scan_hist_bits_shape(int nmc, bool ternary, int* nsh, int* nqt);
 int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st);
 
 }  // namespace xmh

@@ -12,7 +12,7 @@
 // `quarter` of the code words of its item straight from the packed gallery (one or two words), and the label word `quarter` (labels:
 // up to 128 classes = 4 words = two label tiles; their B bytes are 64 / 2^p where the query has the label, so the label chain ends
 // as 0x10000 + 64 * (common labels) and min(., 0x10001) is the counter increment (all << 16 | relevant)).  No operand image, no
-// LDS ring, no barrier; LDS holds the counters only (K = 256: 66 KB per block of 4 waves, two blocks per CU).
+// LDS ring, no barrier in the loop; LDS holds the counters only (K = 256: 66 KB per block of 4 query tiles).
 // The pair cache (16-bit entries, distance << 1 | relevant) is written in k_scan_hist_m's layout for the cached pass 2, and the
 // items of a 16-item group sit in the same C rows (row r <-> item 16 g + 4 (r & 3) + (r >> 2)), so pass 2 is unchanged.
 // NOT compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (no file of the library is): with the results in VGPRs hipcc re-materialises the label
@@ -60,58 +60,71 @@ __device__ __forceinline__ void word_to_weights(uint32_t w, int on, int off, v4i
 // bucket rows).  A lane's quarter of the operand lies wholly in one half (quarters 0, 1: pos; 2, 3: neg), so the planes cost the lane two
 // loads and two ANDs per word instead of one load.  K <= 64 runs as NMC = 2 (a 128-bit operand), K <= 128 as NMC = 4, K <= 256 as NMC = 8.  Entries of the
 // pair cache: 2 (K - q.r) | relevant in 16 bits, the layout of the 129 ... 256-bit binary codes: pass 2 reads them with the same kernels.
-template <int NMC, int NW, bool CACHE, bool TERN>
-__global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
+// Round 6 -- NQT: query tiles per wave: the item operand, the nine operations per word that build it and the loads behind them serve NQT
+// tiles (NQT x GI independent MFMA chains in flight).  NSH: waves that SHARE a counter table -- wave (tiles, share) takes the batches share,
+// share + NSH, ... of the chunk and adds into the same LDS counters (the adds are atomic).  The counters bound the residency of this kernel
+// (257 rows x 64 B per tile: 66 KB per block of four tiles), so sharing them is what keeps two waves on a SIMD when a wave takes two tiles.
+template <int NMC, int NW, int NSH, int NQT, bool CACHE, bool TERN>
+__global__ __launch_bounds__(64 * NW * NSH / NQT) void k_scan_hist_b(xmh::ScanBitsArgs a, uint32_t* __restrict__ chunk_hist, uint4* __restrict__ pair_cache) {
     constexpr int LWC = NMC / 2;                                    // code words per lane (a quarter of the padded code)
     constexpr int WH = TERN ? NMC : 2 * NMC;                        // words of one plane half of the operand (TERN: 2 WH words in all)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // NW x [nb][16] u32 counters
     const int b = blockIdx.x;
     const int qtile = (b >> 3) % a.nqt, chunk_id = (b & 7) + 8 * ((b >> 3) / a.nqt);        // as mfma_map_block (xmh_scan.hip)
     if (chunk_id >= a.nchunk) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NWV = NW / NQT;                                    // waves of one share; each takes NQT query tiles
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NWV, share = (threadIdx.x >> 6) / NWV;
     const int ql = lane & 15, slot = lane >> 4;
-    const int q0 = (qtile * NW + wave) * 16;
-    const int q = q0 + ql;
     const int ncell = a.nb * 16;
-    uint32_t* cnt = lds + wave * ncell;
-    for (int e = lane; e < ncell; e += 64) cnt[e] = 0u;
-    const bool valid = q < a.Q;
-    // B operands: this lane is column ql (its query) and k quarter `slot`
-    v4i bq[NMC], bl[2];
-    int pc = 0;
+    uint32_t* cnt0 = lds + wave * NQT * ncell;                      // this wave's NQT counter tables, one after the other
+    for (int e = lane + 64 * share; e < NQT * ncell; e += 64 * NSH) cnt0[e] = 0u;
     const bool negq = TERN && slot * LWC >= WH;                      // TERN: this lane's quarter lies in the neg half of the operand
-    if (TERN) pc = a.K;                                              // the chain starts at the row of K - 0
-    else if (valid)
-        for (int w = 0; w < a.W; ++w) pc += __popc(a.qbits[(int64_t)q * a.W + w]);
+    v4i bq[NQT][NMC], bl[NQT][2];
+    int pcn[NQT], lanebase[NQT], cinit[NQT], qn[NQT];
+    bool validn[NQT];
 #pragma unroll
-    for (int v = 0; v < LWC; ++v) {
-        if constexpr (TERN) {
-            const int wi = (slot * LWC + v) % WH;                    // word of the plane
-            const bool have = valid && wi < a.W;
-            const uint32_t b = have ? a.qbits[(int64_t)q * a.W + wi] : 0u, z = have ? a.qzero[(int64_t)q * a.W + wi] : 0xffffffffu;
-            const uint32_t qpos = b & ~z, qneg = ~b & ~z;            // (padding bits are set in the zero plane: neither)
-            v4i p0, p1, n0, n1;
-            word_to_weights(qpos, negq ? 1 : -1, 0, p0, p1);         // -q on the pos half, +q on the neg half
-            word_to_weights(qneg, negq ? -1 : 1, 0, n0, n1);
-            bq[2 * v] = p0 | n0;                                     // disjoint bytes
-            bq[2 * v + 1] = p1 | n1;
-        } else {
-            const int wi = slot * LWC + v;
-            const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
-            word_to_weights(w, -1, valid && wi < a.W ? 1 : 0, bq[2 * v], bq[2 * v + 1]);      // no such word: zero weights, whatever the item lane loads
+    for (int n = 0; n < NQT; ++n) {
+        const int q = ((qtile * NW + wave * NQT + n) * 16) + ql;
+        const bool valid = q < a.Q;
+        qn[n] = q;
+        validn[n] = valid;
+        int pc = 0;
+        if (TERN) pc = a.K;                                          // the chain starts at the row of K - 0
+        else if (valid)
+            for (int w = 0; w < a.W; ++w) pc += __popc(a.qbits[(int64_t)q * a.W + w]);
+        pcn[n] = pc;
+#pragma unroll
+        for (int v = 0; v < LWC; ++v) {
+            if constexpr (TERN) {
+                const int wi = (slot * LWC + v) % WH;                // word of the plane
+                const bool have = valid && wi < a.W;
+                const uint32_t b = have ? a.qbits[(int64_t)q * a.W + wi] : 0u, z = have ? a.qzero[(int64_t)q * a.W + wi] : 0xffffffffu;
+                const uint32_t qpos = b & ~z, qneg = ~b & ~z;        // (padding bits are set in the zero plane: neither)
+                v4i p0, p1, n0, n1;
+                word_to_weights(qpos, negq ? 1 : -1, 0, p0, p1);     // -q on the pos half, +q on the neg half
+                word_to_weights(qneg, negq ? -1 : 1, 0, n0, n1);
+                bq[n][2 * v] = p0 | n0;                              // disjoint bytes
+                bq[n][2 * v + 1] = p1 | n1;
+            } else {
+                const int wi = slot * LWC + v;
+                const uint32_t w = valid && wi < a.W ? a.qbits[(int64_t)q * a.W + wi] : 0u;
+                word_to_weights(w, -1, valid && wi < a.W ? 1 : 0, bq[n][2 * v], bq[n][2 * v + 1]);      // no such word: zero weights, whatever the item lane loads
+            }
         }
+        word_to_weights(valid && slot < a.LW ? a.qlab[(int64_t)q * a.LW + slot] : 0u, 1, 0, bl[n][0], bl[n][1]);
+        lanebase[n] = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(cnt0 + n * ncell) + ql * 4;     // this lane's bucket-0 counter
+        cinit[n] = lanebase[n] + 64 * pc;
     }
-    word_to_weights(valid && slot < a.LW ? a.qlab[(int64_t)q * a.LW + slot] : 0u, 1, 0, bl[0], bl[1]);
-    const int lanebase = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cnt + ql * 4;     // this lane's bucket-0 counter
-    const int cinit = lanebase + 64 * pc;
     const int64_t lo = (int64_t)chunk_id * a.chunk;
     const int64_t hi = (lo + a.chunk < a.R) ? lo + a.chunk : a.R;
     const int nbat = (int)((hi - lo + 63) >> 6);
     // A rows: row r of group g is item 16 g + 4 (r & 3) + (r >> 2) (k_scan_hist_m's image order: C register j of lane (slot, query)
     // is item 16 g + 4 j + slot, which is what the pair-cache layout below and the cached pass 2 count on)
     const int rowitem = 4 * (ql & 3) + (ql >> 2);
-    uint4* crow = nullptr;
-    if (CACHE) crow = pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (q >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (q & 7);
+    uint4* crow[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n)
+        crow[n] = CACHE ? pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (qn[n] >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (qn[n] & 7) : nullptr;
     uint32_t cur[4][LWC + 1], nxt[4][LWC + 1];
     // a word index past the end of the record is clamped to the last word: the query operand of that lane quarter is zero (word_to_weights of
     // a zero word with off = 0 for the labels; for the code see wq below), so what is loaded in its place counts for nothing
@@ -154,10 +167,11 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
         }
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the zeroed counters are in place (this wave's own cells)
-    if (nbat > 0) load(cur, 0);
-    for (int i = 0; i < nbat; ++i) {
-        if (i + 1 < nbat) load(nxt, i + 1);
-        uint32_t cw[4], cw2[4];
+    if (NSH > 1) __syncthreads();                                  // ... and those the tile's other waves zeroed
+    if (share < nbat) load(cur, share);
+    for (int i = share; i < nbat; i += NSH) {
+        if (i + NSH < nbat) load(nxt, i + NSH);
+        uint32_t cw[NQT][4], cw2[NQT][4];
         // Round 6: the groups of 16 items go through the matrix pipe GI at a time, their chains interleaved MFMA by MFMA.  With 66 KB of
         // counters per block the kernel runs two waves per SIMD, and one group's chain (four dependent MFMAs + two for the labels) left
         // the pipe waiting on its own results; independent chains of the other groups fill those slots.
@@ -171,49 +185,62 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
                 for (int v = 0; v < LWC; ++v) word_to_bytes(cur[g0 + u][v], am[u][2 * v], am[u][2 * v + 1]);
                 word_to_bytes(cur[g0 + u][LWC], al[u][0], al[u][1]);
             }
-            v4i acc[GI], lab[GI];
+            v4i acc[NQT][GI], lab[NQT][GI];
 #pragma unroll
-            for (int u = 0; u < GI; ++u) {
-                acc[u] = v4i{cinit, cinit, cinit, cinit};
-                lab[u] = v4i{0x10000, 0x10000, 0x10000, 0x10000};
-            }
+            for (int n = 0; n < NQT; ++n)
+#pragma unroll
+                for (int u = 0; u < GI; ++u) {
+                    acc[n][u] = v4i{cinit[n], cinit[n], cinit[n], cinit[n]};
+                    lab[n][u] = v4i{0x10000, 0x10000, 0x10000, 0x10000};
+                }
 #pragma unroll
             for (int m = 0; m < NMC; ++m) {
 #pragma unroll
-                for (int u = 0; u < GI; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[u][m], bq[m], acc[u], 0, 0, 0);
+                for (int n = 0; n < NQT; ++n)
+#pragma unroll
+                    for (int u = 0; u < GI; ++u) acc[n][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am[u][m], bq[n][m], acc[n][u], 0, 0, 0);
                 if (m < 2) {
 #pragma unroll
-                    for (int u = 0; u < GI; ++u) lab[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al[u][m], bl[m], lab[u], 0, 0, 0);
+                    for (int n = 0; n < NQT; ++n)
+#pragma unroll
+                        for (int u = 0; u < GI; ++u) lab[n][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al[u][m], bl[n][m], lab[n][u], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < GI; ++u) {
-                const int g = g0 + u;
-                uint32_t e[4];
+            for (int n = 0; n < NQT; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t inc = min((uint32_t)lab[u][j], 0x10001u);                    // all << 16 | relevant
-                    asm volatile("ds_add_u32 %0, %1" ::"v"(acc[u][j]), "v"(inc) : "memory");
-                    if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[u][j] - lanebase) >> 5);       // entry: distance << 1 | relevant (16 bits)
+                for (int u = 0; u < GI; ++u) {
+                    const int g = g0 + u;
+                    uint32_t e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t inc = min((uint32_t)lab[n][u][j], 0x10001u);                    // all << 16 | relevant
+                        // a builtin, not an asm statement: with 512 threads and more per block hipcc keeps the MFMA results in VGPRs, and only for an
+                        // instruction it placed itself does it keep the wait states between the MFMA and this read of its result
+                        __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(uintptr_t)(uint32_t)acc[n][u][j], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[n][u][j] - lanebase[n]) >> 5);    // entry: distance << 1 | relevant (16 bits)
+                    }
+                    if (CACHE) {                                     // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
+                        cw[n][g] = e[0] | (e[2] << 16);
+                        cw2[n][g] = e[1] | (e[3] << 16);
+                    }
                 }
-                if (CACHE) {                                         // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
-                    cw[g] = e[0] | (e[2] << 16);
-                    cw2[g] = e[1] | (e[3] << 16);
-                }
-            }
         }
         if (CACHE) {
-            uint4* dst = crow + (int64_t)i * 64;
-            __builtin_nontemporal_store(cw[0], &dst->x);
-            __builtin_nontemporal_store(cw[1], &dst->y);
-            __builtin_nontemporal_store(cw[2], &dst->z);
-            __builtin_nontemporal_store(cw[3], &dst->w);
-            __builtin_nontemporal_store(cw2[0], &dst[32].x);
-            __builtin_nontemporal_store(cw2[1], &dst[32].y);
-            __builtin_nontemporal_store(cw2[2], &dst[32].z);
-            __builtin_nontemporal_store(cw2[3], &dst[32].w);
+#pragma unroll
+            for (int n = 0; n < NQT; ++n) {
+                uint4* dst = crow[n] + (int64_t)i * 64;
+                __builtin_nontemporal_store(cw[n][0], &dst->x);
+                __builtin_nontemporal_store(cw[n][1], &dst->y);
+                __builtin_nontemporal_store(cw[n][2], &dst->z);
+                __builtin_nontemporal_store(cw[n][3], &dst->w);
+                __builtin_nontemporal_store(cw2[n][0], &dst[32].x);
+                __builtin_nontemporal_store(cw2[n][1], &dst[32].y);
+                __builtin_nontemporal_store(cw2[n][2], &dst[32].z);
+                __builtin_nontemporal_store(cw2[n][3], &dst[32].w);
+            }
         }
-        if (i + 1 < nbat) {
+        if (i + NSH < nbat) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -223,32 +250,78 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_b(xmh::ScanBitsArgs a, ui
     // the padding items of a ragged last batch are all-zero-bit codes without labels: distance popcount(query) (TERN: empty planes, K - 0), never relevant
     const int npad = nbat * 64 - (int)(hi - lo);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (npad > 0 && slot == 0 && valid) cnt[pc * 16 + ql] -= (uint32_t)npad << 16;
+    if (NSH > 1) __syncthreads();                                  // every wave of the tile has added its batches
+#pragma unroll
+    for (int n = 0; n < NQT; ++n)
+        if (npad > 0 && slot == 0 && validn[n] && share == 0) cnt0[n * ncell + pcn[n] * 16 + ql] -= (uint32_t)npad << 16;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + q0;
-    for (int e = lane; e < ncell; e += 64) out[(int64_t)(e >> 4) * a.qpad + (e & 15)] = cnt[e];
+    if (NSH > 1) __syncthreads();
+    uint32_t* __restrict__ out = chunk_hist + ((int64_t)chunk_id * a.nb) * a.qpad + (qtile * NW + wave * NQT) * 16;
+    for (int e = lane + 64 * share; e < NQT * ncell; e += 64 * NSH) {
+        const int n = e / ncell, c = e - n * ncell;
+        out[(int64_t)(c >> 4) * a.qpad + n * 16 + (c & 15)] = cnt0[e];
+    }
 }
 
-template <int NMC, int NW, bool TERN>
-int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+// (waves per query tile, query tiles per wave) of each instance, measured on configs[4]'s shard and at the COCO shape, A/B in one process
+// on one box (profiles/r06_hist_b_share_ab.txt).  A block stays 4 query tiles = the plan's 64 queries; its waves = 4 NSH / NQT.
+//   256-bit binary      (2, 2): pass 1 of the shard 5.01 -> 3.51 ms, the COCO shape 0.87 -> 0.77 ms per step
+//   ternary <= 64 bits  (2, 2): 0.77 -> 0.62 ms per step;  ternary <= 128 bits (2, 2): 1.01 -> 0.83
+//   ternary <= 256 bits (2, 1): 1.57 -> 1.39 (eight code tiles x two query tiles of B operands spill)
+// Two tiles per wave halve the operand work per pair, two waves per table give the residency back.  One tile per wave with three waves
+// per table gave 6 %, two tiles per wave alone LOST 6 % (one wave per SIMD).
+template <int NMC, bool TERN>
+struct HistBShape {
+    static constexpr int NSH = 2;
+    static constexpr int NQT = TERN && NMC >= 8 ? 1 : 2;
+};
+
+template <int NMC, int NW, int NSH, int NQT, bool TERN>
+int launch_s(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
     const size_t lds = (size_t)NW * a.nb * 16 * 4;
     const dim3 grid((unsigned)(8 * a.nqt * xmh::ceil_div(a.nchunk, 8)));
     xmh::ProfScope prof("scan_hist", st);
     if (cache) {
-        auto kern = k_scan_hist_b<NMC, NW, true, TERN>;
+        auto kern = k_scan_hist_b<NMC, NW, NSH, NQT, true, TERN>;
         if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW * NSH / NQT), lds, st, a, chunk_hist, cache);
     } else {
-        auto kern = k_scan_hist_b<NMC, NW, false, TERN>;
+        auto kern = k_scan_hist_b<NMC, NW, NSH, NQT, false, TERN>;
         if (const int rc = xmh::raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "xmh_hamming_hist")) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a, chunk_hist, cache);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW * NSH / NQT), lds, st, a, chunk_hist, cache);
     }
     return XMH_OK;
+}
+
+template <int NMC, int NW, bool TERN>
+int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
+#ifdef XMH_EXPERIMENTS                                             // XMH_HIST_B_NSH = 1 .. 4, XMH_HIST_B_NQT = 1, 2: every combination, for the A/B
+    const char *e1 = xmh_experiment_env("XMH_HIST_B_NSH"), *e2 = xmh_experiment_env("XMH_HIST_B_NQT");
+    if (e1 || e2) {
+        const int nsh = e1 ? atoi(e1) : 1, nqt = e2 ? atoi(e2) : 1;
+        switch (nsh * 10 + nqt) {
+            case 11: return launch_s<NMC, NW, 1, 1, TERN>(a, chunk_hist, cache, st);
+            case 21: return launch_s<NMC, NW, 2, 1, TERN>(a, chunk_hist, cache, st);
+            case 31: return launch_s<NMC, NW, 3, 1, TERN>(a, chunk_hist, cache, st);
+            case 12: return launch_s<NMC, NW, 1, 2, TERN>(a, chunk_hist, cache, st);
+            case 22: return launch_s<NMC, NW, 2, 2, TERN>(a, chunk_hist, cache, st);
+            case 42: return launch_s<NMC, NW, 4, 2, TERN>(a, chunk_hist, cache, st);
+            default: return xmh::fail(XMH_EINVAL, "XMH_HIST_B_NSH=%d XMH_HIST_B_NQT=%d: no such instance", nsh, nqt);
+        }
+    }
+#endif
+    return launch_s<NMC, NW, HistBShape<NMC, TERN>::NSH, HistBShape<NMC, TERN>::NQT, TERN>(a, chunk_hist, cache, st);
 }
 
 }  // namespace
 
 namespace xmh {
+
+void scan_hist_bits_shape(int nmc, bool ternary, int* nsh, int* nqt) {
+    *nsh = 2;
+    *nqt = ternary && nmc >= 8 ? HistBShape<8, true>::NQT : HistBShape<4, false>::NQT;
+    static_assert(HistBShape<2, true>::NQT == HistBShape<4, false>::NQT && HistBShape<4, true>::NQT == HistBShape<4, false>::NQT && HistBShape<8, true>::NSH == 2, "");
+}
 
 int launch_scan_hist_bits(const ScanBitsArgs& a, int nmc, uint32_t* chunk_hist, uint4* cache, hipStream_t st) {
     if (a.rzero) {

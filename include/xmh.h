@@ -41,7 +41,7 @@ extern "C" {
 typedef void* xmh_stream_t;
 
 int xmh_version(void);
-/* identity of the sources this library was built from: the first 16 hex digits of sha256 over csrc/*.hip, csrc/*.h and include/xmh.h
+/* identity of the sources this library was built from: the first 16 hex digits of sha256 over the .hip and .h files of csrc/ and include/xmh.h
  * (the Makefile's SRCID).  bench.py recomputes it from the files beside the library and reports whether they match. */
 const char* xmh_build_id(void);
 /* thread-local description of the last failure on this thread ("" if none) */
