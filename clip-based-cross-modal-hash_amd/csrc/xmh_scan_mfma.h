@@ -839,6 +839,10 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_r2w(MfmaArgs a, uint32_t*
 // record of the writer's lane (slot8 & 3, 8 h + query8) and takes every other byte of it: the writer's step t holds items 4 t + slot4,
 // so step t' here = the writer's step 2 t' + (slot8 >> 2), items 8 t' + slot8 -- ascending with the lane, as the order of the returning
 // adds requires.  The byte offsets (8 (slot8 >> 2) and 16 more) go into v_bfe as register operands: no instruction more per pair.
+// (Round 6: the same reading of TWO-byte entries, 16 slots x 4 queries, was measured and dropped: twice the waves per CU, but the two
+// 4-query tiles of a record row are different blocks and each fetched the row's lines -- configs[4]'s shard 2.56 -> 5.65 ms.  That pass is
+// bound by the stream of its pair cache; fetching the words four batches ahead instead of two is worth 4 % there, below.  A batch-major record order -- the records
+// of one batch of all query tiles contiguous, so that the blocks running side by side stream one region -- changed nothing at any shape.)
 template <bool CAPPED, int EB, bool HALF = false>
 __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __restrict__ below, const uint2* __restrict__ dpre,
                                                   const uint32_t* __restrict__ cap_ws, float* __restrict__ ap_part,
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         uint32_t d;
         if (HALF) {
             m = (uint32_t)__builtin_amdgcn_sbfe((int)w, j ? hb1 : hb0, 1);
-            d = __builtin_amdgcn_ubfe(w, j ? hd1 : hd0, 7);
+            d = __builtin_amdgcn_ubfe(w, j ? hd1 : hd0, EB - 1);
         } else {
             m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * j, 1);               // 0 / ~0
             d = __builtin_amdgcn_ubfe(w, EB * j + 1, EB - 1);
@@ -977,6 +981,19 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
 #endif
         return nw2;
     };
+    // the steps of ONE batch whose first `count` items exist, through compiler-placed atomics (the ragged last batch)
+    auto slow_batch = [&](const uint4& w4, int count) {
+#pragma unroll
+        for (int t = 0; t < QW; ++t) {
+            if (t * S + slot < count) {
+                const uint32_t w = t < EPW ? w4.x : (t < 2 * EPW ? w4.y : (t < 3 * EPW ? w4.z : w4.w));
+                const uint32_t bit = HALF ? hoff + 16u * (t % EPW) : (uint32_t)(EB * (t % EPW));
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, bit, 1), d = __builtin_amdgcn_ubfe(w, bit + 1u, EB - 1);
+                const unsigned long long o = atomicAdd(&cnt[d * QW + ql], 1ull | ((unsigned long long)m << 32));
+                credit(o, m);
+            }
+        }
+    };
     if (EB == 8 && !HALF) {
         // two groups per batch (A = its first two words, B = the other two); an iteration issues and credits two batches and ends drained,
         // like the one-group form below
@@ -1032,46 +1049,46 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
         // issues and credits four batches (A B A B, each credited while the next one's atomics are in flight) and ends drained; the
         // remainder does the same with two batches, then one.  One LDS round trip exposed per four batches is the price of results that
         // hipcc cannot be tempted to copy early.
-        auto batch = [&](unsigned long long (&old)[8], uint32_t (&m)[8], int bi) {
-            const uint4 nw2 = next_words(bi);
-            issue(old, m, cw.x, cw.y, cw.z, cw.w);
-            cw = nw;
-            nw = nw2;
-        };
+        // Round 6: the cache words are fetched FOUR batches ahead here.  A batch of this form is 8 steps (half the wave time of the one-byte
+        // form's 16) and with 257 bucket rows of 64-bit counters only nine waves fit a CU.  configs[4]'s shard (12.5 GB of pair cache per
+        // pass), words two / four / eight batches ahead: 2.58 / 2.47 / 3.2 ms.  An iteration takes four batches, so the four word registers
+        // keep their roles and no copy is needed: r_j holds batch bi + j and is refilled with batch bi + j + 4 once its atomics are issued.
+        auto words_at = [&](int b) { return cache_words(b < nbatch ? b : nbatch - 1); };
+        auto issue4 = [&](unsigned long long (&old)[8], uint32_t (&m)[8], const uint4& r) { issue(old, m, r.x, r.y, r.z, r.w); };
+        uint4 r0 = cw, r1 = nw, r2 = words_at(2), r3 = words_at(3);
         int bi = 0;
         for (; bi + 3 < nfull; bi += 4) {
-            batch(oldA, mA, bi);
-            batch(oldB, mB, bi + 1);
+            issue4(oldA, mA, r0);
+            r0 = words_at(bi + 4);
+            issue4(oldB, mB, r1);
+            r1 = words_at(bi + 5);
             drain8(oldA, mA);
-            batch(oldA, mA, bi + 2);
+            issue4(oldA, mA, r2);
+            r2 = words_at(bi + 6);
             drain8(oldB, mB);
-            batch(oldB, mB, bi + 3);
+            issue4(oldB, mB, r3);
+            r3 = words_at(bi + 7);
             drain8(oldA, mA);
             drain0(oldB, mB);
         }
-        if (bi + 1 < nfull) {
-            batch(oldA, mA, bi);
-            batch(oldB, mB, bi + 1);
+        const int rem = nfull - bi;                                  // 0 .. 3 whole batches left, in r0, r1, r2; the ragged one's words follow them
+        if (rem >= 2) {
+            issue4(oldA, mA, r0);
+            issue4(oldB, mB, r1);
             drain8(oldA, mA);
             drain0(oldB, mB);
-            bi += 2;
-        }
-        if (bi < nfull) {
-            batch(oldA, mA, bi);
+            if (rem == 3) {
+                issue4(oldA, mA, r2);
+                drain0(oldA, mA);
+            }
+        } else if (rem == 1) {
+            issue4(oldA, mA, r0);
             drain0(oldA, mA);
         }
+        cw = rem == 0 ? r0 : (rem == 1 ? r1 : (rem == 2 ? r2 : r3));
     }
     const int cntb = (int)(hi - lo) - nfull * 64;                    // ragged last batch (cw holds its words)
-#pragma unroll
-    for (int t = 0; t < QW; ++t) {
-        if (t * S + slot < cntb) {
-            const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
-            const uint32_t bit = HALF ? hoff + 16u * (t % EPW) : (uint32_t)(EB * (t % EPW));
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, bit, 1), d = __builtin_amdgcn_ubfe(w, bit + 1u, HALF ? 7 : EB - 1);
-            const unsigned long long o = atomicAdd(&cnt[d * QW + ql], 1ull | ((unsigned long long)m << 32));
-            credit(o, m);
-        }
-    }
+    slow_batch(cw, cntb);
 #pragma unroll
     for (int o = QW; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (slot == 0) ap_part[(int64_t)chunk_id * a.qpad + q] = acc;
