@@ -306,6 +306,7 @@ int launch_t(const xmh::ScanBitsArgs& a, uint32_t* chunk_hist, uint4* cache, hip
             case 12: return launch_s<NMC, NW, 1, 2, TERN>(a, chunk_hist, cache, st);
             case 22: return launch_s<NMC, NW, 2, 2, TERN>(a, chunk_hist, cache, st);
             case 42: return launch_s<NMC, NW, 4, 2, TERN>(a, chunk_hist, cache, st);
+            case 32: return launch_s<NMC, NW, 3, 2, TERN>(a, chunk_hist, cache, st);
             default: return xmh::fail(XMH_EINVAL, "XMH_HIST_B_NSH=%d XMH_HIST_B_NQT=%d: no such instance", nsh, nqt);
         }
     }
