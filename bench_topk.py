@@ -146,7 +146,21 @@ def _result(alg, t, t_call, launches, R, K, Q, k, kind):
             "traffic": _traffic(K, Q), "algorithmic_bytes": alg, "avg_launch_ms": t * 1e3,
             "whole_call_ms": t_call * 1e3, "whole_call_GBps": alg / t_call / 1e9,
             "workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU, %s codes" % (k, Q, R, K, kind),
-            "pairs_per_s_whole_call": Q * R / t_call, "robust_path_launches": _robust_launches(launches)}
+            "pairs_per_s_whole_call": Q * R / t_call, "robust_path_launches": _robust_launches(launches), **_mfma_bound(inst, R, K, Q, t)}
+
+
+I8_MFMA_TOPS = 3944.0      # v_mfma_i32_16x16x64_i8, the guide's measured ceiling (MI355X_MICROARCH.md, "I8 ... >= 3944 TOPS")
+
+
+def _mfma_bound(inst, R, K, Q, t):
+    """From a handful of queries per gallery pass the filter is the matrix-core kernel and its bound is the i8 MFMA rate, not HBM: report
+    the operations it ISSUES (query tiles of 16 columns: 5 .. 16 queries issue the same MFMAs) and the useful ones, against that ceiling."""
+    if not inst.startswith("k_topk_filter_mfma"):
+        return {}
+    tiles = (Q + 15) // 16
+    issued, useful = 2.0 * 16 * tiles * R * K, 2.0 * Q * R * K
+    return {"mfma": {"bound": "mfma", "unit": "TOPS", "peak": I8_MFMA_TOPS, "issued": issued / t / 1e12, "useful": useful / t / 1e12,
+                     "frac_issued": issued / t / 1e12 / I8_MFMA_TOPS, "frac": useful / t / 1e12 / I8_MFMA_TOPS}}
 
 
 def _robust_launches(filter_launches):
@@ -237,7 +251,8 @@ def measure_many_queries(R=10_000_000, K=256, Q=5000, k=100, iters=2):
     key = (dd.to(torch.int64) << 32) | i.to(torch.int64)
     ok = bool((key[:, 1:] > key[:, :-1]).all()) and bool((i >= 0).all()) and bool((i < R).all())
     return {"workload": "exact top-%d of Q=%d queries over R=%d x %d-bit gallery on one GPU, iid codes" % (k, Q, R, K), "whole_call_ms": t * 1e3,
-            "pairs_per_s_whole_call": Q * R / t, "lists_sorted_distinct_in_range": ok, "mean_kth_distance": float(dd[:, -1].float().mean())}
+            "pairs_per_s_whole_call": Q * R / t, "lists_sorted_distinct_in_range": ok, "mean_kth_distance": float(dd[:, -1].float().mean()),
+            "mfma_useful_TOPS_whole_call": 2.0 * Q * R * K / t / 1e12, "mfma_frac_whole_call": 2.0 * Q * R * K / t / 1e12 / I8_MFMA_TOPS}
 
 
 def measure_cache_defeat(R=10_000_000, K=256, k=100, galleries=4, iters=20):
