@@ -131,14 +131,21 @@ def _calc_map_k_one_call(gq: torch.Tensor, gr: torch.Tensor, ql: torch.Tensor, r
         if need > 0.9 * free:
             return None                                  # the composed path knows how to run without the pair cache
         ws = torch.empty(need, dtype=torch.uint8, device=gq.device)
-    m, fl = ctypes.c_double(float("nan")), ctypes.c_int32(0)
+    # the two host words the call writes (value flags, mAP) live in PINNED memory, one 16-byte buffer per thread: a device-to-host copy into
+    # pageable memory goes through the runtime's staging buffer, 10-15 us each at this size (bench_dropin: 493 -> see INTEGRATION section 2)
+    host = _scan_ws.__dict__.get("host")
+    if host is None:
+        host = _scan_ws.host = torch.empty(2, dtype=torch.float64).pin_memory()
+    host[0] = float("nan")
+    host.view(torch.int32)[2] = 0
+    base = host.data_ptr()
     rc = lib.xmh_calc_map_k(ptr(gq), ptr(gr), ptr(ql), ptr(rl), Q, Rn, K, C, 0 if k is None else int(k), ptr(ws), ws.numel(),
-                            ctypes.byref(m), ctypes.byref(fl), current_stream())
+                            ctypes.cast(base, ctypes.POINTER(ctypes.c_double)), ctypes.cast(base + 8, ctypes.POINTER(ctypes.c_int32)), current_stream())
     if ws.numel() <= _KEEP_WS_BYTES:
         _scan_ws.entry = (key, ws)
-    if rc != 0 or (fl.value & 2):
+    if rc != 0 or (int(host.view(torch.int32)[2]) & 2):
         return None                                      # not supported in this form / unquantised codes: the composed path reports or handles it
-    return torch.tensor(m.value, dtype=torch.float32)
+    return torch.tensor(float(host[0]), dtype=torch.float32)
 
 
 def _is_quantised(*packed: R.PackedCodes) -> bool:
