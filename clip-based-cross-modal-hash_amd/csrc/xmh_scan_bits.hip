@@ -15,10 +15,13 @@
 // LDS ring, no barrier in the loop; LDS holds the counters only (K = 256: 66 KB per block of 4 query tiles).
 // The pair cache (16-bit entries, distance << 1 | relevant) is written in k_scan_hist_m's layout for the cached pass 2, and the
 // items of a 16-item group sit in the same C rows (row r <-> item 16 g + 4 (r & 3) + (r >> 2)), so pass 2 is unchanged.
-// NOT compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (no file of the library is): with the results in VGPRs hipcc re-materialises the label
-// chain's start value (v_mov_b64 into the quad) three instructions behind the MFMA that still reads that quad as srcC, and the
-// hardware takes the new value -- wrong distances by a few units for K = 256 (found with tools/diag_bits.py).  In the default
-// AGPR form the start values go through v_accvgpr_write and the hazard table covers them.
+// MFMA results in VGPRs (round 6 correction of a round-3 note).  A round-3 build of this file with -mllvm -amdgpu-mfma-vgpr-form=1 gave wrong
+// distances by a few units at K = 256, and the note here blamed a VALU write onto a quad three wait states behind the MFMA that reads it as
+// srcC.  That pattern is legal (three wait states is what a four-pass MFMA needs) and is in the shipped 512-bit ternary instance, whose blocks
+// of 512 threads make hipcc choose the VGPR form by itself: its histograms equal an exact integer restatement cell for cell
+// (tools/diag_bits_ternary.py).  What broke the round-3 build was the `ds_add_u32` ASM statement reading the MFMA result with no wait states in
+// front of it -- in the AGPR form a v_accvgpr_read sat in between and hid it.  The add is a builtin now (below), and tools/isa_hazards.py
+// rule R1 checks the distance on every instance at build time.
 #include "xmh_common.h"
 #include "xmh_scan_bits.h"
 
