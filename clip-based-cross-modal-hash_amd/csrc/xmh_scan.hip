@@ -1151,7 +1151,10 @@ constexpr int kAp2Waves = 4, kAp2Groups = 2;           // k_scan_ap_r2: waves pe
                                                        // blocks per CU; 2 x 2, 1 x 2 and 1 x 1 measured the same 0.262-0.275 ms at the headline shape)
 constexpr int kMfmaWaves = 4;                          // k_scan_hist_b: waves (16 queries each) per block
 static_assert(xmh::kScanBitsWaves == kMfmaWaves, "k_scan_hist_b takes the plan's query tiles of 64");
-constexpr int kBitsMaxChunk = 8064;                    // chunks of k_scan_hist_b's plan (the size its configs[4] numbers were tuned at), multiple of 64
+// largest chunk of k_scan_hist_b's plan, a multiple of 64.  Round 6: 8064 -> 24192.  The [chunk][bucket][query] tables weigh 257 (513) rows per
+// chunk here: on configs[4]'s shard 159 chunks made k_scan_below 0.5 ms and the counter start values 1.7 GB of pass 2's reads; 8064 / 16128 /
+// 24192 / 32256: 6.6 / 5.97 / 5.93 / 5.99 ms per step (COCO shape: ternary 128 bit 0.83 -> 0.78, 256-bit binary 0.75 -> 0.72)
+constexpr int kBitsMaxChunk = 24192;
 // waves per block x query groups of 16 per wave of k_scan_hist_r2 / r2w, and the blocks per CU the chunk count is sized for: codes of at
 // most 32 bits have so few buckets that one block of 256 queries per CU measured best (Q 5000 x R 117 218, blocks per CU x rounds: K=16
 // 0.416 / 0.350 / 0.367 / 0.352 / 0.368 ms per step for 1 / 2 / 3 / 4 / 6); 33..64 bits: 66 KB of counters per block, two per CU;
@@ -1256,8 +1259,10 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     chunk = xmh::ceil_div(chunk, 8) * 8;
     if (mfma) {                                   // batches of 64 items
         chunk = xmh::ceil_div(chunk, 64) * 64;
-        if (!r2 && chunk > kBitsMaxChunk) {                         // capped: whole XCD groups of equal chunks again
-            nchunk = xmh::ceil_div(xmh::ceil_div(R, (int64_t)kBitsMaxChunk), 8) * 8;
+        int64_t bits_max = kBitsMaxChunk;
+        if (const char* e = xmh_experiment_env("XMH_BITS_MAX_CHUNK")) bits_max = atoll(e) / 64 * 64 > 0 ? atoll(e) / 64 * 64 : bits_max;
+        if (!r2 && chunk > bits_max) {                              // capped: whole XCD groups of equal chunks again
+            nchunk = xmh::ceil_div(xmh::ceil_div(R, bits_max), 8) * 8;
             chunk = xmh::ceil_div(xmh::ceil_div(R, nchunk), 64) * 64;
         }
     }
