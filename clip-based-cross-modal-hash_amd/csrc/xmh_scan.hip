@@ -1247,7 +1247,8 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (mfma) {
         nchunk = (int64_t)3 * xmh::device_cu_count() / nqt;          // k_scan_hist_b: 257 bucket rows, one block of 64 queries per CU, three sets
         if (r2) {                                 // blocks of r2q queries, blocks_per_cu of them per CU, `sets` sets of them
-            const int sets = K > 32 && K <= 64 ? 1 : 2;             // k_scan_hist_r2 at 33..64 bits: one set (1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
+            int sets = K > 32 && K <= 64 ? 1 : 2;                   // k_scan_hist_r2 at 33..64 bits: one set (1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
+            if (const char* e = xmh_experiment_env("XMH_R2_SETS")) sets = atoi(e) > 0 ? atoi(e) : sets;
             nchunk = (int64_t)sets * xmh::device_cu_count() * r2_geom(K).blocks_per_cu / (nqt * 64 / r2q);
         }
     }
