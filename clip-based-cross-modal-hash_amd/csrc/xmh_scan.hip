@@ -1245,7 +1245,11 @@ int make_plan(int64_t Q, int64_t R, int K, int ternary, xmh_scan_plan* p) {
     if (S64 > 8) nchunk = nchunk * 8 / S64;       // long codes: S waves per tile already fill the slots; fewer chunks = smaller tables
     const bool mfma = mfma_shape(K, ternary != 0);
     if (mfma) {
-        nchunk = (int64_t)3 * xmh::device_cu_count() / nqt;          // k_scan_hist_b: 257 bucket rows, one block of 64 queries per CU, three sets
+        // k_scan_hist_b: 257 (513) bucket rows: three sets of blocks (COCO shape, sets 2 / 3 / 4 / 6: ternary 128 bit 0.93 / 0.78 / 0.83 / 0.83 ms, 256-bit
+        // binary 0.85 / 0.73 / 0.75 / 0.76); ternary codes of at most 64 bits have 129 rows and smaller tables: six (0.65 -> 0.62 ms)
+        int64_t bsets = nb <= 129 ? 6 : 3;
+        if (const char* e = xmh_experiment_env("XMH_BITS_SETS")) bsets = atoi(e) > 0 ? atoi(e) : bsets;
+        nchunk = bsets * xmh::device_cu_count() / nqt;
         if (r2) {                                 // blocks of r2q queries, blocks_per_cu of them per CU, `sets` sets of them
             int sets = K > 32 && K <= 64 ? 1 : 2;                   // k_scan_hist_r2 at 33..64 bits: one set (1 / 2 / 3: 0.178 / 0.187 / 0.199 ms)
             if (const char* e = xmh_experiment_env("XMH_R2_SETS")) sets = atoi(e) > 0 ? atoi(e) : sets;
