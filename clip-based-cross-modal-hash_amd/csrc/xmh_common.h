@@ -39,6 +39,15 @@ inline hipStream_t as_stream(xmh_stream_t s) { return reinterpret_cast<hipStream
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Pair cache of the ranking scan, entries of codes above 64 bits and of ternary codes (distance << 1 | relevant, at most 1025): round 6
+// stores them 12 bits each -- the 8 entries of a lane and batch are THREE dwords (entry k = bits [12 k, 12 k + 12) of the 96), a record
+// row of 64 lanes 768 bytes -- instead of 16 bits each in four.  Pass 2 of such codes is bound by the stream of this cache (configs[4]'s
+// shard: 12.5 GB per pass at 5 TB/s); a quarter of the bytes is a quarter of that time.  Entries 2 and 5 straddle a dword.
+constexpr int kCache12Dwords = 3;
+// entry k (compile-time) of a record -> (the dword to extract from, bit offset in it); x = w1:w0 >> 24, y = w2:w1 >> 28 hold the straddlers
+#define XMH_CACHE12_WORD(k, w0, w1, w2, x, y) ((k) < 2 ? (w0) : (k) == 2 ? (x) : (k) < 5 ? (w1) : (k) == 5 ? (y) : (w2))
+#define XMH_CACHE12_BIT(k) ((k) == 0 ? 0 : (k) == 1 ? 12 : (k) == 2 ? 0 : (k) == 3 ? 4 : (k) == 4 ? 16 : (k) == 5 ? 0 : (k) == 6 ? 8 : 20)
+
 int device_cu_count();
 
 // Opt `kern` in to `bytes` (> 64 KB) of dynamic LDS on the CURRENT device.  hipFuncSetAttribute applies to the current device only

@@ -472,12 +472,22 @@ __global__ __launch_bounds__(64 * NW) void k_scan_hist_s(ScanArgs a, uint32_t* _
                 w = __builtin_amdgcn_alignbyte(b, w, EB / 8);
             }
         }
-        if (CACHE) {                                                 // streamed once: non-temporal, so that the 593 MB do not sit dirty in
+        if (CACHE && EB == 8) {                                      // streamed once: non-temporal, so that the 593 MB do not sit dirty in
             uint4* dst = crow + ((base - lo) >> 6) * 64;                 // L2 / Infinity Cache while the small table kernels run
             __builtin_nontemporal_store(cw0, &dst->x);
             __builtin_nontemporal_store(cw1, &dst->y);
             __builtin_nontemporal_store(cw2, &dst->z);
             __builtin_nontemporal_store(cw3, &dst->w);
+        }
+        if (CACHE && EB == 16) {                                     // two-byte class entries go out 12 bits each (xmh_common.h): the four words of
+            // 16-bit pairs become three.  p = E_even | E_odd << 16 with both below 4096: bfi(0xfff, p, p >> 4) = E_even | E_odd << 12
+            const uint32_t a0 = (cw0 & 0xfffu) | ((cw0 >> 4) & ~0xfffu), a1 = (cw1 & 0xfffu) | ((cw1 >> 4) & ~0xfffu);
+            const uint32_t a2 = (cw2 & 0xfffu) | ((cw2 >> 4) & ~0xfffu), a3 = (cw3 & 0xfffu) | ((cw3 >> 4) & ~0xfffu);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(a.pair_cache) +
+                            ((((int64_t)chunk_id * a.nqt + qtile) * nbatch + ((base - lo) >> 6)) * 64 + lane) * xmh::kCache12Dwords;
+            __builtin_nontemporal_store(a0 | (a1 << 24), dst);
+            __builtin_nontemporal_store((a1 >> 8) | (a2 << 16), dst + 1);
+            __builtin_nontemporal_store((a2 >> 16) | (a3 << 8), dst + 2);
         }
         cur = nxt;
     }
@@ -607,43 +617,67 @@ __global__ __launch_bounds__(64 * NW) void k_scan_ap_s(ScanArgs a, const uint2* 
         constexpr int EB = 128 / QW, EPW = 32 / EB;                   // entry bits, entries per word (see k_scan_hist_s)
         static_assert(NW == 1 && (S == 4 || S == 8) && NG == 2 && G == 2 * EPW && !MASKED, "pair cache geometry");
         // one group of 8 steps from two cache words; the returned counters are credited while the next group's adds fly
-        auto issue = [&](uint32_t wa, uint32_t wb, bool have_prev) {
+        // entry k (a constant after unrolling) of a lane's batch record r: 8- and 16-bit class entries; the latter are stored 12 bits each in
+        // three dwords (xmh_common.h), sx / sy = the two entries that straddle a dword, shifted down
+        auto entry = [&](const uint4& r, uint32_t sx, uint32_t sy, int k, uint32_t& d, uint32_t& hit) {
+            if constexpr (EB == 8) {
+                const uint32_t w = k < EPW ? r.x : (k < 2 * EPW ? r.y : (k < 3 * EPW ? r.z : r.w));
+                d = __builtin_amdgcn_ubfe(w, EB * (k % EPW) + 1, EB - 1);
+                hit = __builtin_amdgcn_ubfe(w, EB * (k % EPW), 1);
+            } else {
+                const uint32_t w = XMH_CACHE12_WORD(k, r.x, r.y, r.z, sx, sy);
+                d = __builtin_amdgcn_ubfe(w, XMH_CACHE12_BIT(k) + 1, 11);
+                hit = __builtin_amdgcn_ubfe(w, XMH_CACHE12_BIT(k), 1);
+            }
+        };
+        auto issue = [&](const uint4& r, uint32_t sx, uint32_t sy, int first, bool have_prev) {
             if (have_prev) {
 #pragma unroll
                 for (int u = 0; u < G; ++u) credit(old[u], hitp[u]);
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                const uint32_t w = u < EPW ? wa : wb;
-                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (u % EPW) + 1, EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (u % EPW), 1);
+                uint32_t d, hit;
+                entry(r, sx, sy, first + u, d, hit);
                 hitp[u] = hit;
                 old[u] = atomicAdd(&cnt[d * QW + ql], inc(hit));      // same-address lanes resolve in lane = item order
             }
         };
         const int nbatch = (a.chunk + 63) >> 6;
         const uint4* crow = a.pair_cache + ((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane;
+        const uint32_t* crow12 = reinterpret_cast<const uint32_t*>(a.pair_cache) + (((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane) * xmh::kCache12Dwords;
         const int nfull = (int)((hi - lo) >> 6);                     // whole batches of this chunk
-        auto cache_words = [&](int64_t batch) -> uint4 {             // read once, 1 KB contiguous per wave instruction: non-temporal (see k_scan_ap_c)
-            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
-            return make_uint4(v.x, v.y, v.z, v.w);
+        // read once, 1 KB (12-bit records: 768 B) contiguous per wave instruction: non-temporal (see k_scan_ap_c).  EB == 16: the record's three
+        // dwords come back as x, y, z and its two straddling entries, shifted down, as w (low half: entry 2, high half: entry 5)
+        auto cache_words = [&](int64_t batch) -> uint4 {
+            if constexpr (EB == 8) {
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
+                return make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+                const u32x3_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(crow12 + batch * 64 * xmh::kCache12Dwords));
+                return make_uint4(v.x, v.y, v.z, 0u);
+            }
         };
         uint4 cw = cache_words(0);
         bool prev = false;
         for (int bi = 0; bi < nfull; ++bi) {
             const uint4 nw = cache_words(bi + 1 < nbatch ? bi + 1 : bi);               // unconditional: counted vmcnt, no predication
-            issue(cw.x, cw.y, prev);
+            const uint32_t sx = EB == 16 ? __builtin_amdgcn_alignbit(cw.y, cw.x, 24) : 0u, sy = EB == 16 ? __builtin_amdgcn_alignbit(cw.z, cw.y, 28) : 0u;
+            issue(cw, sx, sy, 0, prev);
             prev = true;
-            issue(cw.z, cw.w, true);
+            issue(cw, sx, sy, G, true);
             cw = nw;
         }
         if (prev) drain();
         const int cntb = (int)(hi - lo) - nfull * 64;                // ragged last batch (cw holds its words)
+        const uint32_t sx = EB == 16 ? __builtin_amdgcn_alignbit(cw.y, cw.x, 24) : 0u, sy = EB == 16 ? __builtin_amdgcn_alignbit(cw.z, cw.y, 28) : 0u;
 #pragma unroll
         for (int t = 0; t < QW; ++t) {
             if (t * S + slot < cntb) {
-                const uint32_t w = t < EPW ? cw.x : (t < 2 * EPW ? cw.y : (t < 3 * EPW ? cw.z : cw.w));
-                const uint32_t d = __builtin_amdgcn_ubfe(w, EB * (t % EPW) + 1, EB - 1), hit = __builtin_amdgcn_ubfe(w, EB * (t % EPW), 1);
+                uint32_t d, hit;
+                entry(cw, sx, sy, t, d, hit);
                 const CT o = atomicAdd(&cnt[d * QW + ql], inc(hit));
                 credit(o, hit);
             }
@@ -1180,7 +1214,10 @@ size_t pair_cache_bytes(const xmh_scan_plan& p, int K, bool ternary) {
     if ((ternary && !tb) || K > 256 || cap_mb <= 0 || (!tb && K <= 32 && !r2_shape(K, ternary))) return 0;
     if (r2_shape(K, ternary) && ap_r2_mode() == 1) return 0;        // k_scan_ap_r2 evaluates the pairs itself
     const int S = tb ? 8 : (K <= 64 ? 4 : 8);                      // slots of the kernels that use it: 64 / S queries per wave
-    const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * 1024;
+    // records of 64 lanes per (chunk, tile of 64 / S queries, batch of 64 items): 16 B per lane for one-byte entries (S = 4), 12 B per lane for the
+    // 12-bit entries of longer and of ternary codes (S = 8; xmh_common.h) -- 65..128-bit codes whose one-byte entries k_scan_hist_r2w writes use
+    // two thirds of that region
+    const size_t bytes = (size_t)p.nchunk * (size_t)(p.nqtile * S) * (size_t)((p.chunk + 63) / 64) * (S == 4 ? 1024 : 64 * 4 * xmh::kCache12Dwords);
     return bytes <= (size_t)cap_mb << 20 ? bytes : 0;
 }
 

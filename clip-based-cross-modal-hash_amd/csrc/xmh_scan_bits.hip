@@ -13,7 +13,7 @@
 // up to 128 classes = 4 words = two label tiles; their B bytes are 64 / 2^p where the query has the label, so the label chain ends
 // as 0x10000 + 64 * (common labels) and min(., 0x10001) is the counter increment (all << 16 | relevant)).  No operand image, no
 // LDS ring, no barrier in the loop; LDS holds the counters only (K = 256: 66 KB per block of 4 query tiles).
-// The pair cache (16-bit entries, distance << 1 | relevant) is written in k_scan_hist_m's layout for the cached pass 2, and the
+// The pair cache (12-bit entries since round 6, distance << 1 | relevant, three dwords per lane and batch: xmh_common.h) is written for the cached pass 2, and the
 // items of a 16-item group sit in the same C rows (row r <-> item 16 g + 4 (r & 3) + (r >> 2)), so pass 2 is unchanged.
 // MFMA results in VGPRs (round 6 correction of a round-3 note).  A round-3 build of this file with -mllvm -amdgpu-mfma-vgpr-form=1 gave wrong
 // distances by a few units at K = 256, and the note here blamed a VALU write onto a quad three wait states behind the MFMA that reads it as
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(64 * NW * NSH / NQT) void k_scan_hist_b(xmh::ScanBi
     // A rows: row r of group g is item 16 g + 4 (r & 3) + (r >> 2) (k_scan_hist_m's image order: C register j of lane (slot, query)
     // is item 16 g + 4 j + slot, which is what the pair-cache layout below and the cached pass 2 count on)
     const int rowitem = 4 * (ql & 3) + (ql >> 2);
-    uint4* crow[NQT];
+    uint32_t* crow[NQT];                                             // this lane's first 12-bit record (xmh_common.h) of each tile; the other one 32 records on
 #pragma unroll
     for (int n = 0; n < NQT; ++n)
-        crow[n] = CACHE ? pair_cache + ((int64_t)chunk_id * (a.qpad >> 3) + (qn[n] >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (qn[n] & 7) : nullptr;
+        crow[n] = CACHE ? reinterpret_cast<uint32_t*>(pair_cache) + (((int64_t)chunk_id * (a.qpad >> 3) + (qn[n] >> 3)) * ((a.chunk + 63) >> 6) * 64 + slot * 8 + (qn[n] & 7)) * xmh::kCache12Dwords : nullptr;
     uint32_t cur[4][LWC + 1], nxt[4][LWC + 1];
     // a word index past the end of the record is clamped to the last word: the query operand of that lane quarter is zero (word_to_weights of
     // a zero word with off = 0 for the labels; for the code see wq below), so what is loaded in its place counts for nothing
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * NW * NSH / NQT) void k_scan_hist_b(xmh::ScanBi
     if (share < nbat) load(cur, share);
     for (int i = share; i < nbat; i += NSH) {
         if (i + NSH < nbat) load(nxt, i + NSH);
-        uint32_t cw[NQT][4], cw2[NQT][4];
+        uint32_t cw[NQT][3], cw2[NQT][3];                              // the two records this lane fills per tile and batch: 8 entries of 12 bits each
         // Round 6: the groups of 16 items go through the matrix pipe GI at a time, their chains interleaved MFMA by MFMA.  With 66 KB of
         // counters per block the kernel runs two waves per SIMD, and one group's chain (four dependent MFMAs + two for the labels) left
         // the pipe waiting on its own results; independent chains of the other groups fill those slots.
@@ -223,24 +223,28 @@ __global__ __launch_bounds__(64 * NW * NSH / NQT) void k_scan_hist_b(xmh::ScanBi
                         __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(uintptr_t)(uint32_t)acc[n][u][j], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (CACHE) e[j] = (inc & 1u) | ((uint32_t)(acc[n][u][j] - lanebase[n]) >> 5);    // entry: distance << 1 | relevant (16 bits)
                     }
-                    if (CACHE) {                                     // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m)
-                        cw[n][g] = e[0] | (e[2] << 16);
-                        cw2[n][g] = e[1] | (e[3] << 16);
+                    if (CACHE) {                                     // steps 2g, 2g+1 of the two 8-slot lanes this lane feeds (k_scan_hist_m): entries 2g, 2g+1
+                        auto put = [&](uint32_t (&d)[3], uint32_t x, uint32_t y) {      // of their records, appended 12 bits each (g is a constant after unrolling)
+                            if (g == 0) d[0] = x | (y << 12);
+                            else if (g == 1) { d[0] |= x << 24; d[1] = (x >> 8) | (y << 4); }
+                            else if (g == 2) { d[1] |= (x << 16) | (y << 28); d[2] = y >> 4; }
+                            else d[2] |= (x << 8) | (y << 20);
+                        };
+                        put(cw[n], e[0], e[2]);
+                        put(cw2[n], e[1], e[3]);
                     }
                 }
         }
         if (CACHE) {
 #pragma unroll
             for (int n = 0; n < NQT; ++n) {
-                uint4* dst = crow[n] + (int64_t)i * 64;
-                __builtin_nontemporal_store(cw[n][0], &dst->x);
-                __builtin_nontemporal_store(cw[n][1], &dst->y);
-                __builtin_nontemporal_store(cw[n][2], &dst->z);
-                __builtin_nontemporal_store(cw[n][3], &dst->w);
-                __builtin_nontemporal_store(cw2[n][0], &dst[32].x);
-                __builtin_nontemporal_store(cw2[n][1], &dst[32].y);
-                __builtin_nontemporal_store(cw2[n][2], &dst[32].z);
-                __builtin_nontemporal_store(cw2[n][3], &dst[32].w);
+                uint32_t* dst = crow[n] + (int64_t)i * 64 * xmh::kCache12Dwords;
+                __builtin_nontemporal_store(cw[n][0], dst);
+                __builtin_nontemporal_store(cw[n][1], dst + 1);
+                __builtin_nontemporal_store(cw[n][2], dst + 2);
+                __builtin_nontemporal_store(cw2[n][0], dst + 32 * xmh::kCache12Dwords);
+                __builtin_nontemporal_store(cw2[n][1], dst + 32 * xmh::kCache12Dwords + 1);
+                __builtin_nontemporal_store(cw2[n][2], dst + 32 * xmh::kCache12Dwords + 2);
             }
         }
         if (i + NSH < nbat) {

@@ -906,11 +906,15 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     };
     const uint32_t hoff = HALF ? 8u * (uint32_t)(slot >> 2) : 0u;    // HALF: this lane's bytes of a word are hoff / 8 and hoff / 8 + 2
     const uint32_t hb0 = hoff, hb1 = hoff + 16u, hd0 = hoff + 1u, hd1 = hoff + 17u;
+    // j: the entry's place in the word (one-byte entries), or -- EB == 16: entries stored 12 bits each, xmh_common.h -- its bit offset there
     auto issue1 = [&](uint32_t w, int j, unsigned long long& old, uint32_t& m) {
         uint32_t d;
         if (HALF) {
             m = (uint32_t)__builtin_amdgcn_sbfe((int)w, j ? hb1 : hb0, 1);
             d = __builtin_amdgcn_ubfe(w, j ? hd1 : hd0, EB - 1);
+        } else if (EB == 16) {
+            m = (uint32_t)__builtin_amdgcn_sbfe((int)w, j, 1);
+            d = __builtin_amdgcn_ubfe(w, j + 1, 11);
         } else {
             m = (uint32_t)__builtin_amdgcn_sbfe((int)w, EB * j, 1);               // 0 / ~0
             d = __builtin_amdgcn_ubfe(w, EB * j + 1, EB - 1);
@@ -937,10 +941,16 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     constexpr bool kFourBatchIterations = true;
     // 8 steps = two cache words of one-byte entries, or all four words of a batch of two-byte entries / of the 8-query-wide reading
     auto issue = [&](unsigned long long (&old)[8], uint32_t (&m)[8], uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd) {
+        if constexpr (EB == 16) {                                    // a 12-bit record: wa, wb, wc; entries 2 and 5 straddle a dword (wd is not used)
+            const uint32_t sx = __builtin_amdgcn_alignbit(wb, wa, 24), sy = __builtin_amdgcn_alignbit(wc, wb, 28);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int wi = u / EPW;
-            issue1(wi == 0 ? wa : (wi == 1 ? wb : (wi == 2 ? wc : wd)), u % EPW, old[u], m[u]);
+            for (int u = 0; u < 8; ++u) issue1(XMH_CACHE12_WORD(u, wa, wb, wc, sx, sy), XMH_CACHE12_BIT(u), old[u], m[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int wi = u / EPW;
+                issue1(wi == 0 ? wa : (wi == 1 ? wb : (wi == 2 ? wc : wd)), u % EPW, old[u], m[u]);
+            }
         }
     };
     auto drain8 = [&](unsigned long long (&old)[8], uint32_t (&m)[8]) {      // this set's returns are in: 8 newer LDS operations are in flight
@@ -962,14 +972,21 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     // takes longer than that (Q 5000 x R 117 218, 64 bit, pass 2 with the words one / two / three batches ahead: 0.187 / 0.178 / 0.181 ms)
     // the cache is read once, 1 KB contiguous per wave instruction: the non-temporal hint pays on exactly this form (round 5, see
     // k_topk_filter_seq): pass 2 at the headline shape 0.192-0.194 -> 0.185-0.187 ms in the ablation harness (XMH_ABL_AP_PLAIN = without)
+    const uint32_t* crow12 = reinterpret_cast<const uint32_t*>(a.pair_cache) + (((int64_t)chunk_id * a.nqt + qtile) * nbatch * 64 + lane) * xmh::kCache12Dwords;
     auto cache_words = [&](int64_t batch) -> uint4 {
+        if constexpr (EB == 16) {                                    // 12-bit records: three dwords per lane, 768 B per wave instruction
+            typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+            const u32x3_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(crow12 + batch * 64 * xmh::kCache12Dwords));
+            return make_uint4(v.x, v.y, v.z, 0u);
+        } else {
 #ifdef XMH_ABL_AP_PLAIN
-        return crow[batch * 64];
+            return crow[batch * 64];
 #else
-        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
-        return make_uint4(v.x, v.y, v.z, v.w);
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(crow + batch * 64));
+            return make_uint4(v.x, v.y, v.z, v.w);
 #endif
+        }
     };
     uint4 cw = cache_words(0);
     uint4 nw = cache_words(1 < nbatch ? 1 : 0);
@@ -983,12 +1000,13 @@ __global__ __launch_bounds__(64) void k_scan_ap_c(ScanArgs a, const uint2* __res
     };
     // the steps of ONE batch whose first `count` items exist, through compiler-placed atomics (the ragged last batch)
     auto slow_batch = [&](const uint4& w4, int count) {
+        const uint32_t sx = EB == 16 ? __builtin_amdgcn_alignbit(w4.y, w4.x, 24) : 0u, sy = EB == 16 ? __builtin_amdgcn_alignbit(w4.z, w4.y, 28) : 0u;
 #pragma unroll
         for (int t = 0; t < QW; ++t) {
             if (t * S + slot < count) {
-                const uint32_t w = t < EPW ? w4.x : (t < 2 * EPW ? w4.y : (t < 3 * EPW ? w4.z : w4.w));
-                const uint32_t bit = HALF ? hoff + 16u * (t % EPW) : (uint32_t)(EB * (t % EPW));
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, bit, 1), d = __builtin_amdgcn_ubfe(w, bit + 1u, EB - 1);
+                const uint32_t w = EB == 16 ? XMH_CACHE12_WORD(t, w4.x, w4.y, w4.z, sx, sy) : (t < EPW ? w4.x : (t < 2 * EPW ? w4.y : (t < 3 * EPW ? w4.z : w4.w)));
+                const uint32_t bit = EB == 16 ? (uint32_t)XMH_CACHE12_BIT(t) : (HALF ? hoff + 16u * (t % EPW) : (uint32_t)(EB * (t % EPW)));
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, bit, 1), d = __builtin_amdgcn_ubfe(w, bit + 1u, EB == 16 ? 11 : EB - 1);
                 const unsigned long long o = atomicAdd(&cnt[d * QW + ql], 1ull | ((unsigned long long)m << 32));
                 credit(o, m);
             }

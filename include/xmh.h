@@ -134,8 +134,9 @@ size_t xmh_scan_pair_cache_bytes(int64_t Q, int64_t R, int K, int ternary);
 /* Byte offset of that pair cache inside the workspace ((size_t)-1 on a bad shape) -- for tests and diagnostics, which decode it
  * and compare every entry with the oracle's distance and relevance.  Layout for codes of at most 64 bits:
  * [chunk][16-query tile][64-item batch of the chunk][lane 0..63][16 bytes]; lane = slot * 16 + query-in-tile, byte t of a lane
- * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant (mod 256).  Two-byte form:
- * [chunk][8-query tile][batch][lane][8 x u16], lane = slot * 8 + query-in-tile, entry t = item 64 * batch + 8 * t + slot. */
+ * is the pair (that query, item 64 * batch + 4 * t + slot of the chunk); entry = distance << 1 | relevant (mod 256).  Longer and ternary codes:
+ * [chunk][8-query tile][batch][lane][3 x u32], lane = slot * 8 + query-in-tile, entry t (12 bits, round 6: bits [12 t, 12 t + 12) of the
+ * 96) = item 64 * batch + 8 * t + slot. */
 size_t xmh_scan_pair_cache_offset(int64_t Q, int64_t R, int K, int ternary);
 /* The workspace of the same plan WITHOUT its pair cache.  xmh_hamming_hist / xmh_hamming_ap / xmh_hamming_map take the size they are handed
  * as the decision: a buffer of at least xmh_scan_plan.ws_bytes runs with the cache, one of at least this size (and smaller than that) runs

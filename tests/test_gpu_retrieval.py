@@ -380,8 +380,15 @@ def test_pair_cache_entries_match_oracle(xr, monkeypatch, Q, R, K, C, m2):
     S, QW = (4, 16) if b8 else (8, 8)                                  # slots x queries of a cache tile; QW entries per lane and batch
     if b8:
         want = want & 0xFF
-        raw = raw[: pl.nchunk * (pl.qpad // QW) * nbatch * 64 * QW]    # 65..128 bits: the region is sized for two-byte entries, the first half is used
-    got = raw.view(np.uint8 if b8 else np.uint16).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
+        raw = raw[: pl.nchunk * (pl.qpad // QW) * nbatch * 64 * QW]    # 65..128 bits: the region is sized for 12-bit entries, the first two thirds are used
+        got = raw.view(np.uint8).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
+    else:
+        # round 6: entries above one byte are stored 12 bits each, the 8 of a lane and batch in three dwords (entry k = bits [12 k, 12 k + 12))
+        rec = raw[: pl.nchunk * (pl.qpad // QW) * nbatch * 64 * 12].view(np.uint32).reshape(-1, 3).astype(np.uint64)
+        bits = rec[:, 0] | (rec[:, 1] << np.uint64(32))                 # entries 0 .. 4 and the low 4 bits of entry 5
+        hi = (rec[:, 1] >> np.uint64(28)) | (rec[:, 2] << np.uint64(4))  # from bit 60 on: entries 5 .. 7
+        ent = [(bits >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(5)] + [(hi >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(3)]
+        got = np.stack(ent, axis=1).reshape(pl.nchunk, pl.qpad // QW, nbatch, 64, QW).astype(np.int64)
     lane = np.arange(64)
     slot, qin = lane // QW, lane % QW
     t = np.arange(QW)
